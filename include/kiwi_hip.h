@@ -1,0 +1,147 @@
+/*
+ * kiwi_hip.h -- C-ABI of the MI355X forward-modelling + misfit engine for Kiwi's inner
+ * inversion loop (trial source -> synthetic seismograms -> misfits).
+ *
+ * This is the drop-in boundary: plain C types only, callable from Fortran through
+ * iso_c_binding (kiwi_amd/fortran/kiwi_hip_binding.f90), from Python through ctypes
+ * (kiwi_amd/engine.py) or from C/C++.  Every function returns 0 on success and a
+ * non-zero code on failure; the message is retrieved with kiwi_hip_last_error() and maps
+ * onto the reference's recoverable-error convention ("<cmd>: nok >" + message,
+ * minimizer.f90:1689-1696).  No function aborts the process.  All arrays are caller-owned,
+ * contiguous, and copied before the call returns.  Indices irec/icomp are 1-based like
+ * the reference's wire protocol (switch_receiver, minimizer.f90:273-312).
+ *
+ * The three private engine steps this library replaces are
+ *     calculate_seismograms()  minimizer_engine.f90:885-907   (-> make_seismogram, seismogram.f90:36)
+ *     scale_seismograms()      minimizer_engine.f90:909-921   (-> receiver.f90:853)
+ *     calculate_misfits()      minimizer_engine.f90:924-945   (-> receiver.f90:407, comparator.f90:911,954)
+ * batched over many trial sources per call (kiwi_hip_eval); the setters mirror the
+ * engine's public state setters, cited one by one below.
+ *
+ * Sample index convention: all 'first' arguments are indices in the reference's strip
+ * index space (t_strip lower bounds, sparse_trace.f90:29-33): a Green's function trace
+ * sample j added with shift s lands on seismogram sample j+s (sparse_trace.f90:605), and a
+ * reference seismogram read from a file starting at time t0 has first = nint((t0 -
+ * reftime)/dt) + 1 (receiver.f90:834-851).
+ */
+#ifndef KIWI_HIP_H
+#define KIWI_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kiwi_hip_ctx kiwi_hip_ctx;
+
+/* misfit method ids = comparator.f90:35-42 */
+#define KIWI_L2NORM 1
+#define KIWI_L1NORM 2
+#define KIWI_AMPSPEC_L2NORM 3
+#define KIWI_AMPSPEC_L1NORM 4
+#define KIWI_SCALAR_PRODUCT 5
+#define KIWI_PEAK 6
+
+/* source type ids = parameterized_source.f90:45-50 */
+#define KIWI_SRC_BILAT 1
+#define KIWI_SRC_CIRCULAR 2
+#define KIWI_SRC_POINT_LP 3
+#define KIWI_SRC_EIKONAL 4
+#define KIWI_SRC_MT_EIKONAL 5
+#define KIWI_SRC_MOMENT_TENSOR 6
+
+/* ---- lifetime: program start / cleanup_minimizer (minimizer_engine.f90:1057-1067) ---- */
+int kiwi_hip_init(int device, kiwi_hip_ctx **ctx);
+int kiwi_hip_destroy(kiwi_hip_ctx *ctx);
+/* copies the last error message (NUL terminated, truncated to buflen); ctx may be NULL for init errors */
+int kiwi_hip_last_error(kiwi_hip_ctx *ctx, char *buf, int buflen);
+
+/* ---- set_database (minimizer_engine.f90:114-139; gfdb.f90:163-264) ----
+ * One-time dense upload replacing the lazy chunk cache (gfdb.f90:952-1031).
+ * G[((ix*nz+iz)*ng+ig)*L + l], l < nsamp[...] : samples of trace (ix,iz,ig) starting at
+ * strip index first[...] (== trace%span(1), sparse_trace.f90:46); interior gaps are zeros;
+ * samples at l >= nsamp are ignored (the last valid sample is the repeated end value,
+ * sparse_trace.f90:696-703).  nsamp == 0 marks a trace that is not stored (gfdb.f90:1003). */
+int kiwi_hip_set_gfdb(kiwi_hip_ctx *ctx, int nx, int nz, int ng, int L,
+                      float dt, float dx, float dz, float firstx, float firstz,
+                      const float *G, const int *first, const int *nsamp);
+
+/* set_local_interpolation + set_spacial_undersampling (minimizer_engine.f90:141-163; minimizer.f90:155-207) */
+int kiwi_hip_set_interp(kiwi_hip_ctx *ctx, int bilinear, int xundersample, int zundersample);
+
+/* set_effective_dt (minimizer_engine.f90:612-620): shortest duration of interest for the discretisers */
+int kiwi_hip_set_effective_dt(kiwi_hip_ctx *ctx, float effective_dt);
+
+/* set_source_location lat lon reftime (minimizer.f90:485-517; degrees, parsed as default real) */
+int kiwi_hip_set_source_location(kiwi_hip_ctx *ctx, float lat_deg, float lon_deg, double ref_time);
+
+/* set_receivers (minimizer_engine.f90:165-286): per receiver lat lon [depth] components;
+ * components is a string over "acrlduesnw" (receiver.f90:35-56), at most 5, no axis twice */
+int kiwi_hip_set_receivers(kiwi_hip_ctx *ctx, int nrec, const double *lat_deg, const double *lon_deg,
+                           const float *depth, const char *const *components);
+/* switch_receiver (minimizer_engine.f90:288-309) */
+int kiwi_hip_switch_receiver(kiwi_hip_ctx *ctx, int irec, int enabled);
+
+/* set_ref_seismograms (minimizer_engine.f90:313-352; receiver.f90:746-851): one trace per receiver component */
+int kiwi_hip_set_reference(kiwi_hip_ctx *ctx, int irec, int icomp, int first, int n, const float *data);
+/* set_misfit_taper / set_misfit_filter (minimizer_engine.f90:632-698; minimizer.f90:875-1016; receiver.f90:355-389):
+ * piecewise linear function control points; npts == 0 removes it */
+int kiwi_hip_set_taper(kiwi_hip_ctx *ctx, int irec, int npts, const float *x, const float *y);
+int kiwi_hip_set_filter(kiwi_hip_ctx *ctx, int irec, int npts, const float *x, const float *y);
+/* set_misfit_method (minimizer_engine.f90:622-630) */
+int kiwi_hip_set_misfit_method(kiwi_hip_ctx *ctx, int method);
+/* set_synthetics_factor (minimizer_engine.f90:700-727; receiver.f90:391-405) */
+int kiwi_hip_set_synthetics_factor(kiwi_hip_ctx *ctx, float factor);
+
+/* ---- trial sources ----
+ * psm_set + psm_to_tdsm on the host (source_all.f90:216-261,431-465): number of parameters
+ * of a source type (<0: unsupported), and one discretisation into a centroid table
+ * cent[ncent][10] = north east depth time mxx myy mzz mxy mxz myz (discrete_source.f90:27-30). */
+int kiwi_hip_source_nparams(int sourcetype);
+int kiwi_hip_discretize(int sourcetype, const float *params, int nparams, float effective_dt,
+                        float *cent, int maxcent, int *ncent, float *moment, float *risetime);
+
+/* upload a batch of discretised trial sources: cent_ofs[nsrc+1] row offsets into cent[][10];
+ * moment / risetime = psm%moment / psm%risetime per source (parameterized_source.f90:70-71) */
+int kiwi_hip_set_sources(kiwi_hip_ctx *ctx, int nsrc, const int *cent_ofs, const float *cent,
+                         const float *moment, const float *risetime);
+/* set_source_params for a whole batch (minimizer_engine.f90:500-523): params[nsrc][nparams] in
+ * wire order; discretised on the host with the current effective dt, then uploaded */
+int kiwi_hip_set_sources_params(kiwi_hip_ctx *ctx, int sourcetype, int nsrc, const float *params);
+
+/* ---- the hot path: calculate_seismograms + scale_seismograms + calculate_misfits for
+ * sources [isrc0, isrc0+nsrc) of the uploaded batch.  Asynchronous on the context's HIP
+ * stream; results stay on the device until fetched. */
+int kiwi_hip_eval(kiwi_hip_ctx *ctx, int isrc0, int nsrc);
+int kiwi_hip_sync(kiwi_hip_ctx *ctx);
+
+/* get_misfits (minimizer_engine.f90:1130-1172): nmis = sum of components over ENABLED receivers,
+ * receiver-major, component-minor */
+int kiwi_hip_nmisfits(kiwi_hip_ctx *ctx, int *nmis);
+/* misfit[nsrc][nmis], norm[nsrc][nmis] (misfits_norm_factors), global[nsrc] =
+ * sqrt(sum m^2)/sqrt(sum n^2) (minimizer_engine.f90:939-942); any pointer may be NULL.  Synchronises. */
+int kiwi_hip_get_misfits(kiwi_hip_ctx *ctx, int isrc0, int nsrc, float *misfit, float *norm, float *global);
+
+/* output_seismograms (minimizer_engine.f90:980-1010): synthetic of one source of the LAST
+ * kiwi_hip_eval range, over the receiver's misfit window.  which: 1 plain (scaled by moment,
+ * rise-time folded), 2 tapered.  Returns first sample index and count. */
+int kiwi_hip_get_synthetics(kiwi_hip_ctx *ctx, int isrc, int irec, int icomp, int which,
+                            int *first, int *n, float *out, int maxn);
+
+/* ---- measurement / inspection ---- */
+/* HIP-event durations [ms] of the last kiwi_hip_eval on the context stream:
+ * ms[0] geometry kernel, ms[1] accumulate kernel(s), ms[2] misfit kernels, ms[3] whole eval;
+ * launches[0..2] = number of launches of each in that eval.  Synchronises. */
+int kiwi_hip_get_kernel_ms(kiwi_hip_ctx *ctx, float ms[4], int launches[3]);
+/* per (source, receiver, centroid) geometry record of the last eval, 20 floats/ints each
+ * (layout in kiwi_amd/csrc/kiwi_kernels.hpp); for parity tests */
+int kiwi_hip_get_geometry(kiwi_hip_ctx *ctx, int isrc, int irec, int maxcent, int *ncent, void *records);
+/* receiver constants computed at set time: azimuth, back-azimuth [rad], distance [m]
+ * (seismogram.f90:99-100), as output_distances prints them (minimizer.f90:1404-1440) */
+int kiwi_hip_get_receiver_geometry(kiwi_hip_ctx *ctx, int irec, double *azi, double *bazi, double *dist);
+/* device memory currently held [bytes] */
+int kiwi_hip_get_device_bytes(kiwi_hip_ctx *ctx, long long *bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

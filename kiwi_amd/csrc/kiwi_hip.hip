@@ -1,0 +1,759 @@
+// kiwi_hip.hip -- context + C-ABI (include/kiwi_hip.h) of the MI355X engine.
+//
+// State mirrors what minimizer_engine.f90:78-108 keeps in module variables (database, receivers,
+// reference probes, misfit setup, source), plus a batch of discretised trial sources; the
+// dirty-flag chain of minimizer_engine.f90:1340-1511 collapses to one "prepared" flag that is
+// cleared by every setter the reference routes through dirtyfy_*.
+#include "../../include/kiwi_hip.h"
+#include "kiwi_host.hpp"
+#include "kiwi_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <stdexcept>
+#include <omp.h>
+
+using namespace kiwi;
+
+namespace {
+
+std::string g_init_error;
+
+struct HipError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+#define HIPCHECK(expr)                                                                             \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            throw HipError(std::string(#expr) + ": " + hipGetErrorString(e_));                      \
+    } while (0)
+
+template <class T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    long long *tally = nullptr;
+    void alloc(size_t count, long long *t)
+    {
+        release();
+        tally = t;
+        if (count == 0) return;
+        HIPCHECK(hipMalloc((void **)&p, count * sizeof(T)));
+        n = count;
+        if (tally) *tally += (long long)(n * sizeof(T));
+    }
+    void ensure(size_t count, long long *t) { if (count > n) alloc(count, t); }
+    void release()
+    {
+        if (p) { (void)hipFree(p); if (tally) *tally -= (long long)(n * sizeof(T)); }
+        p = nullptr; n = 0;
+    }
+    ~DevBuf() { release(); }
+};
+
+struct Receiver {
+    GeoCoords origin;                // radians
+    float depth = 0.f;
+    bool enabled = true;
+    int ncomp = 0;
+    int comp[kMaxComp] = { 0 };      // signed ids, receiver.f90:35-48
+    struct Ref { int first = 0; std::vector<float> data; } ref[kMaxComp];
+    Plf taper, filter;
+    double azi0 = 0, bazi0 = 0, dist0 = 0;
+};
+
+struct EventPair { hipEvent_t a, b; int kind; };
+
+} // namespace
+
+struct kiwi_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    long long dev_bytes = 0;
+
+    // database
+    GfMeta gm{};
+    bool have_db = false;
+    DevBuf<float> G;
+    DevBuf<int2> span;
+
+    // setup
+    int bilinear = 0, xus = 1, zus = 1;
+    float effective_dt = 1.f;                 // minimizer_engine.f90:79
+    GeoCoords src_origin; bool have_origin = false; double ref_time = 0;
+    std::vector<Receiver> recv;
+    int method = KIWI_L2NORM;
+    float syn_factor = 1.f;
+
+    // prepared (derived) state
+    bool prepared = false;
+    int nmis = 0, nrec_en = 0;
+    int halo = 0;
+    size_t syn_stride = 0;
+    std::vector<CompDev> comps;
+    std::vector<float> norm_h;
+    DevBuf<RecvDev> recv_d;
+    DevBuf<CompDev> comps_d;
+    DevBuf<float> reft_d, tw_d, norm_d;
+    DevBuf<int> recfirst_d;
+    int max_wlen = 0;
+
+    // sources
+    int nsrc = 0;
+    std::vector<int> cent_ofs;
+    float max_risetime = 0.f;
+    DevBuf<float> cent_d, moment_d, risetime_d;
+    DevBuf<int> centofs_d;
+
+    // results + workspace
+    DevBuf<float> misfit_d, global_d;
+    DevBuf<GeoRec> recs_d;
+    DevBuf<float> syn_d, proc_d;
+    int last_isrc0 = 0, last_nsrc = 0, last_chunk0 = 0, last_chunkn = 0;
+    int last_proc_which = 0;
+    size_t chunk_bytes_limit = (size_t)3 << 30;
+
+    std::vector<EventPair> events;
+    std::vector<hipEvent_t> event_pool;
+
+    hipEvent_t get_event()
+    {
+        if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
+        hipEvent_t e; HIPCHECK(hipEventCreate(&e)); return e;
+    }
+};
+
+namespace {
+
+int fail(kiwi_hip_ctx *ctx, const std::string &msg)
+{
+    if (ctx) ctx->err = msg; else g_init_error = msg;
+    return 1;
+}
+
+#define GUARD_BEGIN try {
+#define GUARD_END(ctx)                                                                             \
+    } catch (const std::exception &e) { return fail(ctx, e.what()); }                              \
+      catch (...) { return fail(ctx, "unknown error"); }
+
+int component_id(char ch)     // receiver.f90:294-307
+{
+    static const char names[] = "wsulc?ardne";
+    for (int i = 0; i < 11; i++) if (names[i] == ch) return i - 5;
+    return 0;
+}
+
+void update_receiver_geometry(kiwi_hip_ctx *c)
+{
+    if (!c->have_origin) return;
+    for (auto &r : c->recv) {
+        azibazi(c->src_origin, r.origin, r.azi0, r.bazi0);                 // seismogram.f90:99
+        r.dist0 = distance_accurate50m(c->src_origin, r.origin);          // seismogram.f90:100
+    }
+}
+
+int fold_halfwidth(float risetime, float dt)
+{
+    if (!(risetime > 0.f)) return 0;
+    const int n = 1 + 2 * (int)std::round(0.5f * risetime / dt);          // receiver.f90:872
+    return (n - 1) / 2;
+}
+
+// derive windows, tapered references, norm factors and device tables
+void prepare(kiwi_hip_ctx *c)
+{
+    if (c->prepared) return;
+    if (!c->have_db) throw std::runtime_error("no database set");
+    if (!c->have_origin) throw std::runtime_error("no source location set");
+    if (c->recv.empty()) throw std::runtime_error("no receivers set");
+    if (c->method != KIWI_L2NORM && c->method != KIWI_L1NORM && c->method != KIWI_SCALAR_PRODUCT &&
+        c->method != KIWI_PEAK)
+        throw std::runtime_error("misfit method not available in the device comparator yet (time-domain l2norm, "
+                                 "l1norm, scalar_product, peak are)");
+    const float dt = c->gm.dt;
+    const int hs = fold_halfwidth(c->max_risetime, dt);
+    c->halo = hs > 0 ? hs + 2 : 0;
+    const int nrec = (int)c->recv.size();
+    std::vector<RecvDev> rd(nrec);
+    c->comps.clear();
+    c->norm_h.clear();
+    std::vector<float> reft, tw;
+    std::vector<int> recfirst;
+    size_t synofs = 0;
+    c->max_wlen = 0;
+    for (int ir = 0; ir < nrec; ir++) {
+        Receiver &r = c->recv[ir];
+        RecvDev &d = rd[ir];
+        std::memset(&d, 0, sizeof(d));
+        d.azi0 = r.azi0; d.bazi0 = r.bazi0; d.dist0 = r.dist0;
+        d.depth = r.depth;
+        d.cl0 = (float)std::cos(r.bazi0 + (double)kPi);                    // seismogram.f90:270-271
+        d.sl0 = (float)std::sin(r.bazi0 + (double)kPi);
+        d.enabled = r.enabled && r.ncomp > 0;
+        d.ncomp = r.ncomp;
+        d.sd = 0.f;
+        for (int k = 0; k < r.ncomp; k++) {
+            d.comp[k] = std::abs(r.comp[k]);
+            d.sign[k] = r.comp[k] < 0 ? -1.f : 1.f;                        // receiver.f90:331-351
+            if (d.comp[k] == 3) { d.has_d = 1; d.sd = d.sign[k]; } else d.need_h = 1;
+        }
+        if (!d.enabled) continue;
+        if (!r.taper.defined())
+            throw std::runtime_error("receiver " + std::to_string(ir + 1) + ": no misfit taper set (the device "
+                                     "comparator evaluates norms over the taper span, comparator.f90:782-792)");
+        int w[2];
+        discrete_plf_span(r.taper, dt, w);                                 // comparator.f90:1157-1169
+        if (w[1] < w[0]) throw std::runtime_error("receiver " + std::to_string(ir + 1) + ": empty taper span");
+        const int wlen = w[1] - w[0] + 1;
+        d.wbeg = w[0] - c->halo;
+        d.wlen = wlen + 2 * c->halo;
+        c->max_wlen = std::max(c->max_wlen, d.wlen);
+        // taper weights: plf_taper_array applied to ones (piecewise_linear_function.f90:195-237)
+        std::vector<float> tww(wlen, 1.f);
+        plf_taper_array(r.taper, tww.data(), w[0], w[1], dt, IP_COS);
+        recfirst.push_back((int)c->comps.size());
+        for (int k = 0; k < r.ncomp; k++) {
+            const auto &rf = r.ref[k];
+            if (rf.data.empty())
+                throw std::runtime_error("receiver " + std::to_string(ir + 1) + " component " +
+                                         std::to_string(k + 1) + ": no reference seismogram set");
+            CompDev cd;
+            cd.synofs = (int)synofs; cd.halo = c->halo; cd.w0 = w[0]; cd.wlen = wlen;
+            cd.refofs = (int)reft.size(); cd.rec = ir;
+            d.synofs[k] = (int)synofs;
+            synofs += ((size_t)d.wlen + 3) / 4 * 4;
+            // reference probe contents over the window: zeros before the data, last value repeated
+            // after it (probe_set_array, comparator.f90:259-265), then tapered (:1173-1184)
+            const int f0 = rf.first, f1 = rf.first + (int)rf.data.size() - 1;
+            double sum = 0.0, pk = 0.0;
+            for (int t = w[0]; t <= w[1]; t++) {
+                float v = 0.f;
+                if (t >= f0) v = rf.data[std::min(t, f1) - f0] * 1.f;
+                if (t >= f0) v = v * tww[t - w[0]];                         // taper acts from dataspan(1) on
+                reft.push_back(v);
+                switch (c->method) {                                       // probe_norm, comparator.f90:669-697
+                case KIWI_L2NORM: sum += (double)v * (double)v; break;
+                case KIWI_L1NORM: sum += (double)std::fabs(v); break;
+                case KIWI_SCALAR_PRODUCT: sum += (double)(v * v); break;
+                default: pk = std::max(pk, (double)std::fabs(v)); break;
+                }
+            }
+            tw.insert(tw.end(), tww.begin(), tww.end());
+            float nf;
+            switch (c->method) {
+            case KIWI_L2NORM: nf = 1.f * (float)std::sqrt((double)dt * sum); break;
+            case KIWI_L1NORM: nf = 1.f * (float)((double)dt * sum); break;
+            case KIWI_SCALAR_PRODUCT: nf = (1.f * 1.f) * (float)sum; break;
+            default: nf = 1.f * (float)pk; break;
+            }
+            c->norm_h.push_back(nf);
+            c->comps.push_back(cd);
+        }
+    }
+    recfirst.push_back((int)c->comps.size());
+    c->nmis = (int)c->comps.size();
+    c->nrec_en = (int)recfirst.size() - 1;
+    c->syn_stride = synofs;
+    if (c->nmis == 0) throw std::runtime_error("no enabled receiver components");
+
+    c->recv_d.ensure(rd.size(), &c->dev_bytes);
+    c->comps_d.ensure(c->comps.size(), &c->dev_bytes);
+    c->reft_d.ensure(reft.size(), &c->dev_bytes);
+    c->tw_d.ensure(tw.size(), &c->dev_bytes);
+    c->norm_d.ensure(c->norm_h.size(), &c->dev_bytes);
+    c->recfirst_d.ensure(recfirst.size(), &c->dev_bytes);
+    HIPCHECK(hipMemcpyAsync(c->recv_d.p, rd.data(), rd.size() * sizeof(RecvDev), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(c->comps_d.p, c->comps.data(), c->comps.size() * sizeof(CompDev), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(c->reft_d.p, reft.data(), reft.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(c->tw_d.p, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(c->norm_d.p, c->norm_h.data(), c->norm_h.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(c->recfirst_d.p, recfirst.data(), recfirst.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));      // host vectors go out of scope
+    if (c->nsrc > 0) {
+        c->misfit_d.ensure((size_t)c->nsrc * c->nmis, &c->dev_bytes);
+        c->global_d.ensure((size_t)c->nsrc, &c->dev_bytes);
+    }
+    c->prepared = true;
+}
+
+void record(kiwi_hip_ctx *c, int kind, hipEvent_t &a)
+{
+    a = c->get_event();
+    HIPCHECK(hipEventRecord(a, c->stream));
+    (void)kind;
+}
+
+void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
+{
+    const int nrec = (int)c->recv.size();
+    const int cbeg = c->cent_ofs[isrc0], cend = c->cent_ofs[isrc0 + nsrc];
+    int maxnc = 0;
+    for (int s = isrc0; s < isrc0 + nsrc; s++) maxnc = std::max(maxnc, c->cent_ofs[s + 1] - c->cent_ofs[s]);
+    c->recs_d.ensure((size_t)(cend - cbeg) * nrec, &c->dev_bytes);
+    c->syn_d.ensure((size_t)nsrc * c->syn_stride, &c->dev_bytes);
+    float *proc = nullptr;
+    if (proc_which) { c->proc_d.ensure((size_t)nsrc * c->syn_stride, &c->dev_bytes); proc = c->proc_d.p; }
+
+    EvalParams ep{ c->bilinear, c->xus, c->zus, nrec, isrc0 };
+    hipEvent_t e0, e1, e2, e3;
+    record(c, 0, e0);
+    if (maxnc > 0) {
+        dim3 grid((unsigned)((maxnc * nrec + 255) / 256), (unsigned)nsrc);
+        hipLaunchKernelGGL(geometry_kernel, grid, dim3(256), 0, c->stream, c->cent_d.p, c->centofs_d.p, ep, c->gm,
+                           c->span.p, c->recv_d.p, c->recs_d.p);
+    }
+    record(c, 0, e1);
+    {
+        dim3 grid((unsigned)((c->max_wlen + kTile - 1) / kTile), (unsigned)nrec, (unsigned)nsrc);
+        if (c->gm.ng == 10)
+            hipLaunchKernelGGL(accumulate_kernel<10>, grid, dim3(256), 0, c->stream, c->G.p, c->span.p, c->gm.pitch,
+                               c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p, c->syn_stride);
+        else
+            hipLaunchKernelGGL(accumulate_kernel<8>, grid, dim3(256), 0, c->stream, c->G.p, c->span.p, c->gm.pitch,
+                               c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p, c->syn_stride);
+    }
+    record(c, 1, e2);
+    {
+        MisfitParams mp{ c->method, c->gm.dt, c->syn_factor, c->nmis, isrc0, proc_which };
+        hipLaunchKernelGGL(misfit_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream,
+                           c->syn_d.p, c->syn_stride, c->comps_d.p, c->reft_d.p, c->tw_d.p, c->moment_d.p,
+                           c->risetime_d.p, mp, c->misfit_d.p, proc);
+        hipLaunchKernelGGL(global_kernel, dim3((unsigned)((nsrc + 127) / 128)), dim3(128), 0, c->stream,
+                           c->misfit_d.p, c->norm_d.p, c->recfirst_d.p, c->nrec_en, c->nmis, isrc0, nsrc, c->global_d.p);
+    }
+    record(c, 2, e3);
+    HIPCHECK(hipGetLastError());
+    c->events.push_back({ e0, e1, 0 });
+    c->events.push_back({ e1, e2, 1 });
+    c->events.push_back({ e2, e3, 2 });
+    c->last_chunk0 = isrc0; c->last_chunkn = nsrc;
+}
+
+int eval_impl(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
+{
+    if (isrc0 < 0 || nsrc < 0 || isrc0 + nsrc > c->nsrc) throw std::runtime_error("source range out of bounds");
+    HIPCHECK(hipSetDevice(c->device));
+    prepare(c);
+    c->misfit_d.ensure((size_t)c->nsrc * c->nmis, &c->dev_bytes);
+    c->global_d.ensure((size_t)c->nsrc, &c->dev_bytes);
+    const int nrec = (int)c->recv.size();
+    int s = isrc0;
+    while (s < isrc0 + nsrc) {
+        // greedy chunk bounded by workspace bytes
+        size_t bytes = 0;
+        int n = 0;
+        while (s + n < isrc0 + nsrc) {
+            const size_t nc = (size_t)(c->cent_ofs[s + n + 1] - c->cent_ofs[s + n]);
+            const size_t add = nc * nrec * sizeof(GeoRec) + c->syn_stride * sizeof(float) * (proc_which ? 2 : 1);
+            if (n > 0 && (bytes + add > c->chunk_bytes_limit || n >= 65535)) break;
+            bytes += add; n++;
+        }
+        run_chunk(c, s, n, proc_which);
+        s += n;
+    }
+    c->last_isrc0 = isrc0; c->last_nsrc = nsrc; c->last_proc_which = proc_which;
+    return 0;
+}
+
+} // namespace
+
+// ================================================================================================
+extern "C" {
+
+int kiwi_hip_init(int device, kiwi_hip_ctx **out)
+{
+    kiwi_hip_ctx *c = nullptr;
+    try {
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev <= 0)
+            return fail(nullptr, std::string("no HIP device available: ") + hipGetErrorString(e));
+        if (device < 0 || device >= ndev) return fail(nullptr, "device index out of range");
+        HIPCHECK(hipSetDevice(device));
+        c = new kiwi_hip_ctx();
+        c->device = device;
+        HIPCHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        *out = c;
+        return 0;
+    } catch (const std::exception &e) {
+        delete c;
+        return fail(nullptr, e.what());
+    }
+}
+
+int kiwi_hip_destroy(kiwi_hip_ctx *c)
+{
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &ev : c->events) {
+        if (ev.kind == 0) (void)hipEventDestroy(ev.a);
+        (void)hipEventDestroy(ev.b);
+    }
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+int kiwi_hip_last_error(kiwi_hip_ctx *c, char *buf, int buflen)
+{
+    const std::string &m = c ? c->err : g_init_error;
+    if (buf && buflen > 0) { std::snprintf(buf, (size_t)buflen, "%s", m.c_str()); }
+    return 0;
+}
+
+int kiwi_hip_set_gfdb(kiwi_hip_ctx *c, int nx, int nz, int ng, int L, float dt, float dx, float dz,
+                      float firstx, float firstz, const float *G, const int *first, const int *nsamp)
+{
+    GUARD_BEGIN
+    if (nx < 1 || nz < 1 || L < 1) throw std::runtime_error("bad database dimensions");
+    if (ng != 8 && ng != 10) throw std::runtime_error("ng must be 8 or 10 (gfdb.f90:57)");
+    if (!(dt > 0.f) || !(dx > 0.f) || !(dz > 0.f)) throw std::runtime_error("dt, dx, dz must be positive");
+    HIPCHECK(hipSetDevice(c->device));
+    const size_t nrows = (size_t)nx * nz * ng;
+    int lmax = 1;
+    for (size_t i = 0; i < nrows; i++) {
+        if (nsamp[i] < 0 || nsamp[i] > L) throw std::runtime_error("nsamp out of range");
+        lmax = std::max(lmax, nsamp[i]);
+    }
+    const int pitch = (kRowPad + lmax + 8 + 3) / 4 * 4;     // >= pad + n + 5 for load5's clamp
+    // host staging in slabs of rows: [kRowPad zeros | samples | repeated end value]
+    c->G.alloc(nrows * (size_t)pitch, &c->dev_bytes);
+    c->span.alloc(nrows, &c->dev_bytes);
+    std::vector<int2> sp(nrows);
+    const size_t slab = std::max<size_t>(1, ((size_t)64 << 20) / ((size_t)pitch * sizeof(float)));
+    std::vector<float> stage(slab * (size_t)pitch);
+    for (size_t r0 = 0; r0 < nrows; r0 += slab) {
+        const size_t nr = std::min(slab, nrows - r0);
+#pragma omp parallel for schedule(static)
+        for (long long i = 0; i < (long long)nr; i++) {
+            const size_t row = r0 + (size_t)i;
+            float *d = stage.data() + (size_t)i * pitch;
+            const int n = nsamp[row];
+            const float *src = G + row * (size_t)L;
+            for (int k = 0; k < kRowPad; k++) d[k] = 0.f;
+            for (int k = 0; k < n; k++) d[kRowPad + k] = src[k];
+            const float tail = n > 0 ? src[n - 1] : 0.f;
+            for (int k = kRowPad + n; k < pitch; k++) d[k] = tail;
+            sp[row] = make_int2(first[row], first[row] + n - 1);       // n == 0 -> empty span = not stored
+        }
+        HIPCHECK(hipMemcpy(c->G.p + r0 * (size_t)pitch, stage.data(), nr * (size_t)pitch * sizeof(float), hipMemcpyHostToDevice));
+    }
+    HIPCHECK(hipMemcpy(c->span.p, sp.data(), nrows * sizeof(int2), hipMemcpyHostToDevice));
+    c->gm = GfMeta{ nx, nz, ng, pitch, dt, dx, dz, firstx, firstz };
+    c->have_db = true;
+    c->prepared = false;            // dirtyfy_database, minimizer_engine.f90:1483
+    return 0;
+    GUARD_END(c)
+}
+
+int kiwi_hip_set_interp(kiwi_hip_ctx *c, int bilinear, int xus, int zus)
+{
+    if (xus < 1 || zus < 1) return fail(c, "undersampling must be >= 1");
+    c->bilinear = bilinear ? 1 : 0; c->xus = xus; c->zus = zus;
+    return 0;
+}
+
+int kiwi_hip_set_effective_dt(kiwi_hip_ctx *c, float edt)
+{
+    if (!(edt > 0.f)) return fail(c, "effective dt must be positive");
+    c->effective_dt = edt;
+    return 0;
+}
+
+int kiwi_hip_set_source_location(kiwi_hip_ctx *c, float lat_deg, float lon_deg, double ref_time)
+{
+    c->src_origin.lat = (double)d2r(lat_deg);      // minimizer.f90:517: d2r on default reals
+    c->src_origin.lon = (double)d2r(lon_deg);
+    c->ref_time = ref_time;
+    c->have_origin = true;
+    update_receiver_geometry(c);
+    c->prepared = false;                           // dirtyfy_source_location
+    return 0;
+}
+
+int kiwi_hip_set_receivers(kiwi_hip_ctx *c, int nrec, const double *lat_deg, const double *lon_deg,
+                           const float *depth, const char *const *components)
+{
+    GUARD_BEGIN
+    if (nrec < 1) throw std::runtime_error("need at least one receiver");
+    std::vector<Receiver> rs((size_t)nrec);
+    for (int i = 0; i < nrec; i++) {
+        Receiver &r = rs[i];
+        r.origin.lat = d2r(lat_deg[i]);            // d2r(origin), minimizer_engine.f90:262
+        r.origin.lon = d2r(lon_deg[i]);
+        r.depth = depth ? depth[i] : 0.f;
+        const char *cs = components[i];
+        const int nc = (int)std::strlen(cs);
+        if (nc > kMaxComp) throw std::runtime_error("too many components at receiver " + std::to_string(i + 1));
+        for (int k = 0; k < nc; k++) {             // receiver_init, receiver.f90:168-189
+            const int id = component_id(cs[k]);
+            bool bad = (id == 0);
+            for (int j = 0; j < k; j++) if (std::abs(r.comp[j]) == std::abs(id)) bad = true;
+            if (bad)
+                throw std::runtime_error("initializing receiver failed: possibly a forbidden combination of receiver "
+                                         "components has been given at receiver no. " + std::to_string(i + 1));
+            r.comp[k] = id;
+        }
+        r.ncomp = nc;
+        r.enabled = nc > 0;
+    }
+    c->recv.swap(rs);
+    update_receiver_geometry(c);
+    c->prepared = false;                           // dirtyfy_receivers
+    return 0;
+    GUARD_END(c)
+}
+
+int kiwi_hip_switch_receiver(kiwi_hip_ctx *c, int irec, int enabled)
+{
+    if (irec < 1 || irec > (int)c->recv.size()) return fail(c, "receiver index out of range");
+    c->recv[irec - 1].enabled = enabled != 0;
+    c->prepared = false;
+    return 0;
+}
+
+int kiwi_hip_set_reference(kiwi_hip_ctx *c, int irec, int icomp, int first, int n, const float *data)
+{
+    if (irec < 1 || irec > (int)c->recv.size()) return fail(c, "receiver index out of range");
+    Receiver &r = c->recv[irec - 1];
+    if (icomp < 1 || icomp > r.ncomp) return fail(c, "component index out of range");
+    if (n < 1) return fail(c, "empty reference seismogram");
+    r.ref[icomp - 1].first = first;
+    r.ref[icomp - 1].data.assign(data, data + n);
+    c->prepared = false;                           // dirtyfy_ref_probes
+    return 0;
+}
+
+static int set_plf(kiwi_hip_ctx *c, int irec, int npts, const float *x, const float *y, bool taper)
+{
+    if (irec < 1 || irec > (int)c->recv.size()) return fail(c, "receiver index out of range");
+    if (npts == 1) return fail(c, "need at least two control points");
+    Plf p;
+    if (npts > 0) { p.x.assign(x, x + npts); p.y.assign(y, y + npts); }
+    (taper ? c->recv[irec - 1].taper : c->recv[irec - 1].filter) = p;
+    c->prepared = false;
+    return 0;
+}
+
+int kiwi_hip_set_taper(kiwi_hip_ctx *c, int irec, int npts, const float *x, const float *y)
+{
+    return set_plf(c, irec, npts, x, y, true);
+}
+
+int kiwi_hip_set_filter(kiwi_hip_ctx *c, int irec, int npts, const float *x, const float *y)
+{
+    if (npts > 0) return fail(c, "frequency filter not available in the device comparator yet");
+    return set_plf(c, irec, npts, x, y, false);
+}
+
+int kiwi_hip_set_misfit_method(kiwi_hip_ctx *c, int method)
+{
+    if (method < 1 || method > 8) return fail(c, "unknown misfit method");
+    c->method = method;
+    c->prepared = false;
+    return 0;
+}
+
+int kiwi_hip_set_synthetics_factor(kiwi_hip_ctx *c, float factor)
+{
+    c->syn_factor = factor;
+    return 0;
+}
+
+int kiwi_hip_source_nparams(int sourcetype) { return source_nparams(sourcetype); }
+
+int kiwi_hip_discretize(int sourcetype, const float *params, int nparams, float effective_dt,
+                        float *cent, int maxcent, int *ncent, float *moment, float *risetime)
+{
+    try {
+        if (source_nparams(sourcetype) != nparams) return 2;
+        DiscreteSource ds;
+        if (!discretize(sourcetype, params, effective_dt, ds)) return 3;
+        *ncent = (int)ds.centroids.size();
+        if (moment) *moment = ds.moment;
+        if (risetime) *risetime = ds.risetime;
+        if (cent) {
+            if (*ncent > maxcent) return 4;
+            std::memcpy(cent, ds.centroids.data(), ds.centroids.size() * sizeof(Centroid));
+        }
+        return 0;
+    } catch (...) { return 1; }
+}
+
+int kiwi_hip_set_sources(kiwi_hip_ctx *c, int nsrc, const int *cent_ofs, const float *cent,
+                         const float *moment, const float *risetime)
+{
+    GUARD_BEGIN
+    if (nsrc < 1) throw std::runtime_error("need at least one source");
+    if (!c->have_db) throw std::runtime_error("set the database before the sources");
+    HIPCHECK(hipSetDevice(c->device));
+    if (cent_ofs[0] != 0) throw std::runtime_error("cent_ofs[0] must be 0");
+    for (int s = 0; s < nsrc; s++) if (cent_ofs[s + 1] < cent_ofs[s]) throw std::runtime_error("cent_ofs not monotone");
+    const size_t ntot = (size_t)cent_ofs[nsrc];
+    float maxrise = 0.f;
+    for (int s = 0; s < nsrc; s++) maxrise = std::max(maxrise, risetime[s]);
+    if (2 * fold_halfwidth(maxrise, c->gm.dt) + 1 > kMaxFold) throw std::runtime_error("rise time too long for the fold kernel");
+    c->cent_ofs.assign(cent_ofs, cent_ofs + nsrc + 1);
+    c->cent_d.ensure(std::max<size_t>(ntot, 1) * 10, &c->dev_bytes);
+    c->centofs_d.ensure((size_t)nsrc + 1, &c->dev_bytes);
+    c->moment_d.ensure((size_t)nsrc, &c->dev_bytes);
+    c->risetime_d.ensure((size_t)nsrc, &c->dev_bytes);
+    HIPCHECK(hipMemcpy(c->cent_d.p, cent, ntot * 10 * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(c->centofs_d.p, cent_ofs, ((size_t)nsrc + 1) * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(c->moment_d.p, moment, (size_t)nsrc * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(c->risetime_d.p, risetime, (size_t)nsrc * sizeof(float), hipMemcpyHostToDevice));
+    c->nsrc = nsrc;
+    if (fold_halfwidth(maxrise, c->gm.dt) != fold_halfwidth(c->max_risetime, c->gm.dt)) c->prepared = false;
+    c->max_risetime = maxrise;
+    c->last_nsrc = 0;
+    return 0;
+    GUARD_END(c)
+}
+
+int kiwi_hip_set_sources_params(kiwi_hip_ctx *c, int sourcetype, int nsrc, const float *params)
+{
+    GUARD_BEGIN
+    const int np = source_nparams(sourcetype);
+    if (np < 0) throw std::runtime_error("source type not supported by the host discretiser");
+    if (nsrc < 1) throw std::runtime_error("need at least one source");
+    std::vector<DiscreteSource> ds((size_t)nsrc);
+    bool ok = true;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int s = 0; s < nsrc; s++)
+        if (!discretize(sourcetype, params + (size_t)s * np, c->effective_dt, ds[s])) ok = false;
+    if (!ok) throw std::runtime_error("source discretisation failed");
+    std::vector<int> ofs((size_t)nsrc + 1, 0);
+    for (int s = 0; s < nsrc; s++) ofs[s + 1] = ofs[s] + (int)ds[s].centroids.size();
+    std::vector<float> cent((size_t)ofs[nsrc] * 10), mom((size_t)nsrc), rise((size_t)nsrc);
+    for (int s = 0; s < nsrc; s++) {
+        std::memcpy(cent.data() + (size_t)ofs[s] * 10, ds[s].centroids.data(), ds[s].centroids.size() * sizeof(Centroid));
+        mom[s] = ds[s].moment; rise[s] = ds[s].risetime;
+    }
+    return kiwi_hip_set_sources(c, nsrc, ofs.data(), cent.data(), mom.data(), rise.data());
+    GUARD_END(c)
+}
+
+int kiwi_hip_eval(kiwi_hip_ctx *c, int isrc0, int nsrc)
+{
+    GUARD_BEGIN
+    return eval_impl(c, isrc0, nsrc, 0);
+    GUARD_END(c)
+}
+
+int kiwi_hip_sync(kiwi_hip_ctx *c)
+{
+    GUARD_BEGIN
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return 0;
+    GUARD_END(c)
+}
+
+int kiwi_hip_nmisfits(kiwi_hip_ctx *c, int *nmis)
+{
+    GUARD_BEGIN
+    HIPCHECK(hipSetDevice(c->device));
+    prepare(c);
+    *nmis = c->nmis;
+    return 0;
+    GUARD_END(c)
+}
+
+int kiwi_hip_get_misfits(kiwi_hip_ctx *c, int isrc0, int nsrc, float *misfit, float *norm, float *global)
+{
+    GUARD_BEGIN
+    if (!c->prepared) throw std::runtime_error("nothing evaluated yet");
+    if (isrc0 < 0 || nsrc < 0 || isrc0 + nsrc > c->nsrc) throw std::runtime_error("source range out of bounds");
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    if (misfit)
+        HIPCHECK(hipMemcpy(misfit, c->misfit_d.p + (size_t)isrc0 * c->nmis, (size_t)nsrc * c->nmis * sizeof(float), hipMemcpyDeviceToHost));
+    if (norm)
+        for (int s = 0; s < nsrc; s++) std::memcpy(norm + (size_t)s * c->nmis, c->norm_h.data(), (size_t)c->nmis * sizeof(float));
+    if (global)
+        HIPCHECK(hipMemcpy(global, c->global_d.p + isrc0, (size_t)nsrc * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+    GUARD_END(c)
+}
+
+int kiwi_hip_get_synthetics(kiwi_hip_ctx *c, int isrc, int irec, int icomp, int which, int *first, int *n,
+                            float *out, int maxn)
+{
+    GUARD_BEGIN
+    if (which != 1 && which != 2) throw std::runtime_error("which must be 1 (plain) or 2 (tapered)");
+    if (isrc < 0 || isrc >= c->nsrc) throw std::runtime_error("source index out of range");
+    if (irec < 1 || irec > (int)c->recv.size()) throw std::runtime_error("receiver index out of range");
+    // re-evaluate this one source keeping the processed synthetics
+    eval_impl(c, isrc, 1, which);
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    int slot = -1, k = 0;
+    for (size_t i = 0; i < c->comps.size(); i++) {
+        if (c->comps[i].rec == irec - 1) { if (k == icomp - 1) { slot = (int)i; break; } k++; }
+    }
+    if (slot < 0) throw std::runtime_error("receiver disabled or component index out of range");
+    const CompDev &cd = c->comps[slot];
+    *first = cd.w0; *n = cd.wlen;
+    const int m = std::min(cd.wlen, maxn);
+    HIPCHECK(hipMemcpy(out, c->proc_d.p + cd.synofs + cd.halo, (size_t)m * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+    GUARD_END(c)
+}
+
+int kiwi_hip_get_kernel_ms(kiwi_hip_ctx *c, float ms[4], int launches[3])
+{
+    GUARD_BEGIN
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 4; i++) ms[i] = 0.f;
+    for (int i = 0; i < 3; i++) launches[i] = 0;
+    for (auto &ev : c->events) {
+        float t = 0.f;
+        HIPCHECK(hipEventElapsedTime(&t, ev.a, ev.b));
+        ms[ev.kind] += t; ms[3] += t; launches[ev.kind]++;
+    }
+    // events are shared between neighbouring pairs: e0,e1,e2,e3 per chunk
+    for (size_t i = 0; i < c->events.size(); i++) {
+        if (c->events[i].kind == 0) c->event_pool.push_back(c->events[i].a);
+        c->event_pool.push_back(c->events[i].b);
+    }
+    c->events.clear();
+    return 0;
+    GUARD_END(c)
+}
+
+int kiwi_hip_get_geometry(kiwi_hip_ctx *c, int isrc, int irec, int maxcent, int *ncent, void *records)
+{
+    GUARD_BEGIN
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    if (isrc < c->last_chunk0 || isrc >= c->last_chunk0 + c->last_chunkn)
+        throw std::runtime_error("source not in the last evaluated chunk");
+    if (irec < 1 || irec > (int)c->recv.size()) throw std::runtime_error("receiver index out of range");
+    const int nrec = (int)c->recv.size();
+    const int c0 = c->cent_ofs[isrc], nc = c->cent_ofs[isrc + 1] - c0, cb = c->cent_ofs[c->last_chunk0];
+    *ncent = nc;
+    const int m = std::min(nc, maxcent);
+    const size_t base = (size_t)(c0 - cb) * nrec + (size_t)(irec - 1) * nc;
+    HIPCHECK(hipMemcpy(records, c->recs_d.p + base, (size_t)m * sizeof(GeoRec), hipMemcpyDeviceToHost));
+    return 0;
+    GUARD_END(c)
+}
+
+int kiwi_hip_get_receiver_geometry(kiwi_hip_ctx *c, int irec, double *azi, double *bazi, double *dist)
+{
+    if (irec < 1 || irec > (int)c->recv.size()) return fail(c, "receiver index out of range");
+    if (!c->have_origin) return fail(c, "no source location set");
+    const Receiver &r = c->recv[irec - 1];
+    *azi = r.azi0; *bazi = r.bazi0; *dist = r.dist0;
+    return 0;
+}
+
+int kiwi_hip_get_device_bytes(kiwi_hip_ctx *c, long long *bytes)
+{
+    *bytes = c->dev_bytes;
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,493 @@
+// kiwi_kernels.hpp -- CDNA4 (gfx950) kernels of the trial-source hot path.
+//
+//   geometry_kernel    one thread per (source, receiver, centroid): spherical azimuth/distance
+//                      update (orthodrome.f90:77-156), moment-tensor weights (seismogram.f90:316-336),
+//                      GF grid indices and bilinear weights (gfdb.f90:781-815), time shift split
+//                      (sparse_trace.f90:640-645).  fp64 trig; writes one 80-byte GeoRec.
+//   accumulate_kernel  the bandwidth-bound "convolution": for one (source, receiver, 1024-sample
+//                      time tile) walk the centroids IN TABLE ORDER and, per Green's function
+//                      component, stream the 4 neighbour traces, blend them (gfdb.f90:944-949) and
+//                      shift-multiply-add them (sparse_trace.f90:684-703) into register accumulators;
+//                      rotate per centroid (seismogram.f90:158-204) and to north/east at the end
+//                      (seismogram.f90:256-283).  Every output sample is owned by one thread, so the
+//                      fp32 summation order is exactly the reference's.
+//   misfit_kernel      scale by moment, optional rise-time fold (receiver.f90:853-904), taper, and
+//                      the time-domain norms with fp64 accumulation (comparator.f90:619-697).
+//   global_kernel      sqrt(sum m^2)/sqrt(sum n^2) per source (minimizer_engine.f90:924-945).
+//
+// Built with -ffp-contract=off: the reference rounds every multiply and add separately.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "kiwi_libm32.hpp"
+
+namespace kiwi {
+
+constexpr int kRowPad = 8;        // zeros in front of every GF row (>= 5, see load5)
+constexpr int kTile = 1024;       // samples per workgroup: 256 threads x 4 consecutive samples
+constexpr int kMaxComp = 5;
+
+// per (source, receiver, centroid) record, written by geometry_kernel, read (wave-uniformly,
+// through scalar loads) by accumulate_kernel.  20 x 4 B.
+struct GeoRec {
+    int   row[4];     // first GF row (ig = 0) of nodes (ix0,iz0) (ix0,iz1) (ix1,iz0) (ix1,iz1); row[0] < 0: skipped
+    float w[4];       // (1-dix)(1-diz), (1-dix)diz, dix(1-diz), dix diz       gfdb.f90:946-949
+    int   ishift;     // floor(time/dt)                                        sparse_trace.f90:640
+    float wfrac;      // time/dt - ishift                                      sparse_trace.f90:642
+    float f[6];       // make_weights                                          seismogram.f90:329-334
+    float cl, sl;     // cos / sin (bazi - bazi_orig)                          seismogram.f90:164-165
+    int   flags;      // bit0: exactly on a node -> no blend (gfdb.f90:890-893); bit1: rotate (seismogram.f90:160)
+    int   pad;
+};
+static_assert(sizeof(GeoRec) == 80, "GeoRec layout");
+
+struct GfMeta {
+    int nx, nz, ng;
+    int pitch;                 // floats per row (kRowPad zeros | samples | repeated end value)
+    float dt, dx, dz, firstx, firstz;
+};
+
+// per receiver constants
+struct RecvDev {
+    double azi0, bazi0, dist0;    // seismogram.f90:99-100
+    float depth;
+    float cl0, sl0;               // cos/sin(bazi_orig + pi)             seismogram.f90:270-271
+    int   enabled;
+    int   ncomp;
+    int   comp[kMaxComp];         // |id| 1 away 2 right 3 down 4 north 5 east (receiver.f90:35-48)
+    float sign[kMaxComp];
+    int   need_h, has_d;
+    float sd;                     // sign of the down/up component
+    int   wbeg, wlen;             // synthetic window [wbeg, wbeg+wlen) incl. fold halo
+    int   synofs[kMaxComp];       // float offset of each component inside one source's synthetic block
+};
+
+// per misfit slot (enabled receiver component)
+struct CompDev {
+    int synofs;      // offset of the component's synthetic (incl. halo) inside a source block
+    int halo;
+    int w0, wlen;    // misfit window first sample, length
+    int refofs;      // offset into reft / tw arrays
+    int rec;
+};
+
+// ------------------------------------------------------------------------------------------------
+// geometry
+
+__device__ __forceinline__ double clipd(double x, double mi, double ma) { return fmin(fmax(mi, x), ma); }
+__device__ __forceinline__ double wrapd(double x, double mi, double ma) { return x - floor((x - mi) / (ma - mi)) * (ma - mi); }
+
+// The default-real libm calls of the reference host (sin, cos, atan2 -> glibc sinf, cosf, atan2f)
+// are reproduced bit for bit by kiwi_libm32.hpp; the real*8 ones (sin, cos, acos, asin) use the
+// device's fp64 libm, which agrees with glibc to an ulp of fp64 ("tolerances").
+__device__ __forceinline__ float sin32(float x) { return libm32::sinf_glibc(x); }
+__device__ __forceinline__ float cos32(float x) { return libm32::cosf_glibc(x); }
+
+struct EvalParams {
+    int bilinear, xus, zus;
+    int nrec;
+    int isrc0;
+};
+
+__global__ __launch_bounds__(256) void geometry_kernel(
+    const float *__restrict__ cent, const int *__restrict__ cent_ofs, EvalParams ep, GfMeta gm,
+    const int2 *__restrict__ span, const RecvDev *__restrict__ recv, GeoRec *__restrict__ out)
+{
+    const int s = blockIdx.y;
+    const int c0 = cent_ofs[ep.isrc0 + s], nc = cent_ofs[ep.isrc0 + s + 1] - c0;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nc * ep.nrec) return;
+    const int r = idx / nc, c = idx - r * nc;
+    const RecvDev &rv = recv[r];
+    const float *ce = cent + (size_t)(c0 + c) * 10;
+    GeoRec g;
+    g.pad = 0;
+    const float dnorth = ce[0], deast = ce[1], depth = ce[2], time = ce[3];
+    const float pi_f = 3.14159265358979f;           // constants.f90:21
+    const double pi_d = (double)pi_f;               // constants.f90:22
+    const float earthradius = 6371.f * 1000.f;      // constants.f90:23
+
+    // ---- approx_differential_azidist, orthodrome.f90:77-156 (exact branch; r == 0 -> const azimuth)
+    double azi, bazi, dist;
+    {
+        const double azimuth = rv.azi0, backazimuth = rv.bazi0, d0 = rv.dist0;
+        const float rr = sqrtf(dnorth * dnorth + deast * deast);
+        const double rd = (double)rr;
+        if (d0 / rd > 1.79769313486231570815e308) {
+            azi = azimuth; bazi = backazimuth;
+            dist = d0 - ((double)dnorth * cos(azimuth) + (double)deast * sin(azimuth));
+        } else {
+            const double a = rd / (double)earthradius;
+            const double b = d0 / (double)earthradius;
+            const double lambda = (double)libm32::atan2f_glibc(deast, dnorth);
+            const double gamma = azimuth - lambda;
+            const double ca = cos(a), cb = cos(b), sa = sin(a), sb = sin(b), sg = sin(gamma);
+            const double cc = acos(clipd(ca * cb + sa * sb * cos(gamma), -1., 1.));
+            const double sc = sin(cc), cosc = cos(cc);
+            double alpha = asin(clipd(sa * sg / sc, -1., 1.));
+            double beta = asin(clipd(sb * sg / sc, -1., 1.));
+            if (ca - cb * cosc < 0) alpha = (alpha > 0) ? pi_d - alpha : -pi_d - alpha;
+            if (cb - ca * cosc < 0) beta = (beta > 0) ? pi_d - beta : -pi_d - beta;
+            dist = cc * (double)earthradius;
+            bazi = wrapd(backazimuth + alpha, -pi_d, pi_d);
+            azi = wrapd(lambda - pi_d - beta, -pi_d, pi_d);
+        }
+    }
+
+    // ---- make_weights, seismogram.f90:316-336
+    {
+        const float azf = (float)azi;
+        const float sa = sin32(azf), ca = cos32(azf), s2a = sin32(2.f * azf), c2a = cos32(2.f * azf);
+        const float *m = ce + 4;
+        g.f[0] = m[0] * (ca * ca) + m[1] * (sa * sa) + m[3] * s2a;
+        g.f[1] = m[4] * ca + m[5] * sa;
+        g.f[2] = m[2];
+        g.f[3] = 0.5f * (m[1] - m[0]) * s2a + m[3] * c2a;
+        g.f[4] = m[5] * ca - m[4] * sa;
+        g.f[5] = m[0] * (sa * sa) + m[1] * (ca * ca) - m[3] * s2a;
+    }
+
+    // ---- time shift, seismogram.f90:139 + sparse_trace.f90:640-642
+    {
+        const float rshift = time / gm.dt;
+        const float fl = floorf(rshift);
+        g.ishift = (int)fl;
+        g.wfrac = rshift - (float)g.ishift;
+    }
+
+    // ---- rotation of horizontals, seismogram.f90:159-165
+    {
+        const double lambda = bazi - rv.bazi0;
+        g.flags = (lambda != 0.) ? 2 : 0;
+        g.cl = (float)cos(lambda);
+        g.sl = (float)sin(lambda);
+    }
+
+    // ---- GF indices, gfdb.f90:781-815
+    const float x = (float)dist, z = depth - rv.depth;
+    int ix0, iz0, ix1, iz1;
+    float dix = 0.f, diz = 0.f;
+    if (ep.bilinear) {
+        ix0 = (int)floorf((x - gm.firstx) / (gm.dx * (float)ep.xus)) * ep.xus + 1;
+        iz0 = (int)floorf((z - gm.firstz) / (gm.dz * (float)ep.zus)) * ep.zus + 1;
+        ix1 = ix0 + ep.xus; iz1 = iz0 + ep.zus;
+        dix = (x - gm.firstx - (float)(ix0 - 1) * gm.dx) / (gm.dx * (float)ep.xus);
+        diz = (z - gm.firstz - (float)(iz0 - 1) * gm.dz) / (gm.dz * (float)ep.zus);
+    } else {
+        ix0 = (int)roundf((x - gm.firstx) / gm.dx) + 1;       // nint
+        iz0 = (int)roundf((z - gm.firstz) / gm.dz) + 1;
+        ix1 = ix0 + 1; iz1 = iz0 + 1;
+    }
+    const bool direct = (dix == 0.f && diz == 0.f);            // gfdb.f90:890
+    if (direct) g.flags |= 1;
+    g.w[0] = (1.f - dix) * (1.f - diz);
+    g.w[1] = (1.f - dix) * diz;
+    g.w[2] = dix * (1.f - diz);
+    g.w[3] = dix * diz;
+    auto inrange = [&](int ix, int iz) { return ix >= 1 && ix <= gm.nx && iz >= 1 && iz <= gm.nz; };
+    auto rowof = [&](int ix, int iz) { return ((ix - 1) * gm.nz + (iz - 1)) * gm.ng; };
+    bool ok = inrange(ix0, iz0);
+    if (!direct) ok = ok && inrange(ix0, iz1) && inrange(ix1, iz0) && inrange(ix1, iz1);
+    g.row[0] = g.row[1] = g.row[2] = g.row[3] = -1;
+    if (ok) {
+        g.row[0] = rowof(ix0, iz0);
+        if (!direct) { g.row[1] = rowof(ix0, iz1); g.row[2] = rowof(ix1, iz0); g.row[3] = rowof(ix1, iz1); }
+        else { g.row[1] = g.row[2] = g.row[3] = g.row[0]; }
+        // a trace that is not stored makes gfdb_get_trace return null and the centroid is
+        // skipped (seismogram.f90:172 ...); checked here for every component this receiver needs
+        const int nn = direct ? 1 : 4;
+        for (int k = 0; k < nn && ok; k++)
+            for (int ig = 0; ig < gm.ng && ok; ig++) {
+                const bool horiz = (ig <= 4) || (ig == 8);
+                if ((horiz && !rv.need_h) || (!horiz && !rv.has_d)) continue;
+                const int2 sp = span[g.row[k] + ig];
+                if (sp.y < sp.x) ok = false;
+            }
+        if (!ok) g.row[0] = -1;
+    }
+    const size_t base = (size_t)(c0 - cent_ofs[ep.isrc0]) * ep.nrec + (size_t)r * nc + c;
+    out[base] = g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// accumulate
+
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned 16-byte load
+
+// five consecutive samples l-1 .. l+3 of one GF row (l relative to the row's first sample).
+// The row is stored as [kRowPad zeros | n samples | end value repeated up to pitch], so clamping
+// the start position implements "zero before the span, last value repeated after it"
+// (sparse_trace.f90:337-338,696-703) without branches.
+__device__ __forceinline__ void load5(const float *__restrict__ rowp, int l, int pitch, float (&v)[5])
+{
+    int q = kRowPad + l - 1;
+    q = min(max(q, 0), pitch - 5);
+    const float *p = rowp + q;
+    v[0] = p[0];
+    const f4u t = *(const f4u *)(p + 1);
+    v[1] = t.x; v[2] = t.y; v[3] = t.z; v[4] = t.w;
+}
+
+// one Green's function component of one centroid onto 4 consecutive output samples.
+// sparse_trace.f90:640-703 (shift, linear sub-sample interpolation, repeated end point) on top
+// of gfdb.f90:944-949 (4-neighbour blend, summed in the order t00,t01,t10,t11).
+template <bool BLEND>
+__device__ __forceinline__ void gf_add(float (&out)[4], const float *__restrict__ G, const int2 *__restrict__ span,
+                                       int pitch, const GeoRec &g, int ig, float factor, int j0)
+{
+    float b[5];
+    int jend;
+    const int r0 = g.row[0] + ig;
+    const int2 s0 = span[r0];
+    if (BLEND) {
+        const int r1 = g.row[1] + ig, r2 = g.row[2] + ig, r3 = g.row[3] + ig;
+        const int2 s1 = span[r1], s2 = span[r2], s3 = span[r3];
+        jend = max(max(s0.y, s1.y), max(s2.y, s3.y));
+        float v0[5], v1[5], v2[5], v3[5];
+        load5(G + (size_t)r0 * pitch, j0 - s0.x, pitch, v0);
+        load5(G + (size_t)r1 * pitch, j0 - s1.x, pitch, v1);
+        load5(G + (size_t)r2 * pitch, j0 - s2.x, pitch, v2);
+        load5(G + (size_t)r3 * pitch, j0 - s3.x, pitch, v3);
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            float acc = g.w[0] * v0[i];
+            acc = acc + g.w[1] * v1[i];
+            acc = acc + g.w[2] * v2[i];
+            acc = acc + g.w[3] * v3[i];
+            b[i] = acc;
+        }
+    } else {
+        jend = s0.y;
+        load5(G + (size_t)r0 * pitch, j0 - s0.x, pitch, b);
+    }
+    float wr = g.wfrac;
+    float wl = 1.f - wr;
+    wr = wr * factor;
+    wl = wl * factor;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const bool tail = (j0 + i) > jend;            // sparse_trace.f90:698-703
+        const float c1 = tail ? factor : wl;
+        const float c2 = tail ? 0.f : wr;
+        out[i] = out[i] + c1 * b[i + 1];
+        out[i] = out[i] + c2 * b[i];
+    }
+}
+
+template <int NG, bool BLEND>
+__device__ __forceinline__ void centroid_add(float (&ar1)[4], float (&ar2)[4], float (&dz)[4],
+                                             const float *__restrict__ G, const int2 *__restrict__ span, int pitch,
+                                             const GeoRec &g, const RecvDev &rv, int j0)
+{
+    if (rv.need_h) {
+        if (g.flags & 2) {                       // seismogram.f90:160-203
+            float t1[4] = { 0.f, 0.f, 0.f, 0.f }, t2[4] = { 0.f, 0.f, 0.f, 0.f };
+            gf_add<BLEND>(t1, G, span, pitch, g, 0, g.f[0], j0);
+            gf_add<BLEND>(t1, G, span, pitch, g, 1, g.f[1], j0);
+            gf_add<BLEND>(t1, G, span, pitch, g, 2, g.f[2], j0);
+            if (NG == 10) gf_add<BLEND>(t1, G, span, pitch, g, 8, g.f[5], j0);
+            gf_add<BLEND>(t2, G, span, pitch, g, 3, g.f[3], j0);
+            gf_add<BLEND>(t2, G, span, pitch, g, 4, g.f[4], j0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                ar1[i] = ar1[i] + g.cl * t1[i] - g.sl * t2[i];
+                ar2[i] = ar2[i] + g.cl * t2[i] + g.sl * t1[i];
+            }
+        } else {                                 // seismogram.f90:205-231
+            gf_add<BLEND>(ar1, G, span, pitch, g, 0, g.f[0], j0);
+            gf_add<BLEND>(ar1, G, span, pitch, g, 1, g.f[1], j0);
+            gf_add<BLEND>(ar1, G, span, pitch, g, 2, g.f[2], j0);
+            if (NG == 10) gf_add<BLEND>(ar1, G, span, pitch, g, 8, g.f[5], j0);
+            gf_add<BLEND>(ar2, G, span, pitch, g, 3, g.f[3], j0);
+            gf_add<BLEND>(ar2, G, span, pitch, g, 4, g.f[4], j0);
+        }
+    }
+    if (rv.has_d) {                              // seismogram.f90:236-253
+        gf_add<BLEND>(dz, G, span, pitch, g, 5, g.f[0] * rv.sd, j0);
+        gf_add<BLEND>(dz, G, span, pitch, g, 6, g.f[1] * rv.sd, j0);
+        gf_add<BLEND>(dz, G, span, pitch, g, 7, g.f[2] * rv.sd, j0);
+        if (NG == 10) gf_add<BLEND>(dz, G, span, pitch, g, 9, g.f[5] * rv.sd, j0);
+    }
+}
+
+template <int NG>
+__global__ __launch_bounds__(256) void accumulate_kernel(
+    const float *__restrict__ G, const int2 *__restrict__ span, int pitch,
+    const GeoRec *__restrict__ recs, const int *__restrict__ cent_ofs, int isrc0, int nrec,
+    const RecvDev *__restrict__ recv, float *__restrict__ syn, size_t syn_stride)
+{
+    const int tile = blockIdx.x, r = blockIdx.y, s = blockIdx.z;
+    const RecvDev &rv = recv[r];
+    if (!rv.enabled) return;
+    if (tile * kTile >= rv.wlen) return;
+    const int tl = tile * kTile + threadIdx.x * 4;
+    const int t0 = rv.wbeg + tl;
+    const int cb = cent_ofs[isrc0], c0 = cent_ofs[isrc0 + s], nc = cent_ofs[isrc0 + s + 1] - c0;
+    const GeoRec *__restrict__ rc = recs + ((size_t)(c0 - cb) * nrec + (size_t)r * nc);
+
+    float ar1[4] = { 0.f, 0.f, 0.f, 0.f }, ar2[4] = { 0.f, 0.f, 0.f, 0.f }, dz[4] = { 0.f, 0.f, 0.f, 0.f };
+    for (int c = 0; c < nc; c++) {               // seismogram.f90:131, table order
+        const GeoRec &g = rc[c];
+        if (g.row[0] < 0) continue;              // 'cycle' on a missing trace
+        const int j0 = t0 - g.ishift;            // strip(x) += trace(x - itraceshift), sparse_trace.f90:605
+        if (g.flags & 1) centroid_add<NG, false>(ar1, ar2, dz, G, span, pitch, g, rv, j0);
+        else             centroid_add<NG, true>(ar1, ar2, dz, G, span, pitch, g, rv, j0);
+    }
+
+    if (tl >= rv.wlen) return;
+    float *__restrict__ so = syn + (size_t)s * syn_stride + tl;
+    for (int k = 0; k < rv.ncomp; k++) {         // seismogram.f90:256-283
+        float4 o;
+        const float sg = rv.sign[k];
+        switch (rv.comp[k]) {
+        case 1: o = make_float4(ar1[0] * sg, ar1[1] * sg, ar1[2] * sg, ar1[3] * sg); break;
+        case 2: o = make_float4(ar2[0] * sg, ar2[1] * sg, ar2[2] * sg, ar2[3] * sg); break;
+        case 3: o = make_float4(dz[0], dz[1], dz[2], dz[3]); break;       // sign already in the factors (:239)
+        case 4: {
+            float a[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) a[i] = (rv.cl0 * ar1[i] - rv.sl0 * ar2[i]) * sg;
+            o = make_float4(a[0], a[1], a[2], a[3]); break; }
+        default: {
+            float a[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) a[i] = (rv.cl0 * ar2[i] + rv.sl0 * ar1[i]) * sg;
+            o = make_float4(a[0], a[1], a[2], a[3]); break; }
+        }
+        *(float4 *)(so + rv.synofs[k]) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// misfit
+
+constexpr int kMaxFold = 129;
+
+struct MisfitParams {
+    int method;          // comparator.f90:35-40 (time-domain ones)
+    float dt;
+    float syn_factor;    // b%factor (receiver.f90:391-405); a%factor == 1
+    int nmis;
+    int isrc0;
+    int write_tapered;   // keep scaled+folded (+tapered) synthetics for get_synthetics
+};
+
+__global__ __launch_bounds__(256) void misfit_kernel(
+    const float *__restrict__ syn, size_t syn_stride, const CompDev *__restrict__ comps,
+    const float *__restrict__ reft, const float *__restrict__ tw,
+    const float *__restrict__ moment, const float *__restrict__ risetime, MisfitParams mp,
+    float *__restrict__ misfit_out, float *__restrict__ proc /* optional [src][stride] processed synthetics */)
+{
+    const int m = blockIdx.x, s = blockIdx.y;
+    const CompDev cd = comps[m];
+    const float mom = moment[mp.isrc0 + s];
+    const float rise = risetime[mp.isrc0 + s];
+    const float *__restrict__ sy = syn + (size_t)s * syn_stride + cd.synofs + cd.halo;   // sy[i] = sample w0 + i
+    const float *__restrict__ rt = reft + cd.refofs;
+    const float *__restrict__ tp = tw + cd.refofs;
+
+    __shared__ float fw[kMaxFold];
+    __shared__ int fs[kMaxFold];
+    __shared__ float fr[kMaxFold];
+    __shared__ int nfold;
+    __shared__ double red[256];
+    if (threadIdx.x == 0) {                       // receiver.f90:868-886
+        int n = 0;
+        if (rise > 0.f) {
+            const float dt = mp.dt;
+            const float rr0 = -rise / 2.f, rr1 = +rise / 2.f;
+            n = 1 + 2 * (int)roundf(0.5f * rise / dt);
+            if (n > kMaxFold) n = kMaxFold;       // guarded on the host (set_sources)
+            float sum = 0.f;
+            for (int is = 1; is <= n; is++) {
+                const float ts = ((float)(is - 1) - 0.5f * (float)(n - 1)) * dt;
+                const float lo = fmaxf(rr0, ts - dt / 2.f), hi = fminf(rr1, ts + dt / 2.f);
+                fw[is - 1] = fmaxf(0.f, hi - lo);
+                const float sh = ts / dt;
+                const float fl = floorf(sh);
+                fs[is - 1] = (int)fl;
+                fr[is - 1] = sh - (float)(int)fl;
+                sum = sum + fw[is - 1];
+            }
+            for (int i = 0; i < n; i++) fw[i] = fw[i] / sum;
+        }
+        nfold = n;
+    }
+    __syncthreads();
+    const int nf = nfold;
+    const bool unit = (mp.syn_factor == 1.f);
+    double acc = 0.0;
+    double peak = 0.0;
+    for (int i = threadIdx.x; i < cd.wlen; i += 256) {
+        float v;
+        if (nf > 0) {                             // strip_fold, sparse_trace.f90:379-402
+            v = 0.f;
+            for (int k = 0; k < nf; k++) {
+                float wr = fr[k];
+                float wl = 1.f - wr;
+                wr = wr * fw[k]; wl = wl * fw[k];
+                v = v + wl * sy[i - fs[k]];
+                v = v + wr * sy[i - fs[k] - 1];
+            }
+        } else {
+            v = sy[i];
+        }
+        v = v * mom;                              // probe_set_array(..., factor_=moment), comparator.f90:264
+        const float vt = v * tp[i];               // make_array_tapered, comparator.f90:1173-1184
+        if (proc) proc[(size_t)s * syn_stride + cd.synofs + cd.halo + i] = mp.write_tapered == 2 ? vt : v;
+        const float a = rt[i];
+        switch (mp.method) {
+        case 1: {                                 // l2norm_func, comparator.f90:650-659
+            const float d = unit ? (a - vt) : (1.f * a - mp.syn_factor * vt);
+            acc += (double)d * (double)d; break; }
+        case 2: {                                 // l1norm_func, :639-648
+            const float d = unit ? fabsf(a - vt) : fabsf(1.f * a - mp.syn_factor * vt);
+            acc += (double)d; break; }
+        case 5:                                   // scalar_product_2, :627-637
+            acc += unit ? (double)(a * vt) : (double)(a * 1.f * vt * mp.syn_factor); break;
+        default: {                                // maxabs_func, :661-667
+            const double x = (double)(1.f * a), y = (double)(mp.syn_factor * vt);
+            peak = fmax(peak, sqrt(x * x + y * y)); break; }
+        }
+    }
+    red[threadIdx.x] = (mp.method == 6) ? peak : acc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) {
+            if (mp.method == 6) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + st]);
+            else red[threadIdx.x] += red[threadIdx.x + st];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double tot = red[0];
+        float res;
+        switch (mp.method) {
+        case 1: res = (float)sqrt((double)mp.dt * tot); break;
+        case 2: res = (float)((double)mp.dt * tot); break;
+        case 5: res = (float)tot; break;
+        default: res = (float)tot; break;
+        }
+        misfit_out[(size_t)(mp.isrc0 + s) * mp.nmis + m] = res;
+    }
+}
+
+// minimizer_engine.f90:936-942: per receiver sum of squares in fp32, receivers in order
+__global__ void global_kernel(const float *__restrict__ misfit, const float *__restrict__ norm,
+                              const int *__restrict__ rec_first /*[nrec_en+1]*/, int nrec_en, int nmis,
+                              int isrc0, int nsrc, float *__restrict__ global_out)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsrc) return;
+    const float *m = misfit + (size_t)(isrc0 + s) * nmis;
+    float mis = 0.f, nf = 0.f;
+    for (int r = 0; r < nrec_en; r++) {
+        float a = 0.f, b = 0.f;
+        for (int k = rec_first[r]; k < rec_first[r + 1]; k++) a = a + m[k] * m[k];
+        for (int k = rec_first[r]; k < rec_first[r + 1]; k++) b = b + norm[k] * norm[k];
+        mis = mis + a;
+        nf = nf + b;
+    }
+    global_out[isrc0 + s] = sqrtf(mis) / sqrtf(nf);
+}
+
+} // namespace kiwi

@@ -1,0 +1,256 @@
+"""Python host side of the C-ABI: one ``Engine`` == one ``minimizer`` process of the reference.
+
+Method names follow the reference's stdin commands / minimizer_engine procedures
+(minimizer.f90:1729-1811) so that the calling code reads like python/tunguska/seismosizer.py;
+``make_misfits_for_sources`` and ``make_global_misfits`` restate the two Python functions that sit
+directly on the path (seismosizer.py:682-722, 843-922)."""
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _lib
+from .lib import KiwiHipError, c_float_p, c_int_p, c_double_p
+
+SOURCE_TYPES = {"bilateral": 1, "circular": 2, "point_lp": 3, "eikonal": 4, "mt_eikonal": 5,
+                "moment_tensor": 6}          # source_all.f90:88-98
+NORMS = {"l2norm": 1, "l1norm": 2, "ampspec_l2norm": 3, "ampspec_l1norm": 4, "scalar_product": 5,
+         "peak": 6, "floating_l2norm": 7, "floating_l1norm": 8}      # comparator.f90:137-146
+
+GEOREC = np.dtype([("row", np.int32, 4), ("w", np.float32, 4), ("ishift", np.int32), ("wfrac", np.float32),
+                   ("f", np.float32, 6), ("cl", np.float32), ("sl", np.float32), ("flags", np.int32),
+                   ("pad", np.int32)])
+
+
+def _fp(a):
+    return a.ctypes.data_as(c_float_p)
+
+
+def _ip(a):
+    return a.ctypes.data_as(c_int_p)
+
+
+def discretize(sourcetype, params, effective_dt):
+    """psm_set + psm_to_tdsm on the host (kiwi_hip_discretize): (centroids[n,10], moment, risetime)."""
+    L = _lib.load()
+    st = SOURCE_TYPES.get(sourcetype, sourcetype)
+    p = np.ascontiguousarray(params, np.float32)
+    n, mo, ri = C.c_int(), C.c_float(), C.c_float()
+    rc = L.kiwi_hip_discretize(st, _fp(p), len(p), effective_dt, None, 0, C.byref(n), C.byref(mo), C.byref(ri))
+    if rc != 0:
+        raise KiwiHipError("discretize failed (rc=%d): unsupported source type or wrong parameter count" % rc)
+    cent = np.zeros((n.value, 10), np.float32)
+    rc = L.kiwi_hip_discretize(st, _fp(p), len(p), effective_dt, _fp(cent), n.value, C.byref(n), C.byref(mo),
+                               C.byref(ri))
+    if rc != 0:
+        raise KiwiHipError("discretize failed (rc=%d)" % rc)
+    return cent, mo.value, ri.value
+
+
+class Engine:
+    def __init__(self, device=0):
+        self.L = _lib.load()
+        self.h = C.c_void_p()
+        rc = self.L.kiwi_hip_init(device, C.byref(self.h))
+        if rc != 0:
+            buf = C.create_string_buffer(512)
+            self.L.kiwi_hip_last_error(None, buf, 512)
+            self.h = None
+            raise KiwiHipError("kiwi_hip_init: " + buf.value.decode())
+        self.nsrc = 0
+
+    # ------------------------------------------------------------------ plumbing
+    def _ck(self, rc, what):
+        if rc != 0:
+            buf = C.create_string_buffer(1024)
+            self.L.kiwi_hip_last_error(self.h, buf, 1024)
+            raise KiwiHipError("%s: nok > %s" % (what, buf.value.decode()))
+
+    def close(self):
+        if self.h:
+            self.L.kiwi_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ setup commands
+    def set_database(self, dt, dx, dz, firstx, firstz, data, first, nsamp):
+        """data[nx,nz,ng,L] float32, first/nsamp[nx,nz,ng] int32 (see kiwi_hip_set_gfdb)."""
+        data = np.ascontiguousarray(data, np.float32)
+        first = np.ascontiguousarray(first, np.int32)
+        nsamp = np.ascontiguousarray(nsamp, np.int32)
+        nx, nz, ng, L = data.shape
+        assert first.shape == (nx, nz, ng) and nsamp.shape == (nx, nz, ng)
+        self._ck(self.L.kiwi_hip_set_gfdb(self.h, nx, nz, ng, L, dt, dx, dz, firstx, firstz, _fp(data), _ip(first),
+                                          _ip(nsamp)), "set_database")
+        self.dt = dt
+
+    def set_local_interpolation(self, kind):
+        self._interp = (kind in ("bilinear", True, 1))
+        self._ck(self.L.kiwi_hip_set_interp(self.h, int(self._interp), getattr(self, "_xus", 1),
+                                            getattr(self, "_zus", 1)), "set_local_interpolation")
+
+    def set_spacial_undersampling(self, xus, zus):
+        self._xus, self._zus = xus, zus
+        self._ck(self.L.kiwi_hip_set_interp(self.h, int(getattr(self, "_interp", False)), xus, zus),
+                 "set_spacial_undersampling")
+
+    def set_effective_dt(self, dt):
+        self._ck(self.L.kiwi_hip_set_effective_dt(self.h, dt), "set_effective_dt")
+
+    def set_source_location(self, lat_deg, lon_deg, ref_time=0.0):
+        self._ck(self.L.kiwi_hip_set_source_location(self.h, lat_deg, lon_deg, ref_time), "set_source_location")
+
+    def set_receivers(self, lat_deg, lon_deg, depth, components):
+        n = len(lat_deg)
+        lat = np.ascontiguousarray(lat_deg, np.float64)
+        lon = np.ascontiguousarray(lon_deg, np.float64)
+        dep = np.ascontiguousarray(np.zeros(n) if depth is None else depth, np.float32)
+        arr = (C.c_char_p * n)(*[c.encode() for c in components])
+        self._ck(self.L.kiwi_hip_set_receivers(self.h, n, lat.ctypes.data_as(c_double_p),
+                                               lon.ctypes.data_as(c_double_p), _fp(dep), arr), "set_receivers")
+        self.components = list(components)
+        self.enabled = [len(c) > 0 for c in components]
+
+    def switch_receiver(self, irec, state):
+        self._ck(self.L.kiwi_hip_switch_receiver(self.h, irec, int(bool(state))), "switch_receiver")
+        self.enabled[irec - 1] = bool(state)
+
+    def set_ref_seismogram(self, irec, icomp, first, data):
+        d = np.ascontiguousarray(data, np.float32)
+        self._ck(self.L.kiwi_hip_set_reference(self.h, irec, icomp, first, len(d), _fp(d)), "set_ref_seismograms")
+
+    def set_misfit_taper(self, irec, x, y):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.ascontiguousarray(y, np.float32)
+        self._ck(self.L.kiwi_hip_set_taper(self.h, irec, len(x), _fp(x), _fp(y)), "set_misfit_taper")
+
+    def set_misfit_filter(self, irec, x, y):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.ascontiguousarray(y, np.float32)
+        self._ck(self.L.kiwi_hip_set_filter(self.h, irec, len(x), _fp(x), _fp(y)), "set_misfit_filter")
+
+    def set_misfit_method(self, name):
+        if not isinstance(name, int) and name not in NORMS:
+            raise KiwiHipError("set_misfit_method: nok > unknown norm: %s" % name)   # minimizer.f90:842-873
+        self._ck(self.L.kiwi_hip_set_misfit_method(self.h, NORMS.get(name, name)), "set_misfit_method")
+
+    def set_synthetics_factor(self, f):
+        self._ck(self.L.kiwi_hip_set_synthetics_factor(self.h, f), "set_synthetics_factor")
+
+    # ------------------------------------------------------------------ trial sources
+    def set_sources(self, tables, moments=None, risetimes=None):
+        """tables: list of centroid tables [n_i,10]."""
+        ofs = np.zeros(len(tables) + 1, np.int32)
+        ofs[1:] = np.cumsum([len(t) for t in tables])
+        cent = np.ascontiguousarray(np.concatenate(tables, 0) if len(tables) else np.zeros((0, 10)), np.float32)
+        mo = np.ascontiguousarray(np.ones(len(tables)) if moments is None else moments, np.float32)
+        ri = np.ascontiguousarray(np.zeros(len(tables)) if risetimes is None else risetimes, np.float32)
+        self._ck(self.L.kiwi_hip_set_sources(self.h, len(tables), _ip(ofs), _fp(cent), _fp(mo), _fp(ri)),
+                 "set_sources")
+        self.nsrc = len(tables)
+
+    def set_source_params(self, sourcetype, params):
+        """Batch form of `set_source_params type p1..pn`: params[nsrc, nparams]."""
+        p = np.ascontiguousarray(np.atleast_2d(params), np.float32)
+        st = SOURCE_TYPES.get(sourcetype, sourcetype)
+        self._ck(self.L.kiwi_hip_set_sources_params(self.h, st, p.shape[0], _fp(p)), "set_source_params")
+        self.nsrc = p.shape[0]
+
+    # ------------------------------------------------------------------ hot path
+    def eval(self, isrc0=0, nsrc=None):
+        nsrc = self.nsrc - isrc0 if nsrc is None else nsrc
+        self._ck(self.L.kiwi_hip_eval(self.h, isrc0, nsrc), "get_misfits")
+
+    def sync(self):
+        self._ck(self.L.kiwi_hip_sync(self.h), "sync")
+
+    def nmisfits(self):
+        n = C.c_int()
+        self._ck(self.L.kiwi_hip_nmisfits(self.h, C.byref(n)), "get_misfits")
+        return n.value
+
+    def get_misfits(self, isrc0=0, nsrc=None):
+        """(misfit[nsrc,nmis], norm[nsrc,nmis], global[nsrc]) of already evaluated sources."""
+        nsrc = self.nsrc - isrc0 if nsrc is None else nsrc
+        nm = self.nmisfits()
+        m = np.zeros((nsrc, nm), np.float32)
+        n = np.zeros((nsrc, nm), np.float32)
+        g = np.zeros(nsrc, np.float32)
+        self._ck(self.L.kiwi_hip_get_misfits(self.h, isrc0, nsrc, _fp(m), _fp(n), _fp(g)), "get_misfits")
+        return m, n, g
+
+    def get_synthetics(self, isrc, irec, icomp, which=1, maxn=1 << 20):
+        out = np.zeros(maxn, np.float32)
+        first, n = C.c_int(), C.c_int()
+        self._ck(self.L.kiwi_hip_get_synthetics(self.h, isrc, irec, icomp, which, C.byref(first), C.byref(n),
+                                                _fp(out), maxn), "output_seismograms")
+        return first.value, out[:n.value].copy()
+
+    def kernel_ms(self):
+        ms = np.zeros(4, np.float32)
+        ln = np.zeros(3, np.int32)
+        self._ck(self.L.kiwi_hip_get_kernel_ms(self.h, _fp(ms), _ip(ln)), "kernel_ms")
+        return ms, ln
+
+    def get_geometry(self, isrc, irec, maxcent=100000):
+        rec = np.zeros(maxcent, GEOREC)
+        n = C.c_int()
+        self._ck(self.L.kiwi_hip_get_geometry(self.h, isrc, irec, maxcent, C.byref(n), rec.ctypes.data_as(C.c_void_p)),
+                 "get_geometry")
+        return rec[:n.value].copy()
+
+    def receiver_geometry(self, irec):
+        a, b, d = C.c_double(), C.c_double(), C.c_double()
+        self._ck(self.L.kiwi_hip_get_receiver_geometry(self.h, irec, C.byref(a), C.byref(b), C.byref(d)),
+                 "output_distances")
+        return a.value, b.value, d.value
+
+    def device_bytes(self):
+        b = C.c_longlong()
+        self.L.kiwi_hip_get_device_bytes(self.h, C.byref(b))
+        return b.value
+
+    # ------------------------------------------------------------------ seismosizer.py counterparts
+    def make_misfits_for_sources(self, sourcetype=None, params=None):
+        """seismosizer.py:682-722: returns (misfits_by_src[N_s,N_r,N_k], norms_by_src[...]) as float64,
+        receivers in file order, components in string order, disabled receivers as zeros."""
+        if params is not None:
+            self.set_source_params(sourcetype, params)
+        self.eval()
+        m, n, _ = self.get_misfits()
+        nrec = len(self.components)
+        nk = max([len(c) for c in self.components] + [1])
+        mis = np.zeros((self.nsrc, nrec, nk))
+        nor = np.zeros((self.nsrc, nrec, nk))
+        j = 0
+        for ir, comps in enumerate(self.components):
+            if not self.enabled[ir]:
+                continue
+            k = len(comps)
+            mis[:, ir, :k] = m[:, j:j + k]
+            nor[:, ir, :k] = n[:, j:j + k]
+            j += k
+        return mis, nor
+
+
+def make_global_misfits(misfits_by_src, norms_by_src, outer_norm="l2norm", receiver_weights=None):
+    """seismosizer.py:843-922 (no anarchy / bootstrap): per-source global misfit and per
+    source-receiver misfits from [N_s,N_r,N_k] arrays, float64."""
+    m = np.asarray(misfits_by_src, np.float64)
+    n = np.asarray(norms_by_src, np.float64)
+    w = np.ones(m.shape[1]) if receiver_weights is None else np.asarray(receiver_weights, np.float64)
+    if outer_norm == "l1norm":
+        m_sr = m.sum(2) * w
+        n_sr = n.sum(2) * w
+        ms, ns = m_sr.sum(1), n_sr.sum(1)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return np.where(ns > 0, ms / ns, np.nan), m_sr
+    m_sr = np.sqrt((m ** 2).sum(2)) * w
+    n_sr = np.sqrt((n ** 2).sum(2)) * w
+    ms, ns = (m_sr ** 2).sum(1), (n_sr ** 2).sum(1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.where(ns > 0, np.sqrt(ms / ns), np.nan), m_sr

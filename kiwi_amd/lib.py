@@ -1,0 +1,84 @@
+"""Loader for the product library libkiwi_hip.so.  There is NO fallback: if the library (or a
+GPU, at init time) is missing the caller gets an exception."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libkiwi_hip.so")
+HEADER = os.path.join(os.path.dirname(HERE), "include", "kiwi_hip.h")
+
+c_float_p = C.POINTER(C.c_float)
+c_int_p = C.POINTER(C.c_int)
+c_double_p = C.POINTER(C.c_double)
+
+
+class KiwiHipError(RuntimeError):
+    """A C-ABI call returned non-zero; the message is the library's last error
+    (the reference's '<cmd>: nok >' line, minimizer.f90:1689-1696)."""
+
+
+def build(force=False):
+    """Compile kiwi_amd/csrc for gfx950 into kiwi_amd/libkiwi_hip.so (hipcc cross-compiles without a GPU)."""
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "csrc")])
+    return LIB_PATH
+
+
+def declared_symbols():
+    """Every function the public header declares."""
+    txt = open(HEADER).read()
+    return sorted(set(re.findall(r"\b(kiwi_hip_[a-z_0-9]+)\s*\(", txt)))
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KiwiHipError("%s not built -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "or `make -C kiwi_amd/csrc`" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    sig = {
+        "kiwi_hip_init": [C.c_int, C.POINTER(vp)],
+        "kiwi_hip_destroy": [vp],
+        "kiwi_hip_last_error": [vp, C.c_char_p, C.c_int],
+        "kiwi_hip_set_gfdb": [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                              C.c_float, c_float_p, c_int_p, c_int_p],
+        "kiwi_hip_set_interp": [vp, C.c_int, C.c_int, C.c_int],
+        "kiwi_hip_set_effective_dt": [vp, C.c_float],
+        "kiwi_hip_set_source_location": [vp, C.c_float, C.c_float, C.c_double],
+        "kiwi_hip_set_receivers": [vp, C.c_int, c_double_p, c_double_p, c_float_p, C.POINTER(C.c_char_p)],
+        "kiwi_hip_switch_receiver": [vp, C.c_int, C.c_int],
+        "kiwi_hip_set_reference": [vp, C.c_int, C.c_int, C.c_int, C.c_int, c_float_p],
+        "kiwi_hip_set_taper": [vp, C.c_int, C.c_int, c_float_p, c_float_p],
+        "kiwi_hip_set_filter": [vp, C.c_int, C.c_int, c_float_p, c_float_p],
+        "kiwi_hip_set_misfit_method": [vp, C.c_int],
+        "kiwi_hip_set_synthetics_factor": [vp, C.c_float],
+        "kiwi_hip_source_nparams": [C.c_int],
+        "kiwi_hip_discretize": [C.c_int, c_float_p, C.c_int, C.c_float, c_float_p, C.c_int, c_int_p, c_float_p,
+                                c_float_p],
+        "kiwi_hip_set_sources": [vp, C.c_int, c_int_p, c_float_p, c_float_p, c_float_p],
+        "kiwi_hip_set_sources_params": [vp, C.c_int, C.c_int, c_float_p],
+        "kiwi_hip_eval": [vp, C.c_int, C.c_int],
+        "kiwi_hip_sync": [vp],
+        "kiwi_hip_nmisfits": [vp, c_int_p],
+        "kiwi_hip_get_misfits": [vp, C.c_int, C.c_int, c_float_p, c_float_p, c_float_p],
+        "kiwi_hip_get_synthetics": [vp, C.c_int, C.c_int, C.c_int, C.c_int, c_int_p, c_int_p, c_float_p, C.c_int],
+        "kiwi_hip_get_kernel_ms": [vp, c_float_p, c_int_p],
+        "kiwi_hip_get_geometry": [vp, C.c_int, C.c_int, C.c_int, c_int_p, vp],
+        "kiwi_hip_get_receiver_geometry": [vp, C.c_int, c_double_p, c_double_p, c_double_p],
+        "kiwi_hip_get_device_bytes": [vp, C.POINTER(C.c_longlong)],
+    }
+    for name, argtypes in sig.items():
+        f = getattr(L, name)
+        f.argtypes = argtypes
+        f.restype = C.c_int
+    _lib = L
+    return L

@@ -1,0 +1,50 @@
+"""Multi-GPU: the trial-source list shards across ranks (one process per GPU); replicated read-only
+state (GF tensor, receivers, references) needs no exchange.  The only collective is one all-gather of
+per-source misfit scalars (RCCL over xGMI on GPUs, gloo in CPU tests): N_s floats in total, i.e.
+latency bound.  Synthetics are never exchanged.
+
+Trial ordering is the reference's grid ordering (first parameter slowest, source.py:119-164), cut into
+contiguous ranges, so that concatenating the ranks' results restores `misfits_by_src` order
+(seismosizer.py:709-713)."""
+import numpy as np
+
+
+def shard_range(nsrc, world, rank):
+    """Contiguous [lo, hi) of rank's share; sizes differ by at most one."""
+    base, rem = divmod(nsrc, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_misfits(local, dist=None, device_index=None):
+    """All-gather per-source values (1-D or [n, k]) from every rank, restoring global source order.
+    `dist` is torch.distributed (initialised) or None for a single process."""
+    local = np.ascontiguousarray(local, np.float32)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    import torch
+    world = dist.get_world_size()
+    use_cuda = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", device_index if device_index is not None else torch.cuda.current_device()) \
+        if use_cuda else torch.device("cpu")
+    # shard sizes may differ by one: exchange counts, pad to the maximum
+    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    nmax = max(counts)
+    width = int(np.prod(local.shape[1:])) if local.ndim > 1 else 1
+    buf = torch.zeros((nmax, width), dtype=torch.float32, device=dev)
+    buf[:local.shape[0]] = torch.from_numpy(local.reshape(local.shape[0], width)).to(dev)
+    out = torch.empty((world * nmax, width), dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(out, buf)
+    out = out.cpu().numpy().reshape(world, nmax, width)
+    parts = [out[r, :counts[r]] for r in range(world)]
+    res = np.concatenate(parts, 0)
+    return res.reshape((-1,) + local.shape[1:])
+
+
+def best_source(global_misfits):
+    """MisfitGrid's argmin over the trial list (gridsearch.py:250-266): NaNs ignored."""
+    g = np.asarray(global_misfits, np.float64)
+    return int(np.nanargmin(g))

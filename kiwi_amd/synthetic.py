@@ -1,0 +1,90 @@
+"""Deterministic synthetic inputs for tests and bench.py: a closed-form
+Green's function database, a ring of receivers, reference traces' tapers and trial-source grids.
+No file of the reference is needed; everything is numpy."""
+import numpy as np
+
+EARTH_R = 6371000.0
+
+
+def make_gfdb(nx=128, nz=6, ng=10, L=4096, dt=0.5, dx=4000.0, dz=2000.0, firstx=100e3, firstz=6e3,
+              variant="probe"):
+    """Returns dict(dt,dx,dz,firstx,firstz, data[nx,nz,ng,L] f32, first[nx,nz,ng] i32, nsamp[...] i32).
+
+    variant "probe": the survey's probe database -- damped sinusoids, last sample forced to 0.
+    variant "static": adds a non-zero static end value to components 2 and 7 and carves interior
+    zero gaps of 9 samples (> maxgap = 5, sparse_trace.f90:25) so that gap-compressed traces with
+    several strips and repeated non-zero end points are exercised."""
+    ix = np.arange(nx)[:, None, None, None]
+    iz = np.arange(nz)[None, :, None, None]
+    ig = np.arange(1, ng + 1)[None, None, :, None]
+    i = np.arange(L)[None, None, None, :].astype(np.float64)
+    x = firstx + ix * dx
+    val = (1e-20 * np.sin(0.02 * i * (1 + 0.05 * ig) + 0.37 * ig + 0.11 * (iz + 1))
+           * np.exp(-((i - 600 - 40 * ig) / 400.0) ** 2) / (x / 1e5))
+    if variant == "static":
+        ramp = 0.5 * (1 + np.tanh((i - 500.0) / 60.0))
+        stat = np.zeros((1, 1, ng, 1))
+        stat[0, 0, 1, 0] = 3e-22
+        stat[0, 0, 6, 0] = -2e-22
+        val = val + stat * ramp / (x / 1e5)
+        val[..., 300:309] = 0.0
+        val[..., 1000:1009] = 0.0
+    data = val.astype(np.float32)
+    if variant != "static":
+        data[..., -1] = 0.0
+    first = np.rint((firstx + np.arange(nx) * dx) / 6000.0 / dt).astype(np.int32)
+    first = np.broadcast_to(first[:, None, None], (nx, nz, ng)).copy()
+    nsamp = np.full((nx, nz, ng), L, np.int32)
+    return dict(dt=dt, dx=dx, dz=dz, firstx=firstx, firstz=firstz, data=data, first=first, nsamp=nsamp)
+
+
+def make_receivers(nrec=50, lat0=40.0, lon0=30.0, dmin=150e3, dspan=400e3, comps="ned"):
+    """Ring of receivers around (lat0, lon0): azimuth 2 pi (i-1)/N + 0.1, distance dmin + dspan (i-1)/N."""
+    i = np.arange(nrec)
+    az = 2 * np.pi * i / nrec + 0.1
+    d = dmin + dspan * i / nrec
+    lat = lat0 + np.degrees(d * np.cos(az) / EARTH_R)
+    lon = lon0 + np.degrees(d * np.sin(az) / (EARTH_R * np.cos(np.radians(lat0))))
+    return lat, lon, np.zeros(nrec, np.float32), [comps] * nrec, d
+
+
+TRUE_BILAT = [0., 0., 0., 10000., 1e20, 91., 87., 164., 0., 4000., 2000., 4000., 3000., 2.]
+
+
+def bilat_strike_sweep(nsrc, step=0.1, base=None):
+    """`bilateral` trial sources differing in strike by `step` degrees (kiwibench.py:136)."""
+    base = np.array(TRUE_BILAT if base is None else base, np.float32)
+    p = np.tile(base, (nsrc, 1))
+    p[:, 5] = base[5] + step * (1 + np.arange(nsrc))
+    return p
+
+
+def mt_from_sdr(strike, dip, rake, m0=7e18):
+    """Moment tensor (mxx,myy,mzz,mxy,mxz,myz) of a double couple: R m_unrot R^T with
+    R = euler(dip, strike, -rake) (euler.f90:40-43, source_bilat.f90:342,437-438)."""
+    a, b, g = np.radians(dip), np.radians(strike), -np.radians(rake)
+    ca, cb, cg, sa, sb, sg = np.cos(a), np.cos(b), np.cos(g), np.sin(a), np.sin(b), np.sin(g)
+    R = np.array([[cb * cg - ca * sb * sg, -cb * sg - ca * sb * cg, sa * sb],
+                  [sb * cg + ca * cb * sg, -sb * sg + ca * cb * cg, -sa * cb],
+                  [sa * sg, sa * cg, ca]])
+    mu = np.array([[0, 0, -1.], [0, 0, 0], [-1., 0, 0]])
+    m = R @ mu @ R.T * m0
+    return [m[0, 0], m[1, 1], m[2, 2], m[0, 1], m[0, 2], m[1, 2]]
+
+
+def mt_sdr_grid(step=10, depth=10000.0, risetime=1.0, m0=7e18):
+    """cfg2 trial set: moment_tensor sources over strike x dip x rake (first parameter slowest,
+    source.py:119-164): 36 x 10 x 36 = 12 960 at step 10."""
+    out = []
+    for s in range(0, 360, step):
+        for d in range(0, 91, step):
+            for r in range(-180, 180, step):
+                out.append([0., 0., 0., depth] + mt_from_sdr(s, d, r, m0) + [risetime])
+    return np.array(out, np.float32)
+
+
+def full_taper(first, n, dt, ramp=10.0):
+    """4-point cosine taper covering a reference trace that occupies samples first..first+n-1
+    (sample j sits at abscissa j*dt for the taper, piecewise_linear_function.f90:225)."""
+    t0, t1 = first * dt, (first + n - 1) * dt
+    return [t0, t0 + ramp, t1 - ramp, t1], [0., 1., 1., 0.]

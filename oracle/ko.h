@@ -229,6 +229,8 @@ float ko_engine_get_global_misfit(ko_engine *e);
 int  ko_engine_get_displacement(ko_engine *e, int irec1, int icomp1, int *lo, float *out, int maxn);
 /* synthetic probe contents after scale_seismograms: which 1 plain 2 tapered 3 filtered */
 int  ko_engine_get_synthetic(ko_engine *e, int irec1, int icomp1, int which, int *lo, float *out, int maxn);
+/* per (receiver, centroid) geometry record, 20 x 4 bytes, see ko_engine.c */
+void ko_engine_centroid_geometry(ko_engine *e, int irec1, int icent0, void *out20);
 /* per receiver geometry as make_seismogram computes it (seismogram.f90:99-100) */
 void ko_engine_receiver_geometry(ko_engine *e, int irec1, double *azi, double *bazi, double *dist);
 

@@ -103,6 +103,7 @@ def lib():
         L.ko_engine_get_global_misfit.argtypes = [C.c_void_p]
         L.ko_engine_get_displacement.argtypes = [C.c_void_p, C.c_int, C.c_int, c_int_p, c_float_p, C.c_int]
         L.ko_engine_get_synthetic.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, c_int_p, c_float_p, C.c_int]
+        L.ko_engine_centroid_geometry.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.ko_engine_receiver_geometry.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p]
         L.ko_probes_norm.restype = C.c_float
         L.ko_probe_norm.restype = C.c_float
@@ -356,6 +357,13 @@ class Engine:
         lo = C.c_int()
         n = lib().ko_engine_get_synthetic(self.h, irec1, icomp1, which, C.byref(lo), _fp(out), maxn)
         return lo.value, out[:n].copy()
+
+    def centroid_geometry(self, irec1, ncent, dtype):
+        """GeoRec-compatible records of the current centroid table at receiver irec1."""
+        out = np.zeros(ncent, dtype)
+        for i in range(ncent):
+            lib().ko_engine_centroid_geometry(self.h, irec1, i, out[i:i + 1].ctypes.data_as(C.c_void_p))
+        return out
 
     def receiver_geometry(self, irec1):
         a, b, d = C.c_double(), C.c_double(), C.c_double()

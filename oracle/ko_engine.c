@@ -240,6 +240,59 @@ void ko_engine_receiver_geometry(ko_engine *e, int irec1, double *azi, double *b
     *dist = ko_distance_accurate50m(e->origin, r->origin);        /* seismogram.f90:100 */
 }
 
+
+/* The per (receiver, centroid) quantities make_seismogram derives before touching any trace
+ * (seismogram.f90:133-165 + gfdb.f90:781-815 + sparse_trace.f90:640-645), packed like the
+ * product's GeoRec (20 x 4 bytes) so that tests can compare the device geometry kernel field by
+ * field: int row[4] (0-based first GF row of the 4 nodes, -1 = centroid skipped), float w[4],
+ * int ishift, float wfrac, float f[6], float cl, sl, int flags (bit0 direct, bit1 rotate), pad. */
+void ko_engine_centroid_geometry(ko_engine *e, int irec1, int icent0, void *out20)
+{
+    ko_receiver *rec = &e->receivers[irec1 - 1];
+    ko_gfdb *db = e->db;
+    const ko_centroid *c = &e->centroids[icent0];
+    int *oi = (int *)out20; float *of = (float *)out20;
+    double azi_orig, bazi_orig, dist_orig, azi, bazi, dist;
+    ko_azibazi(e->origin, rec->origin, &azi_orig, &bazi_orig);
+    dist_orig = ko_distance_accurate50m(e->origin, rec->origin);
+    ko_approx_differential_azidist(c->north, c->east, azi_orig, bazi_orig, dist_orig, &azi, &bazi, &dist);
+    float f[6];
+    make_weights((float)azi, c->m, f);
+    int ix[2], iz[2]; float dix = 0.f, diz = 0.f;
+    if (e->interpolate) {
+        ko_gfdb_get_indices_bilin(db, (float)dist, c->depth - rec->depth, e->xundersample, e->zundersample, ix, iz, &dix, &diz);
+    } else {
+        ko_gfdb_get_indices(db, (float)dist, c->depth - rec->depth, &ix[0], &iz[0]);
+        ix[1] = ix[0] + 1; iz[1] = iz[0] + 1;
+    }
+    int direct = (dix == 0.f && diz == 0.f);
+    int need_h = component_index(rec, C_AWAY) || component_index(rec, C_RIGHT) || component_index(rec, C_NORTH) || component_index(rec, C_EAST);
+    int has_d = component_index(rec, C_DOWN) != 0;
+    int ok = 1;
+    for (int a = 0; a < (direct ? 1 : 2) && ok; a++)
+        for (int b = 0; b < (direct ? 1 : 2) && ok; b++)
+            for (int ig = 1; ig <= db->ng && ok; ig++) {
+                int horiz = (ig <= 5) || (ig == 9);
+                if ((horiz && !need_h) || (!horiz && !has_d)) continue;
+                int sp[2];
+                if (!ko_gfdb_trace_span(db, ix[a], iz[b], ig, sp)) ok = 0;
+            }
+#define ROW(a, b) (((ix[a] - 1) * db->nz + (iz[b] - 1)) * db->ng)
+    if (!ok) { oi[0] = oi[1] = oi[2] = oi[3] = -1; }
+    else if (direct) { oi[0] = oi[1] = oi[2] = oi[3] = ROW(0, 0); }
+    else { oi[0] = ROW(0, 0); oi[1] = ROW(0, 1); oi[2] = ROW(1, 0); oi[3] = ROW(1, 1); }
+#undef ROW
+    of[4] = (1.f - dix) * (1.f - diz); of[5] = (1.f - dix) * diz; of[6] = dix * (1.f - diz); of[7] = dix * diz;
+    float rshift = c->time / db->dt;
+    int its = (int)floorf(rshift);
+    oi[8] = its; of[9] = rshift - (float)its;
+    for (int k = 0; k < 6; k++) of[10 + k] = f[k];
+    double lambda = bazi - bazi_orig;
+    of[16] = (float)cos(lambda); of[17] = (float)sin(lambda);
+    oi[18] = (direct ? 1 : 0) | (lambda != 0. ? 2 : 0);
+    oi[19] = 0;
+}
+
 /* seismogram.f90:36-301 */
 static void make_seismogram(ko_engine *e, ko_receiver *rec)
 {

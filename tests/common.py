@@ -1,0 +1,100 @@
+"""Shared scenario builders: the same deterministic setup fed to the CPU oracle (oracle/ko.py)
+and to the product (kiwi_amd.Engine)."""
+import numpy as np
+
+from kiwi_amd import synthetic
+from oracle import ko
+
+
+class Scenario:
+    """Small synthetic inversion setup (scaled down)."""
+
+    def __init__(self, nx=10, nz=5, ng=10, L=256, nrec=6, comps="ned", variant="probe", bilinear=True,
+                 dmin=104e3, dspan=24e3, effective_dt=0.5, true_params=None, true_type=1, depths=None,
+                 taper_ramp=10.0, comps_list=None):
+        self.gf = synthetic.make_gfdb(nx=nx, nz=nz, ng=ng, L=L, variant=variant)
+        self.lat, self.lon, self.depth, self.comps, self.dist = synthetic.make_receivers(
+            nrec, dmin=dmin, dspan=dspan, comps=comps)
+        if comps_list is not None:
+            self.comps = list(comps_list)
+        if depths is not None:
+            self.depth = np.asarray(depths, np.float32)
+        self.nrec = nrec
+        self.bilinear = bilinear
+        self.effective_dt = effective_dt
+        self.true_type = true_type
+        self.true_params = np.array(synthetic.TRUE_BILAT if true_params is None else true_params, np.float32)
+        self.taper_ramp = taper_ramp
+        self.refs = {}
+        self.tapers = {}
+
+    # ---------------------------------------------------------------- oracle side
+    def oracle(self, nthreads=1):
+        g = self.gf
+        nx, nz, ng, L = g["data"].shape
+        db = ko.Gfdb(nx, nz, ng, g["dt"], g["dx"], g["dz"], g["firstx"], g["firstz"])
+        for ix in range(nx):
+            for iz in range(nz):
+                for ig in range(ng):
+                    n = int(g["nsamp"][ix, iz, ig])
+                    if n > 0:
+                        db.set_trace(ix + 1, iz + 1, ig + 1, int(g["first"][ix, iz, ig]), g["data"][ix, iz, ig, :n])
+        e = ko.Engine(db)
+        e.set_receivers(self.lat, self.lon, self.depth, self.comps)
+        e.set_source_location(40.0, 30.0, 0.0)
+        e.set_effective_dt(self.effective_dt)
+        e.set_interpolation(self.bilinear)
+        e.set_nthreads(nthreads)
+        self.odb = db
+        return e
+
+    def make_references(self, e):
+        """Reference traces = oracle synthetics of the 'true' source; tapers over the whole trace."""
+        e.set_source_params(self.true_type, self.true_params)
+        e.calculate_seismograms()
+        e.scale_seismograms()
+        dt = self.gf["dt"]
+        for ir in range(self.nrec):
+            for k in range(len(self.comps[ir])):
+                lo, d = e.synthetic(ir + 1, k + 1, 1)
+                self.refs[(ir + 1, k + 1)] = (lo, d)
+            if len(self.comps[ir]):
+                lo, d = self.refs[(ir + 1, 1)]
+                self.tapers[ir + 1] = synthetic.full_taper(lo, len(d), dt, self.taper_ramp)
+
+    def apply_setup(self, eng, is_oracle):
+        for (ir, k), (lo, d) in self.refs.items():
+            if is_oracle:
+                eng.set_reference(ir, k, lo, d)
+            else:
+                eng.set_ref_seismogram(ir, k, lo, d)
+        for ir, (x, y) in self.tapers.items():
+            if is_oracle:
+                eng.set_taper(ir, x, y)
+            else:
+                eng.set_misfit_taper(ir, x, y)
+
+    # ---------------------------------------------------------------- product side
+    def product(self, device=0):
+        from kiwi_amd import Engine
+        g = self.gf
+        first, nsamp, data = self.odb.dense_tables()      # spans exactly as the packed DB stores them
+        p = Engine(device)
+        p.set_database(g["dt"], g["dx"], g["dz"], g["firstx"], g["firstz"], data, first, nsamp)
+        p.set_receivers(self.lat, self.lon, self.depth, self.comps)
+        p.set_source_location(40.0, 30.0, 0.0)
+        p.set_effective_dt(self.effective_dt)
+        p.set_local_interpolation("bilinear" if self.bilinear else "nearest")
+        return p
+
+
+def oracle_misfits(e, sourcetype, params):
+    """Loop of set_source_params + get_misfits (seismosizer.py:703-718) on the oracle."""
+    ms, ns, gs = [], [], []
+    for p in np.atleast_2d(params):
+        e.set_source_params(sourcetype, p)
+        m, n, g = e.get_misfits()
+        ms.append(m)
+        ns.append(n)
+        gs.append(g)
+    return np.array(ms), np.array(ns), np.array(gs, np.float32)

@@ -1,0 +1,245 @@
+"""Parity of the HIP path (through the C-ABI) with the CPU oracle on the same seeded inputs.
+
+Tolerances (stated once, used everywhere):
+  * synthetics: |hip - oracle| <= SYN_RTOL * max|oracle| per trace.  The accumulate kernel itself
+    is bit-exact given identical geometry records (test_accumulate_bitexact_given_geometry); the
+    only source of differences is device libm (fp64 sin/cos/acos/asin/atan2 in the geometry
+    kernel) vs glibc on the host, which moves an fp32 weight by at most an ulp or two.
+  * misfits: relative 1e-6 (BASELINE.json north_star), norm factors bit-exact (host computed).
+"""
+import numpy as np
+import pytest
+
+from kiwi_amd import synthetic
+from tests.common import Scenario, oracle_misfits
+
+pytestmark = pytest.mark.gpu
+
+SYN_RTOL = 2e-6
+MISFIT_RTOL = 1e-6
+
+
+def misfit_close(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    scale = np.maximum(np.abs(b), 1e-30)
+    return np.all(np.abs(a - b) <= MISFIT_RTOL * scale + 0.0)
+
+
+def build(sc, method="l2norm"):
+    e = sc.oracle()
+    sc.make_references(e)
+    sc.apply_setup(e, True)
+    p = sc.product()
+    sc.apply_setup(p, False)
+    mid = {"l2norm": 1, "l1norm": 2, "scalar_product": 5, "peak": 6}[method]
+    e.set_misfit_method(mid)
+    p.set_misfit_method(method)
+    return e, p
+
+
+@pytest.mark.parametrize("bilinear", [False, True])
+@pytest.mark.parametrize("variant", ["probe", "static"])
+def test_bilateral_misfits_match_oracle(bilinear, variant):
+    sc = Scenario(bilinear=bilinear, variant=variant)
+    e, p = build(sc)
+    trials = np.vstack([sc.true_params[None], synthetic.bilat_strike_sweep(12, step=1.5)])
+    trials[5:, 6] -= 7.0          # also move dip, depth and rake
+    trials[8:, 3] += 1500.0
+    trials[10:, 7] += 20.0
+    m, n, g = oracle_misfits(e, 1, trials)
+    p.set_source_params("bilateral", trials)
+    p.eval()
+    pm, pn, pg = p.get_misfits()
+    assert pm.shape == m.shape
+    assert np.array_equal(pn[0], n[0])                     # norm factors: host-side, bit exact
+    assert np.all(pm[0] <= 1e-6 * pn[0])                   # the true source reproduces its references
+    assert misfit_close(pm[1:], m[1:]), np.max(np.abs(pm[1:] - m[1:]) / np.abs(m[1:]))
+    assert misfit_close(pg[1:], g[1:])
+
+
+@pytest.mark.parametrize("method", ["l1norm", "scalar_product", "peak"])
+def test_other_time_domain_norms(method):
+    sc = Scenario()
+    e, p = build(sc, method)
+    trials = synthetic.bilat_strike_sweep(5, step=2.0)
+    m, n, g = oracle_misfits(e, 1, trials)
+    p.set_source_params("bilateral", trials)
+    p.eval()
+    pm, pn, pg = p.get_misfits()
+    assert np.array_equal(pn[0], n[0])
+    assert np.allclose(pm, m, rtol=2e-6, atol=0)
+    assert np.allclose(pg, g, rtol=2e-6, atol=0)
+
+
+def test_synthetics_sample_for_sample():
+    sc = Scenario(variant="static")
+    e, p = build(sc)
+    trial = synthetic.bilat_strike_sweep(1, step=4.0)
+    p.set_source_params("bilateral", trial)
+    p.eval()
+    e.set_source_params(1, trial[0])
+    e.get_misfits()
+    for ir in range(1, sc.nrec + 1):
+        for k in range(1, 4):
+            for which in (1, 2):
+                lo_o, so = e.synthetic(ir, k, which)
+                lo_p, sp = p.get_synthetics(0, ir, k, which)
+                # the product returns the taper window; the oracle its data span (plain) or
+                # taper span /\ data span (tapered): compare on the overlap
+                a = max(lo_o, lo_p)
+                b = min(lo_o + len(so), lo_p + len(sp))
+                assert b - a > 200
+                xo = so[a - lo_o:b - lo_o]
+                xp = sp[a - lo_p:b - lo_p]
+                assert np.max(np.abs(xo - xp)) <= SYN_RTOL * np.max(np.abs(so))
+
+
+def test_geometry_records_match_oracle():
+    """Device geometry kernel vs the oracle's per-centroid quantities, field by field.  Integer
+    fields (GF rows, shift, flags) must be identical; float fields are bit-identical except where
+    the device's fp64 libm differs from glibc's in the last place and that flips an fp32 rounding."""
+    from kiwi_amd.engine import GEOREC
+    sc = Scenario(variant="static", nrec=8)
+    e, p = build(sc)
+    trial = synthetic.bilat_strike_sweep(1, step=3.0)
+    p.set_source_params("bilateral", trial)
+    p.eval()
+    e.set_source_params(1, trial[0])
+    e.get_misfits()
+    nf = nbad = 0
+    for ir in range(1, sc.nrec + 1):
+        g = p.get_geometry(0, ir)
+        o = e.centroid_geometry(ir, len(g), GEOREC)
+        for name in ("row", "ishift", "flags"):
+            assert np.array_equal(g[name], o[name]), name
+        for name in ("w", "wfrac", "f", "cl", "sl"):
+            d = g[name].view(np.int32).astype(np.int64) - o[name].view(np.int32).astype(np.int64)
+            nf += d.size
+            nbad += np.count_nonzero(d)
+            assert np.allclose(g[name], o[name], rtol=1e-5, atol=1e-12), name
+    assert nbad <= 0.002 * nf, (nbad, nf)
+
+
+def test_accumulate_bitexact_given_geometry():
+    """Where the device geometry records are bit-identical to the host's, the synthetics must be
+    bit-identical to the oracle's: the accumulate kernel reproduces the reference's fp32 operation
+    order exactly (shift, interpolation, blend, rotation, repeated end points)."""
+    from kiwi_amd.engine import GEOREC
+    sc = Scenario(variant="static", nrec=8)
+    e, p = build(sc)
+    trial = synthetic.bilat_strike_sweep(1, step=3.0)
+    p.set_source_params("bilateral", trial)
+    p.eval()
+    e.set_source_params(1, trial[0])
+    e.get_misfits()
+    checked = 0
+    for ir in range(1, sc.nrec + 1):
+        g = p.get_geometry(0, ir)
+        o = e.centroid_geometry(ir, len(g), GEOREC)
+        if g.tobytes() != o.tobytes():
+            continue
+        checked += 1
+        for k in (1, 2, 3):
+            lo_o, so = e.synthetic(ir, k, 1)
+            lo_p, sp = p.get_synthetics(0, ir, k, 1)
+            a = max(lo_o, lo_p)
+            b = min(lo_o + len(so), lo_p + len(sp))
+            assert np.array_equal(so[a - lo_o:b - lo_o].view(np.uint32), sp[a - lo_p:b - lo_p].view(np.uint32)), (ir, k)
+    assert checked >= sc.nrec // 2, checked
+
+
+def test_moment_tensor_and_circular_sources():
+    sc = Scenario()
+    e, p = build(sc)
+    mt = synthetic.mt_sdr_grid(step=60, depth=9000.0)[:20]
+    m, n, g = oracle_misfits(e, 6, mt)
+    p.set_source_params("moment_tensor", mt)
+    p.eval()
+    pm, _, pg = p.get_misfits()
+    assert misfit_close(pm, m) and misfit_close(pg, g)
+    circ = np.tile(np.array([0., 0., 0., 10000., 5e19, 80., 70., 100., 3000., 3000., 1.5], np.float32), (4, 1))
+    circ[:, 8] = [1500., 2500., 3500., 4500.]
+    m, n, g = oracle_misfits(e, 2, circ)
+    p.set_source_params("circular", circ)
+    p.eval()
+    pm, _, pg = p.get_misfits()
+    assert misfit_close(pm, m) and misfit_close(pg, g)
+
+
+def test_risetime_fold_and_synthetics_factor():
+    sc = Scenario()
+    e, p = build(sc)
+    trial = synthetic.bilat_strike_sweep(3, step=2.0)
+    tabs, moms = [], []
+    from oracle import ko
+    for t in trial:
+        c, mo, _, _ = ko.discretize(1, t, sc.effective_dt)
+        tabs.append(c)
+        moms.append(mo)
+    rise = [0.0, 1.5, 3.0]
+    ms = []
+    for c, mo, ri in zip(tabs, moms, rise):
+        e.set_centroids(c, mo, ri)
+        e.set_synthetics_factor(1.25)
+        ms.append(e.get_misfits())
+    p.set_sources(tabs, moms, rise)
+    p.set_synthetics_factor(1.25)
+    p.eval()
+    pm, pn, pg = p.get_misfits()
+    for i in range(3):
+        assert misfit_close(pm[i], ms[i][0]), i
+        assert abs(pg[i] - ms[i][2]) <= MISFIT_RTOL * ms[i][2]
+
+
+def test_edge_cases_components_depth_disabled_outofrange():
+    comps = ["ned", "d", "ar", "une", "arn", "e"]
+    sc = Scenario(comps_list=comps, depths=[0., 0., 500., 0., 0., 250.])
+    e, p = build(sc)
+    e.switch_receiver(4, False)
+    p.switch_receiver(4, False)
+    trials = synthetic.bilat_strike_sweep(4, step=2.5)
+    trials[3, 3] = 2000.0          # depth above the first GF depth: bilinear lower node out of range -> centroids skipped
+    m, n, g = oracle_misfits(e, 1, trials)
+    p.set_source_params("bilateral", trials)
+    p.eval()
+    pm, pn, pg = p.get_misfits()
+    assert pm.shape == m.shape == (4, 3 + 1 + 2 + 3 + 1)
+    assert np.array_equal(pn[0], n[0])
+    assert misfit_close(pm, m)
+    assert misfit_close(pg, g)
+    mis, nor = p.make_misfits_for_sources()
+    assert mis.shape == (4, 6, 3) and np.all(mis[:, 3] == 0)
+
+
+def test_chunked_eval_equals_single_launch():
+    sc = Scenario()
+    e, p = build(sc)
+    trials = synthetic.bilat_strike_sweep(9, step=0.7)
+    p.set_source_params("bilateral", trials)
+    p.eval()
+    a = p.get_misfits()
+    p.eval(0, 4)
+    p.eval(4, 5)
+    b = p.get_misfits()
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+def test_errors_are_reported_not_fatal():
+    from kiwi_amd import KiwiHipError
+    sc = Scenario()
+    e = sc.oracle()
+    sc.make_references(e)
+    p = sc.product()
+    p.set_source_params("bilateral", synthetic.bilat_strike_sweep(1))
+    with pytest.raises(KiwiHipError, match="no reference|no misfit taper"):
+        p.eval()
+    with pytest.raises(KiwiHipError):
+        p.switch_receiver(99, True)
+    with pytest.raises(KiwiHipError):
+        p.set_misfit_method("nonsense")
+    sc.apply_setup(p, False)
+    p.eval()                      # recovers after the setup is completed
+    m, n, g = p.get_misfits()
+    assert np.all(np.isfinite(m))

@@ -1,0 +1,65 @@
+"""N > 1 path on CPU: world_size-2 gloo processes shard a trial list and all-gather the results."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from kiwi_amd.shard import shard_range, gather_misfits, best_source
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 7, 8, 9, 100000):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for a, b in zip(spans, spans[1:]):
+                assert a[1] == b[0]
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, nsrc, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_range(nsrc, world, rank)
+    # stand-in for the per-shard device evaluation: a deterministic function of the GLOBAL index
+    idx = np.arange(lo, hi)
+    local_global = np.sqrt(idx + 1.0).astype(np.float32)
+    local_mis = np.stack([idx, idx * 2.0, idx * 3.0], 1).astype(np.float32)
+    g = gather_misfits(local_global, dist)
+    m = gather_misfits(local_mis, dist)
+    if rank == 0:
+        q.put((g, m))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_allgather_restores_order():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    nsrc = 11                               # odd: shards of 6 and 5
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, nsrc, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    g, m = q.get(timeout=120)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    idx = np.arange(nsrc)
+    assert np.array_equal(g, np.sqrt(idx + 1.0).astype(np.float32))
+    assert np.array_equal(m, np.stack([idx, idx * 2.0, idx * 3.0], 1).astype(np.float32))
+    assert best_source(g) == 0
+
+
+def test_single_process_passthrough():
+    x = np.arange(5, dtype=np.float32)
+    assert np.array_equal(gather_misfits(x, None), x)
+    assert best_source([3.0, np.nan, 1.0]) == 2
