@@ -124,6 +124,9 @@ int kiwi_hip_get_misfits(kiwi_hip_ctx *ctx, int isrc0, int nsrc, float *misfit, 
 /* output_seismograms (minimizer_engine.f90:980-1010): synthetic of one source of the LAST
  * kiwi_hip_eval range, over the receiver's misfit window.  which: 1 plain (scaled by moment,
  * rise-time folded), 2 tapered.  Returns first sample index and count. */
+/* keep the processed synthetics of every evaluated chunk on the device (0 off, 1 plain, 2 tapered) so
+ * that kiwi_hip_get_synthetics copies them instead of re-evaluating the source */
+int kiwi_hip_set_keep_synthetics(kiwi_hip_ctx *ctx, int which);
 int kiwi_hip_get_synthetics(kiwi_hip_ctx *ctx, int isrc, int irec, int icomp, int which,
                             int *first, int *n, float *out, int maxn);
 

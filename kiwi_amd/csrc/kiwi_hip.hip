@@ -115,6 +115,9 @@ struct kiwi_hip_ctx {
     DevBuf<float> syn_d, proc_d;
     int last_isrc0 = 0, last_nsrc = 0, last_chunk0 = 0, last_chunkn = 0;
     int last_proc_which = 0;
+    int accum_mode = 0;               // 0 grouped (LDS-staged), 1 direct; env KIWI_HIP_ACCUM
+    int keep_which = 0;               // kiwi_hip_set_keep_synthetics
+    int proc_chunk0 = 0, proc_chunkn = 0, proc_which_held = 0;   // what proc_d currently holds
     size_t chunk_bytes_limit = (size_t)3 << 30;
 
     std::vector<EventPair> events;
@@ -167,6 +170,7 @@ int fold_halfwidth(float risetime, float dt)
 void prepare(kiwi_hip_ctx *c)
 {
     if (c->prepared) return;
+    c->proc_which_held = 0;
     if (!c->have_db) throw std::runtime_error("no database set");
     if (!c->have_origin) throw std::runtime_error("no source location set");
     if (c->recv.empty()) throw std::runtime_error("no receivers set");
@@ -309,12 +313,23 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
     record(c, 0, e1);
     {
         dim3 grid((unsigned)((c->max_wlen + kTile - 1) / kTile), (unsigned)nrec, (unsigned)nsrc);
-        if (c->gm.ng == 10)
-            hipLaunchKernelGGL(accumulate_kernel<10>, grid, dim3(256), 0, c->stream, c->G.p, c->span.p, c->gm.pitch,
-                               c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p, c->syn_stride);
-        else
-            hipLaunchKernelGGL(accumulate_kernel<8>, grid, dim3(256), 0, c->stream, c->G.p, c->span.p, c->gm.pitch,
-                               c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p, c->syn_stride);
+        if (c->accum_mode == 1) {            // KIWI_HIP_ACCUM=direct: A/B reference kernel, no LDS staging
+            if (c->gm.ng == 10)
+                hipLaunchKernelGGL(accumulate_kernel<10>, grid, dim3(256), 0, c->stream, c->G.p, c->span.p, c->gm.pitch,
+                                   c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p, c->syn_stride);
+            else
+                hipLaunchKernelGGL(accumulate_kernel<8>, grid, dim3(256), 0, c->stream, c->G.p, c->span.p, c->gm.pitch,
+                                   c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p, c->syn_stride);
+        } else {
+            if (c->gm.ng == 10)
+                hipLaunchKernelGGL(accumulate_grouped_kernel<10>, grid, dim3(256), 0, c->stream, c->G.p, c->span.p,
+                                   c->gm.pitch, c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p,
+                                   c->syn_stride);
+            else
+                hipLaunchKernelGGL(accumulate_grouped_kernel<8>, grid, dim3(256), 0, c->stream, c->G.p, c->span.p,
+                                   c->gm.pitch, c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p,
+                                   c->syn_stride);
+        }
     }
     record(c, 1, e2);
     {
@@ -331,6 +346,8 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
     c->events.push_back({ e1, e2, 1 });
     c->events.push_back({ e2, e3, 2 });
     c->last_chunk0 = isrc0; c->last_chunkn = nsrc;
+    if (proc_which) { c->proc_chunk0 = isrc0; c->proc_chunkn = nsrc; c->proc_which_held = proc_which; }
+    else c->proc_which_held = c->proc_which_held;   // proc_d untouched
 }
 
 int eval_impl(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
@@ -377,6 +394,7 @@ int kiwi_hip_init(int device, kiwi_hip_ctx **out)
         c = new kiwi_hip_ctx();
         c->device = device;
         HIPCHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        if (const char *m = std::getenv("KIWI_HIP_ACCUM")) c->accum_mode = (std::strcmp(m, "direct") == 0) ? 1 : 0;
         *out = c;
         return 0;
     } catch (const std::exception &e) {
@@ -612,6 +630,7 @@ int kiwi_hip_set_sources(kiwi_hip_ctx *c, int nsrc, const int *cent_ofs, const f
     if (fold_halfwidth(maxrise, c->gm.dt) != fold_halfwidth(c->max_risetime, c->gm.dt)) c->prepared = false;
     c->max_risetime = maxrise;
     c->last_nsrc = 0;
+    c->proc_which_held = 0;
     return 0;
     GUARD_END(c)
 }
@@ -642,8 +661,15 @@ int kiwi_hip_set_sources_params(kiwi_hip_ctx *c, int sourcetype, int nsrc, const
 int kiwi_hip_eval(kiwi_hip_ctx *c, int isrc0, int nsrc)
 {
     GUARD_BEGIN
-    return eval_impl(c, isrc0, nsrc, 0);
+    return eval_impl(c, isrc0, nsrc, c->keep_which);
     GUARD_END(c)
+}
+
+int kiwi_hip_set_keep_synthetics(kiwi_hip_ctx *c, int which)
+{
+    if (which < 0 || which > 2) return fail(c, "which must be 0 (off), 1 (plain) or 2 (tapered)");
+    c->keep_which = which;
+    return 0;
 }
 
 int kiwi_hip_sync(kiwi_hip_ctx *c)
@@ -687,8 +713,15 @@ int kiwi_hip_get_synthetics(kiwi_hip_ctx *c, int isrc, int irec, int icomp, int 
     if (which != 1 && which != 2) throw std::runtime_error("which must be 1 (plain) or 2 (tapered)");
     if (isrc < 0 || isrc >= c->nsrc) throw std::runtime_error("source index out of range");
     if (irec < 1 || irec > (int)c->recv.size()) throw std::runtime_error("receiver index out of range");
-    // re-evaluate this one source keeping the processed synthetics
-    eval_impl(c, isrc, 1, which);
+    // served from the retained chunk when kiwi_hip_set_keep_synthetics(which) was on during the
+    // last eval of this source; otherwise this one source is re-evaluated keeping them
+    size_t srcofs;
+    if (c->prepared && c->proc_which_held == which && isrc >= c->proc_chunk0 && isrc < c->proc_chunk0 + c->proc_chunkn) {
+        srcofs = (size_t)(isrc - c->proc_chunk0) * c->syn_stride;
+    } else {
+        eval_impl(c, isrc, 1, which);
+        srcofs = 0;
+    }
     HIPCHECK(hipStreamSynchronize(c->stream));
     int slot = -1, k = 0;
     for (size_t i = 0; i < c->comps.size(); i++) {
@@ -698,7 +731,7 @@ int kiwi_hip_get_synthetics(kiwi_hip_ctx *c, int isrc, int irec, int icomp, int 
     const CompDev &cd = c->comps[slot];
     *first = cd.w0; *n = cd.wlen;
     const int m = std::min(cd.wlen, maxn);
-    HIPCHECK(hipMemcpy(out, c->proc_d.p + cd.synofs + cd.halo, (size_t)m * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(out, c->proc_d.p + srcofs + cd.synofs + cd.halo, (size_t)m * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
     GUARD_END(c)
 }

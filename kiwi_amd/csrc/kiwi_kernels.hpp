@@ -35,7 +35,8 @@ struct GeoRec {
     float wfrac;      // time/dt - ishift                                      sparse_trace.f90:642
     float f[6];       // make_weights                                          seismogram.f90:329-334
     float cl, sl;     // cos / sin (bazi - bazi_orig)                          seismogram.f90:164-165
-    int   flags;      // bit0: exactly on a node -> no blend (gfdb.f90:890-893); bit1: rotate (seismogram.f90:160)
+    int   flags;      // bit0: exactly on a node -> no blend (gfdb.f90:890-893); bit1: rotate (seismogram.f90:160);
+                      // bit2: same position as the previous centroid
     int   pad;
 };
 static_assert(sizeof(GeoRec) == 80, "GeoRec layout");
@@ -179,6 +180,13 @@ __global__ __launch_bounds__(256) void geometry_kernel(
     }
     const bool direct = (dix == 0.f && diz == 0.f);            // gfdb.f90:890
     if (direct) g.flags |= 1;
+    // bit2: this centroid sits at exactly the same point as its predecessor in the table (the nt
+    // time steps of one sub-fault, source_bilat.f90:443-457): same azimuth, distance, GF nodes and
+    // blend weights, so the blended traces can be reused (accumulate_grouped_kernel)
+    if (c > 0) {
+        const float *pe = ce - 10;
+        if (pe[0] == dnorth && pe[1] == deast && pe[2] == depth) g.flags |= 4;
+    }
     g.w[0] = (1.f - dix) * (1.f - diz);
     g.w[1] = (1.f - dix) * diz;
     g.w[2] = dix * (1.f - diz);
@@ -354,6 +362,197 @@ __global__ __launch_bounds__(256) void accumulate_kernel(
             o = make_float4(a[0], a[1], a[2], a[3]); break; }
         }
         *(float4 *)(so + rv.synofs[k]) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// accumulate, grouped: blended GF tiles staged in LDS and reused by every centroid of a sub-fault
+//
+// Consecutive centroids that sit at the same point (the nt source-time-function steps of one
+// sub-fault) need the SAME blended traces, only shifted by a different number of samples and
+// weighted differently.  The workgroup therefore blends each needed GF component ONCE per group
+// into an LDS tile (coalesced 16-byte global loads, 16-byte LDS stores) that covers the tile plus
+// the spread of the group's integer shifts, and then every centroid of the group does its
+// shift-interpolate-accumulate from LDS (conflict-free: lane l owns samples l, l+256, l+512, l+768
+// of the tile).  Global traffic drops by the group size (5 for the benchmark's bilateral source);
+// per-sample operation order is unchanged, so results are bit-identical to accumulate_kernel.
+
+constexpr int kHalo = 64;                    // LDS tile = kTile + kHalo samples
+constexpr int kLdsTile = kTile + kHalo;
+constexpr int kMaxGroup = 64;
+
+__device__ __forceinline__ f4u load4(const float *__restrict__ rowp, int l, int pitch)
+{
+    int q = kRowPad + l;
+    q = min(max(q, 0), pitch - 4);           // zeros before the span, end value after it (see load5)
+    return *(const f4u *)(rowp + q);
+}
+
+// blend one GF component over LDS positions [p, p+4) (trace index jb + p ...) and store it
+template <bool BLEND>
+__device__ __forceinline__ void build_chunk(float *__restrict__ tile, int p, int jb, const float *__restrict__ G,
+                                            const int2 *__restrict__ span, int pitch, const GeoRec &g, int ig)
+{
+    const int j = jb + p;
+    const int r0 = g.row[0] + ig;
+    const int2 s0 = span[r0];
+    f4u b;
+    if (BLEND) {
+        const int r1 = g.row[1] + ig, r2 = g.row[2] + ig, r3 = g.row[3] + ig;
+        const int2 s1 = span[r1], s2 = span[r2], s3 = span[r3];
+        const f4u v0 = load4(G + (size_t)r0 * pitch, j - s0.x, pitch);
+        const f4u v1 = load4(G + (size_t)r1 * pitch, j - s1.x, pitch);
+        const f4u v2 = load4(G + (size_t)r2 * pitch, j - s2.x, pitch);
+        const f4u v3 = load4(G + (size_t)r3 * pitch, j - s3.x, pitch);
+        b = g.w[0] * v0;                      // gfdb.f90:946-949, summed in this order
+        b = b + g.w[1] * v1;
+        b = b + g.w[2] * v2;
+        b = b + g.w[3] * v3;
+    } else {
+        b = load4(G + (size_t)r0 * pitch, j - s0.x, pitch);
+    }
+    *(float4 *)(tile + p) = make_float4(b.x, b.y, b.z, b.w);
+}
+
+template <bool BLEND>
+__device__ __forceinline__ int group_jend(const int2 *__restrict__ span, const GeoRec &g, int ig)
+{
+    const int2 s0 = span[g.row[0] + ig];
+    if (!BLEND) return s0.y;
+    const int2 s1 = span[g.row[1] + ig], s2 = span[g.row[2] + ig], s3 = span[g.row[3] + ig];
+    return max(max(s0.y, s1.y), max(s2.y, s3.y));
+}
+
+// one GF component of one centroid from its LDS tile onto this lane's 4 samples (stride 256).
+// pb = LDS position of the predecessor b[j-1] of this lane's sample 0, jp0 = trace index of LDS
+// position (pb - tid), i.e. lane 0's; same arithmetic as gf_add.
+__device__ __forceinline__ void tile_add(float (&out)[4], const float *__restrict__ tile, int pb, int jp0, int tid,
+                                         int jend, float factor, float wfrac)
+{
+    float wr = wfrac;
+    float wl = 1.f - wr;
+    wr = wr * factor;
+    wl = wl * factor;
+    if (jp0 + kTile <= jend) {               // workgroup-uniform: no repeated end point inside the tile
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float b0 = tile[pb + 256 * i], b1 = tile[pb + 256 * i + 1];
+            out[i] = out[i] + wl * b1;
+            out[i] = out[i] + wr * b0;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float b0 = tile[pb + 256 * i], b1 = tile[pb + 256 * i + 1];
+            const bool tail = (jp0 + tid + 256 * i + 1) > jend;     // sparse_trace.f90:698-703
+            const float c1 = tail ? factor : wl;
+            const float c2 = tail ? 0.f : wr;
+            out[i] = out[i] + c1 * b1;
+            out[i] = out[i] + c2 * b0;
+        }
+    }
+}
+
+template <int NG>
+__global__ __launch_bounds__(256) void accumulate_grouped_kernel(
+    const float *__restrict__ G, const int2 *__restrict__ span, int pitch,
+    const GeoRec *__restrict__ recs, const int *__restrict__ cent_ofs, int isrc0, int nrec,
+    const RecvDev *__restrict__ recv, float *__restrict__ syn, size_t syn_stride)
+{
+    __shared__ __attribute__((aligned(16))) float tiles[NG][kLdsTile];
+    const int tile = blockIdx.x, r = blockIdx.y, s = blockIdx.z;
+    const RecvDev &rv = recv[r];
+    if (!rv.enabled) return;
+    if (tile * kTile >= rv.wlen) return;
+    const int tid = threadIdx.x;
+    const int t_tile0 = rv.wbeg + tile * kTile;
+    const int cb = cent_ofs[isrc0], c0 = cent_ofs[isrc0 + s], nc = cent_ofs[isrc0 + s + 1] - c0;
+    const GeoRec *__restrict__ rc = recs + ((size_t)(c0 - cb) * nrec + (size_t)r * nc);
+    const bool need_h = rv.need_h != 0, has_d = rv.has_d != 0;
+
+    float ar1[4] = { 0.f, 0.f, 0.f, 0.f }, ar2[4] = { 0.f, 0.f, 0.f, 0.f }, dz[4] = { 0.f, 0.f, 0.f, 0.f };
+    int c = 0;
+    while (c < nc) {
+        const GeoRec &g0 = rc[c];
+        if (g0.row[0] < 0) { c++; continue; }            // 'cycle' on a missing trace
+        // ---- delimit the group: same point, integer shifts within the LDS halo
+        int cend = c + 1, smin = g0.ishift, smax = g0.ishift;
+        while (cend < nc && cend - c < kMaxGroup) {
+            const GeoRec &gn = rc[cend];
+            if (!(gn.flags & 4)) break;
+            const int nmin = min(smin, gn.ishift), nmax = max(smax, gn.ishift);
+            if (nmax - nmin > kHalo - 2) break;
+            smin = nmin; smax = nmax; cend++;
+        }
+        // LDS position p holds blended trace sample jb + p
+        const int jb = t_tile0 - smax - 1;
+        const int npos = kTile + (smax - smin) + 2;      // positions needed (<= kLdsTile)
+        const bool direct = (g0.flags & 1) != 0;
+        int jend[NG];
+        // ---- build: blend every needed component once
+#pragma unroll
+        for (int ig = 0; ig < NG; ig++) {
+            const bool horiz = (ig <= 4) || (ig == 8);
+            if ((horiz && !need_h) || (!horiz && !has_d)) { jend[ig] = 0; continue; }
+            jend[ig] = direct ? group_jend<false>(span, g0, ig) : group_jend<true>(span, g0, ig);
+            if (direct) {
+                build_chunk<false>(tiles[ig], 4 * tid, jb, G, span, pitch, g0, ig);
+                if (4 * (256 + tid) < npos) build_chunk<false>(tiles[ig], 4 * (256 + tid), jb, G, span, pitch, g0, ig);
+            } else {
+                build_chunk<true>(tiles[ig], 4 * tid, jb, G, span, pitch, g0, ig);
+                if (4 * (256 + tid) < npos) build_chunk<true>(tiles[ig], 4 * (256 + tid), jb, G, span, pitch, g0, ig);
+            }
+        }
+        __syncthreads();
+        // ---- apply: every centroid of the group, in table order (seismogram.f90:131)
+        for (int cc = c; cc < cend; cc++) {
+            const GeoRec &g = rc[cc];
+            const int pb = tid + (smax - g.ishift);      // position of b[j-1] for this lane's sample 0
+            const int jp0 = jb + (smax - g.ishift);      // trace index of lane 0's b[j-1]
+#define TADD(acc, ig, fac) tile_add(acc, tiles[ig], pb, jp0, tid, jend[ig], fac, g.wfrac)
+            if (need_h) {
+                if (g.flags & 2) {                       // seismogram.f90:160-203
+                    float t1[4] = { 0.f, 0.f, 0.f, 0.f }, t2[4] = { 0.f, 0.f, 0.f, 0.f };
+                    TADD(t1, 0, g.f[0]); TADD(t1, 1, g.f[1]); TADD(t1, 2, g.f[2]);
+                    if (NG == 10) TADD(t1, 8, g.f[5]);
+                    TADD(t2, 3, g.f[3]); TADD(t2, 4, g.f[4]);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        ar1[i] = ar1[i] + g.cl * t1[i] - g.sl * t2[i];
+                        ar2[i] = ar2[i] + g.cl * t2[i] + g.sl * t1[i];
+                    }
+                } else {                                 // seismogram.f90:205-231
+                    TADD(ar1, 0, g.f[0]); TADD(ar1, 1, g.f[1]); TADD(ar1, 2, g.f[2]);
+                    if (NG == 10) TADD(ar1, 8, g.f[5]);
+                    TADD(ar2, 3, g.f[3]); TADD(ar2, 4, g.f[4]);
+                }
+            }
+            if (has_d) {                                 // seismogram.f90:236-253
+                TADD(dz, 5, g.f[0] * rv.sd); TADD(dz, 6, g.f[1] * rv.sd); TADD(dz, 7, g.f[2] * rv.sd);
+                if (NG == 10) TADD(dz, 9, g.f[5] * rv.sd);
+            }
+#undef TADD
+        }
+        __syncthreads();                                 // tiles are rebuilt by the next group
+        c = cend;
+    }
+
+    float *__restrict__ so = syn + (size_t)s * syn_stride + tile * kTile + tid;
+    for (int k = 0; k < rv.ncomp; k++) {                 // seismogram.f90:256-283
+        const float sg = rv.sign[k];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (tile * kTile + tid + 256 * i >= rv.wlen) continue;
+            float o;
+            switch (rv.comp[k]) {
+            case 1: o = ar1[i] * sg; break;
+            case 2: o = ar2[i] * sg; break;
+            case 3: o = dz[i]; break;
+            case 4: o = (rv.cl0 * ar1[i] - rv.sl0 * ar2[i]) * sg; break;
+            default: o = (rv.cl0 * ar2[i] + rv.sl0 * ar1[i]) * sg; break;
+            }
+            so[rv.synofs[k] + 256 * i] = o;
+        }
     }
 }
 

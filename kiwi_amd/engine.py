@@ -183,6 +183,9 @@ class Engine:
         self._ck(self.L.kiwi_hip_get_misfits(self.h, isrc0, nsrc, _fp(m), _fp(n), _fp(g)), "get_misfits")
         return m, n, g
 
+    def set_keep_synthetics(self, which):
+        self._ck(self.L.kiwi_hip_set_keep_synthetics(self.h, which), "set_keep_synthetics")
+
     def get_synthetics(self, isrc, irec, icomp, which=1, maxn=1 << 20):
         out = np.zeros(maxn, np.float32)
         first, n = C.c_int(), C.c_int()

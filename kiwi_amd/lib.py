@@ -68,6 +68,7 @@ def load():
         "kiwi_hip_set_sources_params": [vp, C.c_int, C.c_int, c_float_p],
         "kiwi_hip_eval": [vp, C.c_int, C.c_int],
         "kiwi_hip_sync": [vp],
+        "kiwi_hip_set_keep_synthetics": [vp, C.c_int],
         "kiwi_hip_nmisfits": [vp, c_int_p],
         "kiwi_hip_get_misfits": [vp, C.c_int, C.c_int, c_float_p, c_float_p, c_float_p],
         "kiwi_hip_get_synthetics": [vp, C.c_int, C.c_int, C.c_int, C.c_int, c_int_p, c_int_p, c_float_p, C.c_int],

@@ -111,8 +111,9 @@ def test_geometry_records_match_oracle():
     for ir in range(1, sc.nrec + 1):
         g = p.get_geometry(0, ir)
         o = e.centroid_geometry(ir, len(g), GEOREC)
-        for name in ("row", "ishift", "flags"):
+        for name in ("row", "ishift"):
             assert np.array_equal(g[name], o[name]), name
+        assert np.array_equal(g["flags"] & 3, o["flags"])        # bit2 (same point as predecessor) is device-only
         for name in ("w", "wfrac", "f", "cl", "sl"):
             d = g[name].view(np.int32).astype(np.int64) - o[name].view(np.int32).astype(np.int64)
             nf += d.size
@@ -137,6 +138,7 @@ def test_accumulate_bitexact_given_geometry():
     for ir in range(1, sc.nrec + 1):
         g = p.get_geometry(0, ir)
         o = e.centroid_geometry(ir, len(g), GEOREC)
+        g["flags"] &= 3
         if g.tobytes() != o.tobytes():
             continue
         checked += 1
