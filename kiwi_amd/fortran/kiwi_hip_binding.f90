@@ -1,0 +1,218 @@
+! kiwi_hip_binding.f90 -- iso_c_binding interface to the C-ABI in include/kiwi_hip.h.
+!
+! This is the Fortran side of the drop-in boundary: a host written in Fortran (the reference's
+! minimizer_engine.f90, or this repo's kiwi_amd/fortran/minimizer_hip.f90) `use`s this module and
+! replaces its calls to make_seismogram / receiver_scaled_seismograms_to_probes /
+! receiver_calculate_misfits by kiwi_hip_* calls (see INTEGRATION.md).  Every function returns
+! 0 on success; on failure kiwi_hip_error_message() gives the text for error() (util.f90:133-145).
+
+module kiwi_hip_binding
+
+    use iso_c_binding
+    implicit none
+
+    interface
+
+        integer(c_int) function kiwi_hip_init( device, ctx ) bind(C, name='kiwi_hip_init')
+            import :: c_int, c_ptr
+            integer(c_int), value :: device
+            type(c_ptr), intent(out) :: ctx
+        end function
+
+        integer(c_int) function kiwi_hip_destroy( ctx ) bind(C, name='kiwi_hip_destroy')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: ctx
+        end function
+
+        integer(c_int) function kiwi_hip_last_error( ctx, buf, buflen ) bind(C, name='kiwi_hip_last_error')
+            import :: c_int, c_ptr, c_char
+            type(c_ptr), value :: ctx
+            character(kind=c_char), intent(out) :: buf(*)
+            integer(c_int), value :: buflen
+        end function
+
+        integer(c_int) function kiwi_hip_set_gfdb( ctx, nx, nz, ng, L, dt, dx, dz, firstx, firstz, G, first, nsamp ) &
+                bind(C, name='kiwi_hip_set_gfdb')
+            import :: c_int, c_ptr, c_float
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: nx, nz, ng, L
+            real(c_float), value :: dt, dx, dz, firstx, firstz
+            real(c_float), intent(in) :: G(*)            ! (L, ng, nz, nx) in Fortran order
+            integer(c_int), intent(in) :: first(*), nsamp(*)   ! (ng, nz, nx)
+        end function
+
+        integer(c_int) function kiwi_hip_set_interp( ctx, bilinear, xus, zus ) bind(C, name='kiwi_hip_set_interp')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: bilinear, xus, zus
+        end function
+
+        integer(c_int) function kiwi_hip_set_effective_dt( ctx, edt ) bind(C, name='kiwi_hip_set_effective_dt')
+            import :: c_int, c_ptr, c_float
+            type(c_ptr), value :: ctx
+            real(c_float), value :: edt
+        end function
+
+        integer(c_int) function kiwi_hip_set_source_location( ctx, lat, lon, reftime ) &
+                bind(C, name='kiwi_hip_set_source_location')
+            import :: c_int, c_ptr, c_float, c_double
+            type(c_ptr), value :: ctx
+            real(c_float), value :: lat, lon              ! degrees, as on the wire (minimizer.f90:511)
+            real(c_double), value :: reftime
+        end function
+
+        integer(c_int) function kiwi_hip_set_receivers( ctx, nrec, lat, lon, depth, components ) &
+                bind(C, name='kiwi_hip_set_receivers')
+            import :: c_int, c_ptr, c_float, c_double
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: nrec
+            real(c_double), intent(in) :: lat(*), lon(*)  ! degrees, as in the receivers file
+            real(c_float), intent(in) :: depth(*)
+            type(c_ptr), intent(in) :: components(*)      ! nrec pointers to NUL-terminated strings
+        end function
+
+        integer(c_int) function kiwi_hip_switch_receiver( ctx, irec, enabled ) bind(C, name='kiwi_hip_switch_receiver')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: irec, enabled
+        end function
+
+        integer(c_int) function kiwi_hip_set_reference( ctx, irec, icomp, first, n, data ) &
+                bind(C, name='kiwi_hip_set_reference')
+            import :: c_int, c_ptr, c_float
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: irec, icomp, first, n
+            real(c_float), intent(in) :: data(*)
+        end function
+
+        integer(c_int) function kiwi_hip_set_taper( ctx, irec, npts, x, y ) bind(C, name='kiwi_hip_set_taper')
+            import :: c_int, c_ptr, c_float
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: irec, npts
+            real(c_float), intent(in) :: x(*), y(*)
+        end function
+
+        integer(c_int) function kiwi_hip_set_filter( ctx, irec, npts, x, y ) bind(C, name='kiwi_hip_set_filter')
+            import :: c_int, c_ptr, c_float
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: irec, npts
+            real(c_float), intent(in) :: x(*), y(*)
+        end function
+
+        integer(c_int) function kiwi_hip_set_misfit_method( ctx, method ) bind(C, name='kiwi_hip_set_misfit_method')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: method
+        end function
+
+        integer(c_int) function kiwi_hip_set_synthetics_factor( ctx, factor ) &
+                bind(C, name='kiwi_hip_set_synthetics_factor')
+            import :: c_int, c_ptr, c_float
+            type(c_ptr), value :: ctx
+            real(c_float), value :: factor
+        end function
+
+        integer(c_int) function kiwi_hip_source_nparams( sourcetype ) bind(C, name='kiwi_hip_source_nparams')
+            import :: c_int
+            integer(c_int), value :: sourcetype
+        end function
+
+        integer(c_int) function kiwi_hip_discretize( sourcetype, params, nparams, effective_dt, cent, maxcent, &
+                                                     ncent, moment, risetime ) bind(C, name='kiwi_hip_discretize')
+            import :: c_int, c_float
+            integer(c_int), value :: sourcetype, nparams, maxcent
+            real(c_float), intent(in) :: params(*)
+            real(c_float), value :: effective_dt
+            real(c_float), intent(out) :: cent(10,*)
+            integer(c_int), intent(out) :: ncent
+            real(c_float), intent(out) :: moment, risetime
+        end function
+
+        integer(c_int) function kiwi_hip_set_sources( ctx, nsrc, cent_ofs, cent, moment, risetime ) &
+                bind(C, name='kiwi_hip_set_sources')
+            import :: c_int, c_ptr, c_float
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: nsrc
+            integer(c_int), intent(in) :: cent_ofs(*)     ! (nsrc+1), 0-based row offsets
+            real(c_float), intent(in) :: cent(10,*), moment(*), risetime(*)
+        end function
+
+        integer(c_int) function kiwi_hip_set_sources_params( ctx, sourcetype, nsrc, params ) &
+                bind(C, name='kiwi_hip_set_sources_params')
+            import :: c_int, c_ptr, c_float
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: sourcetype, nsrc
+            real(c_float), intent(in) :: params(*)        ! (nparams, nsrc)
+        end function
+
+        integer(c_int) function kiwi_hip_eval( ctx, isrc0, nsrc ) bind(C, name='kiwi_hip_eval')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: isrc0, nsrc          ! isrc0 is 0-based
+        end function
+
+        integer(c_int) function kiwi_hip_sync( ctx ) bind(C, name='kiwi_hip_sync')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: ctx
+        end function
+
+        integer(c_int) function kiwi_hip_nmisfits( ctx, nmis ) bind(C, name='kiwi_hip_nmisfits')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: ctx
+            integer(c_int), intent(out) :: nmis
+        end function
+
+        integer(c_int) function kiwi_hip_get_misfits( ctx, isrc0, nsrc, misfit, norm, global ) &
+                bind(C, name='kiwi_hip_get_misfits')
+            import :: c_int, c_ptr, c_float
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: isrc0, nsrc
+            real(c_float), intent(out) :: misfit(*), norm(*), global(*)   ! (nmis,nsrc), (nmis,nsrc), (nsrc)
+        end function
+
+        integer(c_int) function kiwi_hip_set_keep_synthetics( ctx, which ) bind(C, name='kiwi_hip_set_keep_synthetics')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: which
+        end function
+
+        integer(c_int) function kiwi_hip_get_synthetics( ctx, isrc, irec, icomp, which, first, n, out, maxn ) &
+                bind(C, name='kiwi_hip_get_synthetics')
+            import :: c_int, c_ptr, c_float
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: isrc, irec, icomp, which, maxn
+            integer(c_int), intent(out) :: first, n
+            real(c_float), intent(out) :: out(*)
+        end function
+
+        integer(c_int) function kiwi_hip_get_receiver_geometry( ctx, irec, azi, bazi, dist ) &
+                bind(C, name='kiwi_hip_get_receiver_geometry')
+            import :: c_int, c_ptr, c_double
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: irec
+            real(c_double), intent(out) :: azi, bazi, dist
+        end function
+
+    end interface
+
+  contains
+
+  ! the library's last error as a Fortran string, for error() / "<cmd>: nok >" answers
+    function kiwi_hip_error_message( ctx ) result( msg )
+        type(c_ptr), intent(in) :: ctx
+        character(len=:), allocatable :: msg
+        character(kind=c_char) :: buf(1024)
+        integer :: i, n, rc
+        rc = kiwi_hip_last_error( ctx, buf, 1024_c_int )
+        n = 0
+        do i = 1, 1024
+            if (buf(i) == c_null_char) exit
+            n = i
+        end do
+        allocate( character(len=n) :: msg )
+        do i = 1, n
+            msg(i:i) = buf(i)
+        end do
+    end function
+
+end module
