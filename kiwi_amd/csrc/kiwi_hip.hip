@@ -321,14 +321,16 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
                 hipLaunchKernelGGL(accumulate_kernel<8>, grid, dim3(256), 0, c->stream, c->G.p, c->span.p, c->gm.pitch,
                                    c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p, c->syn_stride);
         } else {
+            const int ntiles = (c->max_wlen + kTile - 1) / kTile;
+            dim3 ggrid((unsigned)nsrc, (unsigned)(ntiles * nrec));       // source index fastest (L2 sharing)
             if (c->gm.ng == 10)
-                hipLaunchKernelGGL(accumulate_grouped_kernel<10>, grid, dim3(256), 0, c->stream, c->G.p, c->span.p,
+                hipLaunchKernelGGL(accumulate_grouped_kernel<10>, ggrid, dim3(256), 0, c->stream, c->G.p, c->span.p,
                                    c->gm.pitch, c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p,
-                                   c->syn_stride);
+                                   c->syn_stride, ntiles);
             else
-                hipLaunchKernelGGL(accumulate_grouped_kernel<8>, grid, dim3(256), 0, c->stream, c->G.p, c->span.p,
+                hipLaunchKernelGGL(accumulate_grouped_kernel<8>, ggrid, dim3(256), 0, c->stream, c->G.p, c->span.p,
                                    c->gm.pitch, c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p,
-                                   c->syn_stride);
+                                   c->syn_stride, ntiles);
         }
     }
     record(c, 1, e2);

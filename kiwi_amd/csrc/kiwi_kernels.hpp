@@ -457,10 +457,15 @@ template <int NG>
 __global__ __launch_bounds__(256) void accumulate_grouped_kernel(
     const float *__restrict__ G, const int2 *__restrict__ span, int pitch,
     const GeoRec *__restrict__ recs, const int *__restrict__ cent_ofs, int isrc0, int nrec,
-    const RecvDev *__restrict__ recv, float *__restrict__ syn, size_t syn_stride)
+    const RecvDev *__restrict__ recv, float *__restrict__ syn, size_t syn_stride, int ntiles)
 {
     __shared__ __attribute__((aligned(16))) float tiles[NG][kLdsTile];
-    const int tile = blockIdx.x, r = blockIdx.y, s = blockIdx.z;
+    // 1-D grid, SOURCE index fastest: the workgroups resident at any moment are the same (tile,
+    // receiver) of many neighbouring trial sources, which read (nearly) the same GF rows at the same
+    // time, and blocks b, b+8, ... share an XCD and therefore its L2 (dispatch is round-robin over
+    // the 8 XCDs; speed only, never correctness).
+    const int s = blockIdx.x;
+    const int tile = blockIdx.y % ntiles, r = blockIdx.y / ntiles;
     const RecvDev &rv = recv[r];
     if (!rv.enabled) return;
     if (tile * kTile >= rv.wlen) return;
