@@ -25,6 +25,8 @@ namespace kiwi {
 constexpr int kRowPad = 8;        // zeros in front of every GF row (>= 5, see load5)
 constexpr int kTile = 1024;       // samples per workgroup: 256 threads x 4 consecutive samples
 constexpr int kMaxComp = 5;
+constexpr int kHalo = 64;         // grouped accumulate: LDS tile = kTile + kHalo samples
+constexpr int kMaxGroup = 64;     // centroids per group at most
 
 // per (source, receiver, centroid) record, written by geometry_kernel, read (wave-uniformly,
 // through scalar loads) by accumulate_kernel.  20 x 4 B.
@@ -37,7 +39,7 @@ struct GeoRec {
     float cl, sl;     // cos / sin (bazi - bazi_orig)                          seismogram.f90:164-165
     int   flags;      // bit0: exactly on a node -> no blend (gfdb.f90:890-893); bit1: rotate (seismogram.f90:160);
                       // bit2: same position as the previous centroid
-    int   pad;
+    int   pad;        // group hint: len | (smax-ishift)<<8 | (ishift-smin)<<16, see geometry_kernel
 };
 static_assert(sizeof(GeoRec) == 80, "GeoRec layout");
 
@@ -101,7 +103,6 @@ __global__ __launch_bounds__(256) void geometry_kernel(
     const RecvDev &rv = recv[r];
     const float *ce = cent + (size_t)(c0 + c) * 10;
     GeoRec g;
-    g.pad = 0;
     const float dnorth = ce[0], deast = ce[1], depth = ce[2], time = ce[3];
     const float pi_f = 3.14159265358979f;           // constants.f90:21
     const double pi_d = (double)pi_f;               // constants.f90:22
@@ -211,6 +212,23 @@ __global__ __launch_bounds__(256) void geometry_kernel(
                 if (sp.y < sp.x) ok = false;
             }
         if (!ok) g.row[0] = -1;
+    }
+    // group hint (used by accumulate_grouped_kernel when a group STARTS at this centroid): how many
+    // following centroids sit at this same point with their integer shifts within the LDS halo, and
+    // the spread of those shifts.  pad = len | (smax - ishift) << 8 | (ishift - smin) << 16
+    {
+        int len = 1, smin = g.ishift, smax = g.ishift;
+        if (g.row[0] >= 0) {
+            for (int k = c + 1; k < nc && len < kMaxGroup; k++) {
+                const float *ne = cent + (size_t)(c0 + k) * 10;
+                if (!(ne[0] == dnorth && ne[1] == deast && ne[2] == depth)) break;
+                const int sh = (int)floorf(ne[3] / gm.dt);
+                const int nmin = min(smin, sh), nmax = max(smax, sh);
+                if (nmax - nmin > kHalo - 2) break;
+                smin = nmin; smax = nmax; len++;
+            }
+        }
+        g.pad = len | ((smax - g.ishift) << 8) | ((g.ishift - smin) << 16);
     }
     const size_t base = (size_t)(c0 - cent_ofs[ep.isrc0]) * ep.nrec + (size_t)r * nc + c;
     out[base] = g;
@@ -377,9 +395,6 @@ __global__ __launch_bounds__(256) void accumulate_kernel(
 // of the tile).  Global traffic drops by the group size (5 for the benchmark's bilateral source);
 // per-sample operation order is unchanged, so results are bit-identical to accumulate_kernel.
 
-constexpr int kHalo = 64;                    // LDS tile = kTile + kHalo samples
-constexpr int kLdsTile = kTile + kHalo;
-constexpr int kMaxGroup = 64;
 
 __device__ __forceinline__ f4u load4(const float *__restrict__ rowp, int l, int pitch)
 {
@@ -426,6 +441,7 @@ __device__ __forceinline__ int group_jend(const int2 *__restrict__ span, const G
 // one GF component of one centroid from its LDS tile onto this lane's 4 samples (stride 256).
 // pb = LDS position of the predecessor b[j-1] of this lane's sample 0, jp0 = trace index of LDS
 // position (pb - tid), i.e. lane 0's; same arithmetic as gf_add.
+template <int T>
 __device__ __forceinline__ void tile_add(float (&out)[4], const float *__restrict__ tile, int pb, int jp0, int tid,
                                          int jend, float factor, float wfrac)
 {
@@ -433,18 +449,18 @@ __device__ __forceinline__ void tile_add(float (&out)[4], const float *__restric
     float wl = 1.f - wr;
     wr = wr * factor;
     wl = wl * factor;
-    if (jp0 + kTile <= jend) {               // workgroup-uniform: no repeated end point inside the tile
+    if (jp0 + 4 * T <= jend) {               // workgroup-uniform: no repeated end point inside the tile
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const float b0 = tile[pb + 256 * i], b1 = tile[pb + 256 * i + 1];
+            const float b0 = tile[pb + T * i], b1 = tile[pb + T * i + 1];
             out[i] = out[i] + wl * b1;
             out[i] = out[i] + wr * b0;
         }
     } else {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const float b0 = tile[pb + 256 * i], b1 = tile[pb + 256 * i + 1];
-            const bool tail = (jp0 + tid + 256 * i + 1) > jend;     // sparse_trace.f90:698-703
+            const float b0 = tile[pb + T * i], b1 = tile[pb + T * i + 1];
+            const bool tail = (jp0 + tid + T * i + 1) > jend;     // sparse_trace.f90:698-703
             const float c1 = tail ? factor : wl;
             const float c2 = tail ? 0.f : wr;
             out[i] = out[i] + c1 * b1;
@@ -453,45 +469,71 @@ __device__ __forceinline__ void tile_add(float (&out)[4], const float *__restric
     }
 }
 
-template <int NG>
-__global__ __launch_bounds__(256) void accumulate_grouped_kernel(
+// A GeoRec travels through the grouped kernel "lane-distributed": lane i (< 20) of every wave
+// holds dword i of the record in ONE VGPR (a single coalesced 80-byte load that can be issued a
+// whole centroid ahead), and fields are broadcast to SGPRs with v_readlane when needed.  Compared
+// with scalar loads this removes ~16 serialised SMEM round trips per centroid.
+__device__ __forceinline__ int rec_load(const GeoRec *__restrict__ rc, int c, int nc, int lane)
+{
+    int v = 0;
+    if (c < nc && lane < 20) v = ((const int *)(rc + c))[lane];
+    return v;
+}
+#define REC_I(v, k) __builtin_amdgcn_readlane((v), (k))
+#define REC_F(v, k) __int_as_float(__builtin_amdgcn_readlane((v), (k)))
+
+__device__ __forceinline__ void rec_head(int v, GeoRec &g)
+{
+    g.row[0] = REC_I(v, 0); g.row[1] = REC_I(v, 1); g.row[2] = REC_I(v, 2); g.row[3] = REC_I(v, 3);
+    g.w[0] = REC_F(v, 4); g.w[1] = REC_F(v, 5); g.w[2] = REC_F(v, 6); g.w[3] = REC_F(v, 7);
+    g.ishift = REC_I(v, 8);
+    g.flags = REC_I(v, 18);
+    g.pad = REC_I(v, 19);
+}
+
+template <int NG, int T>
+__global__ __launch_bounds__(T) void accumulate_grouped_kernel(
     const float *__restrict__ G, const int2 *__restrict__ span, int pitch,
     const GeoRec *__restrict__ recs, const int *__restrict__ cent_ofs, int isrc0, int nrec,
     const RecvDev *__restrict__ recv, float *__restrict__ syn, size_t syn_stride, int ntiles)
 {
-    __shared__ __attribute__((aligned(16))) float tiles[NG][kLdsTile];
-    // 1-D grid, SOURCE index fastest: the workgroups resident at any moment are the same (tile,
-    // receiver) of many neighbouring trial sources, which read (nearly) the same GF rows at the same
-    // time, and blocks b, b+8, ... share an XCD and therefore its L2 (dispatch is round-robin over
-    // the 8 XCDs; speed only, never correctness).
+    constexpr int TILE = 4 * T;                          // samples per workgroup
+    constexpr int LDS_TILE = TILE + kHalo;
+    __shared__ __attribute__((aligned(16))) float tiles[NG][LDS_TILE];
+    // SOURCE index fastest in dispatch order: the workgroups resident at any moment are the same
+    // (tile, receiver) of many neighbouring trial sources, which read (nearly) the same GF rows at
+    // the same time, and blocks b, b+8, ... share an XCD and therefore its L2 (dispatch is
+    // round-robin over the 8 XCDs; speed only, never correctness).
     const int s = blockIdx.x;
     const int tile = blockIdx.y % ntiles, r = blockIdx.y / ntiles;
     const RecvDev &rv = recv[r];
     if (!rv.enabled) return;
-    if (tile * kTile >= rv.wlen) return;
+    if (tile * TILE >= rv.wlen) return;
     const int tid = threadIdx.x;
-    const int t_tile0 = rv.wbeg + tile * kTile;
+    const int lane = tid & 63;
+    const int t_tile0 = rv.wbeg + tile * TILE;
     const int cb = cent_ofs[isrc0], c0 = cent_ofs[isrc0 + s], nc = cent_ofs[isrc0 + s + 1] - c0;
     const GeoRec *__restrict__ rc = recs + ((size_t)(c0 - cb) * nrec + (size_t)r * nc);
     const bool need_h = rv.need_h != 0, has_d = rv.has_d != 0;
+    const float sd = rv.sd;
 
     float ar1[4] = { 0.f, 0.f, 0.f, 0.f }, ar2[4] = { 0.f, 0.f, 0.f, 0.f }, dz[4] = { 0.f, 0.f, 0.f, 0.f };
     int c = 0;
+    int cur = rec_load(rc, 0, nc, lane);                 // record c, lane-distributed
     while (c < nc) {
-        const GeoRec &g0 = rc[c];
-        if (g0.row[0] < 0) { c++; continue; }            // 'cycle' on a missing trace
-        // ---- delimit the group: same point, integer shifts within the LDS halo
-        int cend = c + 1, smin = g0.ishift, smax = g0.ishift;
-        while (cend < nc && cend - c < kMaxGroup) {
-            const GeoRec &gn = rc[cend];
-            if (!(gn.flags & 4)) break;
-            const int nmin = min(smin, gn.ishift), nmax = max(smax, gn.ishift);
-            if (nmax - nmin > kHalo - 2) break;
-            smin = nmin; smax = nmax; cend++;
+        GeoRec g0;
+        rec_head(cur, g0);
+        if (g0.row[0] < 0) {                             // 'cycle' on a missing trace
+            c++;
+            cur = rec_load(rc, c, nc, lane);
+            continue;
         }
+        // ---- the group starting here (hint computed by geometry_kernel)
+        const int cend = c + (g0.pad & 0xff);
+        const int smax = g0.ishift + ((g0.pad >> 8) & 0xff), smin = g0.ishift - ((g0.pad >> 16) & 0xff);
         // LDS position p holds blended trace sample jb + p
         const int jb = t_tile0 - smax - 1;
-        const int npos = kTile + (smax - smin) + 2;      // positions needed (<= kLdsTile)
+        const int npos = TILE + (smax - smin) + 2;       // positions needed (<= LDS_TILE)
         const bool direct = (g0.flags & 1) != 0;
         int jend[NG];
         // ---- build: blend every needed component once
@@ -502,52 +544,59 @@ __global__ __launch_bounds__(256) void accumulate_grouped_kernel(
             jend[ig] = direct ? group_jend<false>(span, g0, ig) : group_jend<true>(span, g0, ig);
             if (direct) {
                 build_chunk<false>(tiles[ig], 4 * tid, jb, G, span, pitch, g0, ig);
-                if (4 * (256 + tid) < npos) build_chunk<false>(tiles[ig], 4 * (256 + tid), jb, G, span, pitch, g0, ig);
+                if (4 * (T + tid) < npos) build_chunk<false>(tiles[ig], 4 * (T + tid), jb, G, span, pitch, g0, ig);
             } else {
                 build_chunk<true>(tiles[ig], 4 * tid, jb, G, span, pitch, g0, ig);
-                if (4 * (256 + tid) < npos) build_chunk<true>(tiles[ig], 4 * (256 + tid), jb, G, span, pitch, g0, ig);
+                if (4 * (T + tid) < npos) build_chunk<true>(tiles[ig], 4 * (T + tid), jb, G, span, pitch, g0, ig);
             }
         }
         __syncthreads();
         // ---- apply: every centroid of the group, in table order (seismogram.f90:131)
         for (int cc = c; cc < cend; cc++) {
-            const GeoRec &g = rc[cc];
-            const int pb = tid + (smax - g.ishift);      // position of b[j-1] for this lane's sample 0
-            const int jp0 = jb + (smax - g.ishift);      // trace index of lane 0's b[j-1]
-#define TADD(acc, ig, fac) tile_add(acc, tiles[ig], pb, jp0, tid, jend[ig], fac, g.wfrac)
+            const int nxt = rec_load(rc, cc + 1, nc, lane);      // prefetch the next record
+            const int ishift = REC_I(cur, 8);
+            const float wfrac = REC_F(cur, 9);
+            const float f0 = REC_F(cur, 10), f1 = REC_F(cur, 11), f2 = REC_F(cur, 12), f3 = REC_F(cur, 13),
+                        f4 = REC_F(cur, 14), f5 = REC_F(cur, 15);
+            const float cl = REC_F(cur, 16), sl = REC_F(cur, 17);
+            const int flags = REC_I(cur, 18);
+            const int pb = tid + (smax - ishift);        // position of b[j-1] for this lane's sample 0
+            const int jp0 = jb + (smax - ishift);        // trace index of lane 0's b[j-1]
+#define TADD(acc, ig, fac) tile_add<T>(acc, tiles[ig], pb, jp0, tid, jend[ig], fac, wfrac)
             if (need_h) {
-                if (g.flags & 2) {                       // seismogram.f90:160-203
+                if (flags & 2) {                         // seismogram.f90:160-203
                     float t1[4] = { 0.f, 0.f, 0.f, 0.f }, t2[4] = { 0.f, 0.f, 0.f, 0.f };
-                    TADD(t1, 0, g.f[0]); TADD(t1, 1, g.f[1]); TADD(t1, 2, g.f[2]);
-                    if (NG == 10) TADD(t1, 8, g.f[5]);
-                    TADD(t2, 3, g.f[3]); TADD(t2, 4, g.f[4]);
+                    TADD(t1, 0, f0); TADD(t1, 1, f1); TADD(t1, 2, f2);
+                    if (NG == 10) TADD(t1, 8, f5);
+                    TADD(t2, 3, f3); TADD(t2, 4, f4);
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
-                        ar1[i] = ar1[i] + g.cl * t1[i] - g.sl * t2[i];
-                        ar2[i] = ar2[i] + g.cl * t2[i] + g.sl * t1[i];
+                        ar1[i] = ar1[i] + cl * t1[i] - sl * t2[i];
+                        ar2[i] = ar2[i] + cl * t2[i] + sl * t1[i];
                     }
                 } else {                                 // seismogram.f90:205-231
-                    TADD(ar1, 0, g.f[0]); TADD(ar1, 1, g.f[1]); TADD(ar1, 2, g.f[2]);
-                    if (NG == 10) TADD(ar1, 8, g.f[5]);
-                    TADD(ar2, 3, g.f[3]); TADD(ar2, 4, g.f[4]);
+                    TADD(ar1, 0, f0); TADD(ar1, 1, f1); TADD(ar1, 2, f2);
+                    if (NG == 10) TADD(ar1, 8, f5);
+                    TADD(ar2, 3, f3); TADD(ar2, 4, f4);
                 }
             }
             if (has_d) {                                 // seismogram.f90:236-253
-                TADD(dz, 5, g.f[0] * rv.sd); TADD(dz, 6, g.f[1] * rv.sd); TADD(dz, 7, g.f[2] * rv.sd);
-                if (NG == 10) TADD(dz, 9, g.f[5] * rv.sd);
+                TADD(dz, 5, f0 * sd); TADD(dz, 6, f1 * sd); TADD(dz, 7, f2 * sd);
+                if (NG == 10) TADD(dz, 9, f5 * sd);
             }
 #undef TADD
+            cur = nxt;
         }
         __syncthreads();                                 // tiles are rebuilt by the next group
         c = cend;
     }
 
-    float *__restrict__ so = syn + (size_t)s * syn_stride + tile * kTile + tid;
+    float *__restrict__ so = syn + (size_t)s * syn_stride + tile * TILE + tid;
     for (int k = 0; k < rv.ncomp; k++) {                 // seismogram.f90:256-283
         const float sg = rv.sign[k];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            if (tile * kTile + tid + 256 * i >= rv.wlen) continue;
+            if (tile * TILE + tid + T * i >= rv.wlen) continue;
             float o;
             switch (rv.comp[k]) {
             case 1: o = ar1[i] * sg; break;
@@ -556,7 +605,7 @@ __global__ __launch_bounds__(256) void accumulate_grouped_kernel(
             case 4: o = (rv.cl0 * ar1[i] - rv.sl0 * ar2[i]) * sg; break;
             default: o = (rv.cl0 * ar2[i] + rv.sl0 * ar1[i]) * sg; break;
             }
-            so[rv.synofs[k] + 256 * i] = o;
+            so[rv.synofs[k] + T * i] = o;
         }
     }
 }

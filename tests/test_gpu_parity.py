@@ -139,6 +139,7 @@ def test_accumulate_bitexact_given_geometry():
         g = p.get_geometry(0, ir)
         o = e.centroid_geometry(ir, len(g), GEOREC)
         g["flags"] &= 3
+        g["pad"] = 0                   # device-only group hint
         if g.tobytes() != o.tobytes():
             continue
         checked += 1
