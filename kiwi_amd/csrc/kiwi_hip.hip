@@ -115,6 +115,7 @@ struct kiwi_hip_ctx {
     DevBuf<float> syn_d, proc_d;
     int last_isrc0 = 0, last_nsrc = 0, last_chunk0 = 0, last_chunkn = 0;
     int last_proc_which = 0;
+    int group_spt = 4;                // samples per thread of the grouped kernel; env KIWI_HIP_GROUP_SPT
     int group_threads = 128;          // workgroup size of the grouped kernel (tile = 4x); env KIWI_HIP_GROUP_THREADS
     int accum_mode = 0;               // 0 grouped (LDS-staged), 1 direct; env KIWI_HIP_ACCUM
     int keep_which = 0;               // kiwi_hip_set_keep_synthetics
@@ -322,18 +323,24 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
                 hipLaunchKernelGGL(accumulate_kernel<8>, grid, dim3(256), 0, c->stream, c->G.p, c->span.p, c->gm.pitch,
                                    c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p, c->syn_stride);
         } else {
-            const int T = c->group_threads;
-            const int ntiles = (c->max_wlen + 4 * T - 1) / (4 * T);
+            const int T = c->group_threads, SPT = c->group_spt;
+            const int ntiles = (c->max_wlen + SPT * T - 1) / (SPT * T);
             dim3 ggrid((unsigned)nsrc, (unsigned)(ntiles * nrec));       // source index fastest (L2 sharing)
-#define KIWI_LAUNCH_GROUPED(NGV, TV)                                                                        \
-    hipLaunchKernelGGL((accumulate_grouped_kernel<NGV, TV>), ggrid, dim3(TV), 0, c->stream, c->G.p, c->span.p,   \
+#define KIWI_LAUNCH_GROUPED(NGV, TV, SV)                                                                    \
+    hipLaunchKernelGGL((accumulate_grouped_kernel<NGV, TV, SV>), ggrid, dim3(TV), 0, c->stream, c->G.p, c->span.p, \
                        c->gm.pitch, c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p,          \
                        c->syn_stride, ntiles)
-            if (c->gm.ng == 10) {
-                if (T == 64) KIWI_LAUNCH_GROUPED(10, 64); else if (T == 128) KIWI_LAUNCH_GROUPED(10, 128); else if (T == 512) KIWI_LAUNCH_GROUPED(10, 512); else KIWI_LAUNCH_GROUPED(10, 256);
-            } else {
-                if (T == 64) KIWI_LAUNCH_GROUPED(8, 64); else if (T == 128) KIWI_LAUNCH_GROUPED(8, 128); else if (T == 512) KIWI_LAUNCH_GROUPED(8, 512); else KIWI_LAUNCH_GROUPED(8, 256);
-            }
+#define KIWI_LAUNCH_NG(NGV)                                                                                 \
+    do {                                                                                                    \
+        if (T == 64 && SPT == 4) KIWI_LAUNCH_GROUPED(NGV, 64, 4);                                           \
+        else if (T == 64 && SPT == 8) KIWI_LAUNCH_GROUPED(NGV, 64, 8);                                      \
+        else if (T == 64 && SPT == 16) KIWI_LAUNCH_GROUPED(NGV, 64, 16);                                    \
+        else if (T == 128 && SPT == 8) KIWI_LAUNCH_GROUPED(NGV, 128, 8);                                    \
+        else if (T == 256 && SPT == 4) KIWI_LAUNCH_GROUPED(NGV, 256, 4);                                    \
+        else KIWI_LAUNCH_GROUPED(NGV, 128, 4);                                                              \
+    } while (0)
+            if (c->gm.ng == 10) KIWI_LAUNCH_NG(10); else KIWI_LAUNCH_NG(8);
+#undef KIWI_LAUNCH_NG
 #undef KIWI_LAUNCH_GROUPED
         }
     }
@@ -402,7 +409,11 @@ int kiwi_hip_init(int device, kiwi_hip_ctx **out)
         HIPCHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         if (const char *m = std::getenv("KIWI_HIP_GROUP_THREADS")) {
             const int v = std::atoi(m);
-            if (v == 64 || v == 128 || v == 256 || v == 512) c->group_threads = v;
+            if (v == 64 || v == 128 || v == 256) c->group_threads = v;
+        }
+        if (const char *m = std::getenv("KIWI_HIP_GROUP_SPT")) {
+            const int v = std::atoi(m);
+            if (v == 4 || v == 8 || v == 16) c->group_spt = v;
         }
         if (const char *m = std::getenv("KIWI_HIP_ACCUM")) c->accum_mode = (std::strcmp(m, "direct") == 0) ? 1 : 0;
         *out = c;

@@ -441,24 +441,24 @@ __device__ __forceinline__ int group_jend(const int2 *__restrict__ span, const G
 // one GF component of one centroid from its LDS tile onto this lane's 4 samples (stride 256).
 // pb = LDS position of the predecessor b[j-1] of this lane's sample 0, jp0 = trace index of LDS
 // position (pb - tid), i.e. lane 0's; same arithmetic as gf_add.
-template <int T>
-__device__ __forceinline__ void tile_add(float (&out)[4], const float *__restrict__ tile, int pb, int jp0, int tid,
+template <int T, int SPT>
+__device__ __forceinline__ void tile_add(float (&out)[SPT], const float *__restrict__ tile, int pb, int jp0, int tid,
                                          int jend, float factor, float wfrac)
 {
     float wr = wfrac;
     float wl = 1.f - wr;
     wr = wr * factor;
     wl = wl * factor;
-    if (jp0 + 4 * T <= jend) {               // workgroup-uniform: no repeated end point inside the tile
+    if (jp0 + SPT * T <= jend) {               // workgroup-uniform: no repeated end point inside the tile
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < SPT; i++) {
             const float b0 = tile[pb + T * i], b1 = tile[pb + T * i + 1];
             out[i] = out[i] + wl * b1;
             out[i] = out[i] + wr * b0;
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < SPT; i++) {
             const float b0 = tile[pb + T * i], b1 = tile[pb + T * i + 1];
             const bool tail = (jp0 + tid + T * i + 1) > jend;     // sparse_trace.f90:698-703
             const float c1 = tail ? factor : wl;
@@ -491,13 +491,14 @@ __device__ __forceinline__ void rec_head(int v, GeoRec &g)
     g.pad = REC_I(v, 19);
 }
 
-template <int NG, int T>
+template <int NG, int T, int SPT>
 __global__ __launch_bounds__(T) void accumulate_grouped_kernel(
     const float *__restrict__ G, const int2 *__restrict__ span, int pitch,
     const GeoRec *__restrict__ recs, const int *__restrict__ cent_ofs, int isrc0, int nrec,
     const RecvDev *__restrict__ recv, float *__restrict__ syn, size_t syn_stride, int ntiles)
 {
-    constexpr int TILE = 4 * T;                          // samples per workgroup
+    constexpr int TILE = SPT * T;                        // samples per workgroup (SPT per thread, stride T)
+    static_assert(SPT % 4 == 0, "SPT must be a multiple of 4");
     constexpr int LDS_TILE = TILE + kHalo;
     __shared__ __attribute__((aligned(16))) float tiles[NG][LDS_TILE];
     // SOURCE index fastest in dispatch order: the workgroups resident at any moment are the same
@@ -517,7 +518,9 @@ __global__ __launch_bounds__(T) void accumulate_grouped_kernel(
     const bool need_h = rv.need_h != 0, has_d = rv.has_d != 0;
     const float sd = rv.sd;
 
-    float ar1[4] = { 0.f, 0.f, 0.f, 0.f }, ar2[4] = { 0.f, 0.f, 0.f, 0.f }, dz[4] = { 0.f, 0.f, 0.f, 0.f };
+    float ar1[SPT], ar2[SPT], dz[SPT];
+#pragma unroll
+    for (int i = 0; i < SPT; i++) { ar1[i] = 0.f; ar2[i] = 0.f; dz[i] = 0.f; }
     int c = 0;
     int cur = rec_load(rc, 0, nc, lane);                 // record c, lane-distributed
     while (c < nc) {
@@ -543,11 +546,15 @@ __global__ __launch_bounds__(T) void accumulate_grouped_kernel(
             if ((horiz && !need_h) || (!horiz && !has_d)) { jend[ig] = 0; continue; }
             jend[ig] = direct ? group_jend<false>(span, g0, ig) : group_jend<true>(span, g0, ig);
             if (direct) {
-                build_chunk<false>(tiles[ig], 4 * tid, jb, G, span, pitch, g0, ig);
-                if (4 * (T + tid) < npos) build_chunk<false>(tiles[ig], 4 * (T + tid), jb, G, span, pitch, g0, ig);
+#pragma unroll
+                for (int k = 0; k < SPT / 4; k++) build_chunk<false>(tiles[ig], 4 * (tid + T * k), jb, G, span, pitch, g0, ig);
+                if (4 * (tid + T * (SPT / 4)) < npos)      // halo chunk
+                    build_chunk<false>(tiles[ig], 4 * (tid + T * (SPT / 4)), jb, G, span, pitch, g0, ig);
             } else {
-                build_chunk<true>(tiles[ig], 4 * tid, jb, G, span, pitch, g0, ig);
-                if (4 * (T + tid) < npos) build_chunk<true>(tiles[ig], 4 * (T + tid), jb, G, span, pitch, g0, ig);
+#pragma unroll
+                for (int k = 0; k < SPT / 4; k++) build_chunk<true>(tiles[ig], 4 * (tid + T * k), jb, G, span, pitch, g0, ig);
+                if (4 * (tid + T * (SPT / 4)) < npos)
+                    build_chunk<true>(tiles[ig], 4 * (tid + T * (SPT / 4)), jb, G, span, pitch, g0, ig);
             }
         }
         __syncthreads();
@@ -562,15 +569,17 @@ __global__ __launch_bounds__(T) void accumulate_grouped_kernel(
             const int flags = REC_I(cur, 18);
             const int pb = tid + (smax - ishift);        // position of b[j-1] for this lane's sample 0
             const int jp0 = jb + (smax - ishift);        // trace index of lane 0's b[j-1]
-#define TADD(acc, ig, fac) tile_add<T>(acc, tiles[ig], pb, jp0, tid, jend[ig], fac, wfrac)
+#define TADD(acc, ig, fac) tile_add<T, SPT>(acc, tiles[ig], pb, jp0, tid, jend[ig], fac, wfrac)
             if (need_h) {
                 if (flags & 2) {                         // seismogram.f90:160-203
-                    float t1[4] = { 0.f, 0.f, 0.f, 0.f }, t2[4] = { 0.f, 0.f, 0.f, 0.f };
+                    float t1[SPT], t2[SPT];
+#pragma unroll
+                    for (int i = 0; i < SPT; i++) { t1[i] = 0.f; t2[i] = 0.f; }
                     TADD(t1, 0, f0); TADD(t1, 1, f1); TADD(t1, 2, f2);
                     if (NG == 10) TADD(t1, 8, f5);
                     TADD(t2, 3, f3); TADD(t2, 4, f4);
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
+                    for (int i = 0; i < SPT; i++) {
                         ar1[i] = ar1[i] + cl * t1[i] - sl * t2[i];
                         ar2[i] = ar2[i] + cl * t2[i] + sl * t1[i];
                     }
@@ -595,7 +604,7 @@ __global__ __launch_bounds__(T) void accumulate_grouped_kernel(
     for (int k = 0; k < rv.ncomp; k++) {                 // seismogram.f90:256-283
         const float sg = rv.sign[k];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < SPT; i++) {
             if (tile * TILE + tid + T * i >= rv.wlen) continue;
             float o;
             switch (rv.comp[k]) {

@@ -6,7 +6,7 @@ import re
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libkiwi_hip.so")
+LIB_PATH = os.environ.get("KIWI_HIP_LIB", os.path.join(HERE, "libkiwi_hip.so"))   # override: A/B builds
 HEADER = os.path.join(os.path.dirname(HERE), "include", "kiwi_hip.h")
 
 c_float_p = C.POINTER(C.c_float)
