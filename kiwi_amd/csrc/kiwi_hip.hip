@@ -323,24 +323,18 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
                 hipLaunchKernelGGL(accumulate_kernel<8>, grid, dim3(256), 0, c->stream, c->G.p, c->span.p, c->gm.pitch,
                                    c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p, c->syn_stride);
         } else {
-            const int T = c->group_threads, SPT = c->group_spt;
-            const int ntiles = (c->max_wlen + SPT * T - 1) / (SPT * T);
+            const int T = c->group_threads;
+            const int ntiles = (c->max_wlen + 4 * T - 1) / (4 * T);
             dim3 ggrid((unsigned)nsrc, (unsigned)(ntiles * nrec));       // source index fastest (L2 sharing)
-#define KIWI_LAUNCH_GROUPED(NGV, TV, SV)                                                                    \
-    hipLaunchKernelGGL((accumulate_grouped_kernel<NGV, TV, SV>), ggrid, dim3(TV), 0, c->stream, c->G.p, c->span.p, \
+#define KIWI_LAUNCH_GROUPED(NGV, TV)                                                                        \
+    hipLaunchKernelGGL((accumulate_grouped_kernel<NGV, TV>), ggrid, dim3(TV), 0, c->stream, c->G.p, c->span.p,   \
                        c->gm.pitch, c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p,          \
                        c->syn_stride, ntiles)
-#define KIWI_LAUNCH_NG(NGV)                                                                                 \
-    do {                                                                                                    \
-        if (T == 64 && SPT == 4) KIWI_LAUNCH_GROUPED(NGV, 64, 4);                                           \
-        else if (T == 64 && SPT == 8) KIWI_LAUNCH_GROUPED(NGV, 64, 8);                                      \
-        else if (T == 64 && SPT == 16) KIWI_LAUNCH_GROUPED(NGV, 64, 16);                                    \
-        else if (T == 128 && SPT == 8) KIWI_LAUNCH_GROUPED(NGV, 128, 8);                                    \
-        else if (T == 256 && SPT == 4) KIWI_LAUNCH_GROUPED(NGV, 256, 4);                                    \
-        else KIWI_LAUNCH_GROUPED(NGV, 128, 4);                                                              \
-    } while (0)
-            if (c->gm.ng == 10) KIWI_LAUNCH_NG(10); else KIWI_LAUNCH_NG(8);
-#undef KIWI_LAUNCH_NG
+            if (c->gm.ng == 10) {
+                if (T == 64) KIWI_LAUNCH_GROUPED(10, 64); else if (T == 256) KIWI_LAUNCH_GROUPED(10, 256); else KIWI_LAUNCH_GROUPED(10, 128);
+            } else {
+                if (T == 64) KIWI_LAUNCH_GROUPED(8, 64); else if (T == 256) KIWI_LAUNCH_GROUPED(8, 256); else KIWI_LAUNCH_GROUPED(8, 128);
+            }
 #undef KIWI_LAUNCH_GROUPED
         }
     }

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void geometry_kernel(
                 if (!(ne[0] == dnorth && ne[1] == deast && ne[2] == depth)) break;
                 const int sh = (int)floorf(ne[3] / gm.dt);
                 const int nmin = min(smin, sh), nmax = max(smax, sh);
-                if (nmax - nmin > kHalo - 2) break;
+                if (nmax - nmin > kHalo - 10) break;
                 smin = nmin; smax = nmax; len++;
             }
         }
@@ -438,34 +438,32 @@ __device__ __forceinline__ int group_jend(const int2 *__restrict__ span, const G
     return max(max(s0.y, s1.y), max(s2.y, s3.y));
 }
 
-// one GF component of one centroid from its LDS tile onto this lane's 4 samples (stride 256).
-// pb = LDS position of the predecessor b[j-1] of this lane's sample 0, jp0 = trace index of LDS
-// position (pb - tid), i.e. lane 0's; same arithmetic as gf_add.
-template <int T, int SPT>
-__device__ __forceinline__ void tile_add(float (&out)[SPT], const float *__restrict__ tile, int pb, int jp0, int tid,
-                                         int jend, float factor, float wfrac)
+// one GF component of one centroid from its LDS tile onto this lane's 4 consecutive samples.
+// The lane needs the 5 blended samples b[j-1..j+3] that sit at LDS positions 4*tid + e + (0..4),
+// e = smax - ishift >= 0 (workgroup-uniform).  With e = 4a + R they are elements R..R+4 of the two
+// ALIGNED 16-byte chunks at 4*(tid+a) and 4*(tid+a+1): two full-rate, conflict-free ds_read_b128
+// and a compile-time register selection (R is a template parameter).  Arithmetic as gf_add.
+template <int R, bool TAIL>
+__device__ __forceinline__ void tile_add(float (&out)[4], const float *__restrict__ chunk, int jl, int jend,
+                                         float factor, float wfrac)
 {
+    const float4 A = *(const float4 *)chunk;
+    const float4 B = *(const float4 *)(chunk + 4);
+    const float x[8] = { A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w };
     float wr = wfrac;
     float wl = 1.f - wr;
     wr = wr * factor;
     wl = wl * factor;
-    if (jp0 + SPT * T <= jend) {               // workgroup-uniform: no repeated end point inside the tile
 #pragma unroll
-        for (int i = 0; i < SPT; i++) {
-            const float b0 = tile[pb + T * i], b1 = tile[pb + T * i + 1];
-            out[i] = out[i] + wl * b1;
-            out[i] = out[i] + wr * b0;
+    for (int i = 0; i < 4; i++) {
+        float c1 = wl, c2 = wr;
+        if (TAIL) {                               // sparse_trace.f90:698-703, jl = trace index of this lane's b[j-1]
+            const bool tail = (jl + i + 1) > jend;
+            c1 = tail ? factor : wl;
+            c2 = tail ? 0.f : wr;
         }
-    } else {
-#pragma unroll
-        for (int i = 0; i < SPT; i++) {
-            const float b0 = tile[pb + T * i], b1 = tile[pb + T * i + 1];
-            const bool tail = (jp0 + tid + T * i + 1) > jend;     // sparse_trace.f90:698-703
-            const float c1 = tail ? factor : wl;
-            const float c2 = tail ? 0.f : wr;
-            out[i] = out[i] + c1 * b1;
-            out[i] = out[i] + c2 * b0;
-        }
+        out[i] = out[i] + c1 * x[R + i + 1];
+        out[i] = out[i] + c2 * x[R + i];
     }
 }
 
@@ -491,14 +489,46 @@ __device__ __forceinline__ void rec_head(int v, GeoRec &g)
     g.pad = REC_I(v, 19);
 }
 
-template <int NG, int T, int SPT>
+// all GF components of one centroid (reference order) for one shift residue R
+template <int NG, int LDS_TILE, int R, bool TAIL>
+__device__ __forceinline__ void centroid_apply(float (&ar1)[4], float (&ar2)[4], float (&dz)[4],
+                                               const float *__restrict__ chunk0, int jl, const int (&jend)[NG],
+                                               bool need_h, bool has_d, int flags, float wfrac, float sd,
+                                               float f0, float f1, float f2, float f3, float f4, float f5,
+                                               float cl, float sl)
+{
+#define TADD(acc, ig, fac) tile_add<R, TAIL>(acc, chunk0 + (ig) * LDS_TILE, jl, jend[ig], fac, wfrac)
+    if (need_h) {
+        if (flags & 2) {                         // seismogram.f90:160-203
+            float t1[4] = { 0.f, 0.f, 0.f, 0.f }, t2[4] = { 0.f, 0.f, 0.f, 0.f };
+            TADD(t1, 0, f0); TADD(t1, 1, f1); TADD(t1, 2, f2);
+            if (NG == 10) TADD(t1, 8, f5);
+            TADD(t2, 3, f3); TADD(t2, 4, f4);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                ar1[i] = ar1[i] + cl * t1[i] - sl * t2[i];
+                ar2[i] = ar2[i] + cl * t2[i] + sl * t1[i];
+            }
+        } else {                                 // seismogram.f90:205-231
+            TADD(ar1, 0, f0); TADD(ar1, 1, f1); TADD(ar1, 2, f2);
+            if (NG == 10) TADD(ar1, 8, f5);
+            TADD(ar2, 3, f3); TADD(ar2, 4, f4);
+        }
+    }
+    if (has_d) {                                 // seismogram.f90:236-253
+        TADD(dz, 5, f0 * sd); TADD(dz, 6, f1 * sd); TADD(dz, 7, f2 * sd);
+        if (NG == 10) TADD(dz, 9, f5 * sd);
+    }
+#undef TADD
+}
+
+template <int NG, int T>
 __global__ __launch_bounds__(T) void accumulate_grouped_kernel(
     const float *__restrict__ G, const int2 *__restrict__ span, int pitch,
     const GeoRec *__restrict__ recs, const int *__restrict__ cent_ofs, int isrc0, int nrec,
     const RecvDev *__restrict__ recv, float *__restrict__ syn, size_t syn_stride, int ntiles)
 {
-    constexpr int TILE = SPT * T;                        // samples per workgroup (SPT per thread, stride T)
-    static_assert(SPT % 4 == 0, "SPT must be a multiple of 4");
+    constexpr int TILE = 4 * T;                          // samples per workgroup, 4 consecutive per thread
     constexpr int LDS_TILE = TILE + kHalo;
     __shared__ __attribute__((aligned(16))) float tiles[NG][LDS_TILE];
     // SOURCE index fastest in dispatch order: the workgroups resident at any moment are the same
@@ -518,9 +548,7 @@ __global__ __launch_bounds__(T) void accumulate_grouped_kernel(
     const bool need_h = rv.need_h != 0, has_d = rv.has_d != 0;
     const float sd = rv.sd;
 
-    float ar1[SPT], ar2[SPT], dz[SPT];
-#pragma unroll
-    for (int i = 0; i < SPT; i++) { ar1[i] = 0.f; ar2[i] = 0.f; dz[i] = 0.f; }
+    float ar1[4] = { 0.f, 0.f, 0.f, 0.f }, ar2[4] = { 0.f, 0.f, 0.f, 0.f }, dz[4] = { 0.f, 0.f, 0.f, 0.f };
     int c = 0;
     int cur = rec_load(rc, 0, nc, lane);                 // record c, lane-distributed
     while (c < nc) {
@@ -536,25 +564,23 @@ __global__ __launch_bounds__(T) void accumulate_grouped_kernel(
         const int smax = g0.ishift + ((g0.pad >> 8) & 0xff), smin = g0.ishift - ((g0.pad >> 16) & 0xff);
         // LDS position p holds blended trace sample jb + p
         const int jb = t_tile0 - smax - 1;
-        const int npos = TILE + (smax - smin) + 2;       // positions needed (<= LDS_TILE)
+        const int npos = TILE + (smax - smin) + 8;       // positions read by the group (<= LDS_TILE)
         const bool direct = (g0.flags & 1) != 0;
         int jend[NG];
+        int jend_min = 0x7fffffff;
         // ---- build: blend every needed component once
 #pragma unroll
         for (int ig = 0; ig < NG; ig++) {
             const bool horiz = (ig <= 4) || (ig == 8);
             if ((horiz && !need_h) || (!horiz && !has_d)) { jend[ig] = 0; continue; }
             jend[ig] = direct ? group_jend<false>(span, g0, ig) : group_jend<true>(span, g0, ig);
+            jend_min = min(jend_min, jend[ig]);
             if (direct) {
-#pragma unroll
-                for (int k = 0; k < SPT / 4; k++) build_chunk<false>(tiles[ig], 4 * (tid + T * k), jb, G, span, pitch, g0, ig);
-                if (4 * (tid + T * (SPT / 4)) < npos)      // halo chunk
-                    build_chunk<false>(tiles[ig], 4 * (tid + T * (SPT / 4)), jb, G, span, pitch, g0, ig);
+                build_chunk<false>(tiles[ig], 4 * tid, jb, G, span, pitch, g0, ig);
+                if (4 * (tid + T) < npos) build_chunk<false>(tiles[ig], 4 * (tid + T), jb, G, span, pitch, g0, ig);
             } else {
-#pragma unroll
-                for (int k = 0; k < SPT / 4; k++) build_chunk<true>(tiles[ig], 4 * (tid + T * k), jb, G, span, pitch, g0, ig);
-                if (4 * (tid + T * (SPT / 4)) < npos)
-                    build_chunk<true>(tiles[ig], 4 * (tid + T * (SPT / 4)), jb, G, span, pitch, g0, ig);
+                build_chunk<true>(tiles[ig], 4 * tid, jb, G, span, pitch, g0, ig);
+                if (4 * (tid + T) < npos) build_chunk<true>(tiles[ig], 4 * (tid + T), jb, G, span, pitch, g0, ig);
             }
         }
         __syncthreads();
@@ -567,55 +593,51 @@ __global__ __launch_bounds__(T) void accumulate_grouped_kernel(
                         f4 = REC_F(cur, 14), f5 = REC_F(cur, 15);
             const float cl = REC_F(cur, 16), sl = REC_F(cur, 17);
             const int flags = REC_I(cur, 18);
-            const int pb = tid + (smax - ishift);        // position of b[j-1] for this lane's sample 0
-            const int jp0 = jb + (smax - ishift);        // trace index of lane 0's b[j-1]
-#define TADD(acc, ig, fac) tile_add<T, SPT>(acc, tiles[ig], pb, jp0, tid, jend[ig], fac, wfrac)
-            if (need_h) {
-                if (flags & 2) {                         // seismogram.f90:160-203
-                    float t1[SPT], t2[SPT];
-#pragma unroll
-                    for (int i = 0; i < SPT; i++) { t1[i] = 0.f; t2[i] = 0.f; }
-                    TADD(t1, 0, f0); TADD(t1, 1, f1); TADD(t1, 2, f2);
-                    if (NG == 10) TADD(t1, 8, f5);
-                    TADD(t2, 3, f3); TADD(t2, 4, f4);
-#pragma unroll
-                    for (int i = 0; i < SPT; i++) {
-                        ar1[i] = ar1[i] + cl * t1[i] - sl * t2[i];
-                        ar2[i] = ar2[i] + cl * t2[i] + sl * t1[i];
-                    }
-                } else {                                 // seismogram.f90:205-231
-                    TADD(ar1, 0, f0); TADD(ar1, 1, f1); TADD(ar1, 2, f2);
-                    if (NG == 10) TADD(ar1, 8, f5);
-                    TADD(ar2, 3, f3); TADD(ar2, 4, f4);
+            const int e = smax - ishift;                 // LDS position of lane 0's b[j-1]
+            const float *chunk0 = &tiles[0][4 * (tid + (e >> 2))];
+            const int jl = jb + e + 4 * tid;             // trace index of this lane's b[j-1]
+            const bool tail = (jb + e + TILE) > jend_min;        // workgroup-uniform
+#define APPLY(RV, TV) centroid_apply<NG, LDS_TILE, RV, TV>(ar1, ar2, dz, chunk0, jl, jend, need_h, has_d, flags, \
+                                                          wfrac, sd, f0, f1, f2, f3, f4, f5, cl, sl)
+            if (!tail) {
+                switch (e & 3) {
+                case 0: APPLY(0, false); break;
+                case 1: APPLY(1, false); break;
+                case 2: APPLY(2, false); break;
+                default: APPLY(3, false); break;
+                }
+            } else {
+                switch (e & 3) {
+                case 0: APPLY(0, true); break;
+                case 1: APPLY(1, true); break;
+                case 2: APPLY(2, true); break;
+                default: APPLY(3, true); break;
                 }
             }
-            if (has_d) {                                 // seismogram.f90:236-253
-                TADD(dz, 5, f0 * sd); TADD(dz, 6, f1 * sd); TADD(dz, 7, f2 * sd);
-                if (NG == 10) TADD(dz, 9, f5 * sd);
-            }
-#undef TADD
+#undef APPLY
             cur = nxt;
         }
         __syncthreads();                                 // tiles are rebuilt by the next group
         c = cend;
     }
 
-    float *__restrict__ so = syn + (size_t)s * syn_stride + tile * TILE + tid;
+    const int tl = tile * TILE + 4 * tid;
+    if (tl >= rv.wlen) return;
+    float *__restrict__ so = syn + (size_t)s * syn_stride + tl;
     for (int k = 0; k < rv.ncomp; k++) {                 // seismogram.f90:256-283
         const float sg = rv.sign[k];
+        float o[4];
 #pragma unroll
-        for (int i = 0; i < SPT; i++) {
-            if (tile * TILE + tid + T * i >= rv.wlen) continue;
-            float o;
+        for (int i = 0; i < 4; i++) {
             switch (rv.comp[k]) {
-            case 1: o = ar1[i] * sg; break;
-            case 2: o = ar2[i] * sg; break;
-            case 3: o = dz[i]; break;
-            case 4: o = (rv.cl0 * ar1[i] - rv.sl0 * ar2[i]) * sg; break;
-            default: o = (rv.cl0 * ar2[i] + rv.sl0 * ar1[i]) * sg; break;
+            case 1: o[i] = ar1[i] * sg; break;
+            case 2: o[i] = ar2[i] * sg; break;
+            case 3: o[i] = dz[i]; break;
+            case 4: o[i] = (rv.cl0 * ar1[i] - rv.sl0 * ar2[i]) * sg; break;
+            default: o[i] = (rv.cl0 * ar2[i] + rv.sl0 * ar1[i]) * sg; break;
             }
-            so[rv.synofs[k] + T * i] = o;
         }
+        *(float4 *)(so + rv.synofs[k]) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 
