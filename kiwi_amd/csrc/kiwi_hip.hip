@@ -112,6 +112,7 @@ struct kiwi_hip_ctx {
     // results + workspace
     DevBuf<float> misfit_d, global_d;
     DevBuf<GeoRec> recs_d;
+    DevBuf<int> tab_d;                // grouped kernel load descriptors, 128 ints per GeoRec
     DevBuf<float> syn_d, proc_d;
     int last_isrc0 = 0, last_nsrc = 0, last_chunk0 = 0, last_chunkn = 0;
     int last_proc_which = 0;
@@ -300,6 +301,8 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
     int maxnc = 0;
     for (int s = isrc0; s < isrc0 + nsrc; s++) maxnc = std::max(maxnc, c->cent_ofs[s + 1] - c->cent_ofs[s]);
     c->recs_d.ensure((size_t)(cend - cbeg) * nrec, &c->dev_bytes);
+    int *tab = nullptr;
+    if (c->accum_mode == 0) { c->tab_d.ensure((size_t)(cend - cbeg) * nrec * 128, &c->dev_bytes); tab = c->tab_d.p; }
     c->syn_d.ensure((size_t)nsrc * c->syn_stride, &c->dev_bytes);
     float *proc = nullptr;
     if (proc_which) { c->proc_d.ensure((size_t)nsrc * c->syn_stride, &c->dev_bytes); proc = c->proc_d.p; }
@@ -310,7 +313,7 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
     if (maxnc > 0) {
         dim3 grid((unsigned)((maxnc * nrec + 255) / 256), (unsigned)nsrc);
         hipLaunchKernelGGL(geometry_kernel, grid, dim3(256), 0, c->stream, c->cent_d.p, c->centofs_d.p, ep, c->gm,
-                           c->span.p, c->recv_d.p, c->recs_d.p);
+                           c->span.p, c->recv_d.p, c->recs_d.p, tab);
     }
     record(c, 0, e1);
     {
@@ -329,7 +332,7 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
 #define KIWI_LAUNCH_GROUPED(NGV, TV)                                                                        \
     hipLaunchKernelGGL((accumulate_grouped_kernel<NGV, TV>), ggrid, dim3(TV), 0, c->stream, c->G.p, c->span.p,   \
                        c->gm.pitch, c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p,          \
-                       c->syn_stride, ntiles)
+                       c->syn_stride, ntiles, c->tab_d.p)
             if (c->gm.ng == 10) {
                 if (T == 64) KIWI_LAUNCH_GROUPED(10, 64); else if (T == 256) KIWI_LAUNCH_GROUPED(10, 256); else KIWI_LAUNCH_GROUPED(10, 128);
             } else {
@@ -372,7 +375,7 @@ int eval_impl(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
         int n = 0;
         while (s + n < isrc0 + nsrc) {
             const size_t nc = (size_t)(c->cent_ofs[s + n + 1] - c->cent_ofs[s + n]);
-            const size_t add = nc * nrec * sizeof(GeoRec) + c->syn_stride * sizeof(float) * (proc_which ? 2 : 1);
+            const size_t add = nc * nrec * (sizeof(GeoRec) + (c->accum_mode == 0 ? 512 : 0)) + c->syn_stride * sizeof(float) * (proc_which ? 2 : 1);
             if (n > 0 && (bytes + add > c->chunk_bytes_limit || n >= 65535)) break;
             bytes += add; n++;
         }

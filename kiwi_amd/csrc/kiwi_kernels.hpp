@@ -93,7 +93,8 @@ struct EvalParams {
 
 __global__ __launch_bounds__(256) void geometry_kernel(
     const float *__restrict__ cent, const int *__restrict__ cent_ofs, EvalParams ep, GfMeta gm,
-    const int2 *__restrict__ span, const RecvDev *__restrict__ recv, GeoRec *__restrict__ out)
+    const int2 *__restrict__ span, const RecvDev *__restrict__ recv, GeoRec *__restrict__ out,
+    int *__restrict__ tab)
 {
     const int s = blockIdx.y;
     const int c0 = cent_ofs[ep.isrc0 + s], nc = cent_ofs[ep.isrc0 + s + 1] - c0;
@@ -232,6 +233,26 @@ __global__ __launch_bounds__(256) void geometry_kernel(
     }
     const size_t base = (size_t)(c0 - cent_ofs[ep.isrc0]) * ep.nrec + (size_t)r * nc + c;
     out[base] = g;
+    // load descriptors for accumulate_grouped_kernel, 128 ints per record, laid out so that one
+    // coalesced load per wave brings them in lane-distributed: for component ig and node k
+    //   tab[4*ig + k]      = row*pitch + kRowPad - first   (float index of trace sample 0, minus... + j)
+    //   tab[64 + 4*ig + k] = row*pitch                     (clamp floor; ceiling = floor + pitch - 4)
+    //   tab[40 + ig]       = last stored sample of the blended trace (max over the nodes)
+    if (tab && g.row[0] >= 0) {
+        int *tb = tab + base * 128;
+        const int nn = (g.flags & 1) ? 1 : 4;
+        for (int ig = 0; ig < gm.ng; ig++) {
+            int jend = -0x7fffffff;
+            for (int k = 0; k < 4; k++) {
+                const int row = g.row[k < nn ? k : 0] + ig;
+                const int2 sp = span[row];
+                tb[4 * ig + k] = row * gm.pitch + kRowPad - sp.x;
+                tb[64 + 4 * ig + k] = row * gm.pitch;
+                if (k < nn) jend = max(jend, sp.y);
+            }
+            tb[40 + ig] = jend;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -396,6 +417,28 @@ __global__ __launch_bounds__(256) void accumulate_kernel(
 // per-sample operation order is unchanged, so results are bit-identical to accumulate_kernel.
 
 
+// A GeoRec travels through the grouped kernel "lane-distributed": lane i (< 20) of every wave
+// holds dword i of the record in ONE VGPR (a single coalesced 80-byte load that can be issued a
+// whole centroid ahead), and fields are broadcast to SGPRs with v_readlane when needed.  Compared
+// with scalar loads this removes ~16 serialised SMEM round trips per centroid.
+__device__ __forceinline__ int rec_load(const GeoRec *__restrict__ rc, int c, int nc, int lane)
+{
+    int v = 0;
+    if (c < nc && lane < 20) v = ((const int *)(rc + c))[lane];
+    return v;
+}
+#define REC_I(v, k) __builtin_amdgcn_readlane((v), (k))
+#define REC_F(v, k) __int_as_float(__builtin_amdgcn_readlane((v), (k)))
+
+__device__ __forceinline__ void rec_head(int v, GeoRec &g)
+{
+    g.row[0] = REC_I(v, 0); g.row[1] = REC_I(v, 1); g.row[2] = REC_I(v, 2); g.row[3] = REC_I(v, 3);
+    g.w[0] = REC_F(v, 4); g.w[1] = REC_F(v, 5); g.w[2] = REC_F(v, 6); g.w[3] = REC_F(v, 7);
+    g.ishift = REC_I(v, 8);
+    g.flags = REC_I(v, 18);
+    g.pad = REC_I(v, 19);
+}
+
 __device__ __forceinline__ f4u load4(const float *__restrict__ rowp, int l, int pitch)
 {
     int q = kRowPad + l;
@@ -403,39 +446,32 @@ __device__ __forceinline__ f4u load4(const float *__restrict__ rowp, int l, int 
     return *(const f4u *)(rowp + q);
 }
 
-// blend one GF component over LDS positions [p, p+4) (trace index jb + p ...) and store it
+// blend one GF component over LDS positions [p, p+4) (trace samples jb + p ...) and store it.
+// ta / tb: lane-distributed load descriptors of the group (see geometry_kernel): the float index of
+// sample j of node k's trace is clamp(ta[4ig+k] + j, tb[4ig+k], tb[4ig+k] + pitch - 4), which
+// implements "zero before the span, end value repeated after it" on the padded row.
 template <bool BLEND>
 __device__ __forceinline__ void build_chunk(float *__restrict__ tile, int p, int jb, const float *__restrict__ G,
-                                            const int2 *__restrict__ span, int pitch, const GeoRec &g, int ig)
+                                            int pitch, int ta, int tb, const GeoRec &g, int ig)
 {
     const int j = jb + p;
-    const int r0 = g.row[0] + ig;
-    const int2 s0 = span[r0];
+    f4u v[4];
+#pragma unroll
+    for (int k = 0; k < (BLEND ? 4 : 1); k++) {
+        const int base = REC_I(ta, 4 * ig + k), lo = REC_I(tb, 4 * ig + k);
+        const int idx = min(max(base + j, lo), lo + pitch - 4);
+        v[k] = *(const f4u *)(G + (size_t)(unsigned)idx);
+    }
     f4u b;
     if (BLEND) {
-        const int r1 = g.row[1] + ig, r2 = g.row[2] + ig, r3 = g.row[3] + ig;
-        const int2 s1 = span[r1], s2 = span[r2], s3 = span[r3];
-        const f4u v0 = load4(G + (size_t)r0 * pitch, j - s0.x, pitch);
-        const f4u v1 = load4(G + (size_t)r1 * pitch, j - s1.x, pitch);
-        const f4u v2 = load4(G + (size_t)r2 * pitch, j - s2.x, pitch);
-        const f4u v3 = load4(G + (size_t)r3 * pitch, j - s3.x, pitch);
-        b = g.w[0] * v0;                      // gfdb.f90:946-949, summed in this order
-        b = b + g.w[1] * v1;
-        b = b + g.w[2] * v2;
-        b = b + g.w[3] * v3;
+        b = g.w[0] * v[0];                    // gfdb.f90:946-949, summed in this order
+        b = b + g.w[1] * v[1];
+        b = b + g.w[2] * v[2];
+        b = b + g.w[3] * v[3];
     } else {
-        b = load4(G + (size_t)r0 * pitch, j - s0.x, pitch);
+        b = v[0];
     }
     *(float4 *)(tile + p) = make_float4(b.x, b.y, b.z, b.w);
-}
-
-template <bool BLEND>
-__device__ __forceinline__ int group_jend(const int2 *__restrict__ span, const GeoRec &g, int ig)
-{
-    const int2 s0 = span[g.row[0] + ig];
-    if (!BLEND) return s0.y;
-    const int2 s1 = span[g.row[1] + ig], s2 = span[g.row[2] + ig], s3 = span[g.row[3] + ig];
-    return max(max(s0.y, s1.y), max(s2.y, s3.y));
 }
 
 // one GF component of one centroid from its LDS tile onto this lane's 4 consecutive samples.
@@ -465,28 +501,6 @@ __device__ __forceinline__ void tile_add(float (&out)[4], const float *__restric
         out[i] = out[i] + c1 * x[R + i + 1];
         out[i] = out[i] + c2 * x[R + i];
     }
-}
-
-// A GeoRec travels through the grouped kernel "lane-distributed": lane i (< 20) of every wave
-// holds dword i of the record in ONE VGPR (a single coalesced 80-byte load that can be issued a
-// whole centroid ahead), and fields are broadcast to SGPRs with v_readlane when needed.  Compared
-// with scalar loads this removes ~16 serialised SMEM round trips per centroid.
-__device__ __forceinline__ int rec_load(const GeoRec *__restrict__ rc, int c, int nc, int lane)
-{
-    int v = 0;
-    if (c < nc && lane < 20) v = ((const int *)(rc + c))[lane];
-    return v;
-}
-#define REC_I(v, k) __builtin_amdgcn_readlane((v), (k))
-#define REC_F(v, k) __int_as_float(__builtin_amdgcn_readlane((v), (k)))
-
-__device__ __forceinline__ void rec_head(int v, GeoRec &g)
-{
-    g.row[0] = REC_I(v, 0); g.row[1] = REC_I(v, 1); g.row[2] = REC_I(v, 2); g.row[3] = REC_I(v, 3);
-    g.w[0] = REC_F(v, 4); g.w[1] = REC_F(v, 5); g.w[2] = REC_F(v, 6); g.w[3] = REC_F(v, 7);
-    g.ishift = REC_I(v, 8);
-    g.flags = REC_I(v, 18);
-    g.pad = REC_I(v, 19);
 }
 
 // all GF components of one centroid (reference order) for one shift residue R
@@ -526,7 +540,8 @@ template <int NG, int T>
 __global__ __launch_bounds__(T) void accumulate_grouped_kernel(
     const float *__restrict__ G, const int2 *__restrict__ span, int pitch,
     const GeoRec *__restrict__ recs, const int *__restrict__ cent_ofs, int isrc0, int nrec,
-    const RecvDev *__restrict__ recv, float *__restrict__ syn, size_t syn_stride, int ntiles)
+    const RecvDev *__restrict__ recv, float *__restrict__ syn, size_t syn_stride, int ntiles,
+    const int *__restrict__ tab)
 {
     constexpr int TILE = 4 * T;                          // samples per workgroup, 4 consecutive per thread
     constexpr int LDS_TILE = TILE + kHalo;
@@ -545,18 +560,21 @@ __global__ __launch_bounds__(T) void accumulate_grouped_kernel(
     const int t_tile0 = rv.wbeg + tile * TILE;
     const int cb = cent_ofs[isrc0], c0 = cent_ofs[isrc0 + s], nc = cent_ofs[isrc0 + s + 1] - c0;
     const GeoRec *__restrict__ rc = recs + ((size_t)(c0 - cb) * nrec + (size_t)r * nc);
+    const int *__restrict__ tc = tab + ((size_t)(c0 - cb) * nrec + (size_t)r * nc) * 128;
     const bool need_h = rv.need_h != 0, has_d = rv.has_d != 0;
     const float sd = rv.sd;
 
     float ar1[4] = { 0.f, 0.f, 0.f, 0.f }, ar2[4] = { 0.f, 0.f, 0.f, 0.f }, dz[4] = { 0.f, 0.f, 0.f, 0.f };
     int c = 0;
     int cur = rec_load(rc, 0, nc, lane);                 // record c, lane-distributed
+    int ta = tc[lane], tb = tc[64 + lane];               // load descriptors of record c
     while (c < nc) {
         GeoRec g0;
         rec_head(cur, g0);
         if (g0.row[0] < 0) {                             // 'cycle' on a missing trace
             c++;
             cur = rec_load(rc, c, nc, lane);
+            if (c < nc) { ta = tc[(size_t)c * 128 + lane]; tb = tc[(size_t)c * 128 + 64 + lane]; }
             continue;
         }
         // ---- the group starting here (hint computed by geometry_kernel)
@@ -573,16 +591,18 @@ __global__ __launch_bounds__(T) void accumulate_grouped_kernel(
         for (int ig = 0; ig < NG; ig++) {
             const bool horiz = (ig <= 4) || (ig == 8);
             if ((horiz && !need_h) || (!horiz && !has_d)) { jend[ig] = 0; continue; }
-            jend[ig] = direct ? group_jend<false>(span, g0, ig) : group_jend<true>(span, g0, ig);
+            jend[ig] = REC_I(ta, 40 + ig);
             jend_min = min(jend_min, jend[ig]);
             if (direct) {
-                build_chunk<false>(tiles[ig], 4 * tid, jb, G, span, pitch, g0, ig);
-                if (4 * (tid + T) < npos) build_chunk<false>(tiles[ig], 4 * (tid + T), jb, G, span, pitch, g0, ig);
+                build_chunk<false>(tiles[ig], 4 * tid, jb, G, pitch, ta, tb, g0, ig);
+                if (4 * (tid + T) < npos) build_chunk<false>(tiles[ig], 4 * (tid + T), jb, G, pitch, ta, tb, g0, ig);
             } else {
-                build_chunk<true>(tiles[ig], 4 * tid, jb, G, span, pitch, g0, ig);
-                if (4 * (tid + T) < npos) build_chunk<true>(tiles[ig], 4 * (tid + T), jb, G, span, pitch, g0, ig);
+                build_chunk<true>(tiles[ig], 4 * tid, jb, G, pitch, ta, tb, g0, ig);
+                if (4 * (tid + T) < npos) build_chunk<true>(tiles[ig], 4 * (tid + T), jb, G, pitch, ta, tb, g0, ig);
             }
         }
+        // descriptors of the NEXT group: in flight while this group is applied
+        if (cend < nc) { ta = tc[(size_t)cend * 128 + lane]; tb = tc[(size_t)cend * 128 + 64 + lane]; }
         __syncthreads();
         // ---- apply: every centroid of the group, in table order (seismogram.f90:131)
         for (int cc = c; cc < cend; cc++) {
