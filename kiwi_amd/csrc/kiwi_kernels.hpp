@@ -463,7 +463,7 @@ __device__ __forceinline__ void build_chunk(float *__restrict__ tile, int p, int
         v[k] = *(const f4u *)(G + (size_t)(unsigned)idx);
     }
     f4u b;
-    if (BLEND) {
+    if constexpr (BLEND) {
         b = g.w[0] * v[0];                    // gfdb.f90:946-949, summed in this order
         b = b + g.w[1] * v[1];
         b = b + g.w[2] * v[2];
@@ -472,6 +472,76 @@ __device__ __forceinline__ void build_chunk(float *__restrict__ tile, int p, int
         b = v[0];
     }
     *(float4 *)(tile + p) = make_float4(b.x, b.y, b.z, b.w);
+}
+
+// Build the main chunk (LDS positions [4*tid, 4*tid+4)) of SEVERAL components at once: all 4*N
+// loads are issued before the first blend so that one L2 round trip is paid per batch, not per
+// component (left to itself the compiler serialises load -> blend -> ds_write per component).
+template <bool BLEND, int N>
+__device__ __forceinline__ void build_batch(float *__restrict__ tile0, int lds_tile, const int (&igs)[N], int p, int jb,
+                                            const float *__restrict__ G, int pitch, int ta, int tb, const GeoRec &g)
+{
+    const int j = jb + p;
+    f4u v[N][BLEND ? 4 : 1];
+#pragma unroll
+    for (int q = 0; q < N; q++) {
+#pragma unroll
+        for (int k = 0; k < (BLEND ? 4 : 1); k++) {
+            const int base = REC_I(ta, 4 * igs[q] + k), lo = REC_I(tb, 4 * igs[q] + k);
+            const int idx = min(max(base + j, lo), lo + pitch - 4);
+            v[q][k] = *(const f4u *)(G + (size_t)(unsigned)idx);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < N; q++) {
+        f4u b;
+        if constexpr (BLEND) {
+            b = g.w[0] * v[q][0];             // gfdb.f90:946-949, summed in this order
+            b = b + g.w[1] * v[q][1];
+            b = b + g.w[2] * v[q][2];
+            b = b + g.w[3] * v[q][3];
+        } else {
+            b = v[q][0];
+        }
+        *(float4 *)(tile0 + igs[q] * lds_tile + p) = make_float4(b.x, b.y, b.z, b.w);
+    }
+}
+
+// The halo chunks (LDS positions >= 4*T, a handful per component) of ALL components in one pass:
+// item = chunk * NG + ig is spread over the lanes of wave 0, each lane fetching its own component's
+// descriptors from the lane-distributed tables with a cross-lane read.
+template <bool BLEND, int NG>
+__device__ __forceinline__ void build_halo(float *__restrict__ tile0, int lds_tile, int first_pos, int npos, int lane,
+                                           int jb, const float *__restrict__ G, int pitch, int ta, int tb,
+                                           const GeoRec &g, bool need_h, bool has_d)
+{
+    const int nchunk = (npos - first_pos + 3) >> 2;
+    for (int item = lane; item < nchunk * NG; item += 64) {
+        const int ch = item / NG, ig = item - ch * NG;
+        const bool horiz = (ig <= 4) || (ig == 8);
+        const bool act = horiz ? need_h : has_d;
+        const int p = first_pos + 4 * ch;
+        const int j = jb + p;
+        f4u v[BLEND ? 4 : 1];
+#pragma unroll
+        for (int k = 0; k < (BLEND ? 4 : 1); k++) {
+            const int base = __shfl(ta, 4 * ig + k), lo = __shfl(tb, 4 * ig + k);
+            const int idx = min(max(base + j, lo), lo + pitch - 4);
+            if (act) v[k] = *(const f4u *)(G + (size_t)(unsigned)idx);
+        }
+        if (act) {
+            f4u b;
+            if constexpr (BLEND) {
+                b = g.w[0] * v[0];
+                b = b + g.w[1] * v[1];
+                b = b + g.w[2] * v[2];
+                b = b + g.w[3] * v[3];
+            } else {
+                b = v[0];
+            }
+            *(float4 *)(tile0 + ig * lds_tile + p) = make_float4(b.x, b.y, b.z, b.w);
+        }
+    }
 }
 
 // one GF component of one centroid from its LDS tile onto this lane's 4 consecutive samples.
@@ -516,7 +586,7 @@ __device__ __forceinline__ void centroid_apply(float (&ar1)[4], float (&ar2)[4],
         if (flags & 2) {                         // seismogram.f90:160-203
             float t1[4] = { 0.f, 0.f, 0.f, 0.f }, t2[4] = { 0.f, 0.f, 0.f, 0.f };
             TADD(t1, 0, f0); TADD(t1, 1, f1); TADD(t1, 2, f2);
-            if (NG == 10) TADD(t1, 8, f5);
+            if constexpr (NG == 10) TADD(t1, 8, f5);
             TADD(t2, 3, f3); TADD(t2, 4, f4);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -525,13 +595,13 @@ __device__ __forceinline__ void centroid_apply(float (&ar1)[4], float (&ar2)[4],
             }
         } else {                                 // seismogram.f90:205-231
             TADD(ar1, 0, f0); TADD(ar1, 1, f1); TADD(ar1, 2, f2);
-            if (NG == 10) TADD(ar1, 8, f5);
+            if constexpr (NG == 10) TADD(ar1, 8, f5);
             TADD(ar2, 3, f3); TADD(ar2, 4, f4);
         }
     }
     if (has_d) {                                 // seismogram.f90:236-253
         TADD(dz, 5, f0 * sd); TADD(dz, 6, f1 * sd); TADD(dz, 7, f2 * sd);
-        if (NG == 10) TADD(dz, 9, f5 * sd);
+        if constexpr (NG == 10) TADD(dz, 9, f5 * sd);
     }
 #undef TADD
 }
@@ -586,19 +656,51 @@ __global__ __launch_bounds__(T) void accumulate_grouped_kernel(
         const bool direct = (g0.flags & 1) != 0;
         int jend[NG];
         int jend_min = 0x7fffffff;
-        // ---- build: blend every needed component once
+        // ---- build: blend every needed component once (batched loads, see build_batch)
 #pragma unroll
         for (int ig = 0; ig < NG; ig++) {
             const bool horiz = (ig <= 4) || (ig == 8);
             if ((horiz && !need_h) || (!horiz && !has_d)) { jend[ig] = 0; continue; }
             jend[ig] = REC_I(ta, 40 + ig);
             jend_min = min(jend_min, jend[ig]);
-            if (direct) {
-                build_chunk<false>(tiles[ig], 4 * tid, jb, G, pitch, ta, tb, g0, ig);
-                if (4 * (tid + T) < npos) build_chunk<false>(tiles[ig], 4 * (tid + T), jb, G, pitch, ta, tb, g0, ig);
+        }
+        {
+            float *tile0 = &tiles[0][0];
+            constexpr int H1 = NG / 2;
+            int igA[H1], igB[NG - H1];
+#pragma unroll
+            for (int q = 0; q < H1; q++) igA[q] = q;
+#pragma unroll
+            for (int q = 0; q < NG - H1; q++) igB[q] = H1 + q;
+            if (need_h && has_d) {
+                if (direct) { build_batch<false>(tile0, LDS_TILE, igA, 4 * tid, jb, G, pitch, ta, tb, g0);
+                              build_batch<false>(tile0, LDS_TILE, igB, 4 * tid, jb, G, pitch, ta, tb, g0); }
+                else        { build_batch<true>(tile0, LDS_TILE, igA, 4 * tid, jb, G, pitch, ta, tb, g0);
+                              build_batch<true>(tile0, LDS_TILE, igB, 4 * tid, jb, G, pitch, ta, tb, g0); }
+            } else if (need_h) {
+                if constexpr (NG == 10) {
+                    const int igH[6] = { 0, 1, 2, 3, 4, 8 };                 // horizontals only
+                    if (direct) build_batch<false>(tile0, LDS_TILE, igH, 4 * tid, jb, G, pitch, ta, tb, g0);
+                    else        build_batch<true>(tile0, LDS_TILE, igH, 4 * tid, jb, G, pitch, ta, tb, g0);
+                } else {
+                    const int igH[5] = { 0, 1, 2, 3, 4 };
+                    if (direct) build_batch<false>(tile0, LDS_TILE, igH, 4 * tid, jb, G, pitch, ta, tb, g0);
+                    else        build_batch<true>(tile0, LDS_TILE, igH, 4 * tid, jb, G, pitch, ta, tb, g0);
+                }
             } else {
-                build_chunk<true>(tiles[ig], 4 * tid, jb, G, pitch, ta, tb, g0, ig);
-                if (4 * (tid + T) < npos) build_chunk<true>(tiles[ig], 4 * (tid + T), jb, G, pitch, ta, tb, g0, ig);
+                if constexpr (NG == 10) {
+                    const int igD[4] = { 5, 6, 7, 9 };                       // vertical only
+                    if (direct) build_batch<false>(tile0, LDS_TILE, igD, 4 * tid, jb, G, pitch, ta, tb, g0);
+                    else        build_batch<true>(tile0, LDS_TILE, igD, 4 * tid, jb, G, pitch, ta, tb, g0);
+                } else {
+                    const int igD[3] = { 5, 6, 7 };
+                    if (direct) build_batch<false>(tile0, LDS_TILE, igD, 4 * tid, jb, G, pitch, ta, tb, g0);
+                    else        build_batch<true>(tile0, LDS_TILE, igD, 4 * tid, jb, G, pitch, ta, tb, g0);
+                }
+            }
+            if (tid < 64) {          // wave 0: halo chunks of all components
+                if (direct) build_halo<false, NG>(tile0, LDS_TILE, TILE, npos, lane, jb, G, pitch, ta, tb, g0, need_h, has_d);
+                else        build_halo<true, NG>(tile0, LDS_TILE, TILE, npos, lane, jb, G, pitch, ta, tb, g0, need_h, has_d);
             }
         }
         // descriptors of the NEXT group: in flight while this group is applied
