@@ -553,8 +553,13 @@ template <int R, bool TAIL>
 __device__ __forceinline__ void tile_add(float (&out)[4], const float *__restrict__ chunk, int jl, int jend,
                                          float factor, float wfrac)
 {
-    const float4 A = *(const float4 *)chunk;
-    const float4 B = *(const float4 *)(chunk + 4);
+    // volatile: keeps the two loads whole ds_read_b128 (conflict-free at 16 B per lane); left alone the
+    // compiler narrows them to the 5 elements used (ds_read2_b32 / ds_read_b64), which at a 16-byte
+    // lane stride are 4-way bank conflicts
+    typedef float f4a __attribute__((ext_vector_type(4)));
+    typedef const volatile __attribute__((address_space(3))) f4a *lds_f4p;      // explicit LDS address space
+    const f4a A = *(lds_f4p)(const __attribute__((address_space(3))) float *)chunk;
+    const f4a B = *(lds_f4p)(const __attribute__((address_space(3))) float *)(chunk + 4);
     const float x[8] = { A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w };
     float wr = wfrac;
     float wl = 1.f - wr;
