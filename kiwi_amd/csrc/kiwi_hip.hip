@@ -117,6 +117,7 @@ struct kiwi_hip_ctx {
     int last_isrc0 = 0, last_nsrc = 0, last_chunk0 = 0, last_chunkn = 0;
     int last_proc_which = 0;
     int group_spt = 4;                // samples per thread of the grouped kernel; env KIWI_HIP_GROUP_SPT
+    int group_threads_env = 0;
     int group_threads = 128;          // workgroup size of the grouped kernel (tile = 4x); env KIWI_HIP_GROUP_THREADS
     int accum_mode = 0;               // 0 grouped (LDS-staged), 1 direct; env KIWI_HIP_ACCUM
     int keep_which = 0;               // kiwi_hip_set_keep_synthetics
@@ -326,7 +327,8 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
                 hipLaunchKernelGGL(accumulate_kernel<8>, grid, dim3(256), 0, c->stream, c->G.p, c->span.p, c->gm.pitch,
                                    c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p, c->syn_stride);
         } else {
-            const int T = c->group_threads;
+            // workgroup size: env override, else by window length (halo overhead vs tile fit)
+            const int T = c->group_threads_env ? c->group_threads : (c->max_wlen >= 2048 ? 256 : (c->max_wlen >= 384 ? 128 : 64));
             const int ntiles = (c->max_wlen + 4 * T - 1) / (4 * T);
             dim3 ggrid((unsigned)nsrc, (unsigned)(ntiles * nrec));       // source index fastest (L2 sharing)
 #define KIWI_LAUNCH_GROUPED(NGV, TV)                                                                        \
@@ -406,7 +408,7 @@ int kiwi_hip_init(int device, kiwi_hip_ctx **out)
         HIPCHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         if (const char *m = std::getenv("KIWI_HIP_GROUP_THREADS")) {
             const int v = std::atoi(m);
-            if (v == 64 || v == 128 || v == 256) c->group_threads = v;
+            if (v == 64 || v == 128 || v == 256) { c->group_threads = v; c->group_threads_env = 1; }
         }
         if (const char *m = std::getenv("KIWI_HIP_GROUP_SPT")) {
             const int v = std::atoi(m);

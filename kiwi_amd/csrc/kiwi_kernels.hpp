@@ -507,43 +507,6 @@ __device__ __forceinline__ void build_batch(float *__restrict__ tile0, int lds_t
     }
 }
 
-// The halo chunks (LDS positions >= 4*T, a handful per component) of ALL components in one pass:
-// item = chunk * NG + ig is spread over the lanes of wave 0, each lane fetching its own component's
-// descriptors from the lane-distributed tables with a cross-lane read.
-template <bool BLEND, int NG>
-__device__ __forceinline__ void build_halo(float *__restrict__ tile0, int lds_tile, int first_pos, int npos, int lane,
-                                           int jb, const float *__restrict__ G, int pitch, int ta, int tb,
-                                           const GeoRec &g, bool need_h, bool has_d)
-{
-    const int nchunk = (npos - first_pos + 3) >> 2;
-    for (int item = lane; item < nchunk * NG; item += 64) {
-        const int ch = item / NG, ig = item - ch * NG;
-        const bool horiz = (ig <= 4) || (ig == 8);
-        const bool act = horiz ? need_h : has_d;
-        const int p = first_pos + 4 * ch;
-        const int j = jb + p;
-        f4u v[BLEND ? 4 : 1];
-#pragma unroll
-        for (int k = 0; k < (BLEND ? 4 : 1); k++) {
-            const int base = __shfl(ta, 4 * ig + k), lo = __shfl(tb, 4 * ig + k);
-            const int idx = min(max(base + j, lo), lo + pitch - 4);
-            if (act) v[k] = *(const f4u *)(G + (size_t)(unsigned)idx);
-        }
-        if (act) {
-            f4u b;
-            if constexpr (BLEND) {
-                b = g.w[0] * v[0];
-                b = b + g.w[1] * v[1];
-                b = b + g.w[2] * v[2];
-                b = b + g.w[3] * v[3];
-            } else {
-                b = v[0];
-            }
-            *(float4 *)(tile0 + ig * lds_tile + p) = make_float4(b.x, b.y, b.z, b.w);
-        }
-    }
-}
-
 // one GF component of one centroid from its LDS tile onto this lane's 4 consecutive samples.
 // The lane needs the 5 blended samples b[j-1..j+3] that sit at LDS positions 4*tid + e + (0..4),
 // e = smax - ishift >= 0 (workgroup-uniform).  With e = 4a + R they are elements R..R+4 of the two
@@ -703,9 +666,26 @@ __global__ __launch_bounds__(T) void accumulate_grouped_kernel(
                     else        build_batch<true>(tile0, LDS_TILE, igD, 4 * tid, jb, G, pitch, ta, tb, g0);
                 }
             }
-            if (tid < 64) {          // wave 0: halo chunks of all components
-                if (direct) build_halo<false, NG>(tile0, LDS_TILE, TILE, npos, lane, jb, G, pitch, ta, tb, g0, need_h, has_d);
-                else        build_halo<true, NG>(tile0, LDS_TILE, TILE, npos, lane, jb, G, pitch, ta, tb, g0, need_h, has_d);
+            // halo chunks (LDS positions >= TILE, a handful per component): same batched form, the two
+            // component batches split over the first two waves when there are two
+            const int ph = TILE + 4 * lane;
+            const int wave = tid >> 6;
+            if (ph < npos && wave < 2) {
+                if (need_h && has_d) {
+                    const bool doA = (T == 64) || wave == 0, doB = (T == 64) || wave == 1;
+                    if (direct) { if (doA) build_batch<false>(tile0, LDS_TILE, igA, ph, jb, G, pitch, ta, tb, g0);
+                                  if (doB) build_batch<false>(tile0, LDS_TILE, igB, ph, jb, G, pitch, ta, tb, g0); }
+                    else        { if (doA) build_batch<true>(tile0, LDS_TILE, igA, ph, jb, G, pitch, ta, tb, g0);
+                                  if (doB) build_batch<true>(tile0, LDS_TILE, igB, ph, jb, G, pitch, ta, tb, g0); }
+                } else if (wave == 0) {
+#pragma unroll
+                    for (int ig = 0; ig < NG; ig++) {
+                        const bool horiz = (ig <= 4) || (ig == 8);
+                        if ((horiz && !need_h) || (!horiz && !has_d)) continue;
+                        if (direct) build_chunk<false>(tiles[ig], ph, jb, G, pitch, ta, tb, g0, ig);
+                        else        build_chunk<true>(tiles[ig], ph, jb, G, pitch, ta, tb, g0, ig);
+                    }
+                }
             }
         }
         // descriptors of the NEXT group: in flight while this group is applied

@@ -246,3 +246,30 @@ def test_errors_are_reported_not_fatal():
     p.eval()                      # recovers after the setup is completed
     m, n, g = p.get_misfits()
     assert np.all(np.isfinite(m))
+
+
+@pytest.mark.parametrize("bilinear", [False, True])
+def test_long_windows_span_several_tiles(bilinear):
+    """Windows longer than one workgroup tile (the grouped kernel tiles time in 256..1024-sample
+    pieces with an LDS halo): 1400-sample traces, every tile boundary must be seamless."""
+    sc = Scenario(L=1400, nrec=4, bilinear=bilinear, variant="static")
+    e, p = build(sc)
+    trials = synthetic.bilat_strike_sweep(5, step=2.0)
+    trials[3:, 3] += 1200.0
+    m, n, g = oracle_misfits(e, 1, trials)
+    p.set_source_params("bilateral", trials)
+    p.eval()
+    pm, pn, pg = p.get_misfits()
+    assert np.array_equal(pn[0], n[0])
+    assert misfit_close(pm, m), np.max(np.abs(pm - m) / np.abs(m))
+    assert misfit_close(pg, g)
+    e.set_source_params(1, trials[1])
+    e.get_misfits()
+    for ir in (1, 3):
+        for k in (1, 2, 3):
+            lo_o, so = e.synthetic(ir, k, 1)
+            lo_p, sp = p.get_synthetics(1, ir, k, 1)
+            a = max(lo_o, lo_p)
+            b = min(lo_o + len(so), lo_p + len(sp))
+            assert b - a > 1300
+            assert np.max(np.abs(so[a - lo_o:b - lo_o] - sp[a - lo_p:b - lo_p])) <= SYN_RTOL * np.max(np.abs(so))
