@@ -182,6 +182,19 @@ def main():
         acc_s = float(ms[1]) * 1e-3
         bytes_launched = b_eval * args.batch * args.steps           # rank 0's launches
         achieved = bytes_launched / acc_s / 1e9 if acc_s > 0 else 0.0
+        # fabric (L2 <-> Infinity Cache / HBM) bytes per launch from the committed PMC passes of this same
+        # command (profiles/*_summary.json: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE); PMC
+        # counters cannot be collected from inside this process, so this is null when no profile matches
+        traffic = None
+        try:
+            import glob
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json"))):
+                prof = json.load(open(f))
+                tb = prof.get("traffic_bytes_per_launch")
+                if tb and tb.get("batch") and os.environ.get("KIWI_HIP_ACCUM") != "direct":
+                    traffic = tb["total"] * args.batch / tb["batch"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "trial-source misfit evals/s", "value": value, "unit": "evals/s",
             "n_gpus": ngpus, "steps": args.steps, "warmup": args.warmup,
@@ -193,7 +206,7 @@ def main():
                        "trial_sources_per_gpu_per_step": args.batch, "misfits_per_source": nmis,
                        "parallelism": "trial-source shard x%d, all-gather of global misfits" % ngpus},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "accumulate_grouped_kernel<10>" if os.environ.get("KIWI_HIP_ACCUM") != "direct" else "accumulate_kernel<10>", "launches": int(launches[1]),
                          "avg_launch_ms": float(ms[1]) / max(int(launches[1]), 1),
                          "algorithmic_bytes_per_eval": b_eval,
