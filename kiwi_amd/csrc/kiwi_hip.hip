@@ -9,6 +9,9 @@
 #include "kiwi_kernels.hpp"
 
 #include <hip/hip_runtime.h>
+#include <hipfft/hipfft.h>
+#include <map>
+#include <tuple>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -96,6 +99,7 @@ struct kiwi_hip_ctx {
     size_t syn_stride = 0;
     std::vector<CompDev> comps;
     std::vector<float> norm_h;
+    std::vector<float> reft_h;            // tapered references over the windows (host copy)
     DevBuf<RecvDev> recv_d;
     DevBuf<CompDev> comps_d;
     DevBuf<float> reft_d, tw_d, norm_d;
@@ -123,6 +127,18 @@ struct kiwi_hip_ctx {
     int keep_which = 0;               // kiwi_hip_set_keep_synthetics
     int proc_chunk0 = 0, proc_chunkn = 0, proc_which_held = 0;   // what proc_d currently holds
     size_t chunk_bytes_limit = (size_t)3 << 30;
+
+    // spectral / filtered comparator (hipFFT)
+    bool fft_needed = false, fft_ready = false, any_filter = false;
+    int fft_cap = 0;                        // sources per chunk the FFT buffers are sized for
+    size_t fft_floats_per_src = 0, spec_cplx_per_src = 0;
+    struct FftGroup { int ntrans, nrow; long long fft_base, spec_base; };
+    std::vector<FftGroup> fft_groups;
+    std::vector<int> slot_has_filter;
+    DevBuf<int> spanbuf_d;
+    DevBuf<float> fft_d, refamp_d, filtw_d, reffilt_d, zmask_d;
+    DevBuf<float2> spec_d;
+    std::map<std::tuple<int, int, int>, hipfftHandle> plans;     // (ntrans, batch, type) -> plan
 
     std::vector<EventPair> events;
     std::vector<hipEvent_t> event_pool;
@@ -178,10 +194,9 @@ void prepare(kiwi_hip_ctx *c)
     if (!c->have_db) throw std::runtime_error("no database set");
     if (!c->have_origin) throw std::runtime_error("no source location set");
     if (c->recv.empty()) throw std::runtime_error("no receivers set");
-    if (c->method != KIWI_L2NORM && c->method != KIWI_L1NORM && c->method != KIWI_SCALAR_PRODUCT &&
-        c->method != KIWI_PEAK)
-        throw std::runtime_error("misfit method not available in the device comparator yet (time-domain l2norm, "
-                                 "l1norm, scalar_product, peak are)");
+    if (c->method < KIWI_L2NORM || c->method > KIWI_PEAK)
+        throw std::runtime_error("floating_l1norm / floating_l2norm are not available in the device comparator yet");
+    c->fft_ready = false;
     const float dt = c->gm.dt;
     const int hs = fold_halfwidth(c->max_risetime, dt);
     c->halo = hs > 0 ? hs + 2 : 0;
@@ -263,6 +278,7 @@ void prepare(kiwi_hip_ctx *c)
         }
     }
     recfirst.push_back((int)c->comps.size());
+    c->reft_h = reft;
     c->nmis = (int)c->comps.size();
     c->nrec_en = (int)recfirst.size() - 1;
     c->syn_stride = synofs;
@@ -285,6 +301,9 @@ void prepare(kiwi_hip_ctx *c)
         c->misfit_d.ensure((size_t)c->nsrc * c->nmis, &c->dev_bytes);
         c->global_d.ensure((size_t)c->nsrc, &c->dev_bytes);
     }
+    c->any_filter = false;
+    for (auto &r : c->recv) if (r.enabled && r.ncomp > 0 && r.filter.defined()) c->any_filter = true;
+    c->fft_needed = (c->method == KIWI_AMPSPEC_L2NORM || c->method == KIWI_AMPSPEC_L1NORM || c->any_filter);
     c->prepared = true;
 }
 
@@ -293,6 +312,218 @@ void record(kiwi_hip_ctx *c, int kind, hipEvent_t &a)
     a = c->get_event();
     HIPCHECK(hipEventRecord(a, c->stream));
     (void)kind;
+}
+
+
+#define FFTCHECK(expr)                                                                             \
+    do {                                                                                           \
+        hipfftResult r_ = (expr);                                                                  \
+        if (r_ != HIPFFT_SUCCESS) throw HipError(std::string(#expr) + ": hipfft error " + std::to_string((int)r_)); \
+    } while (0)
+
+hipfftHandle get_plan(kiwi_hip_ctx *c, int ntrans, int batch, hipfftType type)
+{
+    auto key = std::make_tuple(ntrans, batch, (int)type);
+    auto it = c->plans.find(key);
+    if (it != c->plans.end()) return it->second;
+    hipfftHandle h;
+    int n[1] = { ntrans };
+    FFTCHECK(hipfftPlanMany(&h, 1, n, nullptr, 1, ntrans, nullptr, 1, ntrans / 2 + 1, type, batch));
+    FFTCHECK(hipfftSetStream(h, c->stream));
+    c->plans[key] = h;
+    return h;
+}
+
+void fft_forward(kiwi_hip_ctx *c, int nsrc)
+{
+    for (auto &g : c->fft_groups)
+        FFTCHECK(hipfftExecR2C(get_plan(c, g.ntrans, nsrc * g.nrow, HIPFFT_R2C), c->fft_d.p + g.fft_base,
+                               (hipfftComplex *)(c->spec_d.p + g.spec_base)));
+}
+
+void fft_backward(kiwi_hip_ctx *c, int nsrc)
+{
+    for (auto &g : c->fft_groups)
+        FFTCHECK(hipfftExecC2R(get_plan(c, g.ntrans, nsrc * g.nrow, HIPFFT_C2R), (hipfftComplex *)(c->spec_d.p + g.spec_base),
+                               c->fft_d.p + g.fft_base));
+}
+
+int next_pow2(int n) { int m = 1; while (m < n) m *= 2; return m; }      // comparator.f90:1111-1118 (integer form)
+
+__global__ void ref_amp_kernel(const float2 *__restrict__ spec, const CompDev *__restrict__ comps,
+                               const float *__restrict__ filtw, float *__restrict__ refamp)
+{
+    const CompDev cd = comps[blockIdx.x];
+    const int nb = cd.ntrans / 2 + 1;
+    const float2 *row = spec + cd.spec_base + (size_t)cd.fft_row * nb;
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) {
+        const float2 z = row[k];
+        refamp[cd.specofs + k] = hypotf(z.x, z.y) * filtw[cd.specofs + k];
+    }
+}
+
+__global__ void ref_filt_kernel(const float *__restrict__ fftbuf, const CompDev *__restrict__ comps,
+                                const float *__restrict__ zmask, float *__restrict__ ref_filt)
+{
+    const CompDev cd = comps[blockIdx.x];
+    const float *row = fftbuf + cd.fft_base + (size_t)cd.fft_row * cd.ntrans;
+    for (int i = threadIdx.x; i < cd.wlen; i += blockDim.x)
+        ref_filt[cd.refofs + i] = (row[i] / (float)cd.ntrans) * zmask[cd.refofs + i];
+}
+
+// Sizes the transforms (natural synthetic spans of the whole batch, comparator.f90:464-486), lays the
+// slots out in batched groups and pushes the REFERENCE probes through the same device pipeline.
+void prepare_fft(kiwi_hip_ctx *c, const std::vector<float> &reft_host)
+{
+    const int nrec = (int)c->recv.size();
+    const float dt = c->gm.dt;
+    // ---- 1. spans of the synthetic strips over all uploaded sources
+    std::vector<int> sb((size_t)nrec * 4);
+    for (int r = 0; r < nrec; r++) { sb[4 * r] = sb[4 * r + 2] = 0x7fffffff; sb[4 * r + 1] = sb[4 * r + 3] = -0x7fffffff; }
+    c->spanbuf_d.ensure(sb.size(), &c->dev_bytes);
+    HIPCHECK(hipMemcpyAsync(c->spanbuf_d.p, sb.data(), sb.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    for (int s0 = 0; s0 < c->nsrc; s0 += 32768) {
+        const int n = std::min(32768, c->nsrc - s0);
+        int maxnc = 0;
+        for (int s = s0; s < s0 + n; s++) maxnc = std::max(maxnc, c->cent_ofs[s + 1] - c->cent_ofs[s]);
+        if (maxnc == 0) continue;
+        EvalParams ep{ c->bilinear, c->xus, c->zus, nrec, s0 };
+        dim3 grid((unsigned)((maxnc * nrec + 255) / 256), (unsigned)n);
+        hipLaunchKernelGGL(geometry_kernel, grid, dim3(256), 0, c->stream, c->cent_d.p, c->centofs_d.p, ep, c->gm,
+                           c->span.p, c->recv_d.p, (GeoRec *)nullptr, (int *)nullptr, c->spanbuf_d.p);
+    }
+    HIPCHECK(hipMemcpyAsync(sb.data(), c->spanbuf_d.p, sb.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    const int hs = fold_halfwidth(c->max_risetime, dt);
+    // ---- 2. transform length per slot
+    std::vector<int> ntr(c->comps.size());
+    std::map<int, int> rows_of;          // ntrans -> rows so far
+    for (size_t m = 0; m < c->comps.size(); m++) {
+        CompDev &cd = c->comps[m];
+        const Receiver &r = c->recv[cd.rec];
+        int k = 0;
+        for (size_t q = 0; q < m; q++) if (c->comps[q].rec == cd.rec) k++;
+        const int f0 = r.ref[k].first, f1 = f0 + (int)r.ref[k].data.size() - 1;
+        const bool vertical = std::abs(r.comp[k]) == 3;
+        int s0 = sb[4 * cd.rec + (vertical ? 2 : 0)], s1 = sb[4 * cd.rec + (vertical ? 3 : 1)];
+        if (s1 < s0) { s0 = f0; s1 = f0; }                          // no centroid contributed
+        if (hs > 0) { s0 -= hs; s1 += hs + 1; }                     // strip_fold grows the strip
+        const int len_ref = f1 - f0 + 1, len_syn = s1 - s0 + 1;
+        const int len_u = std::max(f1, s1) - std::min(f0, s0) + 1;
+        const int minlength = std::max((int)std::ceil(len_ref * 2.f), (int)std::ceil(len_syn * 2.f));
+        ntr[m] = next_pow2(std::max(len_u, minlength));
+        if (ntr[m] < cd.wlen) ntr[m] = next_pow2(cd.wlen);
+        cd.ntrans = ntr[m];
+        cd.fft_row = rows_of[ntr[m]]++;
+    }
+    // ---- 3. groups and capacities
+    c->fft_groups.clear();
+    c->fft_floats_per_src = 0; c->spec_cplx_per_src = 0;
+    for (auto &kv : rows_of) {
+        c->fft_floats_per_src += (size_t)kv.second * kv.first;
+        c->spec_cplx_per_src += (size_t)kv.second * (kv.first / 2 + 1);
+    }
+    const size_t per_src = c->fft_floats_per_src * 4 + c->spec_cplx_per_src * 8;
+    c->fft_cap = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(c->nsrc, 1), c->chunk_bytes_limit / per_src));
+    long long fb = 0, sbase = 0;
+    for (auto &kv : rows_of) {
+        c->fft_groups.push_back({ kv.first, kv.second, fb, sbase });
+        fb += (long long)c->fft_cap * kv.second * kv.first;
+        sbase += (long long)c->fft_cap * kv.second * (kv.first / 2 + 1);
+    }
+    int specofs = 0;
+    c->slot_has_filter.assign(c->comps.size(), 0);
+    for (size_t m = 0; m < c->comps.size(); m++) {
+        CompDev &cd = c->comps[m];
+        for (auto &g : c->fft_groups) if (g.ntrans == cd.ntrans) { cd.fft_nrow = g.nrow; cd.fft_base = g.fft_base; cd.spec_base = g.spec_base; }
+        cd.specofs = specofs;
+        specofs += cd.ntrans / 2 + 1;
+        c->slot_has_filter[m] = c->recv[cd.rec].filter.defined() ? 1 : 0;
+    }
+    c->fft_d.ensure((size_t)fb, &c->dev_bytes);
+    c->spec_d.ensure((size_t)sbase, &c->dev_bytes);
+    // ---- 4. filter weights per bin (plf_taper_array on ones, abscissa j*df, comparator.f90:1224-1228),
+    //         zero/one mask of the taper over the window (:1254-1258), reference FFT input
+    std::vector<float> fw((size_t)specofs, 1.f), zm(reft_host.size(), 1.f);
+    std::vector<float> fin((size_t)c->fft_floats_per_src * 1, 0.f);       // one "source": rows of all groups
+    // host image of the single-source FFT input uses cap = fft_cap bases, so build per group then copy rows
+    for (size_t m = 0; m < c->comps.size(); m++) {
+        const CompDev &cd = c->comps[m];
+        const Receiver &r = c->recv[cd.rec];
+        const int nb = cd.ntrans / 2 + 1;
+        if (r.filter.defined()) {
+            const float df = 1.f / ((float)cd.ntrans * dt);
+            plf_taper_array(r.filter, fw.data() + cd.specofs, 0, nb - 1, df, IP_COS);
+        }
+        plf_taper_array(r.taper, zm.data() + cd.refofs, cd.w0, cd.w0 + cd.wlen - 1, dt, IP_ZERO_ONE);
+    }
+    c->filtw_d.ensure(fw.size(), &c->dev_bytes);
+    c->zmask_d.ensure(zm.size(), &c->dev_bytes);
+    c->refamp_d.ensure(fw.size(), &c->dev_bytes);
+    c->reffilt_d.ensure(zm.size(), &c->dev_bytes);
+    HIPCHECK(hipMemcpyAsync(c->filtw_d.p, fw.data(), fw.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(c->zmask_d.p, zm.data(), zm.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(c->comps_d.p, c->comps.data(), c->comps.size() * sizeof(CompDev), hipMemcpyHostToDevice, c->stream));
+    // reference rows: source index 0 of every group
+    for (size_t m = 0; m < c->comps.size(); m++) {
+        const CompDev &cd = c->comps[m];
+        std::vector<float> row((size_t)cd.ntrans, 0.f);
+        for (int i = 0; i < cd.wlen; i++) row[i] = reft_host[cd.refofs + i];
+        HIPCHECK(hipMemcpyAsync(c->fft_d.p + cd.fft_base + (size_t)cd.fft_row * cd.ntrans, row.data(),
+                                row.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIPCHECK(hipStreamSynchronize(c->stream));      // 'row' is reused
+    }
+    fft_forward(c, 1);
+    hipLaunchKernelGGL(ref_amp_kernel, dim3((unsigned)c->nmis), dim3(256), 0, c->stream, c->spec_d.p, c->comps_d.p,
+                       c->filtw_d.p, c->refamp_d.p);
+    std::vector<float> ra(fw.size()), rf(zm.size());
+    if (c->any_filter) {
+        SpecParams sp{ c->method, dt, c->syn_factor, c->nmis, 0, 1 };
+        (void)sp;
+        hipLaunchKernelGGL(spec_filter_kernel, dim3((unsigned)c->nmis, 1u), dim3(256), 0, c->stream, c->spec_d.p,
+                           c->comps_d.p, c->filtw_d.p);
+        fft_backward(c, 1);
+        hipLaunchKernelGGL(ref_filt_kernel, dim3((unsigned)c->nmis), dim3(256), 0, c->stream, c->fft_d.p, c->comps_d.p,
+                           c->zmask_d.p, c->reffilt_d.p);
+        HIPCHECK(hipMemcpyAsync(rf.data(), c->reffilt_d.p, rf.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHECK(hipMemcpyAsync(ra.data(), c->refamp_d.p, ra.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    // ---- 5. norm factors of the reference (probe_norm, comparator.f90:954-996)
+    const bool spectral = (c->method == KIWI_AMPSPEC_L2NORM || c->method == KIWI_AMPSPEC_L1NORM);
+    for (size_t m = 0; m < c->comps.size(); m++) {
+        const CompDev &cd = c->comps[m];
+        double sum = 0.0, pk = 0.0;
+        if (spectral) {
+            const int nb = cd.ntrans / 2 + 1;
+            const float df = 1.f / ((float)cd.ntrans * dt);
+            for (int k = 0; k < nb; k++) {
+                const float a = ra[cd.specofs + k];
+                sum += (c->method == KIWI_AMPSPEC_L2NORM) ? (double)a * (double)a : (double)std::fabs(a);
+            }
+            c->norm_h[m] = (c->method == KIWI_AMPSPEC_L2NORM) ? 1.f * (float)std::sqrt((double)df * sum)
+                                                               : 1.f * (float)((double)df * sum);
+        } else if (c->slot_has_filter[m]) {
+            for (int i = 0; i < cd.wlen; i++) {
+                const float a = rf[cd.refofs + i];
+                switch (c->method) {
+                case KIWI_L2NORM: sum += (double)a * (double)a; break;
+                case KIWI_L1NORM: sum += (double)std::fabs(a); break;
+                case KIWI_SCALAR_PRODUCT: sum += (double)(a * a); break;
+                default: pk = std::max(pk, (double)std::fabs(a)); break;
+                }
+            }
+            switch (c->method) {
+            case KIWI_L2NORM: c->norm_h[m] = 1.f * (float)std::sqrt((double)dt * sum); break;
+            case KIWI_L1NORM: c->norm_h[m] = 1.f * (float)((double)dt * sum); break;
+            case KIWI_SCALAR_PRODUCT: c->norm_h[m] = (1.f * 1.f) * (float)sum; break;
+            default: c->norm_h[m] = 1.f * (float)pk; break;
+            }
+        }
+    }
+    HIPCHECK(hipMemcpyAsync(c->norm_d.p, c->norm_h.data(), c->norm_h.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    c->fft_ready = true;
 }
 
 void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
@@ -314,7 +545,7 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
     if (maxnc > 0) {
         dim3 grid((unsigned)((maxnc * nrec + 255) / 256), (unsigned)nsrc);
         hipLaunchKernelGGL(geometry_kernel, grid, dim3(256), 0, c->stream, c->cent_d.p, c->centofs_d.p, ep, c->gm,
-                           c->span.p, c->recv_d.p, c->recs_d.p, tab);
+                           c->span.p, c->recv_d.p, c->recs_d.p, tab, (int *)nullptr);
     }
     record(c, 0, e1);
     {
@@ -345,10 +576,28 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
     }
     record(c, 1, e2);
     {
-        MisfitParams mp{ c->method, c->gm.dt, c->syn_factor, c->nmis, isrc0, proc_which };
+        const bool spectral = (c->method == KIWI_AMPSPEC_L2NORM || c->method == KIWI_AMPSPEC_L1NORM);
+        const int td_method = spectral ? KIWI_L2NORM : c->method;
+        const int fft_mode = !c->fft_needed ? 0 : (spectral ? 3 : 1);        // bit0 write FFT input, bit1 skip the norm
+        MisfitParams mp{ td_method, c->gm.dt, c->syn_factor, c->nmis, isrc0, proc_which == 3 ? 0 : proc_which, fft_mode, nsrc };
         hipLaunchKernelGGL(misfit_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream,
                            c->syn_d.p, c->syn_stride, c->comps_d.p, c->reft_d.p, c->tw_d.p, c->moment_d.p,
-                           c->risetime_d.p, mp, c->misfit_d.p, proc);
+                           c->risetime_d.p, mp, c->misfit_d.p, proc_which == 3 ? nullptr : proc, c->fft_d.p);
+        if (c->fft_needed) {
+            SpecParams sp{ c->method, c->gm.dt, c->syn_factor, c->nmis, isrc0, c->any_filter ? 1 : 0 };
+            fft_forward(c, nsrc);
+            if (spectral) {
+                hipLaunchKernelGGL(spec_norm_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream,
+                                   c->spec_d.p, c->comps_d.p, c->refamp_d.p, c->filtw_d.p, sp, c->misfit_d.p);
+            } else {
+                hipLaunchKernelGGL(spec_filter_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream,
+                                   c->spec_d.p, c->comps_d.p, c->filtw_d.p);
+                fft_backward(c, nsrc);
+                hipLaunchKernelGGL(filtered_norm_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream,
+                                   c->fft_d.p, c->comps_d.p, c->reffilt_d.p, c->zmask_d.p, sp, c->misfit_d.p,
+                                   proc_which == 3 ? proc : nullptr, c->syn_stride);
+            }
+        }
         hipLaunchKernelGGL(global_kernel, dim3((unsigned)((nsrc + 127) / 128)), dim3(128), 0, c->stream,
                            c->misfit_d.p, c->norm_d.p, c->recfirst_d.p, c->nrec_en, c->nmis, isrc0, nsrc, c->global_d.p);
     }
@@ -369,6 +618,7 @@ int eval_impl(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
     prepare(c);
     c->misfit_d.ensure((size_t)c->nsrc * c->nmis, &c->dev_bytes);
     c->global_d.ensure((size_t)c->nsrc, &c->dev_bytes);
+    if (c->fft_needed && !c->fft_ready) prepare_fft(c, c->reft_h);
     const int nrec = (int)c->recv.size();
     int s = isrc0;
     while (s < isrc0 + nsrc) {
@@ -379,6 +629,7 @@ int eval_impl(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
             const size_t nc = (size_t)(c->cent_ofs[s + n + 1] - c->cent_ofs[s + n]);
             const size_t add = nc * nrec * (sizeof(GeoRec) + (c->accum_mode == 0 ? 512 : 0)) + c->syn_stride * sizeof(float) * (proc_which ? 2 : 1);
             if (n > 0 && (bytes + add > c->chunk_bytes_limit || n >= 65535)) break;
+            if (c->fft_needed && n >= c->fft_cap) break;
             bytes += add; n++;
         }
         run_chunk(c, s, n, proc_which);
@@ -433,6 +684,7 @@ int kiwi_hip_destroy(kiwi_hip_ctx *c)
         (void)hipEventDestroy(ev.b);
     }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    for (auto &kv : c->plans) (void)hipfftDestroy(kv.second);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -586,7 +838,6 @@ int kiwi_hip_set_taper(kiwi_hip_ctx *c, int irec, int npts, const float *x, cons
 
 int kiwi_hip_set_filter(kiwi_hip_ctx *c, int irec, int npts, const float *x, const float *y)
 {
-    if (npts > 0) return fail(c, "frequency filter not available in the device comparator yet");
     return set_plf(c, irec, npts, x, y, false);
 }
 
@@ -651,6 +902,7 @@ int kiwi_hip_set_sources(kiwi_hip_ctx *c, int nsrc, const int *cent_ofs, const f
     c->max_risetime = maxrise;
     c->last_nsrc = 0;
     c->proc_which_held = 0;
+    c->fft_ready = false;
     return 0;
     GUARD_END(c)
 }
@@ -687,7 +939,7 @@ int kiwi_hip_eval(kiwi_hip_ctx *c, int isrc0, int nsrc)
 
 int kiwi_hip_set_keep_synthetics(kiwi_hip_ctx *c, int which)
 {
-    if (which < 0 || which > 2) return fail(c, "which must be 0 (off), 1 (plain) or 2 (tapered)");
+    if (which < 0 || which > 3) return fail(c, "which must be 0 (off), 1 (plain), 2 (tapered) or 3 (filtered)");
     c->keep_which = which;
     return 0;
 }
@@ -730,7 +982,8 @@ int kiwi_hip_get_synthetics(kiwi_hip_ctx *c, int isrc, int irec, int icomp, int 
                             float *out, int maxn)
 {
     GUARD_BEGIN
-    if (which != 1 && which != 2) throw std::runtime_error("which must be 1 (plain) or 2 (tapered)");
+    if (which < 1 || which > 3) throw std::runtime_error("which must be 1 (plain), 2 (tapered) or 3 (filtered)");
+    if (which == 3) { prepare(c); if (!c->any_filter || c->method == KIWI_AMPSPEC_L2NORM || c->method == KIWI_AMPSPEC_L1NORM) throw std::runtime_error("filtered synthetics need a misfit filter and a time-domain norm"); }
     if (isrc < 0 || isrc >= c->nsrc) throw std::runtime_error("source index out of range");
     if (irec < 1 || irec > (int)c->recv.size()) throw std::runtime_error("receiver index out of range");
     // served from the retained chunk when kiwi_hip_set_keep_synthetics(which) was on during the

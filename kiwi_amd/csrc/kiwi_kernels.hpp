@@ -71,6 +71,13 @@ struct CompDev {
     int w0, wlen;    // misfit window first sample, length
     int refofs;      // offset into reft / tw arrays
     int rec;
+    // spectral / filtered comparator (comparator.f90:1186-1263): transform length of this probe pair and
+    // where its rows live in the FFT buffers (slots with equal ntrans form one batched plan)
+    int ntrans;
+    int fft_row, fft_nrow;       // row of this slot inside its group, rows per source in the group
+    long long fft_base;          // float offset of the group in the real buffer (per chunk: x nsrc rows)
+    long long spec_base;         // complex offset of the group in the spectrum buffer
+    int specofs;                 // offset of this slot's reference amplitude spectrum / filter weights
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -94,7 +101,7 @@ struct EvalParams {
 __global__ __launch_bounds__(256) void geometry_kernel(
     const float *__restrict__ cent, const int *__restrict__ cent_ofs, EvalParams ep, GfMeta gm,
     const int2 *__restrict__ span, const RecvDev *__restrict__ recv, GeoRec *__restrict__ out,
-    int *__restrict__ tab)
+    int *__restrict__ tab, int *__restrict__ spanbuf)
 {
     const int s = blockIdx.y;
     const int c0 = cent_ofs[ep.isrc0 + s], nc = cent_ofs[ep.isrc0 + s + 1] - c0;
@@ -231,6 +238,23 @@ __global__ __launch_bounds__(256) void geometry_kernel(
         }
         g.pad = len | ((smax - g.ishift) << 8) | ((g.ishift - smin) << 16);
     }
+    // natural span of the synthetic strips (seismogram.f90:102-130 + sparse_trace.f90:648-668): union over
+    // centroids of [first + shift, last + shift + 1], horizontals (all share one span, :196-197) and vertical
+    // separately; only needed to size the comparator's FFT (comparator.f90:464-486)
+    if (spanbuf && g.row[0] >= 0) {
+        const int nn = (g.flags & 1) ? 1 : 4;
+        int lo_h = 0x7fffffff, hi_h = -0x7fffffff, lo_d = 0x7fffffff, hi_d = -0x7fffffff;
+        for (int ig = 0; ig < gm.ng; ig++) {
+            const bool horiz = (ig <= 4) || (ig == 8);
+            if ((horiz && !rv.need_h) || (!horiz && !rv.has_d)) continue;
+            int lo = 0x7fffffff, hi = -0x7fffffff;
+            for (int k = 0; k < nn; k++) { const int2 sp = span[g.row[k] + ig]; lo = min(lo, sp.x); hi = max(hi, sp.y); }
+            if (horiz) { lo_h = min(lo_h, lo); hi_h = max(hi_h, hi); } else { lo_d = min(lo_d, lo); hi_d = max(hi_d, hi); }
+        }
+        if (rv.need_h) { atomicMin(&spanbuf[4 * r + 0], lo_h + g.ishift); atomicMax(&spanbuf[4 * r + 1], hi_h + g.ishift + 1); }
+        if (rv.has_d) { atomicMin(&spanbuf[4 * r + 2], lo_d + g.ishift); atomicMax(&spanbuf[4 * r + 3], hi_d + g.ishift + 1); }
+    }
+    if (!out) return;
     const size_t base = (size_t)(c0 - cent_ofs[ep.isrc0]) * ep.nrec + (size_t)r * nc + c;
     out[base] = g;
     // load descriptors for accumulate_grouped_kernel, 128 ints per record, laid out so that one
@@ -760,13 +784,16 @@ struct MisfitParams {
     int nmis;
     int isrc0;
     int write_tapered;   // keep scaled+folded (+tapered) synthetics for get_synthetics
+    int fft_mode;        // 1: write the tapered synthetic zero-padded to ntrans into fftbuf, no norm
+    int chunk_nsrc;      // sources in this launch (row stride of the FFT groups)
 };
 
 __global__ __launch_bounds__(256) void misfit_kernel(
     const float *__restrict__ syn, size_t syn_stride, const CompDev *__restrict__ comps,
     const float *__restrict__ reft, const float *__restrict__ tw,
     const float *__restrict__ moment, const float *__restrict__ risetime, MisfitParams mp,
-    float *__restrict__ misfit_out, float *__restrict__ proc /* optional [src][stride] processed synthetics */)
+    float *__restrict__ misfit_out, float *__restrict__ proc /* optional [src][stride] processed synthetics */,
+    float *__restrict__ fftbuf)
 {
     const int m = blockIdx.x, s = blockIdx.y;
     const CompDev cd = comps[m];
@@ -808,6 +835,11 @@ __global__ __launch_bounds__(256) void misfit_kernel(
     const bool unit = (mp.syn_factor == 1.f);
     double acc = 0.0;
     double peak = 0.0;
+    float *__restrict__ frow = nullptr;
+    if (mp.fft_mode) {
+        frow = fftbuf + cd.fft_base + ((size_t)s * cd.fft_nrow + cd.fft_row) * cd.ntrans;
+        for (int i = cd.wlen + threadIdx.x; i < cd.ntrans; i += 256) frow[i] = 0.f;      // zero padding
+    }
     for (int i = threadIdx.x; i < cd.wlen; i += 256) {
         float v;
         if (nf > 0) {                             // strip_fold, sparse_trace.f90:379-402
@@ -825,6 +857,7 @@ __global__ __launch_bounds__(256) void misfit_kernel(
         v = v * mom;                              // probe_set_array(..., factor_=moment), comparator.f90:264
         const float vt = v * tp[i];               // make_array_tapered, comparator.f90:1173-1184
         if (proc) proc[(size_t)s * syn_stride + cd.synofs + cd.halo + i] = mp.write_tapered == 2 ? vt : v;
+        if (frow) { frow[i] = vt; continue; }
         const float a = rt[i];
         switch (mp.method) {
         case 1: {                                 // l2norm_func, comparator.f90:650-659
@@ -840,6 +873,7 @@ __global__ __launch_bounds__(256) void misfit_kernel(
             peak = fmax(peak, sqrt(x * x + y * y)); break; }
         }
     }
+    if (mp.fft_mode) return;
     red[threadIdx.x] = (mp.method == 6) ? peak : acc;
     __syncthreads();
     for (int st = 128; st > 0; st >>= 1) {
@@ -859,6 +893,129 @@ __global__ __launch_bounds__(256) void misfit_kernel(
         default: res = (float)tot; break;
         }
         misfit_out[(size_t)(mp.isrc0 + s) * mp.nmis + m] = res;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// spectral comparator (comparator.f90:861-886,1186-1231): amplitude spectra from a batched hipFFT r2c
+// of the tapered, zero-padded synthetics; optional cosine-PLF frequency filter; fp64 accumulation.
+
+struct SpecParams {
+    int method;          // 3 ampspec_l2norm, 4 ampspec_l1norm; or a time-domain id when filtering (1,2,5,6)
+    float dt;
+    float syn_factor;
+    int nmis, isrc0;
+    int has_filter;
+};
+
+__device__ __forceinline__ double block_sum(double v, double *red)
+{
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    return red[0];
+}
+
+__global__ __launch_bounds__(256) void spec_norm_kernel(
+    const float2 *__restrict__ spec, const CompDev *__restrict__ comps, const float *__restrict__ refamp,
+    const float *__restrict__ filtw, SpecParams sp, float *__restrict__ misfit_out)
+{
+    __shared__ double red[256];
+    const int m = blockIdx.x, s = blockIdx.y;
+    const CompDev cd = comps[m];
+    const int nb = cd.ntrans / 2 + 1;
+    const float2 *__restrict__ row = spec + cd.spec_base + ((size_t)s * cd.fft_nrow + cd.fft_row) * nb;
+    const float *__restrict__ ra = refamp + cd.specofs;
+    const float *__restrict__ fw = filtw + cd.specofs;
+    const bool unit = (sp.syn_factor == 1.f);
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < nb; k += 256) {
+        const float2 z = row[k];
+        float b = hypotf(z.x, z.y);                       // amp_spectrum = abs(spectrum), comparator.f90:1213
+        if (sp.has_filter) b = b * fw[k];                 // make_spectrum_filtered, :1226-1228
+        const float a = ra[k];                            // reference, already filtered
+        if (sp.method == 3) {                             // l2norm_func on amplitude spectra
+            const float d = unit ? (a - b) : (1.f * a - sp.syn_factor * b);
+            acc += (double)d * (double)d;
+        } else {
+            const float d = unit ? fabsf(a - b) : fabsf(1.f * a - sp.syn_factor * b);
+            acc += (double)d;
+        }
+    }
+    const double tot = block_sum(acc, red);
+    if (threadIdx.x == 0) {
+        const float df = 1.f / ((float)cd.ntrans * sp.dt);               // comparator.f90:1215
+        misfit_out[(size_t)(sp.isrc0 + s) * sp.nmis + m] =
+            (sp.method == 3) ? (float)sqrt((double)df * tot) : (float)((double)df * tot);
+    }
+}
+
+// spectrum_filtered = spectrum * filter(j df) (comparator.f90:1224-1225), in place, before the c2r
+__global__ __launch_bounds__(256) void spec_filter_kernel(float2 *__restrict__ spec, const CompDev *__restrict__ comps,
+                                                          const float *__restrict__ filtw)
+{
+    const int m = blockIdx.x, s = blockIdx.y;
+    const CompDev cd = comps[m];
+    const int nb = cd.ntrans / 2 + 1;
+    float2 *__restrict__ row = spec + cd.spec_base + ((size_t)s * cd.fft_nrow + cd.fft_row) * nb;
+    const float *__restrict__ fw = filtw + cd.specofs;
+    for (int k = threadIdx.x; k < nb; k += 256) {
+        float2 z = row[k];
+        z.x = z.x * fw[k]; z.y = z.y * fw[k];
+        row[k] = z;
+    }
+}
+
+// time-domain norms on the filtered traces (comparator.f90:810-813,1233-1263): c2r output / ntrans, zeroed
+// where the taper is zero (ip_zero_one mask), against the reference processed the same way
+__global__ __launch_bounds__(256) void filtered_norm_kernel(
+    const float *__restrict__ fftbuf, const CompDev *__restrict__ comps, const float *__restrict__ ref_filt,
+    const float *__restrict__ zmask, SpecParams sp, float *__restrict__ misfit_out, float *__restrict__ proc,
+    size_t syn_stride)
+{
+    __shared__ double red[256];
+    const int m = blockIdx.x, s = blockIdx.y;
+    const CompDev cd = comps[m];
+    const float *__restrict__ row = fftbuf + cd.fft_base + ((size_t)s * cd.fft_nrow + cd.fft_row) * cd.ntrans;
+    const float *__restrict__ rf = ref_filt + cd.refofs;
+    const float *__restrict__ zm = zmask + cd.refofs;
+    const bool unit = (sp.syn_factor == 1.f);
+    double acc = 0.0, peak = 0.0;
+    for (int i = threadIdx.x; i < cd.wlen; i += 256) {
+        float v = row[i] / (float)cd.ntrans;              // normalize result, comparator.f90:1251
+        v = v * zm[i];                                    // :1254-1258
+        if (proc) proc[(size_t)s * syn_stride + cd.synofs + cd.halo + i] = v;
+        const float a = rf[i];
+        switch (sp.method) {
+        case 1: { const float d = unit ? (a - v) : (1.f * a - sp.syn_factor * v); acc += (double)d * (double)d; break; }
+        case 2: { const float d = unit ? fabsf(a - v) : fabsf(1.f * a - sp.syn_factor * v); acc += (double)d; break; }
+        case 5: acc += unit ? (double)(a * v) : (double)(a * 1.f * v * sp.syn_factor); break;
+        default: { const double x = (double)(1.f * a), y = (double)(sp.syn_factor * v); peak = fmax(peak, sqrt(x * x + y * y)); break; }
+        }
+    }
+    double tot;
+    if (sp.method == 6) {
+        red[threadIdx.x] = peak;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (threadIdx.x < st) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + st]);
+            __syncthreads();
+        }
+        tot = red[0];
+    } else {
+        tot = block_sum(acc, red);
+    }
+    if (threadIdx.x == 0) {
+        float res;
+        switch (sp.method) {
+        case 1: res = (float)sqrt((double)sp.dt * tot); break;
+        case 2: res = (float)((double)sp.dt * tot); break;
+        default: res = (float)tot; break;
+        }
+        misfit_out[(size_t)(sp.isrc0 + s) * sp.nmis + m] = res;
     }
 }
 

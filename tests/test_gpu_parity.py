@@ -273,3 +273,78 @@ def test_long_windows_span_several_tiles(bilinear):
             b = min(lo_o + len(so), lo_p + len(sp))
             assert b - a > 1300
             assert np.max(np.abs(so[a - lo_o:b - lo_o] - sp[a - lo_p:b - lo_p])) <= SYN_RTOL * np.max(np.abs(so))
+
+
+@pytest.mark.parametrize("ng", [8, 10])
+@pytest.mark.parametrize("us", [(1, 1), (2, 2)])
+def test_far_field_db_and_spatial_undersampling(ng, us):
+    """ng = 8 (far-field only database, gfdb.f90:57: the f6 / near-field terms drop out) and
+    set_spacial_undersampling (gfdb.f90:794-815: bilinear nodes xus / zus grid steps apart)."""
+    sc = Scenario(ng=ng, nx=12, nz=6)
+    e, p = build(sc)
+    e.set_interpolation(True, us[0], us[1])
+    p.set_spacial_undersampling(us[0], us[1])
+    trials = synthetic.bilat_strike_sweep(4, step=2.0)
+    m, n, g = oracle_misfits(e, 1, trials)
+    p.set_source_params("bilateral", trials)
+    p.eval()
+    pm, pn, pg = p.get_misfits()
+    assert misfit_close(pm, m), np.max(np.abs(pm - m) / np.abs(m))
+    assert misfit_close(pg, g)
+
+
+SPEC_RTOL = 1e-5      # ampspec / filtered norms: FFT libraries differ (hipFFT fp32 vs the oracle's fp64 DFT rounded to fp32)
+
+
+@pytest.mark.parametrize("method", ["ampspec_l2norm", "ampspec_l1norm"])
+@pytest.mark.parametrize("with_filter", [False, True])
+def test_spectral_norms(method, with_filter):
+    """comparator.f90:861-886,1186-1231 on hipFFT: amplitude-spectrum norms, optional frequency filter."""
+    sc = Scenario()
+    e, p = build(sc)
+    mid = {"ampspec_l2norm": 3, "ampspec_l1norm": 4}[method]
+    e.set_misfit_method(mid)
+    p.set_misfit_method(method)
+    if with_filter:
+        fx, fy = [0.01, 0.03, 0.25, 0.4], [0., 1., 1., 0.]
+        for ir in range(1, sc.nrec + 1):
+            e.set_filter(ir, fx, fy)
+            p.set_misfit_filter(ir, fx, fy)
+    trials = synthetic.bilat_strike_sweep(5, step=2.0)
+    m, n, g = oracle_misfits(e, 1, trials)
+    p.set_source_params("bilateral", trials)
+    p.eval()
+    pm, pn, pg = p.get_misfits()
+    assert np.allclose(pn[0], n[0], rtol=SPEC_RTOL, atol=0)
+    assert np.allclose(pm, m, rtol=SPEC_RTOL, atol=1e-7 * np.abs(n[0]).max()), np.max(np.abs(pm - m) / np.abs(m))
+    assert np.allclose(pg, g, rtol=SPEC_RTOL)
+
+
+@pytest.mark.parametrize("method", ["l2norm", "l1norm"])
+def test_time_domain_norms_with_frequency_filter(method):
+    """comparator.f90:810-813,1233-1263: r2c -> cosine PLF filter -> c2r / ntrans -> zero outside the taper."""
+    sc = Scenario()
+    e, p = build(sc, method)
+    fx, fy = [0.01, 0.03, 0.25, 0.4], [0., 1., 1., 0.]
+    for ir in range(1, sc.nrec + 1):
+        if ir != 2:                       # receiver 2 stays unfiltered: both paths in one batch
+            e.set_filter(ir, fx, fy)
+            p.set_misfit_filter(ir, fx, fy)
+    trials = synthetic.bilat_strike_sweep(4, step=2.5)
+    m, n, g = oracle_misfits(e, 1, trials)
+    p.set_source_params("bilateral", trials)
+    p.eval()
+    pm, pn, pg = p.get_misfits()
+    assert np.array_equal(pn[0][3:6], n[0][3:6])              # unfiltered receiver: host-side, exact
+    assert misfit_close(pm[:, 3:6], m[:, 3:6])
+    assert np.allclose(pn[0], n[0], rtol=SPEC_RTOL)
+    assert np.allclose(pm, m, rtol=SPEC_RTOL, atol=1e-7 * np.abs(n[0]).max()), np.max(np.abs(pm - m) / np.abs(m))
+    assert np.allclose(pg, g, rtol=SPEC_RTOL)
+    e.set_source_params(1, trials[1])
+    e.get_misfits()
+    lo_o, so = e.synthetic(1, 3, 3)
+    lo_p, sp = p.get_synthetics(1, 1, 3, 3)
+    a = max(lo_o, lo_p)
+    b = min(lo_o + len(so), lo_p + len(sp))
+    assert b - a > 200
+    assert np.max(np.abs(so[a - lo_o:b - lo_o] - sp[a - lo_p:b - lo_p])) <= 2e-5 * np.max(np.abs(so))
