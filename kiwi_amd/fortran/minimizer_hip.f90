@@ -1,0 +1,727 @@
+! minimizer_hip.f90 -- a Fortran host speaking Kiwi's `minimizer` stdin/stdout command protocol
+! (minimizer.f90:1676-1701,1729-1811) on top of the MI355X engine (include/kiwi_hip.h, through
+! kiwi_hip_binding.f90).  Written from the protocol description, not from the reference's host:
+! one command per line, '#' starts a comment, blanks collapse; answers are "<cmd>: ok",
+! "<cmd>: ok >" + answer line, "<cmd>: nok" or "<cmd>: nok >" + error line, flushed after each.
+!
+! Commands (the subset SURVEY.md 8b lists for the hot path):
+!   set_database <base>                    reads <base>.kiwiflat (flat dense GFDB, see read_flat_gfdb)
+!   set_effective_dt <dt>
+!   set_local_interpolation nearest_neighbor|bilinear
+!   set_spacial_undersampling <nx> <nz>
+!   set_receivers <file> [has_depth]       lines: lat lon [depth] components
+!   switch_receiver <i> on|off
+!   set_source_location <lat> <lon> <reftime>
+!   set_source_params <type> p1 .. pn      bilateral | circular | moment_tensor
+!   set_ref_seismograms <base> table       files <base>-<irec>-<comp>.table (time value)
+!   set_misfit_method <name>;  set_misfit_taper <i> x y ..;  set_misfit_filter <i> x y ..
+!   set_synthetics_factor <f>
+!   get_misfits;  get_global_misfit
+!   output_seismograms <base> table synthetics [plain|tapered|filtered]
+!   output_distances <file>
+!   set_verbose, set_ignore_sigint         accepted, no effect
+! Batch extension (SURVEY.md 8f-1), one pipe round trip for a whole grid:
+!   eval_sources <type> <paramfile> <outfile>   one parameter vector per line in; per source
+!                                               "global m1 n1 m2 n2 .." out; answers the number of sources
+
+program minimizer_hip
+
+    use iso_c_binding
+    use kiwi_hip_binding
+    implicit none
+
+    integer, parameter :: maxline = 262144
+    character(len=maxline) :: line, args
+    character(len=64) :: command
+    character(len=:), allocatable :: answer, errstr
+    type(c_ptr) :: ctx
+    integer :: iostat, rc
+    logical :: ok, have_ctx
+
+  ! engine-side bookkeeping the host needs for file names and answers
+    integer :: nreceivers = 0
+    character(len=8), allocatable :: components(:)
+    logical, allocatable :: enabled(:)
+    real(c_float) :: db_dt = 0.
+    real(c_double) :: ref_time = 0.d0
+    real(c_float) :: effective_dt = 1.
+    logical :: source_set = .false., evaluated = .false.
+    integer(c_int) :: cur_bilinear = 0, cur_xus = 1, cur_zus = 1
+
+    ctx = c_null_ptr
+    have_ctx = .false.
+
+    stdinloop: do
+        read (*,'(a)',iostat=iostat) line
+        if (iostat /= 0) exit stdinloop
+        call reduce_whitespace( line )
+        if (len_trim(line) == 0) cycle
+        call split_first( line, command, args )
+        answer = ''
+        errstr = ''
+        call do_command( trim(command), trim(args), ok )
+        if (ok) then
+            if (len(answer) == 0) then
+                write (*,'(a)') trim(command)//': ok'
+            else
+                write (*,'(a)') trim(command)//': ok >'
+                write (*,'(a)') answer
+            end if
+        else
+            if (len(errstr) == 0) then
+                write (*,'(a)') trim(command)//': nok'
+            else
+                write (*,'(a)') trim(command)//': nok >'
+                write (*,'(a)') errstr
+            end if
+        end if
+        flush (6)
+    end do stdinloop
+
+    if (have_ctx) rc = kiwi_hip_destroy( ctx )
+
+  contains
+
+    subroutine reduce_whitespace( s )
+        character(len=*), intent(inout) :: s
+        character(len=len(s)) :: b
+        integer :: i, j
+        logical :: ws
+        b = ''
+        j = 1
+        ws = .true.
+        do i = 1, len_trim(s)
+            if (s(i:i) == '#') exit
+            if (s(i:i) /= ' ' .and. s(i:i) /= char(9)) then
+                b(j:j) = s(i:i); j = j + 1; ws = .false.
+            else if (.not. ws) then
+                b(j:j) = ' '; j = j + 1; ws = .true.
+            end if
+        end do
+        s = b
+    end subroutine
+
+    subroutine split_first( s, first, rest )
+        character(len=*), intent(in) :: s
+        character(len=*), intent(out) :: first, rest
+        integer :: i
+        i = index( trim(s), ' ' )
+        if (i == 0) then
+            first = trim(s); rest = ''
+        else
+            first = s(1:i-1); rest = adjustl(s(i+1:))
+        end if
+    end subroutine
+
+    integer function count_words( s )
+        character(len=*), intent(in) :: s
+        integer :: i
+        logical :: inword
+        count_words = 0
+        inword = .false.
+        do i = 1, len_trim(s)
+            if (s(i:i) /= ' ') then
+                if (.not. inword) count_words = count_words + 1
+                inword = .true.
+            else
+                inword = .false.
+            end if
+        end do
+    end function
+
+    subroutine fail( msg )
+        character(len=*), intent(in) :: msg
+        errstr = msg
+    end subroutine
+
+  ! turn a C-ABI return code into ok / error text
+    logical function check( rc_ )
+        integer(c_int), intent(in) :: rc_
+        check = (rc_ == 0)
+        if (.not. check) errstr = kiwi_hip_error_message( ctx )
+    end function
+
+    logical function need_ctx()
+        integer(c_int) :: rc_
+        need_ctx = .true.
+        if (have_ctx) return
+        rc_ = kiwi_hip_init( 0_c_int, ctx )
+        if (rc_ /= 0) then
+            errstr = kiwi_hip_error_message( c_null_ptr )
+            need_ctx = .false.
+            return
+        end if
+        have_ctx = .true.
+    end function
+
+    integer function source_type_id( name )
+        character(len=*), intent(in) :: name
+        select case (name)                     ! source_all.f90:88-98 / parameterized_source.f90:45-50
+        case ('bilateral');     source_type_id = 1
+        case ('circular');      source_type_id = 2
+        case ('point_lp');      source_type_id = 3
+        case ('eikonal');       source_type_id = 4
+        case ('mt_eikonal');    source_type_id = 5
+        case ('moment_tensor'); source_type_id = 6
+        case default;           source_type_id = 0
+        end select
+    end function
+
+    integer function norm_id( name )
+        character(len=*), intent(in) :: name
+        select case (name)                     ! comparator.f90:137-146
+        case ('l2norm');          norm_id = 1
+        case ('l1norm');          norm_id = 2
+        case ('ampspec_l2norm');  norm_id = 3
+        case ('ampspec_l1norm');  norm_id = 4
+        case ('scalar_product');  norm_id = 5
+        case ('peak');            norm_id = 6
+        case ('floating_l2norm'); norm_id = 7
+        case ('floating_l1norm'); norm_id = 8
+        case default;             norm_id = 0
+        end select
+    end function
+
+    character function component_char( s, k )
+        character(len=*), intent(in) :: s
+        integer, intent(in) :: k
+        component_char = s(k:k)
+    end function
+
+  ! ------------------------------------------------------------------------------------------
+    subroutine do_command( cmd, a, ok_ )
+        character(len=*), intent(in) :: cmd, a
+        logical, intent(out) :: ok_
+        ok_ = .false.
+        select case (cmd)
+        case ('set_database');              call do_set_database( a, ok_ )
+        case ('set_effective_dt');          call do_set_effective_dt( a, ok_ )
+        case ('set_local_interpolation');   call do_set_local_interpolation( a, ok_ )
+        case ('set_spacial_undersampling'); call do_set_spacial_undersampling( a, ok_ )
+        case ('set_receivers');             call do_set_receivers( a, ok_ )
+        case ('switch_receiver');           call do_switch_receiver( a, ok_ )
+        case ('set_source_location');       call do_set_source_location( a, ok_ )
+        case ('set_source_params');         call do_set_source_params( a, ok_ )
+        case ('set_ref_seismograms');       call do_set_ref_seismograms( a, ok_ )
+        case ('set_misfit_method');         call do_set_misfit_method( a, ok_ )
+        case ('set_misfit_taper');          call do_set_plf( a, .true., ok_ )
+        case ('set_misfit_filter');         call do_set_plf( a, .false., ok_ )
+        case ('set_synthetics_factor');     call do_set_synthetics_factor( a, ok_ )
+        case ('get_misfits');               call do_get_misfits( .false., ok_ )
+        case ('get_global_misfit');         call do_get_misfits( .true., ok_ )
+        case ('output_seismograms');        call do_output_seismograms( a, ok_ )
+        case ('output_distances');          call do_output_distances( a, ok_ )
+        case ('eval_sources');              call do_eval_sources( a, ok_ )
+        case ('set_verbose', 'set_ignore_sigint'); ok_ = .true.
+        case default
+            call fail( 'unknown command: '//cmd )
+        end select
+    end subroutine
+
+  ! flat dense GFDB: stream file <base>.kiwiflat =
+  !   'KIWIFLAT' int32 version(1) nx nz ng L, real32 dt dx dz firstx firstz,
+  !   int32 first(ng,nz,nx), int32 nsamp(ng,nz,nx), real32 data(L,ng,nz,nx)
+    subroutine do_set_database( a, ok_ )
+        character(len=*), intent(in) :: a
+        logical, intent(out) :: ok_
+        character(len=1024) :: base
+        character(len=maxline) :: rest
+        character(len=8) :: magic
+        integer(c_int) :: version, nx, nz, ng, L
+        real(c_float) :: dt, dx, dz, firstx, firstz
+        integer(c_int), allocatable :: first(:), nsamp(:)
+        real(c_float), allocatable :: G(:)
+        integer :: unit, ios
+        ok_ = .false.
+        call split_first( a, base, rest )
+        open( newunit=unit, file=trim(base)//'.kiwiflat', access='stream', form='unformatted', status='old', iostat=ios )
+        if (ios /= 0) then
+            call fail( "can't open file "//trim(base)//'.kiwiflat' ); return
+        end if
+        read (unit, iostat=ios) magic, version, nx, nz, ng, L, dt, dx, dz, firstx, firstz
+        if (ios /= 0 .or. magic /= 'KIWIFLAT' .or. version /= 1) then
+            close( unit ); call fail( 'not a flat kiwi gfdb: '//trim(base)//'.kiwiflat' ); return
+        end if
+        allocate( first(nx*nz*ng), nsamp(nx*nz*ng), G(int(L,8)*nx*nz*ng) )
+        read (unit, iostat=ios) first, nsamp, G
+        close( unit )
+        if (ios /= 0) then
+            call fail( 'truncated gfdb file '//trim(base)//'.kiwiflat' ); return
+        end if
+        if (.not. need_ctx()) return
+        ok_ = check( kiwi_hip_set_gfdb( ctx, nx, nz, ng, L, dt, dx, dz, firstx, firstz, G, first, nsamp ) )
+        if (ok_) db_dt = dt
+        evaluated = .false.
+    end subroutine
+
+    subroutine do_set_effective_dt( a, ok_ )
+        character(len=*), intent(in) :: a
+        logical, intent(out) :: ok_
+        real(c_float) :: v
+        integer :: ios
+        ok_ = .false.
+        read (a,*,iostat=ios) v
+        if (ios /= 0) then
+            call fail( 'usage: set_effective_dt effective_dt' ); return
+        end if
+        if (.not. need_ctx()) return
+        ok_ = check( kiwi_hip_set_effective_dt( ctx, v ) )
+        if (ok_) effective_dt = v
+        evaluated = .false.
+    end subroutine
+
+    subroutine do_set_local_interpolation( a, ok_ )
+        character(len=*), intent(in) :: a
+        logical, intent(out) :: ok_
+        ok_ = .false.
+        if (a == 'nearest_neighbor') then
+            cur_bilinear = 0
+        else if (a == 'bilinear') then
+            cur_bilinear = 1
+        else
+            call fail( 'set_local_interpolation: unknown interpolation method: '//a ); return
+        end if
+        if (.not. need_ctx()) return
+        ok_ = check( kiwi_hip_set_interp( ctx, cur_bilinear, cur_xus, cur_zus ) )
+        evaluated = .false.
+    end subroutine
+
+    subroutine do_set_spacial_undersampling( a, ok_ )
+        character(len=*), intent(in) :: a
+        logical, intent(out) :: ok_
+        integer(c_int) :: xu, zu
+        integer :: ios
+        ok_ = .false.
+        read (a,*,iostat=ios) xu, zu
+        if (ios /= 0 .or. xu < 1 .or. zu < 1) then
+            call fail( 'set_spacial_undersampling: failed to parse arguments' ); return
+        end if
+        if (.not. need_ctx()) return
+        cur_xus = xu; cur_zus = zu
+        ok_ = check( kiwi_hip_set_interp( ctx, cur_bilinear, cur_xus, cur_zus ) )
+        evaluated = .false.
+    end subroutine
+
+    subroutine do_set_receivers( a, ok_ )
+        character(len=*), intent(in) :: a
+        logical, intent(out) :: ok_
+        character(len=1024) :: fn
+        character(len=maxline) :: rest
+        character(len=1024) :: str
+        logical :: has_depth
+        integer :: unit, ios, n, nw, i
+        real(c_double), allocatable :: lat(:), lon(:)
+        real(c_float), allocatable :: depth(:)
+        character(len=8), allocatable :: comps(:)
+        character(kind=c_char, len=9), allocatable, target :: cstr(:)
+        type(c_ptr), allocatable :: cptr(:)
+        ok_ = .false.
+        call split_first( a, fn, rest )
+        has_depth = (trim(rest) == 'has_depth')
+        open( newunit=unit, file=trim(fn), status='old', iostat=ios )
+        if (ios /= 0) then
+            call fail( "can't open file "//trim(fn) ); return
+        end if
+        n = 0
+        do
+            read (unit,'(a)',iostat=ios) str
+            if (ios /= 0) exit
+            call reduce_whitespace( str )
+            if (len_trim(str) > 0) n = n + 1
+        end do
+        rewind( unit )
+        allocate( lat(n), lon(n), depth(n), comps(n), cstr(n), cptr(n) )
+        i = 0
+        do
+            read (unit,'(a)',iostat=ios) str
+            if (ios /= 0) exit
+            call reduce_whitespace( str )
+            if (len_trim(str) == 0) cycle
+            i = i + 1
+            comps(i) = ''
+            depth(i) = 0.
+            nw = count_words( str )
+            ios = 0
+            if (has_depth .and. nw == 4) then
+                read (str,*,iostat=ios) lat(i), lon(i), depth(i), comps(i)
+            else if (has_depth .and. nw == 3) then
+                read (str,*,iostat=ios) lat(i), lon(i), depth(i)
+            else if (.not. has_depth .and. nw == 3) then
+                read (str,*,iostat=ios) lat(i), lon(i), comps(i)
+            else if (.not. has_depth .and. nw == 2) then
+                read (str,*,iostat=ios) lat(i), lon(i)
+            else
+                ios = 1
+            end if
+            if (ios /= 0) then
+                close( unit )
+                write (str,'(a,i0,a)') 'expected two or three words at receiver no ', i, ' while reading '//trim(fn)
+                call fail( trim(str) ); return
+            end if
+        end do
+        close( unit )
+        do i = 1, n
+            cstr(i) = trim(comps(i))//c_null_char
+            cptr(i) = c_loc( cstr(i) )
+        end do
+        if (.not. need_ctx()) return
+        ok_ = check( kiwi_hip_set_receivers( ctx, int(n,c_int), lat, lon, depth, cptr ) )
+        if (ok_) then
+            nreceivers = n
+            if (allocated(components)) deallocate( components, enabled )
+            allocate( components(n), enabled(n) )
+            components = comps
+            do i = 1, n
+                enabled(i) = len_trim(comps(i)) > 0
+            end do
+        end if
+        evaluated = .false.
+    end subroutine
+
+    subroutine do_switch_receiver( a, ok_ )
+        character(len=*), intent(in) :: a
+        logical, intent(out) :: ok_
+        integer(c_int) :: irec
+        character(len=16) :: onoff
+        integer :: ios
+        ok_ = .false.
+        read (a,*,iostat=ios) irec, onoff
+        if (ios /= 0 .or. (onoff /= 'on' .and. onoff /= 'off')) then
+            call fail( 'usage: switch_receiver ireceiver ( on | off )' ); return
+        end if
+        if (.not. need_ctx()) return
+        ok_ = check( kiwi_hip_switch_receiver( ctx, irec, merge(1_c_int, 0_c_int, onoff == 'on') ) )
+        if (ok_) enabled(irec) = (onoff == 'on')
+        evaluated = .false.
+    end subroutine
+
+    subroutine do_set_source_location( a, ok_ )
+        character(len=*), intent(in) :: a
+        logical, intent(out) :: ok_
+        real(c_float) :: lat, lon
+        real(c_double) :: rt
+        integer :: ios
+        ok_ = .false.
+        read (a,*,iostat=ios) lat, lon, rt
+        if (ios /= 0) then
+            call fail( 'usage: set_source_location latitude longitude reference-time' ); return
+        end if
+        if (.not. need_ctx()) return
+        ok_ = check( kiwi_hip_set_source_location( ctx, lat, lon, rt ) )
+        if (ok_) ref_time = rt
+        evaluated = .false.
+    end subroutine
+
+    subroutine do_set_source_params( a, ok_ )
+        character(len=*), intent(in) :: a
+        logical, intent(out) :: ok_
+        character(len=64) :: tname
+        character(len=maxline) :: rest
+        integer :: st, np, ios
+        real(c_float), allocatable :: p(:)
+        ok_ = .false.
+        call split_first( a, tname, rest )
+        st = source_type_id( trim(tname) )
+        if (st == 0) then
+            call fail( 'unknown source type: '//trim(tname) ); return
+        end if
+        np = kiwi_hip_source_nparams( int(st,c_int) )
+        if (np < 0) then
+            call fail( 'source type not available in this host: '//trim(tname) ); return
+        end if
+        if (count_words( rest ) /= np) then
+            write (rest,'(a,i0,a)') 'expected ', np, ' source parameters for source type '//trim(tname)
+            call fail( trim(rest) ); return
+        end if
+        allocate( p(np) )
+        read (rest,*,iostat=ios) p
+        if (ios /= 0) then
+            call fail( 'failed to parse source parameters' ); return
+        end if
+        if (.not. need_ctx()) return
+        ok_ = check( kiwi_hip_set_sources_params( ctx, int(st,c_int), 1_c_int, p ) )
+        source_set = ok_
+        evaluated = .false.
+    end subroutine
+
+  ! table format: two columns time [s], value (seismogram_io.f90:231-245); first = nint((t0-reftime)/dt)+1
+    subroutine do_set_ref_seismograms( a, ok_ )
+        character(len=*), intent(in) :: a
+        logical, intent(out) :: ok_
+        character(len=1024) :: base, fn
+        character(len=maxline) :: fmt_
+        integer :: irec, k, unit, ios, n, i
+        real(c_double) :: t, t0, tlast
+        real(c_float) :: v, deltat
+        real(c_float), allocatable :: d(:)
+        ok_ = .false.
+        call split_first( a, base, fmt_ )
+        if (trim(fmt_) /= 'table') then
+            call fail( 'only the table format is available in this host' ); return
+        end if
+        if (.not. need_ctx()) return
+        do irec = 1, nreceivers
+            if (.not. enabled(irec)) cycle
+            do k = 1, len_trim(components(irec))
+                write (fn,'(a,a,i0,a,a,a)') trim(base), '-', irec, '-', components(irec)(k:k), '.table'
+                open( newunit=unit, file=trim(fn), status='old', iostat=ios )
+                if (ios /= 0) then
+                    call fail( 'failed to read seismogram from file '//trim(fn) ); return
+                end if
+                n = 0
+                do
+                    read (unit,*,iostat=ios) t, v
+                    if (ios /= 0) exit
+                    n = n + 1
+                end do
+                if (n < 2) then
+                    close( unit ); call fail( 'failed to read seismogram from file '//trim(fn) ); return
+                end if
+                rewind( unit )
+                allocate( d(n) )
+                do i = 1, n
+                    read (unit,*) t, d(i)
+                    if (i == 1) t0 = t
+                    tlast = t
+                end do
+                close( unit )
+                deltat = real( (tlast - t0) / (n - 1) )
+                if (abs(deltat - db_dt) > db_dt / 10000.) then        ! receiver.f90:776-781
+                    deallocate( d ); call fail( "sampling rate in file '"//trim(fn)//"' does not match the database" ); return
+                end if
+                ok_ = check( kiwi_hip_set_reference( ctx, int(irec,c_int), int(k,c_int), &
+                                                     int(nint( real(t0 - ref_time) / db_dt ) + 1, c_int), int(n,c_int), d ) )
+                deallocate( d )
+                if (.not. ok_) return
+            end do
+        end do
+        ok_ = .true.
+        evaluated = .false.
+    end subroutine
+
+    subroutine do_set_misfit_method( a, ok_ )
+        character(len=*), intent(in) :: a
+        logical, intent(out) :: ok_
+        integer :: id
+        ok_ = .false.
+        id = norm_id( a )
+        if (id == 0) then
+            call fail( 'unknown norm: '//a ); return
+        end if
+        if (.not. need_ctx()) return
+        ok_ = check( kiwi_hip_set_misfit_method( ctx, int(id,c_int) ) )
+        evaluated = .false.
+    end subroutine
+
+    subroutine do_set_plf( a, taper, ok_ )
+        character(len=*), intent(in) :: a
+        logical, intent(in) :: taper
+        logical, intent(out) :: ok_
+        integer :: n, i, ios
+        integer(c_int) :: irec
+        real(c_float), allocatable :: x(:), y(:)
+        ok_ = .false.
+        n = (count_words( a ) - 1) / 2
+        allocate( x(max(n,1)), y(max(n,1)) )
+        read (a,*,iostat=ios) irec, (x(i), y(i), i=1,n)
+        if (ios /= 0) then
+            call fail( 'failed to parse values' ); return
+        end if
+        if (.not. need_ctx()) return
+        if (taper) then
+            ok_ = check( kiwi_hip_set_taper( ctx, irec, int(n,c_int), x, y ) )
+        else
+            ok_ = check( kiwi_hip_set_filter( ctx, irec, int(n,c_int), x, y ) )
+        end if
+        evaluated = .false.
+    end subroutine
+
+    subroutine do_set_synthetics_factor( a, ok_ )
+        character(len=*), intent(in) :: a
+        logical, intent(out) :: ok_
+        real(c_float) :: f
+        integer :: ios
+        ok_ = .false.
+        read (a,*,iostat=ios) f
+        if (ios /= 0) then
+            call fail( 'usage: set_synthetics_factor factor' ); return
+        end if
+        if (.not. need_ctx()) return
+        ok_ = check( kiwi_hip_set_synthetics_factor( ctx, f ) )
+        evaluated = .false.
+    end subroutine
+
+    logical function update_misfits()
+        update_misfits = .false.
+        if (.not. need_ctx()) return
+        if (.not. source_set) then
+            call fail( 'no source set' ); return
+        end if
+        if (.not. evaluated) then
+            if (.not. check( kiwi_hip_eval( ctx, 0_c_int, 1_c_int ) )) return
+            evaluated = .true.
+        end if
+        update_misfits = .true.
+    end function
+
+  ! get_misfits: "m11 n11 m12 n12 ..." list-directed (minimizer.f90:1263-1275); get_global_misfit: one value
+    subroutine do_get_misfits( global, ok_ )
+        logical, intent(in) :: global
+        logical, intent(out) :: ok_
+        integer(c_int) :: nmis
+        real(c_float), allocatable :: m(:), n(:)
+        real(c_float) :: g(1)
+        character(len=:), allocatable :: buffer
+        integer :: i
+        ok_ = .false.
+        if (.not. update_misfits()) return
+        if (.not. check( kiwi_hip_nmisfits( ctx, nmis ) )) return
+        allocate( m(nmis), n(nmis) )
+        if (.not. check( kiwi_hip_get_misfits( ctx, 0_c_int, 1_c_int, m, n, g ) )) return
+        allocate( character(len=64*max(nmis,1)) :: buffer )
+        if (global) then
+            write (buffer,*) g(1)
+        else
+            write (buffer,*) (m(i), n(i), i=1,nmis)
+        end if
+        answer = trim(buffer)
+        ok_ = .true.
+    end subroutine
+
+    subroutine do_output_seismograms( a, ok_ )
+        character(len=*), intent(in) :: a
+        logical, intent(out) :: ok_
+        character(len=1024) :: base, fn
+        character(len=maxline) :: r1, r2, fmt_, probe, proc
+        integer(c_int) :: which, first, n
+        integer :: irec, k, unit, ios, i
+        real(c_float), allocatable :: d(:)
+        ok_ = .false.
+        call split_first( a, base, r1 )
+        call split_first( r1, fmt_, r2 )
+        call split_first( r2, probe, proc )
+        if (trim(fmt_) /= 'table') then
+            call fail( 'only the table format is available in this host' ); return
+        end if
+        if (trim(probe) == 'references') then
+            call fail( 'only synthetics can be written by this host' ); return
+        end if
+        which = 1
+        if (trim(proc) == 'tapered') which = 2
+        if (trim(proc) == 'filtered') which = 3
+        if (.not. update_misfits()) return
+        allocate( d(1048576) )
+        do irec = 1, nreceivers
+            if (.not. enabled(irec)) cycle
+            do k = 1, len_trim(components(irec))
+                if (.not. check( kiwi_hip_get_synthetics( ctx, 0_c_int, int(irec,c_int), int(k,c_int), which, first, n, &
+                                                          d, 1048576_c_int ) )) return
+                write (fn,'(a,a,i0,a,a,a)') trim(base), '-', irec, '-', components(irec)(k:k), '.table'
+                open( newunit=unit, file=trim(fn), status='unknown', iostat=ios )
+                if (ios /= 0) then
+                    call fail( 'failed to write output file: '//trim(fn) ); return
+                end if
+                do i = 1, n                  ! receiver.f90:649 + seismogram_io.f90:131-133
+                    write (unit,*) ref_time + (first - 1) * real(db_dt,8) + (i - 1) * db_dt, d(i)
+                end do
+                close( unit )
+            end do
+        end do
+        evaluated = .false.       ! get_synthetics re-evaluates with retained traces
+        ok_ = .true.
+    end subroutine
+
+  ! dist_deg dist_m azimuth_deg per receiver (minimizer.f90:1430-1432)
+    subroutine do_output_distances( a, ok_ )
+        character(len=*), intent(in) :: a
+        logical, intent(out) :: ok_
+        integer :: unit, ios, irec
+        real(c_double) :: azi, bazi, dist
+        real(c_float), parameter :: pi = 3.14159265358979, earthradius = 6371.*1000.
+        ok_ = .false.
+        if (.not. need_ctx()) return
+        open( newunit=unit, file=trim(a), status='unknown', iostat=ios )
+        if (ios /= 0) then
+            call fail( 'failed to open file for output: '//trim(a) ); return
+        end if
+        do irec = 1, nreceivers
+            if (.not. check( kiwi_hip_get_receiver_geometry( ctx, int(irec,c_int), azi, bazi, dist ) )) then
+                close( unit ); return
+            end if
+            write (unit,*) 360./2./pi*(dist/earthradius), dist, 360./2./pi*azi
+        end do
+        close( unit )
+        ok_ = .true.
+    end subroutine
+
+  ! batch extension: a whole trial grid in one command
+    subroutine do_eval_sources( a, ok_ )
+        character(len=*), intent(in) :: a
+        logical, intent(out) :: ok_
+        character(len=64) :: tname
+        character(len=1024) :: pfile, ofile
+        character(len=maxline) :: r1, r2, str
+        integer :: st, np, unit, ios, nsrc, i, s
+        integer(c_int) :: nmis
+        real(c_float), allocatable :: p(:), m(:), n(:), g(:)
+        ok_ = .false.
+        call split_first( a, tname, r1 )
+        call split_first( r1, pfile, r2 )
+        ofile = trim(r2)
+        st = source_type_id( trim(tname) )
+        np = -1
+        if (st /= 0) np = kiwi_hip_source_nparams( int(st,c_int) )
+        if (np < 0) then
+            call fail( 'source type not available in this host: '//trim(tname) ); return
+        end if
+        open( newunit=unit, file=trim(pfile), status='old', iostat=ios )
+        if (ios /= 0) then
+            call fail( "can't open file "//trim(pfile) ); return
+        end if
+        nsrc = 0
+        do
+            read (unit,'(a)',iostat=ios) str
+            if (ios /= 0) exit
+            call reduce_whitespace( str )
+            if (len_trim(str) > 0) nsrc = nsrc + 1
+        end do
+        rewind( unit )
+        if (nsrc == 0) then
+            close( unit ); call fail( 'no sources in '//trim(pfile) ); return
+        end if
+        allocate( p(np*nsrc) )
+        s = 0
+        do
+            read (unit,'(a)',iostat=ios) str
+            if (ios /= 0) exit
+            call reduce_whitespace( str )
+            if (len_trim(str) == 0) cycle
+            read (str,*,iostat=ios) p(s*np+1:s*np+np)
+            if (ios /= 0) then
+                close( unit ); call fail( 'failed to parse source parameters in '//trim(pfile) ); return
+            end if
+            s = s + 1
+        end do
+        close( unit )
+        if (.not. need_ctx()) return
+        if (.not. check( kiwi_hip_set_sources_params( ctx, int(st,c_int), int(nsrc,c_int), p ) )) return
+        source_set = .true.
+        if (.not. check( kiwi_hip_eval( ctx, 0_c_int, int(nsrc,c_int) ) )) return
+        if (.not. check( kiwi_hip_nmisfits( ctx, nmis ) )) return
+        allocate( m(nmis*nsrc), n(nmis*nsrc), g(nsrc) )
+        if (.not. check( kiwi_hip_get_misfits( ctx, 0_c_int, int(nsrc,c_int), m, n, g ) )) return
+        open( newunit=unit, file=trim(ofile), status='unknown', iostat=ios )
+        if (ios /= 0) then
+            call fail( 'failed to open file for output: '//trim(ofile) ); return
+        end if
+        do s = 0, nsrc - 1
+            write (unit,'(*(es16.8e3,1x))') g(s+1), (m(s*nmis+i), n(s*nmis+i), i=1,nmis)
+        end do
+        close( unit )
+        evaluated = .true.         ! source 0 of the batch is the "current" source
+        write (str,'(i0)') nsrc
+        answer = trim(str)
+        ok_ = .true.
+    end subroutine
+
+end program

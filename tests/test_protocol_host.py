@@ -1,0 +1,114 @@
+"""The Fortran protocol host (kiwi_amd/fortran/minimizer_hip): wire format on CPU, and on the GPU
+the same answers as the Python host over the same library (and the oracle)."""
+import os
+
+import numpy as np
+import pytest
+
+from kiwi_amd import protocol, synthetic
+from kiwi_amd import lib as klib
+
+HAVE_FLANG = os.path.exists("/opt/rocm/bin/amdflang")
+pytestmark = pytest.mark.skipif(not HAVE_FLANG, reason="amdflang not installed")
+
+
+@pytest.fixture(scope="module")
+def host():
+    klib.build()
+    return protocol.build_host()
+
+
+def test_wire_format_and_errors_without_device(host, tmp_path):
+    p = protocol.MinimizerProcess(host)
+    try:
+        # unknown command -> "<cmd>: nok >" + message (minimizer.f90:1810)
+        with pytest.raises(protocol.SeismosizerReturnedError, match="unknown command: frobnicate"):
+            p.do("frobnicate")
+        # comments and whitespace are ignored (minimizer.f90:1815-1846); commands with no device need answer plainly
+        assert p.do("   set_verbose    T   # trailing comment") == ""
+        assert p.do("set_ignore_sigint T") == ""
+        with pytest.raises(protocol.SeismosizerReturnedError, match="unknown interpolation method"):
+            p.do("set_local_interpolation", "cubic")
+        with pytest.raises(protocol.SeismosizerReturnedError, match="can't open file"):
+            p.do("set_receivers", str(tmp_path / "nofile"))
+        with pytest.raises(protocol.SeismosizerReturnedError, match="unknown source type"):
+            p.do("set_source_params", "banana", 1, 2, 3)
+        with pytest.raises(protocol.SeismosizerReturnedError, match="expected 14 source parameters"):
+            p.do("set_source_params", "bilateral", 1, 2, 3)
+        with pytest.raises(protocol.SeismosizerReturnedError, match="unknown norm"):
+            p.do("set_misfit_method", "l3norm")
+        # the process is still alive and in sync after all those errors
+        assert p.do("set_verbose F") == ""
+    finally:
+        p.close()
+
+
+@pytest.mark.gpu
+def test_protocol_host_matches_python_host_and_oracle(host, tmp_path):
+    from tests.common import Scenario, oracle_misfits
+    sc = Scenario(nrec=4)
+    e = sc.oracle()
+    sc.make_references(e)
+    sc.apply_setup(e, True)
+    gf = dict(sc.gf)
+    first, nsamp, data = sc.odb.dense_tables()
+    gf.update(first=first, nsamp=nsamp, data=data)
+    base = str(tmp_path / "db")
+    protocol.write_flat_gfdb(base, gf)
+    protocol.write_receivers(str(tmp_path / "receivers.table"), sc.lat, sc.lon, sc.comps)
+    dt = gf["dt"]
+    for (ir, k), (lo, d) in sc.refs.items():
+        # sample index lo sits at time (lo-1)*dt (receiver.f90:649,842-849)
+        protocol.write_table(str(tmp_path / ("ref-%d-%s.table" % (ir, sc.comps[ir - 1][k - 1]))), (lo - 1) * dt, dt, d)
+    p = protocol.MinimizerProcess(host)
+    try:
+        p.do("set_database", base)
+        p.do("set_effective_dt", sc.effective_dt)
+        p.do("set_local_interpolation", "bilinear")
+        p.do("set_receivers", str(tmp_path / "receivers.table"))
+        p.do("set_source_location", 40.0, 30.0, 0.0)
+        p.do("set_ref_seismograms", str(tmp_path / "ref"), "table")
+        p.do("set_misfit_method", "l2norm")
+        for ir, (x, y) in sc.tapers.items():
+            p.do("set_misfit_taper", ir, *[v for xy in zip(x, y) for v in xy])
+        trials = synthetic.bilat_strike_sweep(3, step=2.0)
+        m, n, g = oracle_misfits(e, 1, trials)
+        for i, t in enumerate(trials):
+            p.do("set_source_params", "bilateral", *["%.9g" % v for v in t])
+            ans = np.array(p.do("get_misfits").split(), np.float64)
+            assert len(ans) == 2 * m.shape[1]
+            # the reference traces went through a text file (9 significant digits): allow for that
+            assert np.allclose(ans[0::2], m[i], rtol=2e-5, atol=1e-6 * n[i].max())
+            assert np.allclose(ans[1::2], n[i], rtol=1e-5)
+            gl = float(p.do("get_global_misfit"))
+            assert abs(gl - g[i]) <= 2e-5 * g[i]
+        # batch extension
+        pf = tmp_path / "params.txt"
+        with open(pf, "w") as f:
+            for t in trials:
+                f.write(" ".join("%.9g" % v for v in t) + "\n")
+        assert p.do("eval_sources", "bilateral", str(pf), str(tmp_path / "out.txt")) == "3"
+        out = np.loadtxt(tmp_path / "out.txt")
+        assert out.shape == (3, 1 + 2 * m.shape[1])
+        assert np.allclose(out[:, 0], g, rtol=2e-5)
+        # inspection commands
+        p.do("output_distances", str(tmp_path / "dist.txt"))
+        d = np.loadtxt(tmp_path / "dist.txt")
+        assert d.shape == (4, 3)
+        for ir in range(4):
+            az, _, dist = e.receiver_geometry(ir + 1)
+            r2d = float(np.float32(360.) / np.float32(2.) / np.float32(3.14159265358979))     # orthodrome.f90:340-347
+            assert abs(d[ir, 1] - dist) < 1e-3 and abs(d[ir, 2] - r2d * az) < 1e-9 * 360
+        p.do("output_seismograms", str(tmp_path / "syn"), "table", "synthetics", "plain")
+        t, v = protocol.read_table(str(tmp_path / "syn-1-n.table"))
+        e.set_source_params(1, trials[0])
+        e.get_misfits()
+        lo_o, so = e.synthetic(1, 1, 1)
+        i0 = int(round(t[0] / dt)) + 1
+        a, b = max(lo_o, i0), min(lo_o + len(so), i0 + len(v))
+        assert b - a > 200
+        assert np.max(np.abs(so[a - lo_o:b - lo_o] - v[a - i0:b - i0])) <= 1e-5 * np.max(np.abs(so))
+        with pytest.raises(protocol.SeismosizerReturnedError):
+            p.do("switch_receiver", 99, "off")
+    finally:
+        p.close()
