@@ -113,6 +113,20 @@ int ko_psm_set(ko_psm *psm, int sourcetype, const float *params);
 /* discretise; *out is malloc'ed (caller frees), returns ncentroids (<0 on error) */
 int ko_psm_to_tdsm(ko_psm *psm, float shortest_doi, ko_centroid **out);
 
+/* ---------------- source_eikonal.f90 / source_mt_eikonal.f90 (+ eikonal, heap, geometry) ---------------- */
+#define KO_SRC_EIKONAL 4
+#define KO_SRC_MT_EIKONAL 5
+/* t_crust2x2_1d_profile (crust2x2.f90:45-50): 7 layers + the mantle below (index 7) */
+typedef struct { float vp[8], vs[8], rho[8], thickness[7]; } ko_crust_profile;
+void ko_crust_profile_averages(const ko_crust_profile *p, float *vvp, float *vvs, float *vrho, float *vthi);
+void ko_eikonal_solver_fmm(const float *speed, int nx, int ny, const float origin[2], const float delta[2],
+                           const float initialpoint[2], float *times);
+/* constraints: ncon half spaces (point, normal) as psm_set_default_constraints / set_source_constraints give them */
+int ko_psm_to_tdsm_eikonal(int sourcetype, const float *params, float shortest_doi,
+                           const ko_crust_profile *prof_speed, int ncon, const float *con_points,
+                           const float *con_normals, ko_centroid **out, float *moment, float *risetime,
+                           int grid_size[2]);
+
 /* ---------------- gfdb.f90 (read side, in-memory) ---------------- */
 typedef struct {
     float dt, dx, dz, firstx, firstz;

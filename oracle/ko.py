@@ -374,3 +374,42 @@ class Engine:
         if self.h:
             lib().ko_engine_destroy(self.h)
             self.h = None
+
+
+# ---------------------------------------------------------------- eikonal sources
+class CrustProfile(C.Structure):
+    _fields_ = [("vp", C.c_float * 8), ("vs", C.c_float * 8), ("rho", C.c_float * 8), ("thickness", C.c_float * 7)]
+
+
+def crust_profile(vp, vs, rho, thickness):
+    p = CrustProfile()
+    for i in range(8):
+        p.vp[i], p.vs[i], p.rho[i] = vp[i], vs[i], rho[i]
+    for i in range(7):
+        p.thickness[i] = thickness[i]
+    return p
+
+
+def crust_thickness(profile):
+    """crust2x2_get_profile_averages (crust2x2.f90:146-168): total crustal thickness."""
+    v = [C.c_float() for _ in range(4)]
+    lib().ko_crust_profile_averages(C.byref(profile), *[C.byref(x) for x in v])
+    return v[3].value
+
+
+def discretize_eikonal(sourcetype, params, effective_dt, prof_speed, con_points, con_normals):
+    """source_eikonal (4) / source_mt_eikonal (5): (centroids[n,10], moment, risetime, grid) or raises."""
+    L = lib()
+    p = np.ascontiguousarray(params, np.float32)
+    cp = np.ascontiguousarray(con_points, np.float32)
+    cn = np.ascontiguousarray(con_normals, np.float32)
+    out = C.POINTER(Centroid)()
+    mo, ri = C.c_float(), C.c_float()
+    gs = (C.c_int * 2)()
+    n = L.ko_psm_to_tdsm_eikonal(C.c_int(sourcetype), _fp(p), C.c_float(effective_dt), C.byref(prof_speed),
+                                 C.c_int(len(cp)), _fp(cp), _fp(cn), C.byref(out), C.byref(mo), C.byref(ri), gs)
+    if n < 0:
+        raise ValueError("Empty rupture area" if n == -1 else "position of nucleation point is outside of rupture region")
+    arr = np.ctypeslib.as_array(C.cast(out, c_float_p), (n, 10)).copy() if n else np.zeros((0, 10), np.float32)
+    C.CDLL(None).free(out)
+    return arr, mo.value, ri.value, (gs[0], gs[1])

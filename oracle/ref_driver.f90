@@ -20,6 +20,12 @@ module ref_driver
     use source_moment_tensor
     use source_bilat
     use source_circular
+    use source_eikonal
+    use source_mt_eikonal
+    use crust2x2
+    use geometry
+    use eikonal
+    use better_varying_string
 
     implicit none
 
@@ -239,6 +245,95 @@ module ref_driver
         moment = psm%moment
         risetime = psm%risetime
         grid_size(1:size(psm%grid_size)) = psm%grid_size
+        do i=1,min(nc,maxc)
+            cent(1,i) = tdsm%centroids(i)%north
+            cent(2,i) = tdsm%centroids(i)%east
+            cent(3,i) = tdsm%centroids(i)%depth
+            cent(4,i) = tdsm%centroids(i)%time
+            cent(5:10,i) = tdsm%centroids(i)%m(:)
+        end do
+        call tdsm_destroy( tdsm )
+    end subroutine
+
+
+  ! crust2x2_load + crust2x2_get_profile (crust2x2.f90:76-105): 1-D profile at the location GIVEN AS IS
+  ! (the reference calls it both with degrees and, in psm_make_*_grid, with radians)
+    subroutine ref_crust_profile( dir, ndir, lat, lon, vp, vs, rho, thickness, ok ) bind(C, name='ref_crust_profile')
+        integer(c_int), value :: ndir
+        character(kind=c_char), intent(in) :: dir(ndir)
+        real(c_double), value :: lat, lon
+        real(c_float), intent(out) :: vp(8), vs(8), rho(8), thickness(7)
+        integer(c_int), intent(out) :: ok
+        type(t_crust2x2_1d_profile) :: profile
+        type(t_geo_coords) :: loc
+        character(len=ndir) :: d
+        logical :: lok
+        integer :: i
+        ok = 1
+        if (.not. crust2x2_loaded) then
+            do i=1,ndir
+                d(i:i) = dir(i)
+            end do
+            call crust2x2_load( d, lok )
+            if (.not. lok) then
+                ok = 0
+                return
+            end if
+        end if
+        loc%lat = lat; loc%lon = lon
+        call crust2x2_get_profile( loc, profile )
+        vp = profile%vp; vs = profile%vs; rho = profile%rho; thickness = profile%thickness
+    end subroutine
+
+  ! eikonal_solver_fmm (eikonal.f90:29)
+    subroutine ref_eikonal_fmm( nx, ny, speed, origin, delta, initialpoint, times ) bind(C, name='ref_eikonal_fmm')
+        integer(c_int), value :: nx, ny
+        real(c_float), intent(in) :: speed(nx,ny), origin(2), delta(2), initialpoint(2)
+        real(c_float), intent(out) :: times(nx,ny)
+        call eikonal_solver_fmm( speed, origin, delta, initialpoint, times )
+    end subroutine
+
+  ! psm_set_origin_and_time (default constraints from CRUST2.0, parameterized_source.f90:127-145,185-196) +
+  ! psm_set_[mt_]eikonal + psm_to_tdsm_[mt_]eikonal (source_eikonal.f90:205,259; source_mt_eikonal.f90:200,266).
+  ! lat/lon in radians as the engine stores them; crust2x2 must have been loaded (ref_crust_profile).
+    subroutine ref_discretize_eikonal( sourcetype, np, params, effective_dt, lat, lon, thickness_limit, maxc, nc, cent, &
+                                       moment, risetime, grid_size, con_points, con_normals ) &
+                                       bind(C, name='ref_discretize_eikonal')
+        integer(c_int), value :: sourcetype, np, maxc
+        real(c_float), intent(in) :: params(np)
+        real(c_float), value :: effective_dt, thickness_limit
+        real(c_double), value :: lat, lon
+        integer(c_int), intent(out) :: nc, grid_size(2)
+        real(c_float), intent(out) :: cent(10,maxc), moment, risetime, con_points(3,2), con_normals(3,2)
+        type(t_psm), save :: psm
+        type(t_tdsm) :: tdsm
+        type(t_geo_coords) :: origin
+        logical :: omc, ok
+        integer :: i
+        call psm_destroy( psm )
+        origin%lat = lat; origin%lon = lon
+        psm%crustal_thickness_limit = thickness_limit
+        call psm_set_origin_and_time( psm, origin, 0.d0 )
+        do i=1,2
+            con_points(:,i) = psm%constraints(i)%point
+            con_normals(:,i) = psm%constraints(i)%normal
+        end do
+        ok = .false.
+        if (sourcetype == psm_eikonal) then
+            call psm_set_eikonal( psm, params, .false., omc )
+            psm%sourcetype = psm_eikonal
+            call psm_to_tdsm_eikonal( psm, tdsm, effective_dt, ok )
+        else
+            call psm_set_mt_eikonal( psm, params, .false., omc )
+            psm%sourcetype = psm_mt_eikonal
+            call psm_to_tdsm_mt_eikonal( psm, tdsm, effective_dt, ok )
+        end if
+        nc = -1
+        if (.not. ok) return
+        nc = size(tdsm%centroids)
+        moment = psm%moment
+        risetime = psm%risetime
+        grid_size(1:2) = psm%grid_size(1:2)
         do i=1,min(nc,maxc)
             cent(1,i) = tdsm%centroids(i)%north
             cent(2,i) = tdsm%centroids(i)%east
