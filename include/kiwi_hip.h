@@ -100,6 +100,26 @@ int kiwi_hip_source_nparams(int sourcetype);
 int kiwi_hip_discretize(int sourcetype, const float *params, int nparams, float effective_dt,
                         float *cent, int maxcent, int *ncent, float *moment, float *risetime);
 
+/* ---- variable-rupture-speed sources `eikonal` (type 4, 15 params) and `mt_eikonal` (type 5, 20 params)
+ * (source_eikonal.f90, source_mt_eikonal.f90).  A crust profile is 31 floats: vp[8] vs[8] rho[8] thickness[7]
+ * (t_crust2x2_1d_profile, crust2x2.f90:45-50; layer 8 = below the crust).  The CRUST2.0 tables stay with the
+ * caller, which does the two look-ups set_source_location triggers in the reference:
+ *   rupture_profile = crust2x2_get_profile(psm%origin)       -- rupture speeds, source_eikonal.f90:472
+ *                     (the reference passes the origin in RADIANS there; a drop-in caller does the same)
+ *   origin_profile  = crust2x2_get_profile(r2d(psm%origin))  -- crustal thickness, parameterized_source.f90:215
+ * set_source_crust and set_source_crustal_thickness_limit (minimizer_engine.f90:479-486) both re-install the
+ * default constraints (surface at 1500 m, bottom of the crust; parameterized_source.f90:127-145);
+ * set_source_constraints (minimizer_engine.f90:469-477) replaces them: points[n][3], normals[n][3] (ned). */
+int kiwi_hip_set_source_crust(kiwi_hip_ctx *ctx, const float *rupture_profile, const float *origin_profile);
+int kiwi_hip_set_source_crustal_thickness_limit(kiwi_hip_ctx *ctx, float limit);
+int kiwi_hip_get_source_crustal_thickness(kiwi_hip_ctx *ctx, float *thickness);   /* minimizer_engine.f90:488-498 */
+int kiwi_hip_set_source_constraints(kiwi_hip_ctx *ctx, int n, const float *points, const float *normals);
+/* stateless psm_set + psm_to_tdsm of the two types (needs no GPU); returns 5 for "Empty rupture area"
+ * (source_eikonal.f90:284), 6 for a nucleation point outside of the rupture region (:427) */
+int kiwi_hip_discretize_eikonal(int sourcetype, const float *params, int nparams, float effective_dt,
+                                const float *rupture_profile, int ncon, const float *points, const float *normals,
+                                float *cent, int maxcent, int *ncent, float *moment, float *risetime);
+
 /* upload a batch of discretised trial sources: cent_ofs[nsrc+1] row offsets into cent[][10];
  * moment / risetime = psm%moment / psm%risetime per source (parameterized_source.f90:70-71) */
 int kiwi_hip_set_sources(kiwi_hip_ctx *ctx, int nsrc, const int *cent_ofs, const float *cent,

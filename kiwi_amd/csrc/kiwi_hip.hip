@@ -6,6 +6,7 @@
 // cleared by every setter the reference routes through dirtyfy_*.
 #include "../../include/kiwi_hip.h"
 #include "kiwi_host.hpp"
+#include "kiwi_host_eikonal.hpp"
 #include "kiwi_kernels.hpp"
 
 #include <hip/hip_runtime.h>
@@ -91,6 +92,11 @@ struct kiwi_hip_ctx {
     std::vector<Receiver> recv;
     int method = KIWI_L2NORM;
     float syn_factor = 1.f;
+    // variable-rupture-speed sources (parameterized_source.f90:89-90, source_eikonal.f90:472)
+    bool have_crust = false;
+    CrustProfile rupture_profile{}, origin_profile{};
+    float crustal_thickness_limit = 0.f;
+    std::vector<HalfSpace> constraints;
 
     // prepared (derived) state
     bool prepared = false;
@@ -855,7 +861,102 @@ int kiwi_hip_set_synthetics_factor(kiwi_hip_ctx *c, float factor)
     return 0;
 }
 
-int kiwi_hip_source_nparams(int sourcetype) { return source_nparams(sourcetype); }
+static int nparams_any(int sourcetype)
+{
+    const int n = source_nparams(sourcetype);
+    return n > 0 ? n : source_nparams_eikonal(sourcetype);
+}
+
+int kiwi_hip_source_nparams(int sourcetype) { return nparams_any(sourcetype); }
+
+static CrustProfile unpack_profile(const float *p)
+{
+    CrustProfile c;
+    std::memcpy(c.vp, p, 8 * sizeof(float));
+    std::memcpy(c.vs, p + 8, 8 * sizeof(float));
+    std::memcpy(c.rho, p + 16, 8 * sizeof(float));
+    std::memcpy(c.thickness, p + 24, 7 * sizeof(float));
+    return c;
+}
+
+// psm_get_crustal_thickness, parameterized_source.f90:207-222
+static float limited_thickness(const kiwi_hip_ctx *c)
+{
+    float t = crust_thickness(c->origin_profile);
+    if (c->crustal_thickness_limit > 0.f) t = std::min(c->crustal_thickness_limit, t);
+    return t;
+}
+
+// psm_set_default_constraints, parameterized_source.f90:127-145
+static void default_constraints(kiwi_hip_ctx *c)
+{
+    c->constraints.assign(2, HalfSpace{ { 0.f, 0.f, 1500.f }, { 0.f, 0.f, -1.f } });
+    c->constraints[1] = HalfSpace{ { 0.f, 0.f, limited_thickness(c) }, { 0.f, 0.f, 1.f } };
+}
+
+int kiwi_hip_set_source_crust(kiwi_hip_ctx *c, const float *rupture_profile, const float *origin_profile)
+{
+    GUARD_BEGIN
+    if (!rupture_profile || !origin_profile) throw std::runtime_error("crust profiles missing");
+    c->rupture_profile = unpack_profile(rupture_profile);
+    c->origin_profile = unpack_profile(origin_profile);
+    c->have_crust = true;
+    default_constraints(c);
+    return 0;
+    GUARD_END(c)
+}
+
+int kiwi_hip_set_source_crustal_thickness_limit(kiwi_hip_ctx *c, float limit)
+{
+    GUARD_BEGIN
+    c->crustal_thickness_limit = limit;
+    if (c->have_crust) default_constraints(c);
+    return 0;
+    GUARD_END(c)
+}
+
+int kiwi_hip_get_source_crustal_thickness(kiwi_hip_ctx *c, float *thickness)
+{
+    GUARD_BEGIN
+    if (!c->have_crust) throw std::runtime_error("no crust profile set");
+    *thickness = limited_thickness(c);
+    return 0;
+    GUARD_END(c)
+}
+
+int kiwi_hip_set_source_constraints(kiwi_hip_ctx *c, int n, const float *points, const float *normals)
+{
+    GUARD_BEGIN
+    if (n < 0) throw std::runtime_error("negative number of constraints");
+    c->constraints.resize((size_t)n);
+    for (int i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++) { c->constraints[i].point[k] = points[3 * i + k]; c->constraints[i].normal[k] = normals[3 * i + k]; }
+    return 0;
+    GUARD_END(c)
+}
+
+int kiwi_hip_discretize_eikonal(int sourcetype, const float *params, int nparams, float effective_dt,
+                                const float *rupture_profile, int ncon, const float *points, const float *normals,
+                                float *cent, int maxcent, int *ncent, float *moment, float *risetime)
+{
+    try {
+        if (source_nparams_eikonal(sourcetype) != nparams) return 2;
+        std::vector<HalfSpace> cons((size_t)std::max(ncon, 0));
+        for (int i = 0; i < ncon; i++)
+            for (int k = 0; k < 3; k++) { cons[i].point[k] = points[3 * i + k]; cons[i].normal[k] = normals[3 * i + k]; }
+        DiscreteSource ds;
+        const std::string err = discretize_eikonal(sourcetype, params, effective_dt, unpack_profile(rupture_profile), cons, ds);
+        if (!err.empty()) return err[0] == 'E' ? 5 : 6;      // 5: empty rupture area, 6: nucleation point outside
+        *ncent = (int)ds.centroids.size();
+        if (moment) *moment = ds.moment;
+        if (risetime) *risetime = ds.risetime;
+        if (cent) {
+            if (*ncent > maxcent) return 4;
+            std::memcpy(cent, ds.centroids.data(), ds.centroids.size() * sizeof(Centroid));
+        }
+        return 0;
+    } catch (...) { return 1; }
+}
 
 int kiwi_hip_discretize(int sourcetype, const float *params, int nparams, float effective_dt,
                         float *cent, int maxcent, int *ncent, float *moment, float *risetime)
@@ -910,15 +1011,25 @@ int kiwi_hip_set_sources(kiwi_hip_ctx *c, int nsrc, const int *cent_ofs, const f
 int kiwi_hip_set_sources_params(kiwi_hip_ctx *c, int sourcetype, int nsrc, const float *params)
 {
     GUARD_BEGIN
-    const int np = source_nparams(sourcetype);
+    const int np = nparams_any(sourcetype);
     if (np < 0) throw std::runtime_error("source type not supported by the host discretiser");
     if (nsrc < 1) throw std::runtime_error("need at least one source");
+    const bool eikonal = source_nparams_eikonal(sourcetype) > 0;
+    if (eikonal && !c->have_crust) throw std::runtime_error("eikonal sources need the crust profiles (kiwi_hip_set_source_crust)");
     std::vector<DiscreteSource> ds((size_t)nsrc);
-    bool ok = true;
-#pragma omp parallel for schedule(dynamic, 16)
-    for (int s = 0; s < nsrc; s++)
-        if (!discretize(sourcetype, params + (size_t)s * np, c->effective_dt, ds[s])) ok = false;
-    if (!ok) throw std::runtime_error("source discretisation failed");
+    int bad = -1;
+    std::string why = "source discretisation failed";
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int s = 0; s < nsrc; s++) {
+        std::string err;
+        if (eikonal) err = discretize_eikonal(sourcetype, params + (size_t)s * np, c->effective_dt, c->rupture_profile, c->constraints, ds[s]);
+        else if (!discretize(sourcetype, params + (size_t)s * np, c->effective_dt, ds[s])) err = why;
+        if (!err.empty()) {
+#pragma omp critical
+            if (bad < 0 || s < bad) { bad = s; why = err; }
+        }
+    }
+    if (bad >= 0) throw std::runtime_error(why + " (source " + std::to_string(bad + 1) + ")");
     std::vector<int> ofs((size_t)nsrc + 1, 0);
     for (int s = 0; s < nsrc; s++) ofs[s + 1] = ofs[s] + (int)ds[s].centroids.size();
     std::vector<float> cent((size_t)ofs[nsrc] * 10), mom((size_t)nsrc), rise((size_t)nsrc);

@@ -1,0 +1,358 @@
+// kiwi_host_eikonal.hpp -- host discretiser of the variable-rupture-speed sources `eikonal` and
+// `mt_eikonal` (source_eikonal.f90:205-316,435-710; source_mt_eikonal.f90:200-323,442-762):
+//   bounding circle clipped by the constraint half-spaces (geometry.f90:173-256) -> fine grid of
+//   rupture speeds from a 1-D crustal profile (crust2x2.f90:170-195) -> fast-marching arrival
+//   times (eikonal.f90:29-199 with the index heap of heap.f90) -> coarse cells (mean time,
+//   harmonic-mean speed, weight, duration) -> centroid table; the constant rise time is applied
+//   after synthesis (psm%risetime).
+// Sequential, default-real arithmetic in the reference's order; stays on the host.
+#pragma once
+#include "kiwi_host.hpp"
+#include <array>
+#include <limits>
+
+namespace kiwi {
+
+struct CrustProfile {                 // t_crust2x2_1d_profile, crust2x2.f90:45-50 (index 7 = below the crust)
+    float vp[8], vs[8], rho[8], thickness[7];
+};
+
+struct HalfSpace { float point[3], normal[3]; };      // geometry.f90:25-28
+
+// crust2x2_get_profile_averages (crust2x2.f90:146-168): total crustal thickness (ice .. lower crust)
+inline float crust_thickness(const CrustProfile &p)
+{
+    float thi = 0.f;
+    for (int i = 1; i < 7; i++) thi = thi + p.thickness[i];
+    return thi;
+}
+
+namespace eik {
+
+using V3 = std::array<float, 3>;
+
+inline float dot(const float *a, const float *b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+inline V3 mul(const float m[3][3], const V3 &v)
+{
+    V3 o;
+    for (int i = 0; i < 3; i++) o[i] = (m[i][0] * v[0] + m[i][1] * v[1]) + m[i][2] * v[2];
+    return o;
+}
+inline V3 mulT(const float m[3][3], const V3 &v)
+{
+    V3 o;
+    for (int i = 0; i < 3; i++) o[i] = (m[0][i] * v[0] + m[1][i] * v[1]) + m[2][i] * v[2];
+    return o;
+}
+
+inline bool inside(const V3 &p, const HalfSpace &h)                 // point_in_halfspace, geometry.f90:55-64
+{
+    const float d[3] = { h.point[0] - p[0], h.point[1] - p[1], h.point[2] - p[2] };
+    return dot(h.normal, d) >= 0.f;
+}
+
+// get_piercingpoint, geometry.f90:66-118
+struct Pierce { V3 point; bool between, a_inside; };
+inline Pierce pierce(const V3 &a, const V3 &b, const HalfSpace &h)
+{
+    Pierce r;
+    const float ab[3] = { b[0] - a[0], b[1] - a[1], b[2] - a[2] };
+    const float da[3] = { h.point[0] - a[0], h.point[1] - a[1], h.point[2] - a[2] };
+    const float db[3] = { h.point[0] - b[0], h.point[1] - b[1], h.point[2] - b[2] };
+    const float la = dot(h.normal, da), lb = dot(h.normal, db), lab = dot(h.normal, ab);
+    const bool ain = la >= 0.f, bin = lb >= 0.f;
+    r.a_inside = ain;
+    r.between = (ain && !bin) || (bin && !ain);
+    const bool parallel = lab * lab < dot(ab, ab) / 16777216.f;     // 2**digits(real)
+    if (parallel && r.between) r.point = (std::fabs(la) <= std::fabs(lb)) ? a : b;
+    else if (parallel) r.point = { 0.f, 0.f, 0.f };
+    else for (int i = 0; i < 3; i++) r.point[i] = a[i] + ab[i] * la / lab;
+    return r;
+}
+
+// trim_polygon (one half-space, then all of them), geometry.f90:192-256
+inline std::vector<V3> clip(const std::vector<V3> &poly, const HalfSpace &h)
+{
+    const size_t n = poly.size();
+    std::vector<Pierce> pr(n);
+    for (size_t i = 0; i < n; i++) pr[i] = pierce(poly[i], poly[(i + 1) % n], h);
+    std::vector<V3> out;
+    for (size_t i = 0; i < n; i++) {
+        if (pr[i].a_inside) out.push_back(poly[i]);
+        if (pr[i].between) out.push_back(pr[i].point);
+    }
+    return out;
+}
+
+// index heap keyed by an external array, with back pointers (heap.f90); indices 1-based as there
+struct IndexHeap {
+    std::vector<int> h;      // h[1..n]
+    int n = 0;
+    const float *keys;
+    int *bp;
+    IndexHeap(int cap, const float *k, int *b) : h((size_t)cap + 2), keys(k), bp(b) {}
+    float key(int pos) const { return keys[h[pos] - 1]; }
+    void swp(int u, int v) { std::swap(h[u], h[v]); std::swap(bp[h[u] - 1], bp[h[v] - 1]); }
+    void up(int v)                                   // upheap :205-229
+    {
+        while (v > 1) {
+            const int u = (v - 2) / 2 + 1;
+            if (key(u) <= key(v)) return;
+            swp(u, v);
+            v = u;
+        }
+    }
+    void down(int v)                                 // downheap :172-203
+    {
+        int w = 2 * (v - 1) + 2;
+        while (w <= n) {
+            if (w + 1 <= n && key(w + 1) < key(w)) w++;
+            if (key(v) <= key(w)) return;
+            swp(v, w);
+            v = w;
+            w = 2 * (v - 1) + 2;
+        }
+    }
+    void push(int idx) { n++; h[n] = idx; bp[idx - 1] = n; up(n); }          // pushheap :76-101
+    int pop()                                                                // popheap :103-131
+    {
+        if (n == 0) return 0;
+        swp(1, n);
+        bp[h[n] - 1] = 0;
+        const int idx = h[n];
+        n--;
+        down(1);
+        return idx;
+    }
+};
+
+// eikonal_solver_fmm, eikonal.f90:29-199; arrays (nx,ny) with x fastest
+inline void fast_marching(const std::vector<float> &speed, int nx, int ny, const float origin[2], const float delta[2],
+                          const float start[2], std::vector<float> &times)
+{
+    constexpr int FARAWAY = -1, ALIVE = 0;
+    const float inf = std::numeric_limits<float>::max() * 0.1f;
+    const float dx = delta[0], dy = delta[1];
+    times.assign((size_t)nx * ny, inf);
+    std::vector<int> bp((size_t)nx * ny, FARAWAY);
+    auto id = [nx](int x, int y) { return (y - 1) * nx + x; };
+    int ix = (int)((start[0] - origin[0]) / dx) + 1, iy = (int)((start[1] - origin[1]) / dy) + 1;
+    ix = std::min(std::max(ix, 1), nx);
+    iy = std::min(std::max(iy, 1), ny);
+    times[id(ix, iy) - 1] = 0.f;
+    if (nx == 1 && ny == 1) return;
+    bp[id(ix, iy) - 1] = ALIVE;
+    int nalive = 1;
+    IndexHeap heap(nx * ny, times.data(), bp.data());
+    auto T = [&](int x, int y) -> float & { return times[id(x, y) - 1]; };
+    auto S = [&](int x, int y) { return speed[id(x, y) - 1]; };
+    if (1 < ix) T(ix - 1, iy) = dx / S(ix - 1, iy);
+    if (ix < nx) T(ix + 1, iy) = dx / S(ix + 1, iy);
+    if (1 < iy) T(ix, iy - 1) = dy / S(ix, iy - 1);
+    if (iy < ny) T(ix, iy + 1) = dy / S(ix, iy + 1);
+    if (1 < ix) heap.push(id(ix - 1, iy));
+    if (ix < nx) heap.push(id(ix + 1, iy));
+    if (1 < iy) heap.push(id(ix, iy - 1));
+    if (iy < ny) heap.push(id(ix, iy + 1));
+    auto update = [&](int x, int y) {                // update_neighbor :121-186
+        const int i = id(x, y);
+        if (bp[i - 1] == ALIVE) return;
+        if (bp[i - 1] == FARAWAY) heap.push(i);
+        float a = inf, b = inf, c = inf, d = inf;
+        const float told = T(x, y), sp = S(x, y);
+        if (1 < x) a = T(x - 1, y);
+        if (x < nx) b = T(x + 1, y);
+        if (1 < y) c = T(x, y - 1);
+        if (y < ny) d = T(x, y + 1);
+        float t = 0.f;
+        const float aa = std::min(a, b), cc = std::min(c, d);
+        if (std::max(aa, cc) != inf) {
+            const float q = (aa - cc) * sp;
+            const float s = (dx * dx) * (dy * dy) * ((dx * dx) + (dy * dy) - q * q);
+            if (s >= 0.f) t = std::max(t, ((aa * (dy * dy) + cc * (dx * dx)) * sp + std::sqrt(s)) / (sp * ((dx * dx) + (dy * dy))));
+        }
+        if (std::min(c, d) == inf) {
+            if (a < inf) t = std::max(t, a + dx / sp);
+            if (b < inf) t = std::max(t, b + dx / sp);
+        }
+        if (std::min(a, b) == inf) {
+            if (c < inf) t = std::max(t, c + dy / sp);
+            if (d < inf) t = std::max(t, d + dy / sp);
+        }
+        if (t == 0.f) {
+            t = inf;
+            if (a < inf) t = std::min(t, a + dx / sp);
+            if (b < inf) t = std::min(t, b + dx / sp);
+            if (c < inf) t = std::min(t, c + dy / sp);
+            if (d < inf) t = std::min(t, d + dy / sp);
+        }
+        if (t != 0.f && told != t) {                 // updateheap, heap.f90:133-156
+            const float old = times[i - 1];
+            times[i - 1] = t;
+            if (t < old) heap.up(bp[i - 1]);
+            if (t > old) heap.down(bp[i - 1]);
+        }
+    };
+    while (nalive <= nx * ny) {
+        const int imin = heap.pop();
+        if (imin == 0) break;
+        ix = (imin - 1) % nx + 1;
+        iy = (imin - 1) / nx + 1;
+        bp[imin - 1] = ALIVE;
+        nalive++;
+        if (1 < ix) update(ix - 1, iy);
+        if (ix < nx) update(ix + 1, iy);
+        if (1 < iy) update(ix, iy - 1);
+        if (iy < ny) update(ix, iy + 1);
+    }
+}
+
+} // namespace eik
+
+inline int source_nparams_eikonal(int type) { return type == 4 ? 15 : (type == 5 ? 20 : -1); }
+
+// returns "" on success, otherwise the reference's error text
+inline std::string discretize_eikonal(int type, const float *P, float doi, const CrustProfile &prof,
+                                      const std::vector<HalfSpace> &cons, DiscreteSource &out)
+{
+    using namespace eik;
+    const bool mt = (type == 5);
+    const int o = mt ? 0 : 1;                                  // `eikonal` has slip-rake at position 8
+    const float bsx = P[7 + o], bsy = P[8 + o], brad = P[9 + o], nux = P[10 + o], nuy = P[11 + o], relv = P[12 + o];
+    float Rrup[3][3], Rslip[3][3];
+    init_euler(d2r(P[6]), d2r(P[5]), 0.f, Rrup);
+    if (!mt) init_euler(d2r(P[6]), d2r(P[5]), -d2r(P[7]), Rslip);
+    const V3 shift = { P[1], P[2], P[3] };
+    auto rc_to_ned = [&](const V3 &rc) { V3 p = mul(Rrup, rc); for (int k = 0; k < 3; k++) p[k] = p[k] + shift[k]; return p; };
+    auto ned_to_rc = [&](const V3 &p) { return mulT(Rrup, V3{ p[0] - shift[0], p[1] - shift[1], p[2] - shift[2] }); };
+    auto allowed = [&](const V3 &p) { for (auto &h : cons) if (!inside(p, h)) return false; return true; };
+
+    // bounding circle as a 180-gon, clipped by every constraint (psm_borderline_*)
+    const V3 center = rc_to_ned({ bsx, bsy, 0.f });
+    float tr[3][3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) tr[i][j] = -Rrup[i][j] * brad;
+    const int ninit = (brad == 0.f) ? 1 : 180;
+    std::vector<V3> poly((size_t)ninit);
+    for (int i = 1; i <= ninit; i++) {
+        const float ang = (float)i * 2.f * kPi / (float)ninit;
+        const V3 q = mul(tr, V3{ std::cos(ang), std::sin(ang), 0.f });
+        poly[i - 1] = { q[0] + center[0], q[1] + center[1], q[2] + center[2] };
+    }
+    if (cons.empty()) poly.clear();
+    for (auto &h : cons) poly = clip(poly, h);
+    if (poly.empty()) return "Empty rupture area";
+    float lo[2] = { std::numeric_limits<float>::max(), std::numeric_limits<float>::max() }, hi[2] = { -lo[0], -lo[1] };
+    for (auto &p : poly) {
+        const V3 rc = ned_to_rc(p);
+        for (int k = 0; k < 2; k++) { lo[k] = std::min(lo[k], rc[k]); hi[k] = std::max(hi[k], rc[k]); }
+    }
+
+    // fine grid of rupture speeds (psm_make_*_grid)
+    const float dgrid = std::min(100.f * doi / 2.f, 4000.f);
+    const float ext[2] = { hi[0] - lo[0], hi[1] - lo[1] };
+    int nf[2] = { (int)std::ceil(ext[0] / dgrid), (int)std::ceil(ext[1] / dgrid) };
+    if (nf[0] == 0) nf[0] = 1;
+    if (nf[1] == 0) nf[1] = 1;
+    const float fd[2] = { ext[0] / (float)nf[0], ext[1] / (float)nf[1] };
+    {
+        const float nukl = std::sqrt(nux * nux + nuy * nuy);
+        if (!allowed(rc_to_ned({ nux, nuy, 0.f })) || nukl > brad)
+            return "position of nucleation point is outside of rupture region";
+    }
+    const int fx = nf[0], fy = nf[1];
+    std::vector<float> speed((size_t)fx * fy), ftimes;
+    std::vector<V3> fpt((size_t)fx * fy);
+    float minspeed = std::numeric_limits<float>::max();
+    for (int iy = 1; iy <= fy; iy++)
+        for (int ix = 1; ix <= fx; ix++) {
+            const size_t k = (size_t)(iy - 1) * fx + ix - 1;
+            const V3 p = rc_to_ned({ lo[0] + ((float)ix - 0.5f) * fd[0], lo[1] + ((float)iy - 0.5f) * fd[1], 0.f });
+            fpt[k] = p;
+            const float d[3] = { p[0] - center[0], p[1] - center[1], p[2] - center[2] };
+            if (std::sqrt(dot(d, d)) > brad || !allowed(p)) { speed[k] = 0.f; continue; }
+            float vs = prof.vs[7], acc = 0.f;                          // crust2x2_get_at_depth
+            for (int l = 2; l < 7; l++) { acc = acc + prof.thickness[l]; if (acc >= p[2]) { vs = prof.vs[l]; break; } }
+            speed[k] = vs * relv;
+            minspeed = std::min(speed[k], minspeed);
+        }
+    const float invalid = minspeed * 0.5f;
+    for (auto &v : speed) if (v == 0.f) v = invalid;
+    const float start[2] = { nux, nuy };
+    fast_marching(speed, fx, fy, lo, fd, start, ftimes);
+    for (size_t k = 0; k < speed.size(); k++) if (speed[k] == invalid) ftimes[k] = -1.f;
+
+    // coarse grid (psm_to_tdsm_size_*, psm_downsample_grid)
+    const float maxd = 0.5f * doi * minspeed;
+    auto count = [](float size, float maxstep) { int n = (int)std::floor(size / maxstep) + 1; if (n <= 1) n = 2; if (size == 0.f) n = 1; return n; };
+    const int nxc = count(ext[0], maxd), nyc = count(ext[1], maxd);
+    float cd[2] = { (hi[0] - lo[0]) / (float)nxc, (hi[1] - lo[1]) / (float)nyc };
+    if (cd[0] == 0.f) cd[0] = 1.f;
+    if (cd[1] == 0.f) cd[1] = 1.f;
+    const size_t nc = (size_t)nxc * nyc;
+    std::vector<float> cnt(nc, 0.f), ct(nc, -1.f), cs(nc, 0.f), cdur(nc, 0.f), cw(nc, 0.f);
+    std::vector<V3> cp(nc, V3{ 0.f, 0.f, 0.f });
+    auto cell = [&](size_t k) -> long {
+        const V3 rc = ned_to_rc(fpt[k]);
+        const int ixc = (int)std::floor((rc[0] - lo[0]) / cd[0]) + 1, iyc = (int)std::floor((rc[1] - lo[1]) / cd[1]) + 1;
+        if (ixc < 1 || iyc < 1 || ixc > nxc || iyc > nyc) return -1;          // "orphaned point"
+        return (long)(iyc - 1) * nxc + ixc - 1;
+    };
+    int npf = 0;
+    for (size_t k = 0; k < speed.size(); k++) {
+        if (ftimes[k] < 0.f) continue;
+        const long ic = cell(k);
+        if (ic < 0) continue;
+        cnt[ic] = cnt[ic] + 1.f;
+        if (ct[ic] == -1.f) ct[ic] = 0.f;
+        ct[ic] = ct[ic] + ftimes[k];
+        cs[ic] = cs[ic] + 1.f / speed[k];
+        for (int q = 0; q < 3; q++) cp[ic][q] = cp[ic][q] + fpt[k][q];
+        npf++;
+    }
+    for (size_t ic = 0; ic < nc; ic++) if (cnt[ic] > 0.f) {
+        ct[ic] = 1.f / cnt[ic] * ct[ic];
+        cs[ic] = 1.f / (1.f / cnt[ic] * cs[ic]);
+        for (int q = 0; q < 3; q++) cp[ic][q] = 1.f / cnt[ic] * cp[ic][q];
+    }
+    for (size_t ic = 0; ic < nc; ic++) cw[ic] = cnt[ic] / (float)npf;
+    for (size_t k = 0; k < speed.size(); k++) {
+        if (ftimes[k] < 0.f) continue;
+        const long ic = cell(k);
+        if (ic < 0) continue;
+        cdur[ic] = cdur[ic] + std::fabs(ftimes[k] - ct[ic]);
+    }
+    for (size_t ic = 0; ic < nc; ic++) if (cnt[ic] > 0.f) cdur[ic] = 4.f / cnt[ic] * cdur[ic];
+
+    // centroid table (psm_to_tdsm_table_*); rise time deferred to the fold
+    float centertime = 0.f;
+    for (size_t ic = 0; ic < nc; ic++) if (ct[ic] >= 0.f) centertime = centertime + ct[ic] * cw[ic];
+    float m6[6];
+    if (mt) {
+        for (int k = 0; k < 6; k++) m6[k] = P[13 + k];
+    } else {
+        float mr[3][3];
+        detail::double_couple(Rslip, 1, mr);               // R m_unrot R^T (np = 1: not divided)
+        m6[0] = mr[0][0]; m6[1] = mr[1][1]; m6[2] = mr[2][2]; m6[3] = mr[0][1]; m6[4] = mr[0][2]; m6[5] = mr[1][2];
+    }
+    out.centroids.clear();
+    std::vector<float> tw, to;
+    for (size_t ic = 0; ic < nc; ic++) {
+        if (ct[ic] < 0.f) continue;
+        const float dur = cdur[ic];
+        const int nt = (int)std::floor((dur + 0.f) / doi) + 1;          // discretize_subfault_time, risetime 0
+        if (nt == 1) { tw.assign(1, 1.f); to.assign(1, 0.f); }
+        else detail::bin_stf(detail::trapezoid_stf(dur, 0.f), dur + 0.f, nt, tw, to);
+        for (int it = 0; it < nt; it++) {
+            Centroid c;
+            c.north = cp[ic][0]; c.east = cp[ic][1]; c.depth = cp[ic][2];
+            c.time = ct[ic] + to[it] + P[0] - centertime;
+            for (int k = 0; k < 6; k++) c.m[k] = m6[k] * tw[it] * cw[ic];
+            out.centroids.push_back(c);
+        }
+    }
+    out.moment = P[4];
+    out.risetime = mt ? P[19] : P[14];
+    return "";
+}
+
+} // namespace kiwi

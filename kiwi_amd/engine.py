@@ -46,6 +46,40 @@ def discretize(sourcetype, params, effective_dt):
     return cent, mo.value, ri.value
 
 
+def pack_crust_profile(vp, vs, rho, thickness):
+    """t_crust2x2_1d_profile (crust2x2.f90:45-50) as the 31 floats the C-ABI takes."""
+    out = np.concatenate([np.asarray(vp, np.float32), np.asarray(vs, np.float32), np.asarray(rho, np.float32),
+                          np.asarray(thickness, np.float32)])
+    if out.shape != (31,):
+        raise KiwiHipError("a crust profile is vp[8], vs[8], rho[8], thickness[7]")
+    return np.ascontiguousarray(out)
+
+
+_EIKONAL_ERRORS = {5: "Empty rupture area", 6: "position of nucleation point is outside of rupture region"}
+
+
+def discretize_eikonal(sourcetype, params, effective_dt, rupture_profile, con_points, con_normals):
+    """psm_set + psm_to_tdsm of `eikonal` / `mt_eikonal` (kiwi_hip_discretize_eikonal)."""
+    L = _lib.load()
+    st = SOURCE_TYPES.get(sourcetype, sourcetype)
+    p = np.ascontiguousarray(params, np.float32)
+    prof = np.ascontiguousarray(rupture_profile, np.float32)
+    pts = np.ascontiguousarray(con_points, np.float32).reshape(-1, 3)
+    nrm = np.ascontiguousarray(con_normals, np.float32).reshape(-1, 3)
+    n, mo, ri = C.c_int(), C.c_float(), C.c_float()
+
+    def call(cent, maxcent):
+        rc = L.kiwi_hip_discretize_eikonal(st, _fp(p), len(p), effective_dt, _fp(prof), len(pts), _fp(pts), _fp(nrm),
+                                           cent, maxcent, C.byref(n), C.byref(mo), C.byref(ri))
+        if rc != 0:
+            raise KiwiHipError("discretize failed (rc=%d): %s" % (rc, _EIKONAL_ERRORS.get(rc, "bad arguments")))
+
+    call(None, 0)
+    cent = np.zeros((n.value, 10), np.float32)
+    call(_fp(cent), n.value)
+    return cent, mo.value, ri.value
+
+
 class Engine:
     def __init__(self, device=0):
         self.L = _lib.load()
@@ -153,10 +187,33 @@ class Engine:
                  "set_sources")
         self.nsrc = len(tables)
 
+    def set_source_crust(self, rupture_profile, origin_profile):
+        """The two CRUST2.0 look-ups of set_source_location (see include/kiwi_hip.h), 31 floats each."""
+        a = np.ascontiguousarray(rupture_profile, np.float32)
+        b = np.ascontiguousarray(origin_profile, np.float32)
+        self._ck(self.L.kiwi_hip_set_source_crust(self.h, _fp(a), _fp(b)), "set_source_location")
+
+    def set_source_crustal_thickness_limit(self, limit):
+        self._ck(self.L.kiwi_hip_set_source_crustal_thickness_limit(self.h, limit),
+                 "set_source_crustal_thickness_limit")
+
+    def get_source_crustal_thickness(self):
+        t = C.c_float()
+        self._ck(self.L.kiwi_hip_get_source_crustal_thickness(self.h, C.byref(t)), "get_source_crustal_thickness")
+        return t.value
+
+    def set_source_constraints(self, points, normals):
+        pts = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
+        nrm = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+        self._ck(self.L.kiwi_hip_set_source_constraints(self.h, len(pts), _fp(pts), _fp(nrm)),
+                 "set_source_constraints")
+
     def set_source_params(self, sourcetype, params):
         """Batch form of `set_source_params type p1..pn`: params[nsrc, nparams]."""
         p = np.ascontiguousarray(np.atleast_2d(params), np.float32)
         st = SOURCE_TYPES.get(sourcetype, sourcetype)
+        if p.shape[1] != self.L.kiwi_hip_source_nparams(st):
+            raise KiwiHipError("set_source_params: wrong number of source parameters")
         self._ck(self.L.kiwi_hip_set_sources_params(self.h, st, p.shape[0], _fp(p)), "set_source_params")
         self.nsrc = p.shape[0]
 

@@ -128,6 +128,48 @@ module kiwi_hip_binding
             real(c_float), intent(out) :: moment, risetime
         end function
 
+        ! crust profiles are 31 reals: vp(8) vs(8) rho(8) thickness(7)  (t_crust2x2_1d_profile, crust2x2.f90:45-50)
+        integer(c_int) function kiwi_hip_set_source_crust( ctx, rupture_profile, origin_profile ) &
+                bind(C, name='kiwi_hip_set_source_crust')
+            import :: c_int, c_ptr, c_float
+            type(c_ptr), value :: ctx
+            real(c_float), intent(in) :: rupture_profile(31), origin_profile(31)
+        end function
+
+        integer(c_int) function kiwi_hip_set_source_crustal_thickness_limit( ctx, limit ) &
+                bind(C, name='kiwi_hip_set_source_crustal_thickness_limit')
+            import :: c_int, c_ptr, c_float
+            type(c_ptr), value :: ctx
+            real(c_float), value :: limit
+        end function
+
+        integer(c_int) function kiwi_hip_get_source_crustal_thickness( ctx, thickness ) &
+                bind(C, name='kiwi_hip_get_source_crustal_thickness')
+            import :: c_int, c_ptr, c_float
+            type(c_ptr), value :: ctx
+            real(c_float), intent(out) :: thickness
+        end function
+
+        integer(c_int) function kiwi_hip_set_source_constraints( ctx, n, points, normals ) &
+                bind(C, name='kiwi_hip_set_source_constraints')
+            import :: c_int, c_ptr, c_float
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: n
+            real(c_float), intent(in) :: points(3,*), normals(3,*)
+        end function
+
+        integer(c_int) function kiwi_hip_discretize_eikonal( sourcetype, params, nparams, effective_dt, rupture_profile, &
+                                                             ncon, points, normals, cent, maxcent, ncent, moment, &
+                                                             risetime ) bind(C, name='kiwi_hip_discretize_eikonal')
+            import :: c_int, c_float
+            integer(c_int), value :: sourcetype, nparams, ncon, maxcent
+            real(c_float), intent(in) :: params(*), rupture_profile(31), points(3,*), normals(3,*)
+            real(c_float), value :: effective_dt
+            real(c_float), intent(out) :: cent(10,*)
+            integer(c_int), intent(out) :: ncent
+            real(c_float), intent(out) :: moment, risetime
+        end function
+
         integer(c_int) function kiwi_hip_set_sources( ctx, nsrc, cent_ofs, cent, moment, risetime ) &
                 bind(C, name='kiwi_hip_set_sources')
             import :: c_int, c_ptr, c_float

@@ -202,6 +202,10 @@ program minimizer_hip
         case ('switch_receiver');           call do_switch_receiver( a, ok_ )
         case ('set_source_location');       call do_set_source_location( a, ok_ )
         case ('set_source_params');         call do_set_source_params( a, ok_ )
+        case ('set_source_crust');          call do_set_source_crust( a, ok_ )
+        case ('set_source_constraints');    call do_set_source_constraints( a, ok_ )
+        case ('set_source_crustal_thickness_limit'); call do_set_source_crustal_thickness_limit( a, ok_ )
+        case ('get_source_crustal_thickness');       call do_get_source_crustal_thickness( ok_ )
         case ('set_ref_seismograms');       call do_set_ref_seismograms( a, ok_ )
         case ('set_misfit_method');         call do_set_misfit_method( a, ok_ )
         case ('set_misfit_taper');          call do_set_plf( a, .true., ok_ )
@@ -410,6 +414,78 @@ program minimizer_hip
         ok_ = check( kiwi_hip_set_source_location( ctx, lat, lon, rt ) )
         if (ok_) ref_time = rt
         evaluated = .false.
+    end subroutine
+
+    ! set_source_crust r1..r31 o1..o31 : the two CRUST2.0 1-D profiles the reference looks up itself in
+    ! set_source_location (crust2x2.f90 reads its tables from KIWI_HOME/aux; this host takes the profiles on the wire)
+    subroutine do_set_source_crust( a, ok_ )
+        character(len=*), intent(in) :: a
+        logical, intent(out) :: ok_
+        real(c_float) :: prof(31,2)
+        integer :: ios
+        ok_ = .false.
+        if (count_words( a ) /= 62) then
+            call fail( 'usage: set_source_crust vp(8) vs(8) rho(8) thickness(7) [rupture profile] ... [origin profile]' ); return
+        end if
+        read (a,*,iostat=ios) prof
+        if (ios /= 0) then
+            call fail( 'set_source_crust: cannot parse profiles' ); return
+        end if
+        if (.not. need_ctx()) return
+        ok_ = check( kiwi_hip_set_source_crust( ctx, prof(:,1), prof(:,2) ) )
+        evaluated = .false.
+    end subroutine
+
+    ! set_source_constraints px1 py1 pz1 nx1 ny1 nz1 ...   (minimizer.f90:521-579)
+    subroutine do_set_source_constraints( a, ok_ )
+        character(len=*), intent(in) :: a
+        logical, intent(out) :: ok_
+        real(c_float), allocatable :: numbers(:,:), points(:,:), normals(:,:)
+        integer :: n, ios
+        ok_ = .false.
+        n = count_words( a )
+        if (mod(n,6) /= 0) then
+            call fail( 'number of arguments is not divideable by 6' ); return
+        end if
+        allocate( numbers(6,n/6), points(3,n/6), normals(3,n/6) )
+        read (a,*,iostat=ios) numbers
+        if (ios /= 0 .and. n > 0) then
+            call fail( 'failed to parse constraints' ); return
+        end if
+        points = numbers(1:3,:)
+        normals = numbers(4:6,:)
+        if (.not. need_ctx()) return
+        ok_ = check( kiwi_hip_set_source_constraints( ctx, int(n/6,c_int), points, normals ) )
+        evaluated = .false.
+    end subroutine
+
+    ! set_source_crustal_thickness_limit thickness-limit   (minimizer.f90:581-611)
+    subroutine do_set_source_crustal_thickness_limit( a, ok_ )
+        character(len=*), intent(in) :: a
+        logical, intent(out) :: ok_
+        real(c_float) :: limit
+        integer :: ios
+        ok_ = .false.
+        read (a,*,iostat=ios) limit
+        if (ios /= 0) then
+            call fail( 'usage: set_source_crustal_thickness_limit thickness-limit' ); return
+        end if
+        if (.not. need_ctx()) return
+        ok_ = check( kiwi_hip_set_source_crustal_thickness_limit( ctx, limit ) )
+        evaluated = .false.
+    end subroutine
+
+    ! get_source_crustal_thickness   (minimizer.f90:613-640)
+    subroutine do_get_source_crustal_thickness( ok_ )
+        logical, intent(out) :: ok_
+        real(c_float) :: thickness
+        character(len=64) :: buffer
+        ok_ = .false.
+        if (.not. need_ctx()) return
+        if (.not. check( kiwi_hip_get_source_crustal_thickness( ctx, thickness ) )) return
+        write (buffer,*) thickness
+        answer = trim(adjustl(buffer))
+        ok_ = .true.
     end subroutine
 
     subroutine do_set_source_params( a, ok_ )

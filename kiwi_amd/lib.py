@@ -64,6 +64,12 @@ def load():
         "kiwi_hip_source_nparams": [C.c_int],
         "kiwi_hip_discretize": [C.c_int, c_float_p, C.c_int, C.c_float, c_float_p, C.c_int, c_int_p, c_float_p,
                                 c_float_p],
+        "kiwi_hip_set_source_crust": [vp, c_float_p, c_float_p],
+        "kiwi_hip_set_source_crustal_thickness_limit": [vp, C.c_float],
+        "kiwi_hip_get_source_crustal_thickness": [vp, c_float_p],
+        "kiwi_hip_set_source_constraints": [vp, C.c_int, c_float_p, c_float_p],
+        "kiwi_hip_discretize_eikonal": [C.c_int, c_float_p, C.c_int, C.c_float, c_float_p, C.c_int, c_float_p,
+                                        c_float_p, c_float_p, C.c_int, c_int_p, c_float_p, c_float_p],
         "kiwi_hip_set_sources": [vp, C.c_int, c_int_p, c_float_p, c_float_p, c_float_p],
         "kiwi_hip_set_sources_params": [vp, C.c_int, C.c_int, c_float_p],
         "kiwi_hip_eval": [vp, C.c_int, C.c_int],

@@ -1,0 +1,92 @@
+"""Eikonal sources against golden vectors generated from the reference's own modules
+(tests/golden/make_golden_eikonal.py): the oracle restatement and the product's host discretiser
+(kiwi_amd/csrc/kiwi_host_eikonal.hpp through kiwi_hip_discretize_eikonal) must both reproduce the
+reference's centroid tables bit for bit.  Runs without /root/reference and without a GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ko
+from kiwi_amd import engine as ke
+from kiwi_amd.lib import KiwiHipError
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "eikonal_vectors.npz"))
+N = int(G["n"])
+
+
+def oracle_profile(v):
+    return ko.crust_profile(v[0:8], v[8:16], v[16:24], v[24:31])
+
+
+def test_default_constraints():
+    thick = ko.crust_thickness(oracle_profile(G["origin_profile"]))
+    for k in range(N):
+        cp, cn = G["e%d_con" % k]
+        limit = float(G["e%d_limit" % k])
+        assert np.array_equal(cp[0], [0, 0, 1500]) and np.array_equal(cn[0], [0, 0, -1]) and np.array_equal(cn[1], [0, 0, 1])
+        assert cp[1][2] == np.float32(min(limit, thick) if limit > 0 else thick)
+
+
+@pytest.mark.parametrize("k", range(N))
+def test_oracle_matches_reference(k):
+    cp, cn = G["e%d_con" % k]
+    a, mo, ri, _ = ko.discretize_eikonal(int(G["e%d_type" % k]), G["e%d_params" % k], float(G["e%d_edt" % k]),
+                                         oracle_profile(G["rupture_profile"]), cp, cn)
+    assert np.array_equal(a.view(np.uint32), G["e%d_cent" % k].view(np.uint32))
+    assert np.array_equal(np.array([mo, ri], np.float32), G["e%d_mr" % k])
+
+
+@pytest.mark.parametrize("k", range(N))
+def test_product_matches_reference(k):
+    cp, cn = G["e%d_con" % k]
+    a, mo, ri = ke.discretize_eikonal(int(G["e%d_type" % k]), G["e%d_params" % k], float(G["e%d_edt" % k]),
+                                      G["rupture_profile"], cp, cn)
+    assert np.array_equal(a.view(np.uint32), G["e%d_cent" % k].view(np.uint32))
+    assert np.array_equal(np.array([mo, ri], np.float32), G["e%d_mr" % k])
+
+
+def test_failures_reported_like_the_reference():
+    p = G["fail_empty_params"]
+    cp, cn = G["e0_con"]
+    with pytest.raises(ValueError, match="Empty rupture area"):
+        ko.discretize_eikonal(5, p, 1.0, oracle_profile(G["rupture_profile"]), cp, cn)
+    with pytest.raises(KiwiHipError, match="Empty rupture area"):
+        ke.discretize_eikonal(5, p, 1.0, G["rupture_profile"], cp, cn)
+    q = G["e%d_params" % (N - 1)].copy()            # an mt_eikonal case: nucleation point moved out of the circle
+    q[10] = 3 * q[9]
+    with pytest.raises(ValueError, match="nucleation"):
+        ko.discretize_eikonal(5, q, 1.0, oracle_profile(G["rupture_profile"]), cp, cn)
+    with pytest.raises(KiwiHipError, match="nucleation"):
+        ke.discretize_eikonal(5, q, 1.0, G["rupture_profile"], cp, cn)
+    with pytest.raises(KiwiHipError):
+        ke.discretize_eikonal(5, q[:5], 1.0, G["rupture_profile"], cp, cn)
+
+
+def test_product_matches_oracle_on_random_cases():
+    rng = np.random.default_rng(77)
+    prof = G["rupture_profile"]
+    cp, cn = G["e0_con"]
+    done = 0
+    for i in range(60):
+        st = 4 + i % 2
+        common = [rng.uniform(-1, 1), rng.uniform(-3e3, 3e3), rng.uniform(-3e3, 3e3), rng.uniform(2e3, 3e4)]
+        strike, dip = rng.uniform(-180, 180), rng.uniform(0, 90)
+        bord = [rng.uniform(-2e3, 2e3), rng.uniform(-2e3, 2e3), rng.uniform(5e2, 9e3)]
+        nukl = [rng.uniform(-1, 1) * 0.7 * bord[2], rng.uniform(-1, 1) * 0.7 * bord[2]]
+        relv, rise = rng.uniform(0.5, 1.0), rng.uniform(0, 3)
+        if st == 5:
+            p = common + [1.0, strike, dip] + bord + nukl + [relv] + list(rng.standard_normal(6)) + [rise]
+        else:
+            p = common + [1e18, strike, dip, rng.uniform(-180, 180)] + bord + nukl + [relv, rise]
+        edt = float(rng.choice([1.0, 2.0, 4.0]))
+        try:
+            a, mo, ri, _ = ko.discretize_eikonal(st, p, edt, oracle_profile(prof), cp, cn)
+        except ValueError as e:
+            with pytest.raises(KiwiHipError, match=str(e)[:12]):
+                ke.discretize_eikonal(st, p, edt, prof, cp, cn)
+            continue
+        b, bmo, bri = ke.discretize_eikonal(st, p, edt, prof, cp, cn)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and (mo, ri) == (bmo, bri)
+        done += 1
+    assert done >= 20

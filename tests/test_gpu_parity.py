@@ -10,7 +10,7 @@ Tolerances (stated once, used everywhere):
 import numpy as np
 import pytest
 
-from kiwi_amd import synthetic
+from kiwi_amd import synthetic, KiwiHipError
 from tests.common import Scenario, oracle_misfits
 
 pytestmark = pytest.mark.gpu
@@ -348,3 +348,57 @@ def test_time_domain_norms_with_frequency_filter(method):
     b = min(lo_o + len(so), lo_p + len(sp))
     assert b - a > 200
     assert np.max(np.abs(so[a - lo_o:b - lo_o] - sp[a - lo_p:b - lo_p])) <= 2e-5 * np.max(np.abs(so))
+
+
+@pytest.mark.parametrize("stype", ["eikonal", "mt_eikonal"])
+def test_eikonal_sources_with_risetime_fold(stype):
+    """Variable-rupture-speed sources: discretised by the product's host code from the crust
+    profile + constraints, rise time applied by the fold in the misfit kernel."""
+    import os
+    from oracle import ko
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "eikonal_vectors.npz"))
+    prof = G["rupture_profile"]
+    sc = Scenario(nz=6)
+    e, p = build(sc)
+    st = 4 if stype == "eikonal" else 5
+    rng = np.random.default_rng(5 + st)
+    trials = []
+    for i in range(4):
+        common = [0.2 * i, 300.0 * i, -200.0 * i, 10500.0 + 300 * i]
+        bord = [100.0, -50.0, 2500.0 + 400 * i]
+        nukl = [500.0 - 300 * i, 200.0]
+        if st == 5:
+            trials.append(common + [1.0, 80.0 + 5 * i, 70.0] + bord + nukl + [0.8] + list(rng.standard_normal(6) * 7e17) + [0.8 * i])
+        else:
+            trials.append(common + [7e18, 80.0 + 5 * i, 70.0, -170.0 + 10 * i] + bord + nukl + [0.8, 0.8 * i])
+    trials = np.array(trials, np.float32)
+    cp = np.array([[0, 0, 6500.0], [0, 0, 15500.0], [0, -2000.0, 0]], np.float32)
+    cn = np.array([[0, 0, -1.0], [0, 0, 1.0], [0.2, -1.0, 0]], np.float32)
+    p.set_source_crust(prof, G["origin_profile"])
+    thick = ko.crust_thickness(ko.crust_profile(*np.split(G["origin_profile"], [8, 16, 24])))
+    assert p.get_source_crustal_thickness() == thick
+    p.set_source_crustal_thickness_limit(9000.0)
+    assert p.get_source_crustal_thickness() == 9000.0
+    p.set_source_constraints(cp, cn)
+    p.set_source_params(stype, trials)
+    p.eval()
+    pm, pn, pg = p.get_misfits()
+    oprof = ko.crust_profile(*np.split(prof, [8, 16, 24]))
+    ncent = []
+    for i, t in enumerate(trials):
+        c, mo, ri, _ = ko.discretize_eikonal(st, t, sc.effective_dt, oprof, cp, cn)
+        ncent.append(len(c))
+        e.set_centroids(c, mo, ri)
+        m, n, g = e.get_misfits()
+        assert misfit_close(pm[i], m), i
+        assert np.array_equal(pn[i], n)
+        assert abs(pg[i] - g) <= MISFIT_RTOL * g
+    assert min(ncent) > 30 and len(set(ncent)) > 1
+    # an impossible source is reported with the reference's message, not fatal
+    bad = trials[:1].copy()
+    bad[0, 3] = 500.0
+    with pytest.raises(KiwiHipError, match="Empty rupture area"):
+        p.set_source_params(stype, bad)
+    p.set_source_params(stype, trials[:1])
+    p.eval()
+    assert misfit_close(p.get_misfits()[0][0], pm[0])

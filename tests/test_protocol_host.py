@@ -37,6 +37,16 @@ def test_wire_format_and_errors_without_device(host, tmp_path):
             p.do("set_source_params", "bilateral", 1, 2, 3)
         with pytest.raises(protocol.SeismosizerReturnedError, match="unknown norm"):
             p.do("set_misfit_method", "l3norm")
+        with pytest.raises(protocol.SeismosizerReturnedError, match="expected 15 source parameters"):
+            p.do("set_source_params", "eikonal", 1, 2, 3)
+        with pytest.raises(protocol.SeismosizerReturnedError, match="expected 20 source parameters"):
+            p.do("set_source_params", "mt_eikonal", 1, 2, 3)
+        with pytest.raises(protocol.SeismosizerReturnedError, match="not divideable by 6"):
+            p.do("set_source_constraints", 0, 0, 1500, 0, 0)
+        with pytest.raises(protocol.SeismosizerReturnedError, match="usage: set_source_crust "):
+            p.do("set_source_crust", 1, 2, 3)
+        with pytest.raises(protocol.SeismosizerReturnedError, match="usage: set_source_crustal_thickness_limit"):
+            p.do("set_source_crustal_thickness_limit")
         # the process is still alive and in sync after all those errors
         assert p.do("set_verbose F") == ""
     finally:
@@ -110,5 +120,25 @@ def test_protocol_host_matches_python_host_and_oracle(host, tmp_path):
         assert np.max(np.abs(so[a - lo_o:b - lo_o] - v[a - i0:b - i0])) <= 1e-5 * np.max(np.abs(so))
         with pytest.raises(protocol.SeismosizerReturnedError):
             p.do("switch_receiver", 99, "off")
+        # eikonal source over the wire: crust profiles + constraints + 15 parameters
+        from oracle import ko
+        G = np.load(os.path.join(os.path.dirname(__file__), "golden", "eikonal_vectors.npz"))
+        with pytest.raises(protocol.SeismosizerReturnedError, match="crust"):
+            p.do("set_source_params", "eikonal", *G["e0_params"])
+        p.do("set_source_crust", *G["rupture_profile"], *G["origin_profile"])
+        thick = float(p.do("get_source_crustal_thickness"))
+        assert np.float32(thick) == np.float32(ko.crust_thickness(ko.crust_profile(*np.split(G["origin_profile"], [8, 16, 24]))))
+        p.do("set_source_crustal_thickness_limit", 10000)
+        assert float(p.do("get_source_crustal_thickness")) == 10000.0
+        cons = [0, 0, 6500, 0, 0, -1, 0, 0, 13500, 0, 0, 1]
+        p.do("set_source_constraints", *cons)
+        ep = np.array([0.1, 200, -100, 10000, 5e18, 85, 75, -160, 0, 0, 3000, 400, 100, 0.8, 1.2], np.float32)
+        p.do("set_source_params", "eikonal", *["%.9g" % v for v in ep])
+        gl = float(p.do("get_global_misfit"))
+        c, mo, ri, _ = ko.discretize_eikonal(4, ep, sc.effective_dt, ko.crust_profile(*np.split(G["rupture_profile"], [8, 16, 24])),
+                                             np.array(cons, np.float32).reshape(2, 6)[:, :3], np.array(cons, np.float32).reshape(2, 6)[:, 3:])
+        assert len(c) > 20 and ri == np.float32(1.2)
+        e.set_centroids(c, mo, ri)
+        assert abs(gl - e.get_misfits()[2]) <= 2e-5 * gl
     finally:
         p.close()
