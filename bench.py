@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
 """bench.py -- trial-source misfit evaluations per second on MI355X (BASELINE.json metric).
 
-Workload (config.workload = "cfg3-bilat"): BASELINE.json configs[2], the configuration the
+Default workload (config.workload = "cfg3-bilat"): BASELINE.json configs[2], the configuration the
 north_star target is quoted on -- `bilateral` extended rupture discretised into 100 centroids,
 50 receivers x 3 components (n,e,d), 4096-sample Green's functions (ng = 10, bilinear
 interpolation = 4 neighbour traces), time-domain L2 misfit over a 4096-sample tapered window.
+`--workload cfg2|cfg4|cfg5` run the other BASELINE.json configurations (moment-tensor grid;
+mt_eikonal 468 centroids x 200 receivers; spectral comparator with frequency filter) the same way.
 One "step" = one pass of the hot path (geometry -> accumulate -> misfit) over a batch of
---batch trial sources per GPU (a strike sweep, kiwibench.py:136), everything already resident in
-HBM.  N > 1: every rank evaluates its own contiguous shard of the trial list (weak scaling) and
-the per-source global misfits are all-gathered over RCCL.
+--batch trial sources per GPU, everything already resident in HBM.  N > 1: every rank evaluates
+its own contiguous shard of the trial list (weak scaling) and the per-source global misfits are
+all-gathered over RCCL.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` and `cpu_baseline`.
 """
@@ -25,15 +27,14 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-
-# 100 centroids: nx=10, ny=2, nt=5 at effective dt 0.5 (source_bilat.f90:274-315)
-BENCH_BILAT = [0., 0., 0., 10000., 1e20, 91., 87., 164., 0., 4800., 2000., 2000., 3000., 2.]
+NORM_ID = {"l2norm": 1, "l1norm": 2, "ampspec_l2norm": 3, "ampspec_l1norm": 4}
 
 
-def setup_product(device, nrec, L, batch, trial0):
+def setup_product(device, wl, L):
     from kiwi_amd import Engine, synthetic
-    from kiwi_amd.engine import discretize
-    gf = synthetic.make_gfdb(L=L)
+    from kiwi_amd.engine import discretize, discretize_eikonal
+    nrec = wl["nrec"]
+    gf = synthetic.make_gfdb(nx=wl["nx"], L=L)
     lat, lon, depth, comps, dist = synthetic.make_receivers(nrec)
     p = Engine(device)
     p.set_database(gf["dt"], gf["dx"], gf["dz"], gf["firstx"], gf["firstz"], gf["data"], gf["first"], gf["nsamp"])
@@ -41,9 +42,12 @@ def setup_product(device, nrec, L, batch, trial0):
     p.set_source_location(40.0, 30.0, 0.0)
     p.set_effective_dt(0.5)
     p.set_local_interpolation("bilinear")
-    p.set_misfit_method("l2norm")
+    p.set_misfit_method(wl["method"])
+    if wl["crust"] is not None:
+        p.set_source_crust(wl["crust"], wl["crust"])
+        p.set_source_constraints(*wl["constraints"])
     dt = gf["dt"]
-    # reference traces = synthetics of the "true" source over a 4096-sample window per receiver
+    # reference traces = synthetics of the "true" source over an L-sample window per receiver
     firsts = [int(round(d / 6000.0 / dt)) for d in dist]
     tapers = {}
     for ir in range(nrec):
@@ -51,15 +55,16 @@ def setup_product(device, nrec, L, batch, trial0):
             p.set_ref_seismogram(ir + 1, k + 1, firsts[ir], np.zeros(L, np.float32))
         tapers[ir + 1] = synthetic.full_taper(firsts[ir], L, dt)
         p.set_misfit_taper(ir + 1, *tapers[ir + 1])
+        if wl["filter"] is not None:
+            p.set_misfit_filter(ir + 1, *wl["filter"])
     # one full-size launch with the "true" source in slot 0 and the synthetics kept on the device
     # (every accumulate launch of this process then has the same size, so rocprof's per-kernel average
     # is the figure quoted in `roofline`)
-    trials = synthetic.bilat_strike_sweep(batch, step=0.1, base=BENCH_BILAT)
-    trials[:, 5] += 0.1 * trial0
+    trials = wl["trials"]
     first = trials.copy()
-    first[0] = np.array(BENCH_BILAT, np.float32)
+    first[0] = wl["true"]
     p.set_keep_synthetics(1)
-    p.set_source_params("bilateral", first)
+    p.set_source_params(wl["sourcetype"], first)
     p.eval()
     refs = {}
     for ir in range(nrec):
@@ -68,19 +73,26 @@ def setup_product(device, nrec, L, batch, trial0):
     p.set_keep_synthetics(0)
     for (ir, k), (lo, d) in refs.items():
         p.set_ref_seismogram(ir, k, lo, d)
-    p.set_source_params("bilateral", trials)
+    p.set_source_params(wl["sourcetype"], trials)
     for _ in range(3):          # bring clocks and caches to steady state before anything is timed
         p.eval()
     p.sync()
-    ncent = len(discretize("bilateral", trials[0], 0.5)[0])
-    return p, gf, (lat, lon, depth, comps), refs, tapers, trials, ncent
+    sample = trials[:: max(1, len(trials) // 16)]
+    if wl["crust"] is not None:
+        st = 4 if wl["sourcetype"] == "eikonal" else 5
+        nc = [len(discretize_eikonal(st, t, 0.5, wl["crust"], *wl["constraints"])[0]) for t in sample]
+    else:
+        nc = [len(discretize(wl["sourcetype"], t, 0.5)[0]) for t in sample]
+    return p, gf, (lat, lon, depth, comps), refs, tapers, float(np.mean(nc))
 
 
-def cpu_baseline(gf, recv, refs, tapers, trials, gpu_global, budget_s=20.0):
+def cpu_baseline(wl, gf, recv, refs, tapers, gpu_global, budget_s=20.0):
     """The oracle (C restatement, OpenMP over receivers like minimizer_engine.f90:893-903) timed on
     this box's host cores for a bounded number of the SAME trial sources."""
     from oracle import ko
+    from kiwi_amd.engine import SOURCE_TYPES
     cores = os.cpu_count() or 1
+    trials = wl["trials"]
     nx, nz, ng, L = gf["data"].shape
     db = ko.Gfdb(nx, nz, ng, gf["dt"], gf["dx"], gf["dz"], gf["firstx"], gf["firstz"])
     for ix in range(nx):
@@ -94,24 +106,34 @@ def cpu_baseline(gf, recv, refs, tapers, trials, gpu_global, budget_s=20.0):
     e.set_effective_dt(0.5)
     e.set_interpolation(True)
     e.set_nthreads(cores)
+    e.set_misfit_method(NORM_ID[wl["method"]])
     for (ir, k), (lo, d) in refs.items():
         e.set_reference(ir, k, lo, d)
     for ir, (x, y) in tapers.items():
         e.set_taper(ir, x, y)
-    e.set_source_params(1, trials[0])
-    e.get_misfits()                                   # warm-up (allocations)
+        if wl["filter"] is not None:
+            e.set_filter(ir, *wl["filter"])
+    st = SOURCE_TYPES[wl["sourcetype"]]
+    if wl["crust"] is not None:
+        c = wl["crust"]
+        prof = ko.crust_profile(c[0:8], c[8:16], c[16:24], c[24:31])
+
+    def one(t):                                       # set_source_params + get_misfits (seismosizer.py:703-718)
+        if wl["crust"] is not None:
+            cent, mo, ri, _ = ko.discretize_eikonal(st, t, 0.5, prof, *wl["constraints"])
+            e.set_centroids(cent, mo, ri)
+        else:
+            e.set_source_params(st, t)
+        return e.get_misfits()[2]
+
+    one(trials[0])                                    # warm-up (allocations)
     t0 = time.perf_counter()
-    e.set_source_params(1, trials[1 % len(trials)])
-    e.get_misfits()
+    one(trials[1 % len(trials)])
     t1 = time.perf_counter() - t0
     n = int(max(2, min(len(trials), budget_s / max(t1, 1e-3))))
-    gl = []
     t0 = time.perf_counter()
-    for i in range(n):
-        e.set_source_params(1, trials[i])
-        gl.append(e.get_misfits()[2])
+    gl = np.array([one(trials[i]) for i in range(n)])
     dtm = time.perf_counter() - t0
-    gl = np.array(gl)
     err = float(np.max(np.abs(gpu_global[:n] - gl) / np.abs(gl)))
     e.close()
     db.close()
@@ -125,8 +147,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="trial sources per GPU per step")
-    ap.add_argument("--receivers", type=int, default=50)
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
+                    help="BASELINE.json configs[1..4]; cfg3 (default) is the one the metric is quoted on")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="trial sources per GPU per step (default: 12960 cfg2, 256 cfg3/cfg5, 32 cfg4)")
     ap.add_argument("--samples", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -145,8 +169,13 @@ def main():
     ngpus = world
 
     from kiwi_amd.shard import shard_range, gather_misfits
+    from kiwi_amd import synthetic
+    if args.batch <= 0:
+        args.batch = {"cfg2": 12960, "cfg3": 256, "cfg4": 32, "cfg5": 256}[args.workload]
     lo, hi = shard_range(args.batch * ngpus, ngpus, rank)
-    p, gf, recv, refs, tapers, trials, ncent = setup_product(local_rank, args.receivers, args.samples, hi - lo, lo)
+    wl = synthetic.workload(args.workload, hi - lo, lo)
+    p, gf, recv, refs, tapers, ncent = setup_product(local_rank, wl, args.samples)
+    nrec = wl["nrec"]
     nmis = p.nmisfits()
 
     def step():
@@ -162,12 +191,17 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    step_s = []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         allg = step()
+        step_s.append(time.perf_counter() - ts)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("KIWI_BENCH_VERBOSE"):
+        print("rank %d step ms: %s" % (rank, " ".join("%.2f" % (1e3 * v) for v in step_s)), file=sys.stderr)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -178,7 +212,7 @@ def main():
         total_evals = args.batch * ngpus * args.steps
         value = total_evals / elapsed
         n_ip, ng, L, W = 4, gf["data"].shape[2], args.samples, args.samples
-        b_eval = ncent * args.receivers * ng * n_ip * L * 4 + args.receivers * 3 * W * 4 * 2
+        b_eval = int(ncent * nrec * ng * n_ip * L * 4 + nrec * 3 * W * 4 * 2)
         acc_s = float(ms[1]) * 1e-3
         bytes_launched = b_eval * args.batch * args.steps           # rank 0's launches
         achieved = bytes_launched / acc_s / 1e9 if acc_s > 0 else 0.0
@@ -191,7 +225,8 @@ def main():
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json"))):
                 prof = json.load(open(f))
                 tb = prof.get("traffic_bytes_per_launch")
-                if tb and tb.get("batch") and os.environ.get("KIWI_HIP_ACCUM") != "direct":
+                if tb and tb.get("batch") and os.environ.get("KIWI_HIP_ACCUM") != "direct" and \
+                        tb.get("workload", "cfg3") == args.workload:
                     traffic = tb["total"] * args.batch / tb["batch"]
         except Exception:
             traffic = None
@@ -200,21 +235,22 @@ def main():
             "n_gpus": ngpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "cfg3-bilat: bilateral rupture, %d centroids x %d receivers x 3 comp x %d samples, "
-                                   "ng=10, bilinear GF interpolation, time-domain l2norm, tapered %d-sample window"
-                                   % (ncent, args.receivers, L, W),
+            "config": {"workload": "%s: %s source, %.0f centroids x %d receivers x 3 comp x %d samples, "
+                                   "ng=10, bilinear GF interpolation, %s%s, tapered %d-sample window"
+                                   % (wl["name"], wl["sourcetype"], ncent, nrec, L, wl["method"],
+                                      " + frequency filter" if wl["filter"] is not None else "", W),
                        "trial_sources_per_gpu_per_step": args.batch, "misfits_per_source": nmis,
                        "parallelism": "trial-source shard x%d, all-gather of global misfits" % ngpus},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "accumulate_grouped_kernel<10>" if os.environ.get("KIWI_HIP_ACCUM") != "direct" else "accumulate_kernel<10>", "launches": int(launches[1]),
+                         "kernel": "accumulate_grouped_kernel<10,256>" if os.environ.get("KIWI_HIP_ACCUM") != "direct" else "accumulate_kernel<10>", "launches": int(launches[1]),
                          "avg_launch_ms": float(ms[1]) / max(int(launches[1]), 1),
                          "algorithmic_bytes_per_eval": b_eval,
                          "other_kernels_ms_per_step": {"geometry": float(ms[0]) / args.steps,
                                                        "misfit": float(ms[2]) / args.steps}},
         }
         if ngpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(gf, recv, refs, tapers, trials, np.asarray(allg))
+            out["cpu_baseline"] = cpu_baseline(wl, gf, recv, refs, tapers, np.asarray(allg))
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -717,7 +717,9 @@ int kiwi_hip_set_gfdb(kiwi_hip_ctx *c, int nx, int nz, int ng, int L, float dt, 
         if (nsamp[i] < 0 || nsamp[i] > L) throw std::runtime_error("nsamp out of range");
         lmax = std::max(lmax, nsamp[i]);
     }
-    const int pitch = (kRowPad + lmax + 8 + 3) / 4 * 4;     // >= pad + n + 5 for load5's clamp
+    // >= pad + n + 5 for load5's clamp; the extra halo of repeated end values lets the grouped kernel's last
+    // tile (which overhangs the window by up to kHalo samples) take its clamp-free path
+    const int pitch = (kRowPad + lmax + kHalo + 32 + 3) / 4 * 4;
     // host staging in slabs of rows: [kRowPad zeros | samples | repeated end value]
     c->G.alloc(nrows * (size_t)pitch, &c->dev_bytes);
     c->span.alloc(nrows, &c->dev_bytes);

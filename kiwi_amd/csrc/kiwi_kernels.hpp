@@ -22,7 +22,7 @@
 
 namespace kiwi {
 
-constexpr int kRowPad = 8;        // zeros in front of every GF row (>= 5, see load5)
+constexpr int kRowPad = 32;       // zeros in front of every GF row (>= 5, see load5)
 constexpr int kTile = 1024;       // samples per workgroup: 256 threads x 4 consecutive samples
 constexpr int kMaxComp = 5;
 constexpr int kHalo = 64;         // grouped accumulate: LDS tile = kTile + kHalo samples
@@ -262,9 +262,11 @@ __global__ __launch_bounds__(256) void geometry_kernel(
     //   tab[4*ig + k]      = row*pitch + kRowPad - first   (float index of trace sample 0, minus... + j)
     //   tab[64 + 4*ig + k] = row*pitch                     (clamp floor; ceiling = floor + pitch - 4)
     //   tab[40 + ig]       = last stored sample of the blended trace (max over the nodes)
+    //   tab[50], tab[51]   = minimum of those over the horizontal (1-5, 9) / vertical (6-8, 10) components
     if (tab && g.row[0] >= 0) {
         int *tb = tab + base * 128;
         const int nn = (g.flags & 1) ? 1 : 4;
+        int jmin_h = 0x7fffffff, jmin_d = 0x7fffffff;
         for (int ig = 0; ig < gm.ng; ig++) {
             int jend = -0x7fffffff;
             for (int k = 0; k < 4; k++) {
@@ -275,7 +277,11 @@ __global__ __launch_bounds__(256) void geometry_kernel(
                 if (k < nn) jend = max(jend, sp.y);
             }
             tb[40 + ig] = jend;
+            const bool horiz = (ig <= 4) || (ig == 8);
+            if (horiz) jmin_h = min(jmin_h, jend); else jmin_d = min(jmin_d, jend);
         }
+        tb[50] = jmin_h;
+        tb[51] = jmin_d;
     }
 }
 
@@ -454,13 +460,13 @@ __device__ __forceinline__ int rec_load(const GeoRec *__restrict__ rc, int c, in
 #define REC_I(v, k) __builtin_amdgcn_readlane((v), (k))
 #define REC_F(v, k) __int_as_float(__builtin_amdgcn_readlane((v), (k)))
 
-__device__ __forceinline__ void rec_head(int v, GeoRec &g)
+__device__ __forceinline__ void rec_head(int v, int o, GeoRec &g)
 {
-    g.row[0] = REC_I(v, 0); g.row[1] = REC_I(v, 1); g.row[2] = REC_I(v, 2); g.row[3] = REC_I(v, 3);
-    g.w[0] = REC_F(v, 4); g.w[1] = REC_F(v, 5); g.w[2] = REC_F(v, 6); g.w[3] = REC_F(v, 7);
-    g.ishift = REC_I(v, 8);
-    g.flags = REC_I(v, 18);
-    g.pad = REC_I(v, 19);
+    g.row[0] = REC_I(v, o + 0); g.row[1] = REC_I(v, o + 1); g.row[2] = REC_I(v, o + 2); g.row[3] = REC_I(v, o + 3);
+    g.w[0] = REC_F(v, o + 4); g.w[1] = REC_F(v, o + 5); g.w[2] = REC_F(v, o + 6); g.w[3] = REC_F(v, o + 7);
+    g.ishift = REC_I(v, o + 8);
+    g.flags = REC_I(v, o + 18);
+    g.pad = REC_I(v, o + 19);
 }
 
 __device__ __forceinline__ f4u load4(const float *__restrict__ rowp, int l, int pitch)
@@ -474,7 +480,7 @@ __device__ __forceinline__ f4u load4(const float *__restrict__ rowp, int l, int 
 // ta / tb: lane-distributed load descriptors of the group (see geometry_kernel): the float index of
 // sample j of node k's trace is clamp(ta[4ig+k] + j, tb[4ig+k], tb[4ig+k] + pitch - 4), which
 // implements "zero before the span, end value repeated after it" on the padded row.
-template <bool BLEND>
+template <bool BLEND, bool FAST>
 __device__ __forceinline__ void build_chunk(float *__restrict__ tile, int p, int jb, const float *__restrict__ G,
                                             int pitch, int ta, int tb, const GeoRec &g, int ig)
 {
@@ -482,9 +488,15 @@ __device__ __forceinline__ void build_chunk(float *__restrict__ tile, int p, int
     f4u v[4];
 #pragma unroll
     for (int k = 0; k < (BLEND ? 4 : 1); k++) {
-        const int base = REC_I(ta, 4 * ig + k), lo = REC_I(tb, 4 * ig + k);
-        const int idx = min(max(base + j, lo), lo + pitch - 4);
-        v[k] = *(const f4u *)(G + (size_t)(unsigned)idx);
+        const int base = REC_I(ta, 4 * ig + k);
+        if constexpr (FAST) {                 // whole tile inside the padded row: scalar row base + lane offset
+            const float *rowp = G + (size_t)(unsigned)(base + jb);
+            v[k] = *(const f4u *)((const char *)rowp + (unsigned)(4 * p));
+        } else {
+            const int lo = REC_I(tb, 4 * ig + k);
+            const int idx = min(max(base + j, lo), lo + pitch - 4);
+            v[k] = *(const f4u *)(G + (size_t)(unsigned)idx);
+        }
     }
     f4u b;
     if constexpr (BLEND) {
@@ -501,7 +513,10 @@ __device__ __forceinline__ void build_chunk(float *__restrict__ tile, int p, int
 // Build the main chunk (LDS positions [4*tid, 4*tid+4)) of SEVERAL components at once: all 4*N
 // loads are issued before the first blend so that one L2 round trip is paid per batch, not per
 // component (left to itself the compiler serialises load -> blend -> ds_write per component).
-template <bool BLEND, int N>
+// FAST: every row of the group covers the whole tile without clamping (checked once per group), so a
+// load address is a wave-uniform row base (SGPR pair) plus the lane's position -- no per-load VALU
+// address arithmetic.
+template <bool BLEND, bool FAST, int N>
 __device__ __forceinline__ void build_batch(float *__restrict__ tile0, int lds_tile, const int (&igs)[N], int p, int jb,
                                             const float *__restrict__ G, int pitch, int ta, int tb, const GeoRec &g)
 {
@@ -511,9 +526,15 @@ __device__ __forceinline__ void build_batch(float *__restrict__ tile0, int lds_t
     for (int q = 0; q < N; q++) {
 #pragma unroll
         for (int k = 0; k < (BLEND ? 4 : 1); k++) {
-            const int base = REC_I(ta, 4 * igs[q] + k), lo = REC_I(tb, 4 * igs[q] + k);
-            const int idx = min(max(base + j, lo), lo + pitch - 4);
-            v[q][k] = *(const f4u *)(G + (size_t)(unsigned)idx);
+            const int base = REC_I(ta, 4 * igs[q] + k);
+            if constexpr (FAST) {
+                const float *rowp = G + (size_t)(unsigned)(base + jb);
+                v[q][k] = *(const f4u *)((const char *)rowp + (unsigned)(4 * p));      // saddr + 32-bit voffset
+            } else {
+                const int lo = REC_I(tb, 4 * igs[q] + k);
+                const int idx = min(max(base + j, lo), lo + pitch - 4);
+                v[q][k] = *(const f4u *)(G + (size_t)(unsigned)idx);
+            }
         }
     }
 #pragma unroll
@@ -531,43 +552,74 @@ __device__ __forceinline__ void build_batch(float *__restrict__ tile0, int lds_t
     }
 }
 
-// one GF component of one centroid from its LDS tile onto this lane's 4 consecutive samples.
-// The lane needs the 5 blended samples b[j-1..j+3] that sit at LDS positions 4*tid + e + (0..4),
-// e = smax - ishift >= 0 (workgroup-uniform).  With e = 4a + R they are elements R..R+4 of the two
-// ALIGNED 16-byte chunks at 4*(tid+a) and 4*(tid+a+1): two full-rate, conflict-free ds_read_b128
-// and a compile-time register selection (R is a template parameter).  Arithmetic as gf_add.
-template <int R, bool TAIL>
-__device__ __forceinline__ void tile_add(float (&out)[4], const float *__restrict__ chunk, int jl, int jend,
-                                         float factor, float wfrac)
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+// (x[S], x[S+1]) out of the four aligned register pairs p[0..3] = x[0..7]: an aligned pair as it is,
+// a straddling one assembled with one v_pk_mov_b32
+template <int S>
+__device__ __forceinline__ f2v pair_at(const f2v (&p)[4])
+{
+    if constexpr ((S & 1) == 0) return p[S / 2];
+    else return __builtin_shufflevector(p[S / 2], p[S / 2 + 1], 1, 2);
+}
+
+// the lane's 8 blended samples around its 4 output samples, as four aligned register pairs
+struct TileRegs { f2v p[4]; };
+
+__device__ __forceinline__ TileRegs tile_load(const float *__restrict__ chunk)
 {
     // volatile: keeps the two loads whole ds_read_b128 (conflict-free at 16 B per lane); left alone the
     // compiler narrows them to the 5 elements used (ds_read2_b32 / ds_read_b64), which at a 16-byte
     // lane stride are 4-way bank conflicts
     typedef float f4a __attribute__((ext_vector_type(4)));
     typedef const volatile __attribute__((address_space(3))) f4a *lds_f4p;      // explicit LDS address space
+#ifdef KIWI_DBG_NO_LDS_READ
+    const f4a A = { (float)(size_t)chunk, 1.f, 2.f, 3.f }, B = { 4.f, 5.f, 6.f, (float)(size_t)chunk };
+#else
     const f4a A = *(lds_f4p)(const __attribute__((address_space(3))) float *)chunk;
     const f4a B = *(lds_f4p)(const __attribute__((address_space(3))) float *)(chunk + 4);
-    const float x[8] = { A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w };
+#endif
+    TileRegs t;
+    t.p[0] = A.xy; t.p[1] = A.zw; t.p[2] = B.xy; t.p[3] = B.zw;
+    return t;
+}
+
+// The lane's 4 output samples are held as two register pairs so that the multiplies and adds are
+// v_pk_mul_f32 / v_pk_add_f32 (two IEEE fp32 operations per lane and instruction, each rounded
+// separately exactly like the scalar form; no FMA).
+template <int R, bool TAIL>
+__device__ __forceinline__ void tile_fma(f2v (&out)[2], const TileRegs &t, int jl, int jend, float factor, float wfrac)
+{
     float wr = wfrac;
     float wl = 1.f - wr;
     wr = wr * factor;
     wl = wl * factor;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        float c1 = wl, c2 = wr;
+    for (int h = 0; h < 2; h++) {
+        f2v c1 = { wl, wl }, c2 = { wr, wr };
         if (TAIL) {                               // sparse_trace.f90:698-703, jl = trace index of this lane's b[j-1]
-            const bool tail = (jl + i + 1) > jend;
-            c1 = tail ? factor : wl;
-            c2 = tail ? 0.f : wr;
+            const bool t0 = (jl + 2 * h + 1) > jend, t1 = (jl + 2 * h + 2) > jend;
+            c1.x = t0 ? factor : wl; c2.x = t0 ? 0.f : wr;
+            c1.y = t1 ? factor : wl; c2.y = t1 ? 0.f : wr;
         }
-        out[i] = out[i] + c1 * x[R + i + 1];
-        out[i] = out[i] + c2 * x[R + i];
+        const f2v hi = (h == 0) ? pair_at<R + 1>(t.p) : pair_at<(R + 3 < 7 ? R + 3 : 6)>(t.p);
+        const f2v lo = (h == 0) ? pair_at<R>(t.p) : pair_at<R + 2>(t.p);
+        out[h] = out[h] + c1 * hi;
+        out[h] = out[h] + c2 * lo;
     }
+}
+
+template <int R, bool TAIL>
+__device__ __forceinline__ void tile_add(f2v (&out)[2], const float *__restrict__ chunk, int jl, int jend,
+                                         float factor, float wfrac)
+{
+    const TileRegs t = tile_load(chunk);
+    tile_fma<R, TAIL>(out, t, jl, jend, factor, wfrac);
 }
 
 // all GF components of one centroid (reference order) for one shift residue R
 template <int NG, int LDS_TILE, int R, bool TAIL>
-__device__ __forceinline__ void centroid_apply(float (&ar1)[4], float (&ar2)[4], float (&dz)[4],
+__device__ __forceinline__ void centroid_apply(f2v (&ar1)[2], f2v (&ar2)[2], f2v (&dz)[2],
                                                const float *__restrict__ chunk0, int jl, const int (&jend)[NG],
                                                bool need_h, bool has_d, int flags, float wfrac, float sd,
                                                float f0, float f1, float f2, float f3, float f4, float f5,
@@ -576,12 +628,12 @@ __device__ __forceinline__ void centroid_apply(float (&ar1)[4], float (&ar2)[4],
 #define TADD(acc, ig, fac) tile_add<R, TAIL>(acc, chunk0 + (ig) * LDS_TILE, jl, jend[ig], fac, wfrac)
     if (need_h) {
         if (flags & 2) {                         // seismogram.f90:160-203
-            float t1[4] = { 0.f, 0.f, 0.f, 0.f }, t2[4] = { 0.f, 0.f, 0.f, 0.f };
+            f2v t1[2] = { { 0.f, 0.f }, { 0.f, 0.f } }, t2[2] = { { 0.f, 0.f }, { 0.f, 0.f } };
             TADD(t1, 0, f0); TADD(t1, 1, f1); TADD(t1, 2, f2);
             if constexpr (NG == 10) TADD(t1, 8, f5);
             TADD(t2, 3, f3); TADD(t2, 4, f4);
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < 2; i++) {
                 ar1[i] = ar1[i] + cl * t1[i] - sl * t2[i];
                 ar2[i] = ar2[i] + cl * t2[i] + sl * t1[i];
             }
@@ -598,6 +650,57 @@ __device__ __forceinline__ void centroid_apply(float (&ar1)[4], float (&ar2)[4],
 #undef TADD
 }
 
+// The common case (receiver with horizontal and vertical components), software-pipelined: the LDS reads
+// of component i + kAhead are issued before the arithmetic of component i, so that a lone wave is not
+// stalled for a full LDS round trip per component (a wave can only issue every 4th cycle; with 3 waves per
+// SIMD exposed latency is what bounds this kernel).  Same operations in the same order as centroid_apply.
+template <int NG, int LDS_TILE, int R, bool TAIL>
+__device__ __forceinline__ void centroid_apply_hd(f2v (&ar1)[2], f2v (&ar2)[2], f2v (&dz)[2],
+                                                  const float *__restrict__ chunk0, int jl, const int (&jend)[NG],
+                                                  int flags, float wfrac, float sd,
+                                                  float f0, float f1, float f2, float f3, float f4, float f5,
+                                                  float cl, float sl)
+{
+    constexpr int kAhead = 2;
+    constexpr int seq10[10] = { 0, 1, 2, 8, 3, 4, 5, 6, 7, 9 }, seq8[8] = { 0, 1, 2, 3, 4, 5, 6, 7 };
+    constexpr int nH1 = (NG == 10) ? 4 : 3;      // components summed into the radial trace
+    const float fac10[10] = { f0, f1, f2, f5, f3, f4, f0 * sd, f1 * sd, f2 * sd, f5 * sd };
+    const float fac8[8] = { f0, f1, f2, f3, f4, f0 * sd, f1 * sd, f2 * sd };
+    const bool rot = (flags & 2) != 0;           // seismogram.f90:160-203 vs :205-231
+    f2v t1[2] = { { 0.f, 0.f }, { 0.f, 0.f } }, t2[2] = { { 0.f, 0.f }, { 0.f, 0.f } };
+    if (!rot) { t1[0] = ar1[0]; t1[1] = ar1[1]; t2[0] = ar2[0]; t2[1] = ar2[1]; }
+    TileRegs tr[NG];
+#pragma unroll
+    for (int i = 0; i < kAhead; i++) tr[i] = tile_load(chunk0 + ((NG == 10) ? seq10[i] : seq8[i]) * LDS_TILE);
+#pragma unroll
+    for (int i = 0; i < NG; i++) {
+        if (i + kAhead < NG) tr[i + kAhead] = tile_load(chunk0 + ((NG == 10) ? seq10[i + kAhead] : seq8[i + kAhead]) * LDS_TILE);
+        __builtin_amdgcn_sched_barrier(0);
+        const int ig = (NG == 10) ? seq10[i] : seq8[i];
+        const float fac = (NG == 10) ? fac10[i] : fac8[i];
+        if (i < nH1) tile_fma<R, TAIL>(t1, tr[i], jl, jend[ig], fac, wfrac);
+        else if (i < nH1 + 2) tile_fma<R, TAIL>(t2, tr[i], jl, jend[ig], fac, wfrac);
+        else tile_fma<R, TAIL>(dz, tr[i], jl, jend[ig], fac, wfrac);
+        if (i == nH1 + 1) {
+            if (rot) {
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    ar1[k] = ar1[k] + cl * t1[k] - sl * t2[k];
+                    ar2[k] = ar2[k] + cl * t2[k] + sl * t1[k];
+                }
+            } else {
+                ar1[0] = t1[0]; ar1[1] = t1[1]; ar2[0] = t2[0]; ar2[1] = t2[1];
+            }
+        }
+    }
+}
+
+#ifdef KIWI_DBG_STAMPS                                    // in-kernel phase timing, experiments only
+#define STAMP(k) do { const long long t_ = __builtin_readcyclecounter(); dbg_t[k] += t_ - dbg_last; dbg_last = t_; } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 template <int NG, int T>
 __global__ __launch_bounds__(T) void accumulate_grouped_kernel(
     const float *__restrict__ G, const int2 *__restrict__ span, int pitch,
@@ -608,6 +711,10 @@ __global__ __launch_bounds__(T) void accumulate_grouped_kernel(
     constexpr int TILE = 4 * T;                          // samples per workgroup, 4 consecutive per thread
     constexpr int LDS_TILE = TILE + kHalo;
     __shared__ __attribute__((aligned(16))) float tiles[NG][LDS_TILE];
+#ifdef KIWI_DBG_LDS_PAD                                   // occupancy experiment only
+    __shared__ float dbg_pad[KIWI_DBG_LDS_PAD];
+    if (blockIdx.x == 0x7fffffff) dbg_pad[threadIdx.x] = 1.f;
+#endif
     // SOURCE index fastest in dispatch order: the workgroups resident at any moment are the same
     // (tile, receiver) of many neighbouring trial sources, which read (nearly) the same GF rows at
     // the same time, and blocks b, b+8, ... share an XCD and therefore its L2 (dispatch is
@@ -626,13 +733,17 @@ __global__ __launch_bounds__(T) void accumulate_grouped_kernel(
     const bool need_h = rv.need_h != 0, has_d = rv.has_d != 0;
     const float sd = rv.sd;
 
-    float ar1[4] = { 0.f, 0.f, 0.f, 0.f }, ar2[4] = { 0.f, 0.f, 0.f, 0.f }, dz[4] = { 0.f, 0.f, 0.f, 0.f };
+    f2v ar1[2] = { { 0.f, 0.f }, { 0.f, 0.f } }, ar2[2] = { { 0.f, 0.f }, { 0.f, 0.f } }, dz[2] = { { 0.f, 0.f }, { 0.f, 0.f } };
     int c = 0;
     int cur = rec_load(rc, 0, nc, lane);                 // record c, lane-distributed
     int ta = tc[lane], tb = tc[64 + lane];               // load descriptors of record c
+#ifdef KIWI_DBG_STAMPS
+    long long dbg_t[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, dbg_last = __builtin_readcyclecounter();
+    const long long dbg_t0 = dbg_last;
+#endif
     while (c < nc) {
         GeoRec g0;
-        rec_head(cur, g0);
+        rec_head(cur, 0, g0);
         if (g0.row[0] < 0) {                             // 'cycle' on a missing trace
             c++;
             cur = rec_load(rc, c, nc, lane);
@@ -646,90 +757,86 @@ __global__ __launch_bounds__(T) void accumulate_grouped_kernel(
         const int jb = t_tile0 - smax - 1;
         const int npos = TILE + (smax - smin) + 8;       // positions read by the group (<= LDS_TILE)
         const bool direct = (g0.flags & 1) != 0;
+        // end indices of the blended traces (tail rule); their minima over the horizontal / vertical components
+        // come precomputed from geometry_kernel so that no per-component branching is needed here
         int jend[NG];
-        int jend_min = 0x7fffffff;
-        // ---- build: blend every needed component once (batched loads, see build_batch)
 #pragma unroll
-        for (int ig = 0; ig < NG; ig++) {
-            const bool horiz = (ig <= 4) || (ig == 8);
-            if ((horiz && !need_h) || (!horiz && !has_d)) { jend[ig] = 0; continue; }
-            jend[ig] = REC_I(ta, 40 + ig);
-            jend_min = min(jend_min, jend[ig]);
-        }
+        for (int ig = 0; ig < NG; ig++) jend[ig] = REC_I(ta, 40 + ig);
+        const int jend_h = REC_I(ta, 50), jend_d = REC_I(ta, 51);
+        const int jend_min = min(need_h ? jend_h : 0x7fffffff, has_d ? jend_d : 0x7fffffff);
+#ifndef KIWI_DBG_SKIP_BUILD
         {
             float *tile0 = &tiles[0][0];
+            // all 40 rows of the group cover [jb, jb + LDS_TILE) inside their padded storage?  (lane l < 40 holds
+            // row l's descriptors; workgroup-uniform because every wave holds the same table)
+            const bool lane_ok = lane >= 40 || (ta + jb >= tb && ta + jb + LDS_TILE <= tb + pitch);
+            const bool fast = __builtin_amdgcn_ballot_w64(lane_ok) == ~0ull;
+#define BUILD_B(IGS, P) do { \
+                if (fast) { if (direct) build_batch<false, true>(tile0, LDS_TILE, IGS, P, jb, G, pitch, ta, tb, g0); \
+                            else        build_batch<true, true>(tile0, LDS_TILE, IGS, P, jb, G, pitch, ta, tb, g0); } \
+                else      { if (direct) build_batch<false, false>(tile0, LDS_TILE, IGS, P, jb, G, pitch, ta, tb, g0); \
+                            else        build_batch<true, false>(tile0, LDS_TILE, IGS, P, jb, G, pitch, ta, tb, g0); } \
+            } while (0)
             constexpr int H1 = NG / 2;
             int igA[H1], igB[NG - H1];
 #pragma unroll
             for (int q = 0; q < H1; q++) igA[q] = q;
 #pragma unroll
             for (int q = 0; q < NG - H1; q++) igB[q] = H1 + q;
-            if (need_h && has_d) {
-                if (direct) { build_batch<false>(tile0, LDS_TILE, igA, 4 * tid, jb, G, pitch, ta, tb, g0);
-                              build_batch<false>(tile0, LDS_TILE, igB, 4 * tid, jb, G, pitch, ta, tb, g0); }
-                else        { build_batch<true>(tile0, LDS_TILE, igA, 4 * tid, jb, G, pitch, ta, tb, g0);
-                              build_batch<true>(tile0, LDS_TILE, igB, 4 * tid, jb, G, pitch, ta, tb, g0); }
-            } else if (need_h) {
-                if constexpr (NG == 10) {
-                    const int igH[6] = { 0, 1, 2, 3, 4, 8 };                 // horizontals only
-                    if (direct) build_batch<false>(tile0, LDS_TILE, igH, 4 * tid, jb, G, pitch, ta, tb, g0);
-                    else        build_batch<true>(tile0, LDS_TILE, igH, 4 * tid, jb, G, pitch, ta, tb, g0);
-                } else {
-                    const int igH[5] = { 0, 1, 2, 3, 4 };
-                    if (direct) build_batch<false>(tile0, LDS_TILE, igH, 4 * tid, jb, G, pitch, ta, tb, g0);
-                    else        build_batch<true>(tile0, LDS_TILE, igH, 4 * tid, jb, G, pitch, ta, tb, g0);
-                }
-            } else {
-                if constexpr (NG == 10) {
-                    const int igD[4] = { 5, 6, 7, 9 };                       // vertical only
-                    if (direct) build_batch<false>(tile0, LDS_TILE, igD, 4 * tid, jb, G, pitch, ta, tb, g0);
-                    else        build_batch<true>(tile0, LDS_TILE, igD, 4 * tid, jb, G, pitch, ta, tb, g0);
-                } else {
-                    const int igD[3] = { 5, 6, 7 };
-                    if (direct) build_batch<false>(tile0, LDS_TILE, igD, 4 * tid, jb, G, pitch, ta, tb, g0);
-                    else        build_batch<true>(tile0, LDS_TILE, igD, 4 * tid, jb, G, pitch, ta, tb, g0);
-                }
-            }
+            const int igH10[6] = { 0, 1, 2, 3, 4, 8 }, igD10[4] = { 5, 6, 7, 9 };      // horizontals / vertical only
+            const int igH8[5] = { 0, 1, 2, 3, 4 }, igD8[3] = { 5, 6, 7 };
             // halo chunks (LDS positions >= TILE, a handful per component): same batched form, the two
             // component batches split over the first two waves when there are two
             const int ph = TILE + 4 * lane;
             const int wave = tid >> 6;
-            if (ph < npos && wave < 2) {
-                if (need_h && has_d) {
-                    const bool doA = (T == 64) || wave == 0, doB = (T == 64) || wave == 1;
-                    if (direct) { if (doA) build_batch<false>(tile0, LDS_TILE, igA, ph, jb, G, pitch, ta, tb, g0);
-                                  if (doB) build_batch<false>(tile0, LDS_TILE, igB, ph, jb, G, pitch, ta, tb, g0); }
-                    else        { if (doA) build_batch<true>(tile0, LDS_TILE, igA, ph, jb, G, pitch, ta, tb, g0);
-                                  if (doB) build_batch<true>(tile0, LDS_TILE, igB, ph, jb, G, pitch, ta, tb, g0); }
-                } else if (wave == 0) {
-#pragma unroll
-                    for (int ig = 0; ig < NG; ig++) {
-                        const bool horiz = (ig <= 4) || (ig == 8);
-                        if ((horiz && !need_h) || (!horiz && !has_d)) continue;
-                        if (direct) build_chunk<false>(tiles[ig], ph, jb, G, pitch, ta, tb, g0, ig);
-                        else        build_chunk<true>(tiles[ig], ph, jb, G, pitch, ta, tb, g0, ig);
-                    }
-                }
+            const bool halo = ph < npos && wave < 2;
+            if (need_h && has_d) {
+                STAMP(0);
+                BUILD_B(igA, 4 * tid);
+                STAMP(1);
+                BUILD_B(igB, 4 * tid);
+                STAMP(2);
+                if (halo && ((T == 64) || wave == 0)) BUILD_B(igA, ph);
+                if (halo && ((T == 64) || wave == 1)) BUILD_B(igB, ph);
+                STAMP(3);
+            } else if (need_h) {
+                if constexpr (NG == 10) { BUILD_B(igH10, 4 * tid); if (halo && wave == 0) BUILD_B(igH10, ph); }
+                else                    { BUILD_B(igH8, 4 * tid);  if (halo && wave == 0) BUILD_B(igH8, ph); }
+            } else {
+                if constexpr (NG == 10) { BUILD_B(igD10, 4 * tid); if (halo && wave == 0) BUILD_B(igD10, ph); }
+                else                    { BUILD_B(igD8, 4 * tid);  if (halo && wave == 0) BUILD_B(igD8, ph); }
             }
+#undef BUILD_B
         }
+#endif
         // descriptors of the NEXT group: in flight while this group is applied
         if (cend < nc) { ta = tc[(size_t)cend * 128 + lane]; tb = tc[(size_t)cend * 128 + 64 + lane]; }
         __syncthreads();
+        STAMP(4);
         // ---- apply: every centroid of the group, in table order (seismogram.f90:131)
+#ifdef KIWI_DBG_SKIP_APPLY
+        for (int cc = cend; cc < cend; cc++) {
+#else
         for (int cc = c; cc < cend; cc++) {
+#endif
             const int nxt = rec_load(rc, cc + 1, nc, lane);      // prefetch the next record
-            const int ishift = REC_I(cur, 8);
-            const float wfrac = REC_F(cur, 9);
-            const float f0 = REC_F(cur, 10), f1 = REC_F(cur, 11), f2 = REC_F(cur, 12), f3 = REC_F(cur, 13),
-                        f4 = REC_F(cur, 14), f5 = REC_F(cur, 15);
-            const float cl = REC_F(cur, 16), sl = REC_F(cur, 17);
-            const int flags = REC_I(cur, 18);
+            constexpr int ro = 0;
+            const int ishift = REC_I(cur, ro + 8);
+            const float wfrac = REC_F(cur, ro + 9);
+            const float f0 = REC_F(cur, ro + 10), f1 = REC_F(cur, ro + 11), f2 = REC_F(cur, ro + 12), f3 = REC_F(cur, ro + 13),
+                        f4 = REC_F(cur, ro + 14), f5 = REC_F(cur, ro + 15);
+            const float cl = REC_F(cur, ro + 16), sl = REC_F(cur, ro + 17);
+            const int flags = REC_I(cur, ro + 18);
             const int e = smax - ishift;                 // LDS position of lane 0's b[j-1]
             const float *chunk0 = &tiles[0][4 * (tid + (e >> 2))];
             const int jl = jb + e + 4 * tid;             // trace index of this lane's b[j-1]
             const bool tail = (jb + e + TILE) > jend_min;        // workgroup-uniform
-#define APPLY(RV, TV) centroid_apply<NG, LDS_TILE, RV, TV>(ar1, ar2, dz, chunk0, jl, jend, need_h, has_d, flags, \
-                                                          wfrac, sd, f0, f1, f2, f3, f4, f5, cl, sl)
+#define APPLY(RV, TV) do { \
+                if (need_h && has_d) centroid_apply_hd<NG, LDS_TILE, RV, TV>(ar1, ar2, dz, chunk0, jl, jend, flags, wfrac, sd, \
+                                                                            f0, f1, f2, f3, f4, f5, cl, sl); \
+                else centroid_apply<NG, LDS_TILE, RV, TV>(ar1, ar2, dz, chunk0, jl, jend, need_h, has_d, flags, \
+                                                          wfrac, sd, f0, f1, f2, f3, f4, f5, cl, sl); } while (0)
+            STAMP(7);
             if (!tail) {
                 switch (e & 3) {
                 case 0: APPLY(0, false); break;
@@ -747,25 +854,34 @@ __global__ __launch_bounds__(T) void accumulate_grouped_kernel(
             }
 #undef APPLY
             cur = nxt;
+            STAMP(5);
         }
         __syncthreads();                                 // tiles are rebuilt by the next group
+        STAMP(6);
         c = cend;
     }
+#ifdef KIWI_DBG_STAMPS
+    if ((blockIdx.x == 0 || blockIdx.x == 131) && (blockIdx.y == 0 || blockIdx.y == 101) && (tid == 0 || tid == 192))
+        printf("wg(%d,%d) tid %d total %lld : pre %lld A %lld B %lld halo %lld bar1 %lld apply %lld bar2 %lld decode %lld\n", blockIdx.x, blockIdx.y, tid,
+               (long long)__builtin_readcyclecounter() - dbg_t0, dbg_t[0], dbg_t[1], dbg_t[2], dbg_t[3], dbg_t[4], dbg_t[5], dbg_t[6], dbg_t[7]);
+#endif
 
     const int tl = tile * TILE + 4 * tid;
     if (tl >= rv.wlen) return;
     float *__restrict__ so = syn + (size_t)s * syn_stride + tl;
+    const float a1[4] = { ar1[0].x, ar1[0].y, ar1[1].x, ar1[1].y }, a2[4] = { ar2[0].x, ar2[0].y, ar2[1].x, ar2[1].y },
+                ad[4] = { dz[0].x, dz[0].y, dz[1].x, dz[1].y };
     for (int k = 0; k < rv.ncomp; k++) {                 // seismogram.f90:256-283
         const float sg = rv.sign[k];
         float o[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             switch (rv.comp[k]) {
-            case 1: o[i] = ar1[i] * sg; break;
-            case 2: o[i] = ar2[i] * sg; break;
-            case 3: o[i] = dz[i]; break;
-            case 4: o[i] = (rv.cl0 * ar1[i] - rv.sl0 * ar2[i]) * sg; break;
-            default: o[i] = (rv.cl0 * ar2[i] + rv.sl0 * ar1[i]) * sg; break;
+            case 1: o[i] = a1[i] * sg; break;
+            case 2: o[i] = a2[i] * sg; break;
+            case 3: o[i] = ad[i]; break;
+            case 4: o[i] = (rv.cl0 * a1[i] - rv.sl0 * a2[i]) * sg; break;
+            default: o[i] = (rv.cl0 * a2[i] + rv.sl0 * a1[i]) * sg; break;
             }
         }
         *(float4 *)(so + rv.synofs[k]) = make_float4(o[0], o[1], o[2], o[3]);

@@ -88,3 +88,79 @@ def full_taper(first, n, dt, ramp=10.0):
     (sample j sits at abscissa j*dt for the taper, piecewise_linear_function.f90:225)."""
     t0, t1 = first * dt, (first + n - 1) * dt
     return [t0, t0 + ramp, t1 - ramp, t1], [0., 1., 1., 0.]
+
+
+# generic continental crust, own values (t_crust2x2_1d_profile layout: vp[8] vs[8] rho[8] thickness[7];
+# layers: water, ice, soft sed., hard sed., upper, middle, lower crust, below the crust); m/s, kg/m3, m
+SYNTH_CRUST = np.array([1500., 3810., 2500., 4000., 6000., 6400., 6900., 8100.,
+                        0., 1940., 1200., 2300., 3500., 3700., 3900., 4600.,
+                        1020., 920., 2100., 2400., 2750., 2850., 3000., 3350.,
+                        0., 0., 1000., 1000., 10000., 10000., 10000.], np.float32)
+
+# mt_eikonal source of cfg4: vertical fault, 15 km bounding circle clipped to the depth range of the
+# synthetic GF database by the constraints below (source_mt_eikonal.f90:71-72 for the parameter order)
+CFG4_MT_EIKONAL = [0., 0., 0., 11000., 1., 91., 90., 0., 0., 15000., 2000., 0., 0.9] + \
+    mt_from_sdr(91., 87., 164., 1e20) + [1.0]
+CFG4_CONSTRAINTS = (np.array([[0, 0, 6500.], [0, 0, 15500.]], np.float32),
+                    np.array([[0, 0, -1.], [0, 0, 1.]], np.float32))
+SPECTRAL_FILTER = ([0.01, 0.02, 0.1, 0.2], [0., 1., 1., 0.])       # Hz, SURVEY.md 8d
+
+
+def mt_eikonal_location_grid(n_north=10, n_east=10, n_depth=5, base=None):
+    """cfg4 trial set: grid over (north-shift, east-shift, depth), first parameter slowest."""
+    base = np.array(CFG4_MT_EIKONAL if base is None else base, np.float32)
+    out = []
+    for a in range(n_north):
+        for b in range(n_east):
+            for c in range(n_depth):
+                p = base.copy()
+                p[1] += 400.0 * (a - n_north // 2)
+                p[2] += 400.0 * (b - n_east // 2)
+                p[3] += 250.0 * (c - n_depth // 2)
+                out.append(p)
+    return np.array(out, np.float32)
+
+
+def bilat_sweep_5d(nsrc, base=None):
+    """cfg5 trial set: the first `nsrc` points of a 10 x 10 x 10 x 10 x 10 product grid over
+    (strike, dip, slip-rake, depth, time), last parameter fastest (source.py:119-164)."""
+    base = np.array(TRUE_BILAT if base is None else base, np.float32)
+    idx = np.arange(nsrc)
+    p = np.tile(base, (nsrc, 1))
+    p[:, 0] = base[0] + 0.05 * (idx % 10 - 5)
+    p[:, 3] = base[3] + 200.0 * ((idx // 10) % 10 - 5)
+    p[:, 7] = base[7] + 1.0 * ((idx // 100) % 10 - 5)
+    p[:, 6] = base[6] - 0.5 * ((idx // 1000) % 10)
+    p[:, 5] = base[5] + 0.5 * ((idx // 10000) % 10 - 5)
+    return p
+
+
+def workload(name, nsrc=None, trial0=0):
+    """The BASELINE.json configurations as data: dict(name, sourcetype, true, trials, nrec, nx, method,
+    filter, crust, constraints, batch) -- `trials` starts at index `trial0` of the config's trial list."""
+    if name == "cfg2":
+        grid = mt_sdr_grid()
+        n = len(grid) if nsrc is None else nsrc
+        tr = grid[(trial0 + np.arange(n)) % len(grid)]
+        return dict(name="cfg2-mt-grid", sourcetype="moment_tensor", true=grid[4000], trials=tr, nrec=50, nx=128,
+                    method="l2norm", filter=None, crust=None, constraints=None)
+    if name == "cfg3":
+        base = [0., 0., 0., 10000., 1e20, 91., 87., 164., 0., 4800., 2000., 2000., 3000., 2.]   # 100 centroids
+        n = 256 if nsrc is None else nsrc
+        tr = bilat_strike_sweep(n, step=0.1, base=base)
+        tr[:, 5] += 0.1 * trial0
+        return dict(name="cfg3-bilat", sourcetype="bilateral", true=np.array(base, np.float32), trials=tr, nrec=50,
+                    nx=128, method="l2norm", filter=None, crust=None, constraints=None)
+    if name == "cfg4":
+        grid = mt_eikonal_location_grid()
+        n = 32 if nsrc is None else nsrc
+        tr = grid[(trial0 + np.arange(n)) % len(grid)]
+        return dict(name="cfg4-mt-eikonal", sourcetype="mt_eikonal", true=np.array(CFG4_MT_EIKONAL, np.float32),
+                    trials=tr, nrec=200, nx=160, method="l2norm", filter=None, crust=SYNTH_CRUST,
+                    constraints=CFG4_CONSTRAINTS)
+    if name == "cfg5":
+        n = 256 if nsrc is None else nsrc
+        tr = bilat_sweep_5d(n + trial0)[trial0:]
+        return dict(name="cfg5-spectral", sourcetype="bilateral", true=np.array(TRUE_BILAT, np.float32), trials=tr,
+                    nrec=50, nx=128, method="ampspec_l2norm", filter=SPECTRAL_FILTER, crust=None, constraints=None)
+    raise ValueError("unknown workload " + name)
