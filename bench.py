@@ -145,8 +145,8 @@ def cpu_baseline(wl, gf, recv, refs, tapers, gpu_global, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
                     help="BASELINE.json configs[1..4]; cfg3 (default) is the one the metric is quoted on")
     ap.add_argument("--batch", type=int, default=0,

@@ -476,39 +476,10 @@ __device__ __forceinline__ f4u load4(const float *__restrict__ rowp, int l, int 
     return *(const f4u *)(rowp + q);
 }
 
-// blend one GF component over LDS positions [p, p+4) (trace samples jb + p ...) and store it.
-// ta / tb: lane-distributed load descriptors of the group (see geometry_kernel): the float index of
-// sample j of node k's trace is clamp(ta[4ig+k] + j, tb[4ig+k], tb[4ig+k] + pitch - 4), which
-// implements "zero before the span, end value repeated after it" on the padded row.
-template <bool BLEND, bool FAST>
-__device__ __forceinline__ void build_chunk(float *__restrict__ tile, int p, int jb, const float *__restrict__ G,
-                                            int pitch, int ta, int tb, const GeoRec &g, int ig)
-{
-    const int j = jb + p;
-    f4u v[4];
-#pragma unroll
-    for (int k = 0; k < (BLEND ? 4 : 1); k++) {
-        const int base = REC_I(ta, 4 * ig + k);
-        if constexpr (FAST) {                 // whole tile inside the padded row: scalar row base + lane offset
-            const float *rowp = G + (size_t)(unsigned)(base + jb);
-            v[k] = *(const f4u *)((const char *)rowp + (unsigned)(4 * p));
-        } else {
-            const int lo = REC_I(tb, 4 * ig + k);
-            const int idx = min(max(base + j, lo), lo + pitch - 4);
-            v[k] = *(const f4u *)(G + (size_t)(unsigned)idx);
-        }
-    }
-    f4u b;
-    if constexpr (BLEND) {
-        b = g.w[0] * v[0];                    // gfdb.f90:946-949, summed in this order
-        b = b + g.w[1] * v[1];
-        b = b + g.w[2] * v[2];
-        b = b + g.w[3] * v[3];
-    } else {
-        b = v[0];
-    }
-    *(float4 *)(tile + p) = make_float4(b.x, b.y, b.z, b.w);
-}
+// Load descriptors (see geometry_kernel): ta / tb are the lane-distributed halves of the group's descriptor row;
+// the float index of sample j of node k's trace of component ig is
+// clamp(ta[4ig+k] + j, tb[4ig+k], tb[4ig+k] + pitch - 4), which implements "zero before the span, end value
+// repeated after it" on the padded row.
 
 // Build the main chunk (LDS positions [4*tid, 4*tid+4)) of SEVERAL components at once: all 4*N
 // loads are issued before the first blend so that one L2 round trip is paid per batch, not per
@@ -573,12 +544,8 @@ __device__ __forceinline__ TileRegs tile_load(const float *__restrict__ chunk)
     // lane stride are 4-way bank conflicts
     typedef float f4a __attribute__((ext_vector_type(4)));
     typedef const volatile __attribute__((address_space(3))) f4a *lds_f4p;      // explicit LDS address space
-#ifdef KIWI_DBG_NO_LDS_READ
-    const f4a A = { (float)(size_t)chunk, 1.f, 2.f, 3.f }, B = { 4.f, 5.f, 6.f, (float)(size_t)chunk };
-#else
     const f4a A = *(lds_f4p)(const __attribute__((address_space(3))) float *)chunk;
     const f4a B = *(lds_f4p)(const __attribute__((address_space(3))) float *)(chunk + 4);
-#endif
     TileRegs t;
     t.p[0] = A.xy; t.p[1] = A.zw; t.p[2] = B.xy; t.p[3] = B.zw;
     return t;
@@ -695,12 +662,6 @@ __device__ __forceinline__ void centroid_apply_hd(f2v (&ar1)[2], f2v (&ar2)[2], 
     }
 }
 
-#ifdef KIWI_DBG_STAMPS                                    // in-kernel phase timing, experiments only
-#define STAMP(k) do { const long long t_ = __builtin_readcyclecounter(); dbg_t[k] += t_ - dbg_last; dbg_last = t_; } while (0)
-#else
-#define STAMP(k) do { } while (0)
-#endif
-
 template <int NG, int T>
 __global__ __launch_bounds__(T) void accumulate_grouped_kernel(
     const float *__restrict__ G, const int2 *__restrict__ span, int pitch,
@@ -711,10 +672,6 @@ __global__ __launch_bounds__(T) void accumulate_grouped_kernel(
     constexpr int TILE = 4 * T;                          // samples per workgroup, 4 consecutive per thread
     constexpr int LDS_TILE = TILE + kHalo;
     __shared__ __attribute__((aligned(16))) float tiles[NG][LDS_TILE];
-#ifdef KIWI_DBG_LDS_PAD                                   // occupancy experiment only
-    __shared__ float dbg_pad[KIWI_DBG_LDS_PAD];
-    if (blockIdx.x == 0x7fffffff) dbg_pad[threadIdx.x] = 1.f;
-#endif
     // SOURCE index fastest in dispatch order: the workgroups resident at any moment are the same
     // (tile, receiver) of many neighbouring trial sources, which read (nearly) the same GF rows at
     // the same time, and blocks b, b+8, ... share an XCD and therefore its L2 (dispatch is
@@ -737,10 +694,6 @@ __global__ __launch_bounds__(T) void accumulate_grouped_kernel(
     int c = 0;
     int cur = rec_load(rc, 0, nc, lane);                 // record c, lane-distributed
     int ta = tc[lane], tb = tc[64 + lane];               // load descriptors of record c
-#ifdef KIWI_DBG_STAMPS
-    long long dbg_t[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, dbg_last = __builtin_readcyclecounter();
-    const long long dbg_t0 = dbg_last;
-#endif
     while (c < nc) {
         GeoRec g0;
         rec_head(cur, 0, g0);
@@ -764,7 +717,6 @@ __global__ __launch_bounds__(T) void accumulate_grouped_kernel(
         for (int ig = 0; ig < NG; ig++) jend[ig] = REC_I(ta, 40 + ig);
         const int jend_h = REC_I(ta, 50), jend_d = REC_I(ta, 51);
         const int jend_min = min(need_h ? jend_h : 0x7fffffff, has_d ? jend_d : 0x7fffffff);
-#ifndef KIWI_DBG_SKIP_BUILD
         {
             float *tile0 = &tiles[0][0];
             // all 40 rows of the group cover [jb, jb + LDS_TILE) inside their padded storage?  (lane l < 40 holds
@@ -791,14 +743,10 @@ __global__ __launch_bounds__(T) void accumulate_grouped_kernel(
             const int wave = tid >> 6;
             const bool halo = ph < npos && wave < 2;
             if (need_h && has_d) {
-                STAMP(0);
                 BUILD_B(igA, 4 * tid);
-                STAMP(1);
                 BUILD_B(igB, 4 * tid);
-                STAMP(2);
                 if (halo && ((T == 64) || wave == 0)) BUILD_B(igA, ph);
                 if (halo && ((T == 64) || wave == 1)) BUILD_B(igB, ph);
-                STAMP(3);
             } else if (need_h) {
                 if constexpr (NG == 10) { BUILD_B(igH10, 4 * tid); if (halo && wave == 0) BUILD_B(igH10, ph); }
                 else                    { BUILD_B(igH8, 4 * tid);  if (halo && wave == 0) BUILD_B(igH8, ph); }
@@ -808,17 +756,11 @@ __global__ __launch_bounds__(T) void accumulate_grouped_kernel(
             }
 #undef BUILD_B
         }
-#endif
         // descriptors of the NEXT group: in flight while this group is applied
         if (cend < nc) { ta = tc[(size_t)cend * 128 + lane]; tb = tc[(size_t)cend * 128 + 64 + lane]; }
         __syncthreads();
-        STAMP(4);
         // ---- apply: every centroid of the group, in table order (seismogram.f90:131)
-#ifdef KIWI_DBG_SKIP_APPLY
-        for (int cc = cend; cc < cend; cc++) {
-#else
         for (int cc = c; cc < cend; cc++) {
-#endif
             const int nxt = rec_load(rc, cc + 1, nc, lane);      // prefetch the next record
             constexpr int ro = 0;
             const int ishift = REC_I(cur, ro + 8);
@@ -836,7 +778,6 @@ __global__ __launch_bounds__(T) void accumulate_grouped_kernel(
                                                                             f0, f1, f2, f3, f4, f5, cl, sl); \
                 else centroid_apply<NG, LDS_TILE, RV, TV>(ar1, ar2, dz, chunk0, jl, jend, need_h, has_d, flags, \
                                                           wfrac, sd, f0, f1, f2, f3, f4, f5, cl, sl); } while (0)
-            STAMP(7);
             if (!tail) {
                 switch (e & 3) {
                 case 0: APPLY(0, false); break;
@@ -854,17 +795,10 @@ __global__ __launch_bounds__(T) void accumulate_grouped_kernel(
             }
 #undef APPLY
             cur = nxt;
-            STAMP(5);
         }
         __syncthreads();                                 // tiles are rebuilt by the next group
-        STAMP(6);
         c = cend;
     }
-#ifdef KIWI_DBG_STAMPS
-    if ((blockIdx.x == 0 || blockIdx.x == 131) && (blockIdx.y == 0 || blockIdx.y == 101) && (tid == 0 || tid == 192))
-        printf("wg(%d,%d) tid %d total %lld : pre %lld A %lld B %lld halo %lld bar1 %lld apply %lld bar2 %lld decode %lld\n", blockIdx.x, blockIdx.y, tid,
-               (long long)__builtin_readcyclecounter() - dbg_t0, dbg_t[0], dbg_t[1], dbg_t[2], dbg_t[3], dbg_t[4], dbg_t[5], dbg_t[6], dbg_t[7]);
-#endif
 
     const int tl = tile * TILE + 4 * tid;
     if (tl >= rv.wlen) return;

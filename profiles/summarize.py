@@ -15,7 +15,7 @@ out = {"tag": tag, "command": "rocprofv3 ... -- python3 bench.py --steps 10 --wa
 
 
 def counters(d, match):
-    fs = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))
+    fs = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv")) + glob.glob(os.path.join(src, d, "*_counter_collection.csv"))
     res = {}
     if not fs:
         return res
@@ -33,14 +33,31 @@ for d, key, match in ((prefix + "_fetch", "grouped", "accumulate_grouped"), (pre
                       (prefix + "_l2", "grouped", "accumulate_grouped"), (prefix + "_sq", "grouped", "accumulate_grouped"),
                       (prefix + "_sq2", "grouped", "accumulate_grouped"), (prefix + "_fetch_direct", "direct", "accumulate_kernel")):
     out.setdefault(key, {}).update(counters(d, match))
+old = {}
+try:
+    old = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), tag + "_summary.json")))
+except Exception:
+    pass
+for k in ("direct", "kernel_stats_direct.csv"):          # the A/B baseline kernel is profiled once per round
+    if k in old:
+        out[k] = old[k]
 for d, name in ((prefix + "_kt", "kernel_stats.csv"), (prefix + "_kt_direct", "kernel_stats_direct.csv")):
-    fs = glob.glob(os.path.join(src, d, "*", "*_kernel_stats.csv"))
+    fs = glob.glob(os.path.join(src, d, "*", "*_kernel_stats.csv")) + glob.glob(os.path.join(src, d, "*_kernel_stats.csv"))
     if fs:
         dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "%s_%s" % (tag, name))
         shutil.copy(fs[0], dst)
         rows = list(csv.DictReader(open(fs[0])))
         out[name] = [{"name": r["Name"][:60], "calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
                       "pct": float(r["Percentage"])} for r in rows[:6]]
+# per-dispatch durations from the kernel trace: the first launches of a process run at warm-up clocks
+# (and the very first one loads the code object), so the median is the steady-state figure
+fs = glob.glob(os.path.join(src, prefix + "_kt", "*", "*_kernel_trace.csv")) + glob.glob(os.path.join(src, prefix + "_kt", "*_kernel_trace.csv"))
+if fs:
+    dur = {}
+    for r in csv.DictReader(open(fs[0])):
+        dur.setdefault(r["Kernel_Name"][:60], []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    out["kernel_trace_ms"] = {k: {"median": sorted(v)[len(v) // 2], "min": min(v), "max": max(v), "calls": len(v)}
+                              for k, v in dur.items() if "kiwi::" in k}
 bj = os.path.join(src, prefix + "_bench_under_rocprof.json")
 if os.path.exists(bj):
     out["bench_line_under_rocprof"] = json.loads(open(bj).read().strip().splitlines()[-1])
@@ -50,6 +67,7 @@ if "FETCH_SIZE" in g and "WRITE_SIZE" in g:
     rd = g["FETCH_SIZE"]["median"] * 1024 * 2
     wr = g["WRITE_SIZE"]["median"] * 1024
     out["traffic_bytes_per_launch"] = {"read_corrected": rd, "write": wr, "total": rd + wr,
-                                       "batch": out.get("bench_line_under_rocprof", {}).get("config", {}).get("trial_sources_per_gpu_per_step")}
+                                       "batch": out.get("bench_line_under_rocprof", {}).get("config", {}).get("trial_sources_per_gpu_per_step"),
+                                       "workload": "cfg3"}
 json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), tag + "_summary.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])
