@@ -297,20 +297,44 @@ class Engine:
         return mis, nor
 
 
-def make_global_misfits(misfits_by_src, norms_by_src, outer_norm="l2norm", receiver_weights=None):
-    """seismosizer.py:843-922 (no anarchy / bootstrap): per-source global misfit and per
-    source-receiver misfits from [N_s,N_r,N_k] arrays, float64."""
+def make_global_misfits(misfits_by_src, norms_by_src, outer_norm="l2norm", receiver_weights=None, receiver_mask=None,
+                        anarchy=False, bootstrap=False, rng=None):
+    """seismosizer.py:843-922: per-source global misfit and per source-receiver misfits from [N_s,N_r,N_k]
+    arrays, float64.  `anarchy` divides each receiver's weight by its norm (:884-888); `bootstrap` multiplies
+    the weights by a resampling count drawn over the enabled receivers (:855-869; sqrt of it for l2, :901-902).
+    Differences, deliberate: the reference draws from numpy's global RandomState -- pass `rng` (a
+    numpy Generator) for reproducible draws; its anarchy + per-receiver-weights combination under l2norm
+    raises a broadcasting error for more than one source (:898), here it works as under l1norm."""
     m = np.asarray(misfits_by_src, np.float64)
     n = np.asarray(norms_by_src, np.float64)
-    w = np.ones(m.shape[1]) if receiver_weights is None else np.asarray(receiver_weights, np.float64)
+    nrec = m.shape[1]
+    w = np.ones(nrec) if receiver_weights is None else np.broadcast_to(np.asarray(receiver_weights, np.float64), (nrec,))
+    rweights = np.tile(w, (m.shape[0], 1))
+    if bootstrap:
+        mask = np.ones(nrec, bool) if receiver_mask is None else np.asarray(receiver_mask, bool)
+        if receiver_weights is not None:
+            mask = np.logical_and(mask, w != 0)
+        enabled = np.arange(nrec)[mask]
+        rng = np.random.default_rng() if rng is None else rng
+        draw = enabled[rng.integers(0, len(enabled), len(enabled))]
+        bweights = np.bincount(draw, minlength=nrec).astype(np.float64)
     if outer_norm == "l1norm":
-        m_sr = m.sum(2) * w
-        n_sr = n.sum(2) * w
-        ms, ns = m_sr.sum(1), n_sr.sum(1)
-        with np.errstate(divide="ignore", invalid="ignore"):
-            return np.where(ns > 0, ms / ns, np.nan), m_sr
-    m_sr = np.sqrt((m ** 2).sum(2)) * w
-    n_sr = np.sqrt((n ** 2).sum(2)) * w
-    ms, ns = (m_sr ** 2).sum(1), (n_sr ** 2).sum(1)
+        m_sr, n_sr = m.sum(2), n.sum(2)
+    elif outer_norm == "l2norm":
+        m_sr, n_sr = np.sqrt((m ** 2).sum(2)), np.sqrt((n ** 2).sum(2))
+    else:
+        raise KiwiHipError("unknown norm method: %s" % outer_norm)
+    if anarchy:
+        rweights = np.maximum(rweights / np.where(n_sr != 0., n_sr, -1.), 0.)
+    if bootstrap:
+        rweights = rweights * (bweights if outer_norm == "l1norm" else np.sqrt(bweights))
+    m_sr = m_sr * rweights
+    n_sr = n_sr * rweights
     with np.errstate(divide="ignore", invalid="ignore"):
-        return np.where(ns > 0, np.sqrt(ms / ns), np.nan), m_sr
+        if outer_norm == "l1norm":
+            ms, ns = m_sr.sum(1), n_sr.sum(1)
+            g = np.where(ns > 0, ms / ns, -1.)
+        else:
+            ms, ns = (m_sr ** 2).sum(1), (n_sr ** 2).sum(1)
+            g = np.where(ns > 0, np.sqrt(ms / ns), -1.)
+    return np.where(g < 0, np.nan, g), m_sr

@@ -63,3 +63,48 @@ def test_single_process_passthrough():
     x = np.arange(5, dtype=np.float32)
     assert np.array_equal(gather_misfits(x, None), x)
     assert best_source([3.0, np.nan, 1.0]) == 2
+
+
+class _FakeEngine:
+    components = ["ned", "d"]
+    enabled = [True, True]
+
+    def make_misfits_for_sources(self, sourcetype, params):
+        p = np.atleast_2d(params)
+        m = np.zeros((len(p), 2, 3))
+        n = np.ones((len(p), 2, 3))
+        m[:, 0, :] = p[:, :1] * np.array([1., 2., 3.])
+        m[:, 1, :1] = p[:, :1] + 0.5
+        return m, n
+
+
+def _grid_worker(rank, world, port, q):
+    from kiwi_amd.shard import sharded_misfits_for_sources
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    params = np.arange(7, dtype=np.float32)[:, None] * np.ones((1, 4), np.float32)
+    m, n = sharded_misfits_for_sources(_FakeEngine(), "x", params, dist)
+    q.put((rank, m, n))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_misfits_for_sources():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grid_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    params = np.arange(7, dtype=np.float32)[:, None] * np.ones((1, 4), np.float32)
+    m0, n0 = _FakeEngine().make_misfits_for_sources("x", params)
+    for rank, m, n in res:                     # every rank ends up with the full ordered arrays
+        assert m.shape == (7, 2, 3) and np.array_equal(m, m0) and np.array_equal(n, n0)
