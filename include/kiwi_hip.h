@@ -40,6 +40,8 @@ typedef struct kiwi_hip_ctx kiwi_hip_ctx;
 #define KIWI_AMPSPEC_L1NORM 4
 #define KIWI_SCALAR_PRODUCT 5
 #define KIWI_PEAK 6
+#define KIWI_FLOATING_L2NORM 7
+#define KIWI_FLOATING_L1NORM 8
 
 /* source type ids = parameterized_source.f90:45-50 */
 #define KIWI_SRC_BILAT 1
@@ -89,6 +91,11 @@ int kiwi_hip_set_taper(kiwi_hip_ctx *ctx, int irec, int npts, const float *x, co
 int kiwi_hip_set_filter(kiwi_hip_ctx *ctx, int irec, int npts, const float *x, const float *y);
 /* set_misfit_method (minimizer_engine.f90:622-630) */
 int kiwi_hip_set_misfit_method(kiwi_hip_ctx *ctx, int method);
+/* set_floating_shiftrange ireceiver min-shift max-shift (minimizer_engine.f90:421-451; minimizer.f90:388-419): range in
+ * seconds for floating_l1norm / floating_l2norm (receiver.f90:439-510), ireceiver 0 = all; and get_floating_shifts
+ * (minimizer_engine.f90:1095-1128): the winning shift in seconds per source and ENABLED receiver, shifts[nsrc][n_enabled] */
+int kiwi_hip_set_floating_shiftrange(kiwi_hip_ctx *ctx, int irec, float min_shift, float max_shift);
+int kiwi_hip_get_floating_shifts(kiwi_hip_ctx *ctx, int isrc0, int nsrc, float *shifts);
 /* set_synthetics_factor (minimizer_engine.f90:700-727; receiver.f90:391-405) */
 int kiwi_hip_set_synthetics_factor(kiwi_hip_ctx *ctx, float factor);
 

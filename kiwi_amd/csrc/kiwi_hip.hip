@@ -66,6 +66,7 @@ struct Receiver {
     int comp[kMaxComp] = { 0 };      // signed ids, receiver.f90:35-48
     struct Ref { int first = 0; std::vector<float> data; } ref[kMaxComp];
     Plf taper, filter;
+    int float_lo = 0, float_hi = 0;  // floating_shiftrange in samples (receiver.f90:94)
     double azi0 = 0, bazi0 = 0, dist0 = 0;
 };
 
@@ -124,6 +125,11 @@ struct kiwi_hip_ctx {
     DevBuf<GeoRec> recs_d;
     DevBuf<int> tab_d;                // grouped kernel load descriptors, 128 ints per GeoRec
     DevBuf<float> syn_d, proc_d;
+    // floating norms
+    bool floating = false;
+    int max_ns = 1;
+    DevBuf<float> refx_d, vt_d, partial_d;
+    DevBuf<int> fshift_d;
     int last_isrc0 = 0, last_nsrc = 0, last_chunk0 = 0, last_chunkn = 0;
     int last_proc_which = 0;
     int group_spt = 4;                // samples per thread of the grouped kernel; env KIWI_HIP_GROUP_SPT
@@ -200,8 +206,12 @@ void prepare(kiwi_hip_ctx *c)
     if (!c->have_db) throw std::runtime_error("no database set");
     if (!c->have_origin) throw std::runtime_error("no source location set");
     if (c->recv.empty()) throw std::runtime_error("no receivers set");
-    if (c->method < KIWI_L2NORM || c->method > KIWI_PEAK)
-        throw std::runtime_error("floating_l1norm / floating_l2norm are not available in the device comparator yet");
+    if (c->method < KIWI_L2NORM || c->method > KIWI_FLOATING_L1NORM) throw std::runtime_error("unknown misfit method");
+    c->floating = (c->method == KIWI_FLOATING_L2NORM || c->method == KIWI_FLOATING_L1NORM);
+    // the norm evaluated inside a floating norm (receiver.f90:452-458)
+    const int eval_method = c->method == KIWI_FLOATING_L2NORM ? KIWI_L2NORM : (c->method == KIWI_FLOATING_L1NORM ? KIWI_L1NORM : c->method);
+    c->max_ns = 1;
+    std::vector<float> refx;
     c->fft_ready = false;
     const float dt = c->gm.dt;
     const int hs = fold_halfwidth(c->max_risetime, dt);
@@ -251,8 +261,10 @@ void prepare(kiwi_hip_ctx *c)
                 throw std::runtime_error("receiver " + std::to_string(ir + 1) + " component " +
                                          std::to_string(k + 1) + ": no reference seismogram set");
             CompDev cd;
+            std::memset(&cd, 0, sizeof(cd));
             cd.synofs = (int)synofs; cd.halo = c->halo; cd.w0 = w[0]; cd.wlen = wlen;
             cd.refofs = (int)reft.size(); cd.rec = ir;
+            cd.fl_lo = 0; cd.fl_ns = 1; cd.refxofs = 0;
             d.synofs[k] = (int)synofs;
             synofs += ((size_t)d.wlen + 3) / 4 * 4;
             // reference probe contents over the window: zeros before the data, last value repeated
@@ -264,7 +276,7 @@ void prepare(kiwi_hip_ctx *c)
                 if (t >= f0) v = rf.data[std::min(t, f1) - f0] * 1.f;
                 if (t >= f0) v = v * tww[t - w[0]];                         // taper acts from dataspan(1) on
                 reft.push_back(v);
-                switch (c->method) {                                       // probe_norm, comparator.f90:669-697
+                switch (eval_method) {                                     // probe_norm, comparator.f90:669-697
                 case KIWI_L2NORM: sum += (double)v * (double)v; break;
                 case KIWI_L1NORM: sum += (double)std::fabs(v); break;
                 case KIWI_SCALAR_PRODUCT: sum += (double)(v * v); break;
@@ -273,11 +285,37 @@ void prepare(kiwi_hip_ctx *c)
             }
             tw.insert(tw.end(), tww.begin(), tww.end());
             float nf;
-            switch (c->method) {
+            switch (eval_method) {
             case KIWI_L2NORM: nf = 1.f * (float)std::sqrt((double)dt * sum); break;
             case KIWI_L1NORM: nf = 1.f * (float)((double)dt * sum); break;
             case KIWI_SCALAR_PRODUCT: nf = (1.f * 1.f) * (float)sum; break;
             default: nf = 1.f * (float)pk; break;
+            }
+            if (c->floating) {
+                // receiver_calculate_floating_misfits, receiver.f90:439-510: the reference DATA are moved by every
+                // integer shift of the range (probe_shift, comparator.f90:273-288), the taper stays; the norm factor
+                // is the mean over the shifts of probe_norm of the shifted reference (:502)
+                const int lo = r.float_lo, hi = r.float_hi, ns = hi - lo + 1;
+                if (ns < 1) throw std::runtime_error("receiver " + std::to_string(ir + 1) + ": empty floating shift range");
+                if (ns > kMaxFloatShifts) throw std::runtime_error("receiver " + std::to_string(ir + 1) + ": floating shift range too long");
+                c->max_ns = std::max(c->max_ns, ns);
+                cd.fl_lo = lo; cd.fl_ns = ns; cd.refxofs = (int)refx.size();
+                // un-tapered reference at t = w0 - hi ... w1 - lo (zeros before the data, end value after)
+                for (int t = w[0] - hi; t <= w[1] - lo; t++) refx.push_back(t >= f0 ? rf.data[std::min(t, f1) - f0] * 1.f : 0.f);
+                float nsum = 0.f;
+                for (int q = 0; q < ns; q++) {
+                    const int sh = lo + q;
+                    double acc = 0.0;
+                    for (int t = w[0]; t <= w[1]; t++) {
+                        const int ts = t - sh;
+                        float v = 0.f;
+                        if (ts >= f0) v = (rf.data[std::min(ts, f1) - f0] * 1.f) * tww[t - w[0]];
+                        acc += eval_method == KIWI_L2NORM ? (double)v * (double)v : (double)std::fabs(v);
+                    }
+                    const float nq = eval_method == KIWI_L2NORM ? 1.f * (float)std::sqrt((double)dt * acc) : 1.f * (float)((double)dt * acc);
+                    nsum = nsum + nq;
+                }
+                nf = nsum / (float)ns;
             }
             c->norm_h.push_back(nf);
             c->comps.push_back(cd);
@@ -307,8 +345,13 @@ void prepare(kiwi_hip_ctx *c)
         c->misfit_d.ensure((size_t)c->nsrc * c->nmis, &c->dev_bytes);
         c->global_d.ensure((size_t)c->nsrc, &c->dev_bytes);
     }
+    if (c->floating) {
+        c->refx_d.ensure(std::max<size_t>(refx.size(), 1), &c->dev_bytes);
+        HIPCHECK(hipMemcpy(c->refx_d.p, refx.data(), refx.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     c->any_filter = false;
     for (auto &r : c->recv) if (r.enabled && r.ncomp > 0 && r.filter.defined()) c->any_filter = true;
+    if (c->floating && c->any_filter) throw std::runtime_error("floating norms with a misfit filter are not supported by the device comparator");
     c->fft_needed = (c->method == KIWI_AMPSPEC_L2NORM || c->method == KIWI_AMPSPEC_L1NORM || c->any_filter);
     c->prepared = true;
 }
@@ -583,12 +626,28 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
     record(c, 1, e2);
     {
         const bool spectral = (c->method == KIWI_AMPSPEC_L2NORM || c->method == KIWI_AMPSPEC_L1NORM);
-        const int td_method = spectral ? KIWI_L2NORM : c->method;
+        const int fl_method = c->method == KIWI_FLOATING_L2NORM ? KIWI_L2NORM : KIWI_L1NORM;
+        const int td_method = spectral ? KIWI_L2NORM : (c->floating ? fl_method : c->method);
         const int fft_mode = !c->fft_needed ? 0 : (spectral ? 3 : 1);        // bit0 write FFT input, bit1 skip the norm
-        MisfitParams mp{ td_method, c->gm.dt, c->syn_factor, c->nmis, isrc0, proc_which == 3 ? 0 : proc_which, fft_mode, nsrc };
+        MisfitParams mp{ td_method, c->gm.dt, c->syn_factor, c->nmis, isrc0, proc_which == 3 ? 0 : proc_which, fft_mode, nsrc,
+                         c->floating ? 1 : 0 };
+        if (c->floating) {
+            c->vt_d.ensure((size_t)nsrc * c->syn_stride, &c->dev_bytes);
+            c->partial_d.ensure((size_t)nsrc * c->nmis * c->max_ns, &c->dev_bytes);
+            c->fshift_d.ensure((size_t)c->nsrc * c->nrec_en, &c->dev_bytes);
+        }
         hipLaunchKernelGGL(misfit_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream,
                            c->syn_d.p, c->syn_stride, c->comps_d.p, c->reft_d.p, c->tw_d.p, c->moment_d.p,
-                           c->risetime_d.p, mp, c->misfit_d.p, proc_which == 3 ? nullptr : proc, c->fft_d.p);
+                           c->risetime_d.p, mp, c->misfit_d.p, proc_which == 3 ? nullptr : proc, c->fft_d.p, c->vt_d.p);
+        if (c->floating) {
+            hipLaunchKernelGGL(floating_norm_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream,
+                               c->vt_d.p, c->syn_stride, c->comps_d.p, c->refx_d.p, c->tw_d.p, fl_method, c->gm.dt,
+                               c->syn_factor, c->nmis, c->max_ns, c->partial_d.p);
+            const int nth = nsrc * c->nrec_en;
+            hipLaunchKernelGGL(floating_select_kernel, dim3((unsigned)((nth + 127) / 128)), dim3(128), 0, c->stream,
+                               c->partial_d.p, c->comps_d.p, c->recfirst_d.p, c->nrec_en, c->nmis, c->max_ns, fl_method,
+                               isrc0, nsrc, c->misfit_d.p, c->fshift_d.p);
+        }
         if (c->fft_needed) {
             SpecParams sp{ c->method, c->gm.dt, c->syn_factor, c->nmis, isrc0, c->any_filter ? 1 : 0 };
             fft_forward(c, nsrc);
@@ -633,7 +692,7 @@ int eval_impl(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
         int n = 0;
         while (s + n < isrc0 + nsrc) {
             const size_t nc = (size_t)(c->cent_ofs[s + n + 1] - c->cent_ofs[s + n]);
-            const size_t add = nc * nrec * (sizeof(GeoRec) + (c->accum_mode == 0 ? 512 : 0)) + c->syn_stride * sizeof(float) * (proc_which ? 2 : 1);
+            const size_t add = nc * nrec * (sizeof(GeoRec) + (c->accum_mode == 0 ? 512 : 0)) + c->syn_stride * sizeof(float) * ((proc_which ? 2 : 1) + (c->floating ? 1 : 0));
             if (n > 0 && (bytes + add > c->chunk_bytes_limit || n >= 65535)) break;
             if (c->fft_needed && n >= c->fft_cap) break;
             bytes += add; n++;
@@ -855,6 +914,35 @@ int kiwi_hip_set_misfit_method(kiwi_hip_ctx *c, int method)
     c->method = method;
     c->prepared = false;
     return 0;
+}
+
+int kiwi_hip_set_floating_shiftrange(kiwi_hip_ctx *c, int irec, float min_shift, float max_shift)
+{
+    GUARD_BEGIN
+    if (!c->have_db) throw std::runtime_error("set the database first (shifts are converted with its sampling interval)");
+    const int lo = (int)std::lround(min_shift / c->gm.dt), hi = (int)std::lround(max_shift / c->gm.dt);   // nint, minimizer_engine.f90:432
+    if (irec == 0) {
+        for (auto &r : c->recv) { r.float_lo = lo; r.float_hi = hi; }
+    } else {
+        if (irec < 1 || irec > (int)c->recv.size()) throw std::runtime_error("receiver index out of range");
+        c->recv[irec - 1].float_lo = lo; c->recv[irec - 1].float_hi = hi;
+    }
+    c->prepared = false;
+    return 0;
+    GUARD_END(c)
+}
+
+int kiwi_hip_get_floating_shifts(kiwi_hip_ctx *c, int isrc0, int nsrc, float *shifts)
+{
+    GUARD_BEGIN
+    if (!c->prepared || !c->floating) throw std::runtime_error("no floating norm evaluated");
+    if (isrc0 < 0 || nsrc < 0 || isrc0 + nsrc > c->nsrc) throw std::runtime_error("source range out of bounds");
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    std::vector<int> sh((size_t)nsrc * c->nrec_en);
+    HIPCHECK(hipMemcpy(sh.data(), c->fshift_d.p + (size_t)isrc0 * c->nrec_en, sh.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < sh.size(); i++) shifts[i] = (float)sh[i] * c->gm.dt;          // minimizer_engine.f90:1122
+    return 0;
+    GUARD_END(c)
 }
 
 int kiwi_hip_set_synthetics_factor(kiwi_hip_ctx *c, float factor)

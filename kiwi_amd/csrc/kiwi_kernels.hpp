@@ -78,6 +78,9 @@ struct CompDev {
     long long fft_base;          // float offset of the group in the real buffer (per chunk: x nsrc rows)
     long long spec_base;         // complex offset of the group in the spectrum buffer
     int specofs;                 // offset of this slot's reference amplitude spectrum / filter weights
+    // floating norms (receiver.f90:439-510): integer shift range of the receiver and where the un-tapered
+    // reference over [w0 - fl_hi, w0 + wlen - 1 - fl_lo] lives
+    int fl_lo, fl_ns, refxofs;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -826,6 +829,7 @@ __global__ __launch_bounds__(T) void accumulate_grouped_kernel(
 // misfit
 
 constexpr int kMaxFold = 129;
+constexpr int kMaxFloatShifts = 513;   // integer shifts tried by a floating norm at most
 
 struct MisfitParams {
     int method;          // comparator.f90:35-40 (time-domain ones)
@@ -836,6 +840,7 @@ struct MisfitParams {
     int write_tapered;   // keep scaled+folded (+tapered) synthetics for get_synthetics
     int fft_mode;        // 1: write the tapered synthetic zero-padded to ntrans into fftbuf, no norm
     int chunk_nsrc;      // sources in this launch (row stride of the FFT groups)
+    int skip_norm;       // floating norms: only produce the tapered synthetics (vt_out), norms follow in floating_norm_kernel
 };
 
 __global__ __launch_bounds__(256) void misfit_kernel(
@@ -843,7 +848,7 @@ __global__ __launch_bounds__(256) void misfit_kernel(
     const float *__restrict__ reft, const float *__restrict__ tw,
     const float *__restrict__ moment, const float *__restrict__ risetime, MisfitParams mp,
     float *__restrict__ misfit_out, float *__restrict__ proc /* optional [src][stride] processed synthetics */,
-    float *__restrict__ fftbuf)
+    float *__restrict__ fftbuf, float *__restrict__ vt_out /* optional [src][stride] tapered synthetics */)
 {
     const int m = blockIdx.x, s = blockIdx.y;
     const CompDev cd = comps[m];
@@ -908,6 +913,7 @@ __global__ __launch_bounds__(256) void misfit_kernel(
         const float vt = v * tp[i];               // make_array_tapered, comparator.f90:1173-1184
         if (proc) proc[(size_t)s * syn_stride + cd.synofs + cd.halo + i] = mp.write_tapered == 2 ? vt : v;
         if (frow) { frow[i] = vt; continue; }
+        if (mp.skip_norm) { vt_out[(size_t)s * syn_stride + cd.synofs + cd.halo + i] = vt; continue; }
         const float a = rt[i];
         switch (mp.method) {
         case 1: {                                 // l2norm_func, comparator.f90:650-659
@@ -923,7 +929,7 @@ __global__ __launch_bounds__(256) void misfit_kernel(
             peak = fmax(peak, sqrt(x * x + y * y)); break; }
         }
     }
-    if (mp.fft_mode) return;
+    if (mp.fft_mode || mp.skip_norm) return;
     red[threadIdx.x] = (mp.method == 6) ? peak : acc;
     __syncthreads();
     for (int st = 128; st > 0; st >>= 1) {
@@ -1067,6 +1073,76 @@ __global__ __launch_bounds__(256) void filtered_norm_kernel(
         }
         misfit_out[(size_t)(sp.isrc0 + s) * sp.nmis + m] = res;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// floating norms (receiver.f90:439-510): the reference is tried at every integer shift of the receiver's range
+// (probe_shift, comparator.f90:273-288: the data move, the taper stays), each time against the same tapered
+// synthetic; the shift with the smallest sum over the components (of the misfits, or of their squares) wins.
+// partial[(s * nmis + m) * maxns + q] = misfit of slot m at shift fl_lo + q.
+__global__ __launch_bounds__(256) void floating_norm_kernel(
+    const float *__restrict__ vt, size_t syn_stride, const CompDev *__restrict__ comps,
+    const float *__restrict__ refx, const float *__restrict__ tw, int method /* 1 l2, 2 l1 */, float dt,
+    float syn_factor, int nmis, int maxns, float *__restrict__ partial)
+{
+    __shared__ double red[256];
+    const int m = blockIdx.x, s = blockIdx.y;
+    const CompDev cd = comps[m];
+    const float *__restrict__ sy = vt + (size_t)s * syn_stride + cd.synofs + cd.halo;
+    const float *__restrict__ rx = refx + cd.refxofs;
+    const float *__restrict__ tp = tw + cd.refofs;
+    const bool unit = (syn_factor == 1.f);
+    for (int q = 0; q < cd.fl_ns; q++) {
+        // reference value at window sample i for shift fl_lo + q: un-tapered reference at w0 + i - (fl_lo + q)
+        const float *__restrict__ rq = rx + (cd.fl_ns - 1 - q);
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < cd.wlen; i += 256) {
+            const float a = rq[i] * tp[i];                 // make_array_tapered, comparator.f90:1173-1184
+            const float b = sy[i];
+            if (method == 1) {
+                const float d = unit ? (a - b) : (1.f * a - syn_factor * b);
+                acc += (double)d * (double)d;
+            } else {
+                const float d = unit ? fabsf(a - b) : fabsf(1.f * a - syn_factor * b);
+                acc += (double)d;
+            }
+        }
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0)
+            partial[((size_t)s * nmis + m) * maxns + q] = (method == 1) ? (float)sqrt((double)dt * red[0])
+                                                                        : (float)((double)dt * red[0]);
+        __syncthreads();
+    }
+}
+
+// minloc over the shifts of sum_k misfit (l1) or sum_k misfit^2 (l2), fp32, first minimum (receiver.f90:490-500)
+__global__ void floating_select_kernel(const float *__restrict__ partial, const CompDev *__restrict__ comps,
+                                       const int *__restrict__ rec_first, int nrec_en, int nmis, int maxns, int method,
+                                       int isrc0, int nsrc, float *__restrict__ misfit_out, int *__restrict__ shift_out)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nsrc * nrec_en) return;
+    const int s = idx / nrec_en, r = idx - s * nrec_en;
+    const int k0 = rec_first[r], k1 = rec_first[r + 1];
+    const CompDev cd = comps[k0];
+    const float *p = partial + (size_t)s * nmis * maxns;
+    int iloc = 0;
+    float best = 0.f;
+    for (int q = 0; q < cd.fl_ns; q++) {
+        float sum = 0.f;
+        for (int k = k0; k < k1; k++) {
+            const float v = p[(size_t)k * maxns + q];
+            sum = sum + (method == 2 ? v : v * v);
+        }
+        if (q == 0 || sum < best) { best = sum; iloc = q; }
+    }
+    for (int k = k0; k < k1; k++) misfit_out[(size_t)(isrc0 + s) * nmis + k] = p[(size_t)k * maxns + iloc];
+    shift_out[(size_t)(isrc0 + s) * nrec_en + r] = cd.fl_lo + iloc;
 }
 
 // minimizer_engine.f90:936-942: per receiver sum of squares in fp32, receivers in order

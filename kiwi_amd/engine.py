@@ -172,6 +172,18 @@ class Engine:
             raise KiwiHipError("set_misfit_method: nok > unknown norm: %s" % name)   # minimizer.f90:842-873
         self._ck(self.L.kiwi_hip_set_misfit_method(self.h, NORMS.get(name, name)), "set_misfit_method")
 
+    def set_floating_shiftrange(self, irec, min_shift, max_shift):
+        """`set_floating_shiftrange ireceiver min-shift max-shift` (seconds; ireceiver 0 = all receivers)."""
+        self._ck(self.L.kiwi_hip_set_floating_shiftrange(self.h, irec, min_shift, max_shift), "set_floating_shiftrange")
+
+    def get_floating_shifts(self, isrc0=0, nsrc=None):
+        """`get_floating_shifts` for a batch: [nsrc, n_enabled_receivers] in seconds."""
+        nsrc = self.nsrc - isrc0 if nsrc is None else nsrc
+        nen = sum(1 for e, c in zip(self.enabled, self.components) if e and len(c))
+        out = np.zeros((nsrc, nen), np.float32)
+        self._ck(self.L.kiwi_hip_get_floating_shifts(self.h, isrc0, nsrc, _fp(out)), "get_floating_shifts")
+        return out
+
     def set_synthetics_factor(self, f):
         self._ck(self.L.kiwi_hip_set_synthetics_factor(self.h, f), "set_synthetics_factor")
 

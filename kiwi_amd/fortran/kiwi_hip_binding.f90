@@ -105,6 +105,22 @@ module kiwi_hip_binding
             integer(c_int), value :: method
         end function
 
+        integer(c_int) function kiwi_hip_set_floating_shiftrange( ctx, irec, min_shift, max_shift ) &
+                bind(C, name='kiwi_hip_set_floating_shiftrange')
+            import :: c_int, c_ptr, c_float
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: irec
+            real(c_float), value :: min_shift, max_shift
+        end function
+
+        integer(c_int) function kiwi_hip_get_floating_shifts( ctx, isrc0, nsrc, shifts ) &
+                bind(C, name='kiwi_hip_get_floating_shifts')
+            import :: c_int, c_ptr, c_float
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: isrc0, nsrc
+            real(c_float), intent(out) :: shifts(*)
+        end function
+
         integer(c_int) function kiwi_hip_set_synthetics_factor( ctx, factor ) &
                 bind(C, name='kiwi_hip_set_synthetics_factor')
             import :: c_int, c_ptr, c_float

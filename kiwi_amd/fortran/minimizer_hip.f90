@@ -211,6 +211,8 @@ program minimizer_hip
         case ('set_misfit_taper');          call do_set_plf( a, .true., ok_ )
         case ('set_misfit_filter');         call do_set_plf( a, .false., ok_ )
         case ('set_synthetics_factor');     call do_set_synthetics_factor( a, ok_ )
+        case ('set_floating_shiftrange');   call do_set_floating_shiftrange( a, ok_ )
+        case ('get_floating_shifts');       call do_get_floating_shifts( ok_ )
         case ('get_misfits');               call do_get_misfits( .false., ok_ )
         case ('get_global_misfit');         call do_get_misfits( .true., ok_ )
         case ('output_seismograms');        call do_output_seismograms( a, ok_ )
@@ -625,6 +627,40 @@ program minimizer_hip
         if (.not. need_ctx()) return
         ok_ = check( kiwi_hip_set_synthetics_factor( ctx, f ) )
         evaluated = .false.
+    end subroutine
+
+    ! set_floating_shiftrange ireceiver min-shift max-shift   (minimizer.f90:388-419)
+    subroutine do_set_floating_shiftrange( a, ok_ )
+        character(len=*), intent(in) :: a
+        logical, intent(out) :: ok_
+        integer(c_int) :: irec
+        real(c_float) :: lo, hi
+        integer :: ios
+        ok_ = .false.
+        read (a,*,iostat=ios) irec, lo, hi
+        if (ios /= 0) then
+            call fail( 'usage: set_floating_shiftrange ireceiver min-shift max-shift' ); return
+        end if
+        if (.not. need_ctx()) return
+        ok_ = check( kiwi_hip_set_floating_shiftrange( ctx, irec, lo, hi ) )
+        evaluated = .false.
+    end subroutine
+
+    ! get_floating_shifts   (minimizer.f90:421-445): one value per enabled receiver
+    subroutine do_get_floating_shifts( ok_ )
+        logical, intent(out) :: ok_
+        real(c_float), allocatable :: sh(:)
+        character(len=:), allocatable :: buffer
+        integer :: n, i
+        ok_ = .false.
+        if (.not. update_misfits()) return
+        n = count( enabled )
+        allocate( sh(max(n,1)) )
+        if (.not. check( kiwi_hip_get_floating_shifts( ctx, 0_c_int, 1_c_int, sh ) )) return
+        allocate( character(len=32*max(n,1)) :: buffer )
+        write (buffer,*) (sh(i), i=1,n)
+        answer = trim(buffer)
+        ok_ = .true.
     end subroutine
 
     logical function update_misfits()

@@ -95,6 +95,8 @@ def lib():
         L.ko_engine_set_misfit_method.argtypes = [C.c_void_p, C.c_int]
         L.ko_engine_set_synthetics_factor.argtypes = [C.c_void_p, C.c_float]
         L.ko_engine_set_floating_shiftrange.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.ko_engine_get_floating_shift.argtypes = [C.c_void_p, C.c_int]
+        L.ko_engine_get_floating_shift.restype = C.c_int
         L.ko_engine_set_nthreads.argtypes = [C.c_void_p, C.c_int]
         for f in ("calculate_seismograms", "scale_seismograms", "calculate_misfits"):
             getattr(L, "ko_engine_" + f).argtypes = [C.c_void_p]
@@ -328,6 +330,13 @@ class Engine:
 
     def set_synthetics_factor(self, f):
         lib().ko_engine_set_synthetics_factor(self.h, f)
+
+    def set_floating_shiftrange(self, irec1, lo, hi):
+        """shift range in SAMPLES (set_floating_shiftrange converts seconds with nint(shift/dt), minimizer_engine.f90:432)"""
+        lib().ko_engine_set_floating_shiftrange(self.h, irec1, lo, hi)
+
+    def floating_shift(self, irec1):
+        return lib().ko_engine_get_floating_shift(self.h, irec1)
 
     def set_nthreads(self, n):
         lib().ko_engine_set_nthreads(self.h, n)

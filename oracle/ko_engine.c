@@ -208,6 +208,9 @@ void ko_engine_set_floating_shiftrange(ko_engine *e, int irec1, int lo, int hi)
     e->receivers[irec1 - 1].floating_shiftrange[1] = hi;
 }
 
+/* receiver%floating_shift after calculate_misfits with a floating norm (receiver.f90:498), in samples */
+int ko_engine_get_floating_shift(ko_engine *e, int irec1) { return e->receivers[irec1 - 1].floating_shift; }
+
 /* seismogram.f90:316-336 */
 static void make_weights(float azimuth, const float m[6], float f[6])
 {

@@ -402,3 +402,45 @@ def test_eikonal_sources_with_risetime_fold(stype):
     p.set_source_params(stype, trials[:1])
     p.eval()
     assert misfit_close(p.get_misfits()[0][0], pm[0])
+
+
+@pytest.mark.parametrize("method", ["floating_l2norm", "floating_l1norm"])
+def test_floating_norms(method):
+    """A15 (receiver.f90:439-510): argmin over integer shifts of the reference, per receiver."""
+    sc = Scenario(nrec=5, comps_list=["ned", "ne", "d", "ned", "n"])
+    e, p = build(sc)
+    mid = 7 if method == "floating_l2norm" else 8
+    e.set_misfit_method(mid)
+    p.set_misfit_method(method)
+    dt = sc.gf["dt"]
+    ranges = [(-4, 3), (-2, 2), (0, 5), (-6, 0), (1, 1)]
+    for ir, (lo, hi) in enumerate(ranges):
+        e.set_floating_shiftrange(ir + 1, lo, hi)
+        p.set_floating_shiftrange(ir + 1, lo * dt + 0.1 * dt, hi * dt - 0.1 * dt)       # nint() of seconds / dt
+    trials = synthetic.bilat_strike_sweep(6, step=1.5)
+    trials[:, 0] = [-1.6, -0.7, 0.0, 0.4, 1.1, 2.3]              # origin times: the best shift follows them
+    m, n, g = oracle_misfits(e, 1, trials)
+    shifts = []
+    for t in trials:
+        e.set_source_params(1, t)
+        e.get_misfits()
+        shifts.append([e.floating_shift(ir + 1) * dt for ir in range(5)])
+    p.set_source_params("bilateral", trials)
+    p.eval()
+    pm, pn, pg = p.get_misfits()
+    assert np.array_equal(pn[0], n[0])
+    assert misfit_close(pm, m)
+    assert misfit_close(pg, g)
+    ps = p.get_floating_shifts()
+    assert np.array_equal(ps, np.array(shifts, np.float32))
+    assert len(set(ps[:, 0])) > 2                                 # the winning shift does move with the origin time
+    # a single shift of zero is the plain norm
+    p.set_floating_shiftrange(0, 0.0, 0.0)
+    p.eval()
+    fm, fn, fg = p.get_misfits()
+    p.set_misfit_method(method[len("floating_"):])
+    p.eval()
+    qm, qn, qg = p.get_misfits()
+    assert np.array_equal(fm, qm) and np.array_equal(fn, qn) and np.array_equal(fg, qg)
+    with pytest.raises(KiwiHipError):
+        p.set_floating_shiftrange(99, 0., 1.)

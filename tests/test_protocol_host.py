@@ -140,5 +140,19 @@ def test_protocol_host_matches_python_host_and_oracle(host, tmp_path):
         assert len(c) > 20 and ri == np.float32(1.2)
         e.set_centroids(c, mo, ri)
         assert abs(gl - e.get_misfits()[2]) <= 2e-5 * gl
+        # floating norms over the wire (minimizer.f90:388-445)
+        p.do("set_source_params", "bilateral", *["%.9g" % v for v in trials[1]])
+        plain = float(p.do("get_global_misfit"))
+        p.do("set_misfit_method", "floating_l2norm")
+        p.do("set_floating_shiftrange", 0, 0, 0)
+        assert float(p.do("get_global_misfit")) == plain
+        assert np.array_equal(np.array(p.do("get_floating_shifts").split(), float), np.zeros(4))
+        p.do("set_floating_shiftrange", 0, -1.0, 1.0)
+        p.do("set_floating_shiftrange", 2, -2.0, 0.5)
+        sh = np.array(p.do("get_floating_shifts").split(), float)
+        assert sh.shape == (4,) and np.all(np.abs(sh) <= 2.0) and np.all(np.abs(sh / dt - np.rint(sh / dt)) < 1e-6)
+        assert float(p.do("get_global_misfit")) <= plain * (1 + 1e-6)
+        with pytest.raises(protocol.SeismosizerReturnedError, match="usage: set_floating_shiftrange"):
+            p.do("set_floating_shiftrange", 1)
     finally:
         p.close()
