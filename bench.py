@@ -184,6 +184,9 @@ def main():
         _, _, g = p.get_misfits()
         return gather_misfits(g, dist, local_rank)
 
+    if dist is not None:                             # RCCL sets itself up lazily at the first collective: not in the timed region
+        dist.barrier()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         allg = step()
     p.kernel_ms()                                   # reset the HIP-event accumulators

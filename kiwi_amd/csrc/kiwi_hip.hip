@@ -711,6 +711,7 @@ extern "C" {
 
 int kiwi_hip_init(int device, kiwi_hip_ctx **out)
 {
+    kmp_set_blocktime(0);          // LLVM OpenMP runtime: workers sleep right after a parallel region instead of spinning
     kiwi_hip_ctx *c = nullptr;
     try {
         int ndev = 0;
@@ -1109,7 +1110,10 @@ int kiwi_hip_set_sources_params(kiwi_hip_ctx *c, int sourcetype, int nsrc, const
     std::vector<DiscreteSource> ds((size_t)nsrc);
     int bad = -1;
     std::string why = "source discretisation failed";
-#pragma omp parallel for schedule(dynamic, 4)
+    // a few threads only: the discretisers take microseconds per source, and idle OpenMP workers spin for their
+    // block time after the loop, competing with the HIP runtime's own threads for the caller's next calls
+    const int nthreads = std::max(1, std::min({ omp_get_max_threads(), (nsrc + 31) / 32, eikonal ? 64 : 16 }));
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
     for (int s = 0; s < nsrc; s++) {
         std::string err;
         if (eikonal) err = discretize_eikonal(sourcetype, params + (size_t)s * np, c->effective_dt, c->rupture_profile, c->constraints, ds[s]);
