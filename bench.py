@@ -86,13 +86,11 @@ def setup_product(device, wl, L):
     return p, gf, (lat, lon, depth, comps), refs, tapers, float(np.mean(nc))
 
 
-def cpu_baseline(wl, gf, recv, refs, tapers, gpu_global, budget_s=20.0):
-    """The oracle (C restatement, OpenMP over receivers like minimizer_engine.f90:893-903) timed on
-    this box's host cores for a bounded number of the SAME trial sources."""
+def oracle_engine(wl, gf, recv, refs, tapers, cores):
+    """The CPU oracle set up exactly like the product in setup_product; returns (engine, db, evaluate) where
+    evaluate(params) = set_source_params + get_misfits (seismosizer.py:703-718) -> (misfits, norms, global)."""
     from oracle import ko
     from kiwi_amd.engine import SOURCE_TYPES
-    cores = os.cpu_count() or 1
-    trials = wl["trials"]
     nx, nz, ng, L = gf["data"].shape
     db = ko.Gfdb(nx, nz, ng, gf["dt"], gf["dx"], gf["dz"], gf["firstx"], gf["firstz"])
     for ix in range(nx):
@@ -118,13 +116,26 @@ def cpu_baseline(wl, gf, recv, refs, tapers, gpu_global, budget_s=20.0):
         c = wl["crust"]
         prof = ko.crust_profile(c[0:8], c[8:16], c[16:24], c[24:31])
 
-    def one(t):                                       # set_source_params + get_misfits (seismosizer.py:703-718)
+    def evaluate(t):
         if wl["crust"] is not None:
             cent, mo, ri, _ = ko.discretize_eikonal(st, t, 0.5, prof, *wl["constraints"])
             e.set_centroids(cent, mo, ri)
         else:
             e.set_source_params(st, t)
-        return e.get_misfits()[2]
+        return e.get_misfits()
+
+    return e, db, evaluate
+
+
+def cpu_baseline(wl, gf, recv, refs, tapers, gpu_global, budget_s=20.0):
+    """The oracle (C restatement, OpenMP over receivers like minimizer_engine.f90:893-903) timed on
+    this box's host cores for a bounded number of the SAME trial sources."""
+    cores = os.cpu_count() or 1
+    trials = wl["trials"]
+    e, db, evaluate = oracle_engine(wl, gf, recv, refs, tapers, cores)
+
+    def one(t):
+        return evaluate(t)[2]
 
     one(trials[0])                                    # warm-up (allocations)
     t0 = time.perf_counter()
