@@ -101,6 +101,7 @@ struct kiwi_hip_ctx {
 
     // prepared (derived) state
     bool prepared = false;
+    bool synth_only = false;              // some enabled receiver has no taper / reference yet: synthetics only
     int nmis = 0, nrec_en = 0;
     int halo = 0;
     size_t syn_stride = 0;
@@ -199,6 +200,30 @@ int fold_halfwidth(float risetime, float dt)
 }
 
 // derive windows, tapered references, norm factors and device tables
+// Natural spans of the synthetic strips over all uploaded sources (seismogram.f90:102-130 with
+// sparse_trace.f90:648-668): per receiver [lo_h, hi_h, lo_d, hi_d], reduced on the device by geometry_kernel.
+// Needs recv_d (geometry part) uploaded.
+void natural_spans(kiwi_hip_ctx *c, std::vector<int> &sb)
+{
+    const int nrec = (int)c->recv.size();
+    sb.assign((size_t)nrec * 4, 0);
+    for (int r = 0; r < nrec; r++) { sb[4 * r] = sb[4 * r + 2] = 0x7fffffff; sb[4 * r + 1] = sb[4 * r + 3] = -0x7fffffff; }
+    c->spanbuf_d.ensure(sb.size(), &c->dev_bytes);
+    HIPCHECK(hipMemcpyAsync(c->spanbuf_d.p, sb.data(), sb.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    for (int s0 = 0; s0 < c->nsrc; s0 += 32768) {
+        const int n = std::min(32768, c->nsrc - s0);
+        int maxnc = 0;
+        for (int s = s0; s < s0 + n; s++) maxnc = std::max(maxnc, c->cent_ofs[s + 1] - c->cent_ofs[s]);
+        if (maxnc == 0) continue;
+        EvalParams ep{ c->bilinear, c->xus, c->zus, nrec, s0 };
+        dim3 grid((unsigned)((maxnc * nrec + 255) / 256), (unsigned)n);
+        hipLaunchKernelGGL(geometry_kernel, grid, dim3(256), 0, c->stream, c->cent_d.p, c->centofs_d.p, ep, c->gm,
+                           c->span.p, c->recv_d.p, (GeoRec *)nullptr, (int *)nullptr, c->spanbuf_d.p);
+    }
+    HIPCHECK(hipMemcpyAsync(sb.data(), c->spanbuf_d.p, sb.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+}
+
 void prepare(kiwi_hip_ctx *c)
 {
     if (c->prepared) return;
@@ -220,6 +245,31 @@ void prepare(kiwi_hip_ctx *c)
     std::vector<RecvDev> rd(nrec);
     c->comps.clear();
     c->norm_h.clear();
+    // Before any reference or taper is set the engine can still synthesise (output_seismograms is how a
+    // "synthetic reference" is made, minimizer.f90:1296-1380): then every window is the natural span of the
+    // synthetic strips and misfits are not available.
+    c->synth_only = false;
+    for (auto &r : c->recv) {
+        if (!r.enabled || r.ncomp == 0) continue;
+        if (!r.taper.defined()) c->synth_only = true;
+        for (int k = 0; k < r.ncomp; k++) if (r.ref[k].data.empty()) c->synth_only = true;
+    }
+    std::vector<int> nat;
+    if (c->synth_only) {
+        if (c->nsrc == 0) throw std::runtime_error("no source set");
+        c->floating = false;
+        for (int ir = 0; ir < nrec; ir++) {                 // geometry part of the receiver records only
+            Receiver &r = c->recv[ir];
+            RecvDev &d = rd[ir];
+            std::memset(&d, 0, sizeof(d));
+            d.azi0 = r.azi0; d.bazi0 = r.bazi0; d.dist0 = r.dist0; d.depth = r.depth;
+            d.enabled = r.enabled && r.ncomp > 0;
+            for (int k = 0; k < r.ncomp; k++) { if (std::abs(r.comp[k]) == 3) d.has_d = 1; else d.need_h = 1; }
+        }
+        c->recv_d.ensure(rd.size(), &c->dev_bytes);
+        HIPCHECK(hipMemcpyAsync(c->recv_d.p, rd.data(), rd.size() * sizeof(RecvDev), hipMemcpyHostToDevice, c->stream));
+        natural_spans(c, nat);
+    }
     std::vector<float> reft, tw;
     std::vector<int> recfirst;
     size_t synofs = 0;
@@ -241,25 +291,27 @@ void prepare(kiwi_hip_ctx *c)
             if (d.comp[k] == 3) { d.has_d = 1; d.sd = d.sign[k]; } else d.need_h = 1;
         }
         if (!d.enabled) continue;
-        if (!r.taper.defined())
-            throw std::runtime_error("receiver " + std::to_string(ir + 1) + ": no misfit taper set (the device "
-                                     "comparator evaluates norms over the taper span, comparator.f90:782-792)");
         int w[2];
-        discrete_plf_span(r.taper, dt, w);                                 // comparator.f90:1157-1169
-        if (w[1] < w[0]) throw std::runtime_error("receiver " + std::to_string(ir + 1) + ": empty taper span");
+        if (c->synth_only) {
+            w[0] = std::min(nat[4 * ir], nat[4 * ir + 2]);
+            w[1] = std::max(nat[4 * ir + 1], nat[4 * ir + 3]);
+            if (w[1] < w[0]) { w[0] = 0; w[1] = 0; }                        // no centroid reached this receiver
+            else if (hs > 0) { w[0] -= hs; w[1] += hs + 1; }                // strip_fold grows the strip, sparse_trace.f90:379-402
+        } else {
+            discrete_plf_span(r.taper, dt, w);                             // comparator.f90:1157-1169
+            if (w[1] < w[0]) throw std::runtime_error("receiver " + std::to_string(ir + 1) + ": empty taper span");
+        }
         const int wlen = w[1] - w[0] + 1;
         d.wbeg = w[0] - c->halo;
         d.wlen = wlen + 2 * c->halo;
         c->max_wlen = std::max(c->max_wlen, d.wlen);
         // taper weights: plf_taper_array applied to ones (piecewise_linear_function.f90:195-237)
         std::vector<float> tww(wlen, 1.f);
-        plf_taper_array(r.taper, tww.data(), w[0], w[1], dt, IP_COS);
+        if (!c->synth_only) plf_taper_array(r.taper, tww.data(), w[0], w[1], dt, IP_COS);
         recfirst.push_back((int)c->comps.size());
         for (int k = 0; k < r.ncomp; k++) {
-            const auto &rf = r.ref[k];
-            if (rf.data.empty())
-                throw std::runtime_error("receiver " + std::to_string(ir + 1) + " component " +
-                                         std::to_string(k + 1) + ": no reference seismogram set");
+            static const Receiver::Ref no_ref = { 0, std::vector<float>(1, 0.f) };
+            const auto &rf = c->synth_only ? no_ref : r.ref[k];
             CompDev cd;
             std::memset(&cd, 0, sizeof(cd));
             cd.synofs = (int)synofs; cd.halo = c->halo; cd.w0 = w[0]; cd.wlen = wlen;
@@ -352,7 +404,7 @@ void prepare(kiwi_hip_ctx *c)
     c->any_filter = false;
     for (auto &r : c->recv) if (r.enabled && r.ncomp > 0 && r.filter.defined()) c->any_filter = true;
     if (c->floating && c->any_filter) throw std::runtime_error("floating norms with a misfit filter are not supported by the device comparator");
-    c->fft_needed = (c->method == KIWI_AMPSPEC_L2NORM || c->method == KIWI_AMPSPEC_L1NORM || c->any_filter);
+    c->fft_needed = !c->synth_only && (c->method == KIWI_AMPSPEC_L2NORM || c->method == KIWI_AMPSPEC_L1NORM || c->any_filter);
     c->prepared = true;
 }
 
@@ -427,22 +479,8 @@ void prepare_fft(kiwi_hip_ctx *c, const std::vector<float> &reft_host)
     const int nrec = (int)c->recv.size();
     const float dt = c->gm.dt;
     // ---- 1. spans of the synthetic strips over all uploaded sources
-    std::vector<int> sb((size_t)nrec * 4);
-    for (int r = 0; r < nrec; r++) { sb[4 * r] = sb[4 * r + 2] = 0x7fffffff; sb[4 * r + 1] = sb[4 * r + 3] = -0x7fffffff; }
-    c->spanbuf_d.ensure(sb.size(), &c->dev_bytes);
-    HIPCHECK(hipMemcpyAsync(c->spanbuf_d.p, sb.data(), sb.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    for (int s0 = 0; s0 < c->nsrc; s0 += 32768) {
-        const int n = std::min(32768, c->nsrc - s0);
-        int maxnc = 0;
-        for (int s = s0; s < s0 + n; s++) maxnc = std::max(maxnc, c->cent_ofs[s + 1] - c->cent_ofs[s]);
-        if (maxnc == 0) continue;
-        EvalParams ep{ c->bilinear, c->xus, c->zus, nrec, s0 };
-        dim3 grid((unsigned)((maxnc * nrec + 255) / 256), (unsigned)n);
-        hipLaunchKernelGGL(geometry_kernel, grid, dim3(256), 0, c->stream, c->cent_d.p, c->centofs_d.p, ep, c->gm,
-                           c->span.p, c->recv_d.p, (GeoRec *)nullptr, (int *)nullptr, c->spanbuf_d.p);
-    }
-    HIPCHECK(hipMemcpyAsync(sb.data(), c->spanbuf_d.p, sb.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(hipStreamSynchronize(c->stream));
+    std::vector<int> sb;
+    natural_spans(c, sb);
     const int hs = fold_halfwidth(c->max_risetime, dt);
     // ---- 2. transform length per slot
     std::vector<int> ntr(c->comps.size());
@@ -1092,6 +1130,7 @@ int kiwi_hip_set_sources(kiwi_hip_ctx *c, int nsrc, const int *cent_ofs, const f
     c->nsrc = nsrc;
     if (fold_halfwidth(maxrise, c->gm.dt) != fold_halfwidth(c->max_risetime, c->gm.dt)) c->prepared = false;
     c->max_risetime = maxrise;
+    if (c->synth_only) c->prepared = false;          // windows = natural spans of the uploaded sources
     c->last_nsrc = 0;
     c->proc_which_held = 0;
     c->fft_ready = false;
@@ -1171,6 +1210,8 @@ int kiwi_hip_get_misfits(kiwi_hip_ctx *c, int isrc0, int nsrc, float *misfit, fl
 {
     GUARD_BEGIN
     if (!c->prepared) throw std::runtime_error("nothing evaluated yet");
+    if (c->synth_only) throw std::runtime_error("misfits need a reference seismogram and a misfit taper for every enabled receiver component "
+                                                "(the device comparator evaluates norms over the taper span, comparator.f90:782-792)");
     if (isrc0 < 0 || nsrc < 0 || isrc0 + nsrc > c->nsrc) throw std::runtime_error("source range out of bounds");
     HIPCHECK(hipStreamSynchronize(c->stream));
     if (misfit)

@@ -236,8 +236,9 @@ def test_errors_are_reported_not_fatal():
     sc.make_references(e)
     p = sc.product()
     p.set_source_params("bilateral", synthetic.bilat_strike_sweep(1))
-    with pytest.raises(KiwiHipError, match="no reference|no misfit taper"):
-        p.eval()
+    p.eval()                      # synthesis works without references (that is how references get made) ...
+    with pytest.raises(KiwiHipError, match="misfits need a reference seismogram and a misfit taper"):
+        p.get_misfits()           # ... misfits do not
     with pytest.raises(KiwiHipError):
         p.switch_receiver(99, True)
     with pytest.raises(KiwiHipError):
@@ -444,3 +445,40 @@ def test_floating_norms(method):
     assert np.array_equal(fm, qm) and np.array_equal(fn, qn) and np.array_equal(fg, qg)
     with pytest.raises(KiwiHipError):
         p.set_floating_shiftrange(99, 0., 1.)
+
+
+def test_synthesis_before_any_reference_is_set():
+    """output_seismograms on a fresh engine (minimizer.f90:1296-1380, how a synthetic reference is made): the window of
+    every receiver is the natural span of its synthetic strips (seismogram.f90:102-130)."""
+    sc = Scenario(comps_list=["ned", "d", "ne", "ned", "e", "ned"])
+    e = sc.oracle()
+    p = sc.product()
+    for rise in (0.0, 2.0):
+        trial = synthetic.bilat_strike_sweep(2, step=3.0)
+        from oracle import ko
+        tabs = [ko.discretize(1, t, sc.effective_dt) for t in trial]
+        p.set_sources([t[0] for t in tabs], [t[1] for t in tabs], [rise, rise])
+        p.set_keep_synthetics(1)
+        p.eval()
+        for i in range(2):
+            e.set_centroids(tabs[i][0], tabs[i][1], rise)
+            e.calculate_seismograms()
+            e.scale_seismograms()
+            for ir, comps in enumerate(sc.comps):
+                for k in range(len(comps)):
+                    lo_o, so = e.synthetic(ir + 1, k + 1, 1)
+                    lo_p, sp = p.get_synthetics(i, ir + 1, k + 1, 1)
+                    a, b = max(lo_o, lo_p), min(lo_o + len(so), lo_p + len(sp))
+                    assert b - a >= len(so) - 2                   # the device window covers the oracle's strip
+                    assert np.max(np.abs(so[a - lo_o:b - lo_o] - sp[a - lo_p:b - lo_p])) <= SYN_RTOL * np.max(np.abs(so))
+    # once references and tapers are in, misfits work on the same engine
+    sc.make_references(e)
+    sc.apply_setup(p, False)
+    sc.apply_setup(e, True)
+    p.set_keep_synthetics(0)
+    trials = synthetic.bilat_strike_sweep(3, step=2.0)
+    m, n, g = oracle_misfits(e, 1, trials)
+    p.set_source_params("bilateral", trials)
+    p.eval()
+    pm, pn, pg = p.get_misfits()
+    assert misfit_close(pm, m) and misfit_close(pg, g)

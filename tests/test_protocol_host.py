@@ -156,3 +156,68 @@ def test_protocol_host_matches_python_host_and_oracle(host, tmp_path):
             p.do("set_floating_shiftrange", 1)
     finally:
         p.close()
+
+
+@pytest.mark.gpu
+def test_config1_mini_inp_command_sequence(host, tmp_path):
+    """BASELINE.json configs[0]: the command sequence of the reference's benchmark/mini.inp (first block) through the
+    protocol host, with the Izmit receiver table (tests/golden/izmit-receivers.table, the reference's own data file)
+    and a synthetic database in place of the 20000-km GEMINI one; `mseed` output replaced by `table`."""
+    from oracle import ko
+    gf = synthetic.make_gfdb(nx=64, nz=7, ng=10, L=512, dx=25e3, dz=2000.0, firstx=300e3, firstz=4e3)
+    base = str(tmp_path / "db")
+    protocol.write_flat_gfdb(base, gf)
+    table = os.path.join(os.path.dirname(__file__), "golden", "izmit-receivers.table")
+    rec = [l.split() for l in open(table) if l.strip()]
+    lat, lon, comps = [float(r[0]) for r in rec], [float(r[1]) for r in rec], [r[2] for r in rec]
+    assert len(rec) == 11 and set(comps) == {"ned"}
+    src = ["0 0 0 10000 2e20  91 87 164  0  20000 10000 9000  3500 2", "0 0 0 10000 2e20  92 87 164  0  20000 10000 9000  3500 2"]
+    p = protocol.MinimizerProcess(host)
+    out = {}
+    try:
+        p.do("set_database           ", base)
+        p.do("set_effective_dt        0.5")
+        p.do("set_local_interpolation bilinear")
+        p.do("set_receivers          ", table)
+        p.do("set_source_location     40.75 29.86 0")
+        for rep in range(2):                                   # mini.inp alternates the two sources eight times
+            for k, sp in enumerate(src):
+                p.do("set_source_params       bilateral " + sp)
+                stem = str(tmp_path / ("izmit-seismogram%d%d" % (rep, k)))
+                p.do("output_seismograms     ", stem, " table synthetics plain")
+                out[(rep, k)] = [protocol.read_table("%s-%d-%s.table" % (stem, ir + 1, c)) for ir in range(11) for c in "ned"]
+    finally:
+        p.close()
+    # repeated evaluation of the same source gives the same file, the two sources differ
+    for a, b in zip(out[(0, 0)], out[(1, 0)]):
+        assert np.array_equal(a[1], b[1])
+    assert any(not np.array_equal(a[1], b[1]) for a, b in zip(out[(0, 0)], out[(0, 1)]))
+    # against the oracle
+    nx, nz, ng, L = gf["data"].shape
+    db = ko.Gfdb(nx, nz, ng, gf["dt"], gf["dx"], gf["dz"], gf["firstx"], gf["firstz"])
+    for ix in range(nx):
+        for iz in range(nz):
+            for ig in range(ng):
+                db.set_trace(ix + 1, iz + 1, ig + 1, int(gf["first"][ix, iz, ig]), gf["data"][ix, iz, ig])
+    e = ko.Engine(db)
+    e.set_receivers(np.array(lat), np.array(lon), np.zeros(11, np.float32), comps)
+    e.set_source_location(40.75, 29.86, 0.0)
+    e.set_effective_dt(0.5)
+    e.set_interpolation(True)
+    dt = gf["dt"]
+    for k, sp in enumerate(src):
+        params = np.array(sp.split(), np.float32)
+        assert len(ko.discretize(1, params, 0.5)[0]) > 500          # an extended rupture: ~1000 centroids
+        e.set_source_params(1, params)
+        e.calculate_seismograms()
+        e.scale_seismograms()
+        for ir in range(11):
+            for ic in range(3):
+                t, v = out[(0, k)][3 * ir + ic]
+                lo_o, so = e.synthetic(ir + 1, ic + 1, 1)
+                i0 = int(round(t[0] / dt)) + 1
+                a, b = max(lo_o, i0), min(lo_o + len(so), i0 + len(v))
+                assert b - a > 300
+                assert np.max(np.abs(so[a - lo_o:b - lo_o] - v[a - i0:b - i0])) <= 1e-5 * np.max(np.abs(so))
+    e.close()
+    db.close()
