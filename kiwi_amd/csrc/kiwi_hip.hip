@@ -476,7 +476,6 @@ __global__ void ref_filt_kernel(const float *__restrict__ fftbuf, const CompDev 
 // slots out in batched groups and pushes the REFERENCE probes through the same device pipeline.
 void prepare_fft(kiwi_hip_ctx *c, const std::vector<float> &reft_host)
 {
-    const int nrec = (int)c->recv.size();
     const float dt = c->gm.dt;
     // ---- 1. spans of the synthetic strips over all uploaded sources
     std::vector<int> sb;
@@ -1151,7 +1150,10 @@ int kiwi_hip_set_sources_params(kiwi_hip_ctx *c, int sourcetype, int nsrc, const
     std::string why = "source discretisation failed";
     // a few threads only: the discretisers take microseconds per source, and idle OpenMP workers spin for their
     // block time after the loop, competing with the HIP runtime's own threads for the caller's next calls
-    const int nthreads = std::max(1, std::min({ omp_get_max_threads(), (nsrc + 31) / 32, eikonal ? 64 : 16 }));
+    // (the eikonal discretisers run a fast-marching solve per source: milliseconds, one thread per source pays)
+    const int nthreads = std::max(1, eikonal ? std::min({ omp_get_max_threads(), nsrc, 64 })
+                                             : std::min({ omp_get_max_threads(), (nsrc + 31) / 32, 16 }));
+    (void)nthreads;
 #pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
     for (int s = 0; s < nsrc; s++) {
         std::string err;
