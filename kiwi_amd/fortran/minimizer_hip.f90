@@ -241,6 +241,12 @@ program minimizer_hip
         ok_ = .false.
         call split_first( a, base, rest )
         open( newunit=unit, file=trim(base)//'.kiwiflat', access='stream', form='unformatted', status='old', iostat=ios )
+#ifdef HAVE_GFDB_HDF5
+        if (ios /= 0) then        ! the reference's own on-disk format: <base>.index + <base>.<i>.chunk (gfdb_io_hdf.f90)
+            call set_database_hdf5( trim(base), ok_ )
+            return
+        end if
+#endif
         if (ios /= 0) then
             call fail( "can't open file "//trim(base)//'.kiwiflat' ); return
         end if
@@ -259,6 +265,62 @@ program minimizer_hip
         if (ok_) db_dt = dt
         evaluated = .false.
     end subroutine
+
+#ifdef HAVE_GFDB_HDF5
+    subroutine set_database_hdf5( base, ok_ )
+        character(len=*), intent(in) :: base
+        logical, intent(out) :: ok_
+        type, bind(C) :: t_index
+            real(c_float) :: dt, dx, dz, firstx, firstz
+            integer(c_int) :: nchunks, nx, nxc, nz, ng
+        end type
+        interface
+            integer(c_int) function kiwi_gfdb_read_index( base, ix, err, errlen ) bind(C, name='kiwi_gfdb_read_index')
+                import :: c_int, c_char, t_index
+                character(kind=c_char), intent(in) :: base(*)
+                type(t_index), intent(out) :: ix
+                character(kind=c_char), intent(out) :: err(*)
+                integer(c_int), value :: errlen
+            end function
+            integer(c_int) function kiwi_gfdb_read_dense( base, L, G, first, nsamp, lmax, err, errlen ) &
+                    bind(C, name='kiwi_gfdb_read_dense')
+                import :: c_int, c_char, c_float, c_ptr
+                character(kind=c_char), intent(in) :: base(*)
+                integer(c_int), value :: L, errlen
+                type(c_ptr), value :: G
+                integer(c_int), intent(out) :: first(*), nsamp(*), lmax
+                character(kind=c_char), intent(out) :: err(*)
+            end function
+        end interface
+        type(t_index) :: ix
+        character(kind=c_char) :: err(512)
+        character(len=512) :: msg
+        integer(c_int), allocatable :: first(:), nsamp(:)
+        real(c_float), allocatable, target :: G(:)
+        integer(c_int) :: lmax
+        integer :: i
+        ok_ = .false.
+        err = c_null_char
+        if (kiwi_gfdb_read_index( base//c_null_char, ix, err, 512_c_int ) /= 0) goto 10
+        allocate( first(ix%nx*ix%nz*ix%ng), nsamp(ix%nx*ix%nz*ix%ng) )
+        if (kiwi_gfdb_read_dense( base//c_null_char, 0_c_int, c_null_ptr, first, nsamp, lmax, err, 512_c_int ) /= 0) goto 10
+        lmax = max(lmax, 1)
+        allocate( G(int(lmax,8)*ix%nx*ix%nz*ix%ng) )
+        if (kiwi_gfdb_read_dense( base//c_null_char, lmax, c_loc(G), first, nsamp, lmax, err, 512_c_int ) /= 0) goto 10
+        if (.not. need_ctx()) return
+        ok_ = check( kiwi_hip_set_gfdb( ctx, ix%nx, ix%nz, ix%ng, lmax, ix%dt, ix%dx, ix%dz, ix%firstx, ix%firstz, G, first, nsamp ) )
+        if (ok_) db_dt = ix%dt
+        evaluated = .false.
+        return
+10      continue
+        msg = ''
+        do i=1,512
+            if (err(i) == c_null_char) exit
+            msg(i:i) = err(i)
+        end do
+        call fail( trim(msg) )
+    end subroutine
+#endif
 
     subroutine do_set_effective_dt( a, ok_ )
         character(len=*), intent(in) :: a
