@@ -96,6 +96,13 @@ int kiwi_hip_set_misfit_method(kiwi_hip_ctx *ctx, int method);
  * (minimizer_engine.f90:1095-1128): the winning shift in seconds per source and ENABLED receiver, shifts[nsrc][n_enabled] */
 int kiwi_hip_set_floating_shiftrange(kiwi_hip_ctx *ctx, int irec, float min_shift, float max_shift);
 int kiwi_hip_get_floating_shifts(kiwi_hip_ctx *ctx, int isrc0, int nsrc, float *shifts);
+/* shift_ref_seismogram ireceiver shift (minimizer_engine.f90:354-378): move a receiver's reference traces by nint(shift/dt)
+ * samples.  autoshift_ref_seismogram ireceiver min-shift max-shift (:380-419; receiver.f90:816-832;
+ * comparator.f90:1061-1090): cross-correlate the tapered synthetics of uploaded source `isrc` with the references over
+ * the integer shifts of the range, move the references of receiver `irec` (0 = all) to the best shift and return the
+ * shifts applied in seconds (shifts[nrec] for irec == 0, else shifts[1]).  Setup-time operations, computed on the host. */
+int kiwi_hip_shift_ref_seismogram(kiwi_hip_ctx *ctx, int irec, float shift);
+int kiwi_hip_autoshift_ref_seismogram(kiwi_hip_ctx *ctx, int irec, float min_shift, float max_shift, int isrc, float *shifts);
 /* set_synthetics_factor (minimizer_engine.f90:700-727; receiver.f90:391-405) */
 int kiwi_hip_set_synthetics_factor(kiwi_hip_ctx *ctx, float factor);
 

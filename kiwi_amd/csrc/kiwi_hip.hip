@@ -20,6 +20,7 @@
 #include <vector>
 #include <stdexcept>
 #include <omp.h>
+#include <limits>
 
 using namespace kiwi;
 
@@ -1253,6 +1254,92 @@ int kiwi_hip_get_synthetics(kiwi_hip_ctx *c, int isrc, int irec, int icomp, int 
     *first = cd.w0; *n = cd.wlen;
     const int m = std::min(cd.wlen, maxn);
     HIPCHECK(hipMemcpy(out, c->proc_d.p + srcofs + cd.synofs + cd.halo, (size_t)m * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+    GUARD_END(c)
+}
+
+int kiwi_hip_shift_ref_seismogram(kiwi_hip_ctx *c, int irec, float shift)
+{
+    GUARD_BEGIN
+    if (!c->have_db) throw std::runtime_error("no database set");
+    if (irec < 1 || irec > (int)c->recv.size()) throw std::runtime_error("receiver index out of range");
+    const int ishift = (int)std::lround(shift / c->gm.dt);                        // minimizer_engine.f90:373
+    Receiver &r = c->recv[irec - 1];
+    for (int k = 0; k < r.ncomp; k++) r.ref[k].first += ishift;                   // probe_shift, comparator.f90:273-288
+    c->prepared = false;
+    return 0;
+    GUARD_END(c)
+}
+
+int kiwi_hip_autoshift_ref_seismogram(kiwi_hip_ctx *c, int irec, float min_shift, float max_shift, int isrc, float *shifts)
+{
+    GUARD_BEGIN
+    if (irec < 0 || irec > (int)c->recv.size()) throw std::runtime_error("receiver index out of range");
+    if (isrc < 0 || isrc >= c->nsrc) throw std::runtime_error("source index out of range");
+    HIPCHECK(hipSetDevice(c->device));
+    prepare(c);
+    if (c->synth_only) throw std::runtime_error("autoshift needs reference seismograms and misfit tapers");
+    const float dt = c->gm.dt;
+    const int lo = (int)std::lround(min_shift / dt), hi = (int)std::lround(max_shift / dt), ns = hi - lo + 1;   // :397
+    if (ns < 1) throw std::runtime_error("empty shift range");
+    // tapered, scaled synthetics of the current source (update_misfits, minimizer_engine.f90:393)
+    eval_impl(c, isrc, 1, 2);
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    std::vector<float> syn(c->syn_stride);
+    HIPCHECK(hipMemcpy(syn.data(), c->proc_d.p, c->syn_stride * sizeof(float), hipMemcpyDeviceToHost));
+    const int r0 = irec == 0 ? 0 : irec - 1, r1 = irec == 0 ? (int)c->recv.size() : irec;
+    std::vector<int> applied;
+    for (int ir = r0; ir < r1; ir++) {
+        Receiver &r = c->recv[ir];
+        int ishift = 0;
+        if (r.enabled && r.ncomp > 0) {                                          // receiver.f90:816-832
+            int w[2];
+            discrete_plf_span(r.taper, dt, w);
+            const int wlen = w[1] - w[0] + 1;
+            std::vector<float> tww(wlen, 1.f);
+            plf_taper_array(r.taper, tww.data(), w[0], w[1], dt, IP_COS);
+            std::vector<float> cc((size_t)ns * r.ncomp);
+            int slot0 = -1;
+            for (size_t i = 0; i < c->comps.size(); i++) if (c->comps[i].rec == ir) { slot0 = (int)i; break; }
+            float ccmax = -std::numeric_limits<float>::infinity();
+            for (int k = 0; k < r.ncomp; k++) {
+                const CompDev &cd = c->comps[slot0 + k];
+                const float *a = syn.data() + cd.synofs + cd.halo;               // tapered synthetic over the window
+                const auto &rf = r.ref[k];
+                const int f0 = rf.first, f1 = f0 + (int)rf.data.size() - 1;
+                for (int q = 0; q < ns; q++) {                                   // probes_windowed_cross_corr, comparator.f90:1061-1090
+                    const int sh = lo + q;
+                    double acc = 0.0;
+                    for (int t = w[0]; t <= w[1]; t++) {
+                        const int ts = t - sh;
+                        float b = 0.f;
+                        if (ts >= f0) b = (rf.data[std::min(ts, f1) - f0] * 1.f) * tww[t - w[0]];
+                        const float av = a[t - w[0]];
+                        acc += (c->syn_factor == 1.f) ? (double)(av * b) : (double)(av * c->syn_factor * b * 1.f);   // scalar_product_2, :627-637
+                    }
+                    cc[(size_t)k * ns + q] = (float)acc;
+                    ccmax = std::max(ccmax, (float)acc);
+                }
+            }
+            // imax = maxloc( sum( max(cc / max(1, maxval(cc)), 0)**2, over components ) ), first maximum
+            const float den = std::max(1.f, ccmax);
+            int imax = 0;
+            float best = 0.f;
+            for (int q = 0; q < ns; q++) {
+                float sum = 0.f;
+                for (int k = 0; k < r.ncomp; k++) { const float x = std::max(cc[(size_t)k * ns + q] / den, 0.f); sum = sum + x * x; }
+                if (q == 0 || sum > best) { best = sum; imax = q; }
+            }
+            ishift = lo + imax;
+        }
+        applied.push_back(ishift);
+        shifts[ir - r0] = (float)ishift * dt;
+    }
+    for (int ir = r0; ir < r1; ir++) {
+        Receiver &r = c->recv[ir];
+        for (int k = 0; k < r.ncomp; k++) r.ref[k].first += applied[ir - r0];
+    }
+    c->prepared = false;
     return 0;
     GUARD_END(c)
 }

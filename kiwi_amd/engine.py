@@ -172,6 +172,18 @@ class Engine:
             raise KiwiHipError("set_misfit_method: nok > unknown norm: %s" % name)   # minimizer.f90:842-873
         self._ck(self.L.kiwi_hip_set_misfit_method(self.h, NORMS.get(name, name)), "set_misfit_method")
 
+    def shift_ref_seismogram(self, irec, shift):
+        """`shift_ref_seismogram ireceiver shift` (seconds)."""
+        self._ck(self.L.kiwi_hip_shift_ref_seismogram(self.h, irec, shift), "shift_ref_seismogram")
+
+    def autoshift_ref_seismogram(self, irec, min_shift, max_shift, isrc=0):
+        """`autoshift_ref_seismogram ireceiver min-shift max-shift` against uploaded source `isrc`; returns the shifts
+        applied, in seconds (one per receiver for irec == 0)."""
+        out = np.zeros(len(self.components) if irec == 0 else 1, np.float32)
+        self._ck(self.L.kiwi_hip_autoshift_ref_seismogram(self.h, irec, min_shift, max_shift, isrc, _fp(out)),
+                 "autoshift_ref_seismogram")
+        return out
+
     def set_floating_shiftrange(self, irec, min_shift, max_shift):
         """`set_floating_shiftrange ireceiver min-shift max-shift` (seconds; ireceiver 0 = all receivers)."""
         self._ck(self.L.kiwi_hip_set_floating_shiftrange(self.h, irec, min_shift, max_shift), "set_floating_shiftrange")

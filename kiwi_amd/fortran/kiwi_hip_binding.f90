@@ -105,6 +105,22 @@ module kiwi_hip_binding
             integer(c_int), value :: method
         end function
 
+        integer(c_int) function kiwi_hip_shift_ref_seismogram( ctx, irec, shift ) bind(C, name='kiwi_hip_shift_ref_seismogram')
+            import :: c_int, c_ptr, c_float
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: irec
+            real(c_float), value :: shift
+        end function
+
+        integer(c_int) function kiwi_hip_autoshift_ref_seismogram( ctx, irec, min_shift, max_shift, isrc, shifts ) &
+                bind(C, name='kiwi_hip_autoshift_ref_seismogram')
+            import :: c_int, c_ptr, c_float
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: irec, isrc
+            real(c_float), value :: min_shift, max_shift
+            real(c_float), intent(out) :: shifts(*)
+        end function
+
         integer(c_int) function kiwi_hip_set_floating_shiftrange( ctx, irec, min_shift, max_shift ) &
                 bind(C, name='kiwi_hip_set_floating_shiftrange')
             import :: c_int, c_ptr, c_float

@@ -212,6 +212,8 @@ program minimizer_hip
         case ('set_misfit_filter');         call do_set_plf( a, .false., ok_ )
         case ('set_synthetics_factor');     call do_set_synthetics_factor( a, ok_ )
         case ('set_floating_shiftrange');   call do_set_floating_shiftrange( a, ok_ )
+        case ('shift_ref_seismogram');      call do_shift_ref_seismogram( a, ok_ )
+        case ('autoshift_ref_seismogram');  call do_autoshift_ref_seismogram( a, ok_ )
         case ('get_floating_shifts');       call do_get_floating_shifts( ok_ )
         case ('get_misfits');               call do_get_misfits( .false., ok_ )
         case ('get_global_misfit');         call do_get_misfits( .true., ok_ )
@@ -689,6 +691,52 @@ program minimizer_hip
         if (.not. need_ctx()) return
         ok_ = check( kiwi_hip_set_synthetics_factor( ctx, f ) )
         evaluated = .false.
+    end subroutine
+
+    ! shift_ref_seismogram ireceiver shift   (minimizer.f90:355-386)
+    subroutine do_shift_ref_seismogram( a, ok_ )
+        character(len=*), intent(in) :: a
+        logical, intent(out) :: ok_
+        integer(c_int) :: irec
+        real(c_float) :: shift
+        integer :: ios
+        ok_ = .false.
+        read (a,*,iostat=ios) irec, shift
+        if (ios /= 0) then
+            call fail( 'usage: shift_ref_seismogram ireceiver shift' ); return
+        end if
+        if (.not. need_ctx()) return
+        ok_ = check( kiwi_hip_shift_ref_seismogram( ctx, irec, shift ) )
+        evaluated = .false.
+    end subroutine
+
+    ! autoshift_ref_seismogram ireceiver min-shift max-shift   (minimizer.f90:447-486): answers the shifts applied
+    subroutine do_autoshift_ref_seismogram( a, ok_ )
+        character(len=*), intent(in) :: a
+        logical, intent(out) :: ok_
+        integer(c_int) :: irec
+        real(c_float) :: lo, hi
+        real(c_float), allocatable :: sh(:)
+        character(len=:), allocatable :: buffer
+        integer :: ios, n, i
+        ok_ = .false.
+        read (a,*,iostat=ios) irec, lo, hi
+        if (ios /= 0) then
+            call fail( 'usage: autoshift_ref_seismogram ireceiver min-shift max-shift' ); return
+        end if
+        if (.not. need_ctx()) return
+        if (.not. source_set) then
+            call fail( 'no source set' ); return
+        end if
+        n = 1
+        if (irec == 0) n = size(enabled)
+        allocate( sh(max(n,1)) )
+        if (.not. check( kiwi_hip_autoshift_ref_seismogram( ctx, irec, lo, hi, 0_c_int, sh ) )) return
+        allocate( character(len=32*max(n,1)) :: buffer )
+        write (buffer,*) (sh(i), i=1,n)
+        answer = trim(buffer)
+        evaluated = .false.
+        ok_ = .true.
     end subroutine
 
     ! set_floating_shiftrange ireceiver min-shift max-shift   (minimizer.f90:388-419)

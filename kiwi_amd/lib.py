@@ -61,6 +61,8 @@ def load():
         "kiwi_hip_set_filter": [vp, C.c_int, C.c_int, c_float_p, c_float_p],
         "kiwi_hip_set_misfit_method": [vp, C.c_int],
         "kiwi_hip_set_synthetics_factor": [vp, C.c_float],
+        "kiwi_hip_shift_ref_seismogram": [vp, C.c_int, C.c_float],
+        "kiwi_hip_autoshift_ref_seismogram": [vp, C.c_int, C.c_float, C.c_float, C.c_int, c_float_p],
         "kiwi_hip_set_floating_shiftrange": [vp, C.c_int, C.c_float, C.c_float],
         "kiwi_hip_get_floating_shifts": [vp, C.c_int, C.c_int, c_float_p],
         "kiwi_hip_source_nparams": [C.c_int],

@@ -95,6 +95,9 @@ def lib():
         L.ko_engine_set_misfit_method.argtypes = [C.c_void_p, C.c_int]
         L.ko_engine_set_synthetics_factor.argtypes = [C.c_void_p, C.c_float]
         L.ko_engine_set_floating_shiftrange.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.ko_engine_shift_ref_seismogram.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.ko_engine_autoshift_ref_seismogram.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.ko_engine_autoshift_ref_seismogram.restype = C.c_int
         L.ko_engine_get_floating_shift.argtypes = [C.c_void_p, C.c_int]
         L.ko_engine_get_floating_shift.restype = C.c_int
         L.ko_engine_set_nthreads.argtypes = [C.c_void_p, C.c_int]
@@ -334,6 +337,13 @@ class Engine:
     def set_floating_shiftrange(self, irec1, lo, hi):
         """shift range in SAMPLES (set_floating_shiftrange converts seconds with nint(shift/dt), minimizer_engine.f90:432)"""
         lib().ko_engine_set_floating_shiftrange(self.h, irec1, lo, hi)
+
+    def shift_ref_seismogram(self, irec1, ishift):
+        lib().ko_engine_shift_ref_seismogram(self.h, irec1, ishift)
+
+    def autoshift_ref_seismogram(self, irec1, lo, hi):
+        """needs current synthetics (get_misfits first); range and result in samples"""
+        return lib().ko_engine_autoshift_ref_seismogram(self.h, irec1, lo, hi)
 
     def floating_shift(self, irec1):
         return lib().ko_engine_get_floating_shift(self.h, irec1)

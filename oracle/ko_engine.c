@@ -208,6 +208,38 @@ void ko_engine_set_floating_shiftrange(ko_engine *e, int irec1, int lo, int hi)
     e->receivers[irec1 - 1].floating_shiftrange[1] = hi;
 }
 
+/* receiver_shift_ref_seismogram, receiver.f90:800-814 (shift in samples) */
+void ko_engine_shift_ref_seismogram(ko_engine *e, int irec1, int ishift)
+{
+    ko_receiver *r = &e->receivers[irec1 - 1];
+    for (int k = 0; k < r->ncomponents; k++) ko_probe_shift(&r->ref_probes[k], ishift);
+}
+
+/* receiver_autoshift_ref_seismogram, receiver.f90:816-832 (range in samples; synthetics must be current).
+ * Returns the shift applied. */
+int ko_engine_autoshift_ref_seismogram(ko_engine *e, int irec1, int lo, int hi)
+{
+    ko_receiver *r = &e->receivers[irec1 - 1];
+    if (!r->enabled || r->ncomponents == 0) return 0;
+    const int ns = hi - lo + 1, nc = r->ncomponents;
+    float *cc = (float *)malloc(sizeof(float) * (size_t)(ns * nc));
+    for (int k = 0; k < nc; k++)                     /* receiver_calculate_cross_correlations, :597-616 */
+        ko_probes_windowed_cross_corr(&r->syn_probes[k], &r->ref_probes[k], lo, hi, cc + (size_t)k * ns);
+    float mx = cc[0];
+    for (int i = 1; i < ns * nc; i++) if (cc[i] > mx) mx = cc[i];
+    const float den = mx > 1.f ? mx : 1.f;
+    int imax = 0; float best = 0.f;
+    for (int q = 0; q < ns; q++) {
+        float s = 0.f;
+        for (int k = 0; k < nc; k++) { float x = cc[(size_t)k * ns + q] / den; if (x < 0.f) x = 0.f; s = s + x * x; }
+        if (q == 0 || s > best) { best = s; imax = q; }
+    }
+    free(cc);
+    const int ishift = imax + lo;
+    ko_engine_shift_ref_seismogram(e, irec1, ishift);
+    return ishift;
+}
+
 /* receiver%floating_shift after calculate_misfits with a floating norm (receiver.f90:498), in samples */
 int ko_engine_get_floating_shift(ko_engine *e, int irec1) { return e->receivers[irec1 - 1].floating_shift; }
 

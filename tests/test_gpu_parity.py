@@ -482,3 +482,32 @@ def test_synthesis_before_any_reference_is_set():
     p.eval()
     pm, pn, pg = p.get_misfits()
     assert misfit_close(pm, m) and misfit_close(pg, g)
+
+
+def test_shift_and_autoshift_of_reference_seismograms():
+    """shift_ref_seismogram / autoshift_ref_seismogram (minimizer_engine.f90:354-419, receiver.f90:800-832)."""
+    sc = Scenario(nrec=4, comps_list=["ned", "ne", "d", "ned"])
+    e, p = build(sc)
+    dt = sc.gf["dt"]
+    trial = synthetic.bilat_strike_sweep(1, step=2.0)
+    trial[0, 0] = 1.2                                    # the synthetics arrive later than the references
+    # plain shift of receiver 2 by -3 samples
+    e.shift_ref_seismogram(2, -3)
+    p.shift_ref_seismogram(2, -3 * dt + 0.1 * dt)
+    m, n, g = oracle_misfits(e, 1, trial)
+    p.set_source_params("bilateral", trial)
+    p.eval()
+    pm, pn, pg = p.get_misfits()
+    assert misfit_close(pm, m) and np.array_equal(pn[0], n[0])
+    # autoshift all receivers within [-5, +5] samples against the current source
+    want = [e.autoshift_ref_seismogram(ir + 1, -5, 5) * dt for ir in range(4)]
+    got = p.autoshift_ref_seismogram(0, -5 * dt, 5 * dt, isrc=0)
+    assert np.array_equal(got, np.array(want, np.float32))
+    assert len(set(want)) > 1 and max(np.abs(want)) > 0
+    m2, n2, g2 = oracle_misfits(e, 1, trial)
+    p.eval()
+    pm2, pn2, pg2 = p.get_misfits()
+    assert misfit_close(pm2, m2) and np.array_equal(pn2[0], n2[0]) and misfit_close(pg2, g2)
+    # one receiver only
+    one = e.autoshift_ref_seismogram(3, -2, 2) * dt
+    assert p.autoshift_ref_seismogram(3, -2 * dt, 2 * dt)[0] == np.float32(one)
