@@ -121,6 +121,16 @@ struct kiwi_hip_ctx {
     float max_risetime = 0.f;
     DevBuf<float> cent_d, moment_d, risetime_d;
     DevBuf<int> centofs_d;
+    // runs of consecutive sources with identical centroid geometry (points and times), single group each: the
+    // grouped kernel builds their blended tiles once (env KIWI_HIP_RUNS=0 switches the sharing off)
+    std::vector<unsigned long long> geo_hash;
+    std::vector<char> single_group;
+    DevBuf<int> runfirst_d;
+    int share_runs = 1, max_run = 64;
+    // fused comparator (time-domain norms, no fold, nothing kept): env KIWI_HIP_FUSE=0 switches it off
+    int fuse_enabled = 1;
+    bool fuse_now = false;
+    DevBuf<double> fusepart_d;
 
     // results + workspace
     DevBuf<float> misfit_d, global_d;
@@ -310,6 +320,7 @@ void prepare(kiwi_hip_ctx *c)
         std::vector<float> tww(wlen, 1.f);
         if (!c->synth_only) plf_taper_array(r.taper, tww.data(), w[0], w[1], dt, IP_COS);
         recfirst.push_back((int)c->comps.size());
+        d.slot0 = (int)c->comps.size();
         for (int k = 0; k < r.ncomp; k++) {
             static const Receiver::Ref no_ref = { 0, std::vector<float>(1, 0.f) };
             const auto &rf = c->synth_only ? no_ref : r.ref[k];
@@ -319,6 +330,7 @@ void prepare(kiwi_hip_ctx *c)
             cd.refofs = (int)reft.size(); cd.rec = ir;
             cd.fl_lo = 0; cd.fl_ns = 1; cd.refxofs = 0;
             d.synofs[k] = (int)synofs;
+            d.refofs[k] = cd.refofs;
             synofs += ((size_t)d.wlen + 3) / 4 * 4;
             // reference probe contents over the window: zeros before the data, last value repeated
             // after it (probe_set_array, comparator.f90:259-265), then tapered (:1173-1184)
@@ -613,6 +625,17 @@ void prepare_fft(kiwi_hip_ctx *c, const std::vector<float> &reft_host)
     c->fft_ready = true;
 }
 
+// may this evaluation compare inside the accumulate kernel (no synthetics in memory)?
+bool can_fuse(const kiwi_hip_ctx *c, int proc_which, int isrc0, int nsrc)
+{
+    // it pays where writing and re-reading the synthetics is a large share of the work (point sources, few centroids);
+    // with ~100 centroids per source the separate misfit kernel costs less than the fused epilogue's registers
+    const int ncent = nsrc > 0 ? (c->cent_ofs[isrc0 + nsrc] - c->cent_ofs[isrc0]) / nsrc : 0;
+    if (c->fuse_enabled < 2 && ncent > 32) return false;               // KIWI_HIP_FUSE=2 forces it
+    return c->fuse_enabled && c->accum_mode == 0 && proc_which == 0 && !c->fft_needed && !c->floating && !c->synth_only &&
+           c->halo == 0 && (c->method == KIWI_L2NORM || c->method == KIWI_L1NORM || c->method == KIWI_SCALAR_PRODUCT || c->method == KIWI_PEAK);
+}
+
 void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
 {
     const int nrec = (int)c->recv.size();
@@ -622,7 +645,8 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
     c->recs_d.ensure((size_t)(cend - cbeg) * nrec, &c->dev_bytes);
     int *tab = nullptr;
     if (c->accum_mode == 0) { c->tab_d.ensure((size_t)(cend - cbeg) * nrec * 128, &c->dev_bytes); tab = c->tab_d.p; }
-    c->syn_d.ensure((size_t)nsrc * c->syn_stride, &c->dev_bytes);
+    const bool fuse = c->fuse_now;
+    if (!fuse) c->syn_d.ensure((size_t)nsrc * c->syn_stride, &c->dev_bytes);
     float *proc = nullptr;
     if (proc_which) { c->proc_d.ensure((size_t)nsrc * c->syn_stride, &c->dev_bytes); proc = c->proc_d.p; }
 
@@ -635,6 +659,7 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
                            c->span.p, c->recv_d.p, c->recs_d.p, tab, (int *)nullptr);
     }
     record(c, 0, e1);
+    int fuse_T = 0, fuse_ntiles = 0;
     {
         dim3 grid((unsigned)((c->max_wlen + kTile - 1) / kTile), (unsigned)nrec, (unsigned)nsrc);
         if (c->accum_mode == 1) {            // KIWI_HIP_ACCUM=direct: A/B reference kernel, no LDS staging
@@ -648,17 +673,54 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
             // workgroup size: env override, else by window length (halo overhead vs tile fit)
             const int T = c->group_threads_env ? c->group_threads : (c->max_wlen >= 2048 ? 256 : (c->max_wlen >= 384 ? 128 : 64));
             const int ntiles = (c->max_wlen + 4 * T - 1) / (4 * T);
-            dim3 ggrid((unsigned)nsrc, (unsigned)(ntiles * nrec));       // source index fastest (L2 sharing)
-#define KIWI_LAUNCH_GROUPED(NGV, TV)                                                                        \
-    hipLaunchKernelGGL((accumulate_grouped_kernel<NGV, TV>), ggrid, dim3(TV), 0, c->stream, c->G.p, c->span.p,   \
+            // runs of geometry-identical single-group sources (chunk-local indices); singletons otherwise
+            int *runs = nullptr;
+            unsigned gx = (unsigned)nsrc;
+            if (c->share_runs) {
+                std::vector<int> rf;
+                // keep enough workgroups in flight: no run longer than nsrc / 1024 rounded up, nor than max_run
+                const int cap = std::max(1, std::min(c->max_run, (nsrc * ntiles * nrec) / 8192));
+                int s = 0;
+                while (s < nsrc) {
+                    int e = s + 1;
+                    const int g = isrc0 + s;
+                    if (c->single_group[g])
+                        while (e < nsrc && e - s < cap && c->single_group[isrc0 + e] && c->geo_hash[isrc0 + e] == c->geo_hash[g] &&
+                               c->cent_ofs[isrc0 + e + 1] - c->cent_ofs[isrc0 + e] == c->cent_ofs[g + 1] - c->cent_ofs[g]) e++;
+                    rf.push_back(s);
+                    s = e;
+                }
+                if ((int)rf.size() < nsrc) {
+                    rf.push_back(nsrc);
+                    c->runfirst_d.ensure(rf.size(), &c->dev_bytes);
+                    HIPCHECK(hipMemcpyAsync(c->runfirst_d.p, rf.data(), rf.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+                    HIPCHECK(hipStreamSynchronize(c->stream));         // rf goes out of scope
+                    runs = c->runfirst_d.p;
+                    gx = (unsigned)rf.size() - 1;
+                }
+            }
+            dim3 ggrid(gx, (unsigned)(ntiles * nrec));                   // source index fastest (L2 sharing)
+            FuseParams fp{ nullptr, nullptr, nullptr, nullptr, 0, 1.f, 0, 0, 0 };
+            if (fuse) {
+                const int nparts = ntiles * (T / 64);
+                c->fusepart_d.ensure((size_t)nsrc * c->nmis * nparts, &c->dev_bytes);
+                fp = FuseParams{ c->reft_d.p, c->tw_d.p, c->moment_d.p, c->fusepart_d.p, c->method, c->syn_factor, c->nmis, nparts, isrc0 };
+            }
+            fuse_T = T; fuse_ntiles = ntiles;
+#define KIWI_LAUNCH_G2(NGV, TV, FV, RV)                                                                     \
+    hipLaunchKernelGGL((accumulate_grouped_kernel<NGV, TV, FV, RV>), ggrid, dim3(TV), 0, c->stream, c->G.p, c->span.p,   \
                        c->gm.pitch, c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p,          \
-                       c->syn_stride, ntiles, c->tab_d.p)
+                       c->syn_stride, ntiles, c->tab_d.p, runs, fp)
+#define KIWI_LAUNCH_GROUPED(NGV, TV)                                                                        \
+    do { if (fuse) { if (runs) KIWI_LAUNCH_G2(NGV, TV, true, true); else KIWI_LAUNCH_G2(NGV, TV, true, false); }   \
+         else      { if (runs) KIWI_LAUNCH_G2(NGV, TV, false, true); else KIWI_LAUNCH_G2(NGV, TV, false, false); } } while (0)
             if (c->gm.ng == 10) {
                 if (T == 64) KIWI_LAUNCH_GROUPED(10, 64); else if (T == 256) KIWI_LAUNCH_GROUPED(10, 256); else KIWI_LAUNCH_GROUPED(10, 128);
             } else {
                 if (T == 64) KIWI_LAUNCH_GROUPED(8, 64); else if (T == 256) KIWI_LAUNCH_GROUPED(8, 256); else KIWI_LAUNCH_GROUPED(8, 128);
             }
 #undef KIWI_LAUNCH_GROUPED
+#undef KIWI_LAUNCH_G2
         }
     }
     record(c, 1, e2);
@@ -674,6 +736,12 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
             c->partial_d.ensure((size_t)nsrc * c->nmis * c->max_ns, &c->dev_bytes);
             c->fshift_d.ensure((size_t)c->nsrc * c->nrec_en, &c->dev_bytes);
         }
+        if (fuse) {
+            const int nth = nsrc * c->nmis;
+            hipLaunchKernelGGL(misfit_finish_kernel, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, c->stream,
+                               c->fusepart_d.p, c->comps_d.p, c->nmis, fuse_ntiles * (fuse_T / 64), fuse_T / 64, 4 * fuse_T,
+                               c->method, c->gm.dt, isrc0, nsrc, c->misfit_d.p);
+        } else
         hipLaunchKernelGGL(misfit_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream,
                            c->syn_d.p, c->syn_stride, c->comps_d.p, c->reft_d.p, c->tw_d.p, c->moment_d.p,
                            c->risetime_d.p, mp, c->misfit_d.p, proc_which == 3 ? nullptr : proc, c->fft_d.p, c->vt_d.p);
@@ -723,6 +791,7 @@ int eval_impl(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
     c->global_d.ensure((size_t)c->nsrc, &c->dev_bytes);
     if (c->fft_needed && !c->fft_ready) prepare_fft(c, c->reft_h);
     const int nrec = (int)c->recv.size();
+    c->fuse_now = can_fuse(c, proc_which, isrc0, nsrc);
     int s = isrc0;
     while (s < isrc0 + nsrc) {
         // greedy chunk bounded by workspace bytes
@@ -730,7 +799,9 @@ int eval_impl(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
         int n = 0;
         while (s + n < isrc0 + nsrc) {
             const size_t nc = (size_t)(c->cent_ofs[s + n + 1] - c->cent_ofs[s + n]);
-            const size_t add = nc * nrec * (sizeof(GeoRec) + (c->accum_mode == 0 ? 512 : 0)) + c->syn_stride * sizeof(float) * ((proc_which ? 2 : 1) + (c->floating ? 1 : 0));
+            const size_t syn_bytes = c->fuse_now ? (size_t)c->nmis * 64 * sizeof(double)
+                                                             : c->syn_stride * sizeof(float) * ((proc_which ? 2 : 1) + (c->floating ? 1 : 0));
+            const size_t add = nc * nrec * (sizeof(GeoRec) + (c->accum_mode == 0 ? 512 : 0)) + syn_bytes;
             if (n > 0 && (bytes + add > c->chunk_bytes_limit || n >= 65535)) break;
             if (c->fft_needed && n >= c->fft_cap) break;
             bytes += add; n++;
@@ -770,6 +841,12 @@ int kiwi_hip_init(int device, kiwi_hip_ctx **out)
             if (v == 4 || v == 8 || v == 16) c->group_spt = v;
         }
         if (const char *m = std::getenv("KIWI_HIP_ACCUM")) c->accum_mode = (std::strcmp(m, "direct") == 0) ? 1 : 0;
+        if (const char *m = std::getenv("KIWI_HIP_FUSE")) c->fuse_enabled = std::atoi(m);
+        if (const char *m = std::getenv("KIWI_HIP_RUNS")) {          // 0: no tile sharing across sources; n > 1: longest run
+            const int v = std::atoi(m);
+            c->share_runs = v != 0;
+            if (v > 1) c->max_run = v;
+        }
         *out = c;
         return 0;
     } catch (const std::exception &e) {
@@ -1119,6 +1196,33 @@ int kiwi_hip_set_sources(kiwi_hip_ctx *c, int nsrc, const int *cent_ofs, const f
     for (int s = 0; s < nsrc; s++) maxrise = std::max(maxrise, risetime[s]);
     if (2 * fold_halfwidth(maxrise, c->gm.dt) + 1 > kMaxFold) throw std::runtime_error("rise time too long for the fold kernel");
     c->cent_ofs.assign(cent_ofs, cent_ofs + nsrc + 1);
+    c->geo_hash.assign((size_t)nsrc, 0ull);
+    c->single_group.assign((size_t)nsrc, 0);
+    {
+        const float dt = c->gm.dt;
+#pragma omp parallel for schedule(static) num_threads(std::max(1, std::min(8, nsrc / 512)))
+        for (int s = 0; s < nsrc; s++) {
+            const float *ce = cent + (size_t)cent_ofs[s] * 10;
+            const int nc = cent_ofs[s + 1] - cent_ofs[s];
+            unsigned long long h = 1469598103934665603ull ^ (unsigned long long)nc;        // FNV-1a over the bit patterns of (north, east, depth, time)
+            bool one = nc >= 1 && nc <= kMaxGroup;
+            int smin = 0, smax = 0;
+            for (int k = 0; k < nc; k++) {
+                unsigned int w[4];
+                std::memcpy(w, ce + (size_t)k * 10, sizeof(w));
+                for (int q = 0; q < 4; q++) { h ^= w[q]; h *= 1099511628211ull; }
+                if (one) {
+                    const float *p = ce + (size_t)k * 10;
+                    if (!(p[0] == ce[0] && p[1] == ce[1] && p[2] == ce[2])) one = false;
+                    const int sh = (int)std::floor(p[3] / dt);                              // as geometry_kernel's group hint
+                    if (k == 0) smin = smax = sh; else { smin = std::min(smin, sh); smax = std::max(smax, sh); }
+                    if (smax - smin > kHalo - 10) one = false;
+                }
+            }
+            c->geo_hash[s] = h;
+            c->single_group[s] = one ? 1 : 0;
+        }
+    }
     c->cent_d.ensure(std::max<size_t>(ntot, 1) * 10, &c->dev_bytes);
     c->centofs_d.ensure((size_t)nsrc + 1, &c->dev_bytes);
     c->moment_d.ensure((size_t)nsrc, &c->dev_bytes);

@@ -62,6 +62,18 @@ struct RecvDev {
     float sd;                     // sign of the down/up component
     int   wbeg, wlen;             // synthetic window [wbeg, wbeg+wlen) incl. fold halo
     int   synofs[kMaxComp];       // float offset of each component inside one source's synthetic block
+    int   slot0;                  // first misfit slot of this receiver (its components follow)
+    int   refofs[kMaxComp];       // offset of each component's tapered reference / taper weights (= CompDev::refofs)
+};
+
+// fused comparator of the grouped accumulate kernel (time-domain norms without rise-time fold): the synthetics are
+// compared with the references where they are produced and never written to memory
+struct FuseParams {
+    const float *reft, *tw, *moment;      // tapered references, taper weights, moment per source
+    double *partial;                      // [source][slot][part] partial sums (peak: maxima); part = tile * waves + wave
+    int method;                           // 1 l2norm, 2 l1norm, 5 scalar_product, 6 peak
+    float syn_factor;
+    int nmis, nparts, isrc0;
 };
 
 // per misfit slot (enabled receiver component)
@@ -665,13 +677,18 @@ __device__ __forceinline__ void centroid_apply_hd(f2v (&ar1)[2], f2v (&ar2)[2], 
     }
 }
 
-template <int NG, int T>
+template <int NG, int T, bool FUSE, bool RUNS>
 __global__ __launch_bounds__(T) void accumulate_grouped_kernel(
     const float *__restrict__ G, const int2 *__restrict__ span, int pitch,
     const GeoRec *__restrict__ recs, const int *__restrict__ cent_ofs, int isrc0, int nrec,
     const RecvDev *__restrict__ recv, float *__restrict__ syn, size_t syn_stride, int ntiles,
-    const int *__restrict__ tab)
+    const int *__restrict__ tab, const int *__restrict__ run_first, FuseParams fp)
 {
+    // run_first != nullptr: blockIdx.x indexes RUNS of consecutive trial sources [run_first[b], run_first[b+1]) that the
+    // host found to have identical centroid geometry (same points and times: only the moment tensors differ, e.g. a
+    // strike/dip/rake grid at a fixed location) and to consist of a single centroid group each.  The blended tiles
+    // are then built ONCE and every source of the run is applied from them -- the sharing across trial sources
+    // SURVEY.md 8d asks to report separately.  Per-source operations and their order are unchanged.
     constexpr int TILE = 4 * T;                          // samples per workgroup, 4 consecutive per thread
     constexpr int LDS_TILE = TILE + kHalo;
     __shared__ __attribute__((aligned(16))) float tiles[NG][LDS_TILE];
@@ -679,7 +696,9 @@ __global__ __launch_bounds__(T) void accumulate_grouped_kernel(
     // (tile, receiver) of many neighbouring trial sources, which read (nearly) the same GF rows at
     // the same time, and blocks b, b+8, ... share an XCD and therefore its L2 (dispatch is
     // round-robin over the 8 XCDs; speed only, never correctness).
-    const int s = blockIdx.x;
+    const int s = RUNS ? run_first[blockIdx.x] : (int)blockIdx.x;               // first (or only) source of this workgroup
+    const int s_end = RUNS ? run_first[blockIdx.x + 1] : s + 1;
+    const bool multi = RUNS && s_end - s > 1;
     const int tile = blockIdx.y % ntiles, r = blockIdx.y / ntiles;
     const RecvDev &rv = recv[r];
     if (!rv.enabled) return;
@@ -694,6 +713,60 @@ __global__ __launch_bounds__(T) void accumulate_grouped_kernel(
     const float sd = rv.sd;
 
     f2v ar1[2] = { { 0.f, 0.f }, { 0.f, 0.f } }, ar2[2] = { { 0.f, 0.f }, { 0.f, 0.f } }, dz[2] = { { 0.f, 0.f }, { 0.f, 0.f } };
+    // rotation to N/E, signs and store of one source's accumulators (seismogram.f90:256-283)
+    auto store = [&](int js) {
+        const int tl = tile * TILE + 4 * tid;
+        if (!FUSE && tl >= rv.wlen) return;
+        float *__restrict__ so = syn + (size_t)js * syn_stride + tl;
+        const float a1[4] = { ar1[0].x, ar1[0].y, ar1[1].x, ar1[1].y }, a2[4] = { ar2[0].x, ar2[0].y, ar2[1].x, ar2[1].y },
+                    ad[4] = { dz[0].x, dz[0].y, dz[1].x, dz[1].y };
+        float mom = 0.f;
+        if constexpr (FUSE) mom = fp.moment[fp.isrc0 + js];
+        const bool unit = (fp.syn_factor == 1.f);
+        for (int k = 0; k < rv.ncomp; k++) {
+            const float sg = rv.sign[k];
+            float o[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                switch (rv.comp[k]) {
+                case 1: o[i] = a1[i] * sg; break;
+                case 2: o[i] = a2[i] * sg; break;
+                case 3: o[i] = ad[i]; break;
+                case 4: o[i] = (rv.cl0 * a1[i] - rv.sl0 * a2[i]) * sg; break;
+                default: o[i] = (rv.cl0 * a2[i] + rv.sl0 * a1[i]) * sg; break;
+                }
+            }
+            if constexpr (!FUSE) {
+                *(float4 *)(so + rv.synofs[k]) = make_float4(o[0], o[1], o[2], o[3]);
+                continue;
+            }
+            // ---- fused comparator: what misfit_kernel does per sample (comparator.f90:264,1173-1184,627-667), then a
+            // wave reduction; the partial of (source, slot, tile, wave) is summed by misfit_finish_kernel in a fixed order
+            double acc = 0.0;
+            const float *__restrict__ rt = fp.reft + rv.refofs[k] + tl, *__restrict__ tp = fp.tw + rv.refofs[k] + tl;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (tl + i >= rv.wlen) break;
+                const float v = o[i] * mom;
+                const float vt = v * tp[i];
+                const float a = rt[i];
+                switch (fp.method) {
+                case 1: { const float d = unit ? (a - vt) : (1.f * a - fp.syn_factor * vt); acc += (double)d * (double)d; break; }
+                case 2: { const float d = unit ? fabsf(a - vt) : fabsf(1.f * a - fp.syn_factor * vt); acc += (double)d; break; }
+                case 5: acc += unit ? (double)(a * vt) : (double)(a * 1.f * vt * fp.syn_factor); break;
+                default: { const double x = (double)(1.f * a), y = (double)(fp.syn_factor * vt); acc = fmax(acc, sqrt(x * x + y * y)); break; }
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double other = __shfl_down(acc, off, 64);
+                acc = (fp.method == 6) ? fmax(acc, other) : acc + other;
+            }
+            if (lane == 0)
+                fp.partial[((size_t)js * fp.nmis + rv.slot0 + k) * fp.nparts + tile * (T / 64) + (tid >> 6)] = acc;
+        }
+    };
+    bool stored = false;
     int c = 0;
     int cur = rec_load(rc, 0, nc, lane);                 // record c, lane-distributed
     int ta = tc[lane], tb = tc[64 + lane];               // load descriptors of record c
@@ -762,9 +835,17 @@ __global__ __launch_bounds__(T) void accumulate_grouped_kernel(
         // descriptors of the NEXT group: in flight while this group is applied
         if (cend < nc) { ta = tc[(size_t)cend * 128 + lane]; tb = tc[(size_t)cend * 128 + 64 + lane]; }
         __syncthreads();
-        // ---- apply: every centroid of the group, in table order (seismogram.f90:131)
+        // ---- apply: every centroid of the group, in table order (seismogram.f90:131); in a run, source after source
+        for (int js = s; js < s_end; js++) {
+        const GeoRec *__restrict__ rcj = multi ? recs + ((size_t)(cent_ofs[isrc0 + js] - cb) * nrec + (size_t)r * nc) : rc;
+        // first record of the NEXT source of the run: in flight while this one is applied
+        int cur_next_src = 0;
+        if (multi) {
+            if (js + 1 < s_end) cur_next_src = rec_load(recs + ((size_t)(cent_ofs[isrc0 + js + 1] - cb) * nrec + (size_t)r * nc), c, nc, lane);
+            ar1[0] = ar1[1] = ar2[0] = ar2[1] = dz[0] = dz[1] = f2v{ 0.f, 0.f };
+        }
         for (int cc = c; cc < cend; cc++) {
-            const int nxt = rec_load(rc, cc + 1, nc, lane);      // prefetch the next record
+            const int nxt = rec_load(rcj, cc + 1, nc, lane);     // prefetch the next record
             constexpr int ro = 0;
             const int ishift = REC_I(cur, ro + 8);
             const float wfrac = REC_F(cur, ro + 9);
@@ -799,29 +880,16 @@ __global__ __launch_bounds__(T) void accumulate_grouped_kernel(
 #undef APPLY
             cur = nxt;
         }
+        if (multi) { store(js); cur = cur_next_src; }
+        }
+        stored = multi;
         __syncthreads();                                 // tiles are rebuilt by the next group
         c = cend;
     }
-
-    const int tl = tile * TILE + 4 * tid;
-    if (tl >= rv.wlen) return;
-    float *__restrict__ so = syn + (size_t)s * syn_stride + tl;
-    const float a1[4] = { ar1[0].x, ar1[0].y, ar1[1].x, ar1[1].y }, a2[4] = { ar2[0].x, ar2[0].y, ar2[1].x, ar2[1].y },
-                ad[4] = { dz[0].x, dz[0].y, dz[1].x, dz[1].y };
-    for (int k = 0; k < rv.ncomp; k++) {                 // seismogram.f90:256-283
-        const float sg = rv.sign[k];
-        float o[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            switch (rv.comp[k]) {
-            case 1: o[i] = a1[i] * sg; break;
-            case 2: o[i] = a2[i] * sg; break;
-            case 3: o[i] = ad[i]; break;
-            case 4: o[i] = (rv.cl0 * a1[i] - rv.sl0 * a2[i]) * sg; break;
-            default: o[i] = (rv.cl0 * a2[i] + rv.sl0 * a1[i]) * sg; break;
-            }
-        }
-        *(float4 *)(so + rv.synofs[k]) = make_float4(o[0], o[1], o[2], o[3]);
+    if (!multi) store(s);
+    else if (!stored) {                                  // every centroid skipped: the run's synthetics are zero
+        ar1[0] = ar1[1] = ar2[0] = ar2[1] = dz[0] = dz[1] = f2v{ 0.f, 0.f };
+        for (int js = s; js < s_end; js++) store(js);
     }
 }
 
@@ -1073,6 +1141,27 @@ __global__ __launch_bounds__(256) void filtered_norm_kernel(
         }
         misfit_out[(size_t)(sp.isrc0 + s) * sp.nmis + m] = res;
     }
+}
+
+// second half of the fused comparator: sum (peak: max) the per-tile, per-wave partials of a slot in a fixed order
+__global__ void misfit_finish_kernel(const double *__restrict__ partial, const CompDev *__restrict__ comps, int nmis, int nparts,
+                                     int waves_per_tile, int tile_len, int method, float dt, int isrc0, int nsrc,
+                                     float *__restrict__ misfit_out)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nsrc * nmis) return;
+    const int s = idx / nmis, m = idx - s * nmis;
+    const int np = ((comps[m].wlen + tile_len - 1) / tile_len) * waves_per_tile;      // tiles this slot's window spans
+    const double *p = partial + (size_t)idx * nparts;
+    double tot = 0.0;
+    for (int q = 0; q < np; q++) tot = (method == 6) ? fmax(tot, p[q]) : tot + p[q];
+    float res;
+    switch (method) {
+    case 1: res = (float)sqrt((double)dt * tot); break;
+    case 2: res = (float)((double)dt * tot); break;
+    default: res = (float)tot; break;
+    }
+    misfit_out[(size_t)(isrc0 + s) * nmis + m] = res;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -511,3 +511,62 @@ def test_shift_and_autoshift_of_reference_seismograms():
     # one receiver only
     one = e.autoshift_ref_seismogram(3, -2, 2) * dt
     assert p.autoshift_ref_seismogram(3, -2 * dt, 2 * dt)[0] == np.float32(one)
+
+
+def test_sources_sharing_geometry_reuse_blended_tiles(monkeypatch):
+    """Runs of consecutive trial sources with identical centroid points and times (a moment-tensor grid at a fixed
+    location) are applied from ONE build of the blended tiles: results must be the bits of the unshared path."""
+    sc = Scenario(nrec=5, comps_list=["ned", "ne", "d", "ned", "e"], true_type=6,
+                  true_params=synthetic.mt_sdr_grid(step=30)[17])
+    grid = synthetic.mt_sdr_grid(step=30)                      # 12 x 4 x 12 sources, all at one point
+    other = grid[5:9].copy()
+    other[:, 3] += 700.0                                       # a second location in the middle: breaks the run
+    tr = np.vstack([grid[:40], other, grid[40:90], grid[90:91] * np.float32(1.0)])
+    tr[60, 10] = 3.0                                           # a different rise time: different centroid times
+    e, p = build(sc)
+    p.set_source_params("moment_tensor", tr)
+    p.set_keep_synthetics(1)
+    p.eval()
+    pm, pn, pg = p.get_misfits()
+    syn = [p.get_synthetics(i, 1, 1, 1)[1].copy() for i in (0, 39, 41, 60, 94)]
+    p.close()
+    monkeypatch.setenv("KIWI_HIP_RUNS", "0")
+    q = sc.product()
+    sc.apply_setup(q, False)
+    q.set_source_params("moment_tensor", tr)
+    q.set_keep_synthetics(1)
+    q.eval()
+    qm, qn, qg = q.get_misfits()
+    assert np.array_equal(pm, qm) and np.array_equal(pg, qg)
+    for a, i in zip(syn, (0, 39, 41, 60, 94)):
+        assert np.array_equal(a, q.get_synthetics(i, 1, 1, 1)[1])
+    m, n, g = oracle_misfits(e, 6, tr[[0, 17, 41, 60, 94]])
+    assert misfit_close(pm[[0, 41, 60, 94]], m[[0, 2, 3, 4]]) and np.all(pm[17] <= 1e-6 * pn[17])
+
+
+@pytest.mark.parametrize("method", ["l2norm", "l1norm", "scalar_product", "peak"])
+def test_fused_comparator_equals_separate_misfit_kernel(monkeypatch, method):
+    """Few-centroid sources without rise-time fold are compared inside the accumulate kernel (no synthetics written);
+    KIWI_HIP_FUSE=0 keeps the two-kernel path.  Same samples, fp64 partial sums in a different (fixed) order."""
+    sc = Scenario(nrec=5, comps_list=["ned", "ne", "d", "ned", "e"], true_type=6,
+                  true_params=synthetic.mt_sdr_grid(step=30)[17])
+    tr = synthetic.mt_sdr_grid(step=30)[:60]
+    tr[30:, 3] += 900.0
+    e, p = build(sc, method)
+    p.set_synthetics_factor(1.5 if method == "l1norm" else 1.0)
+    e.set_synthetics_factor(1.5 if method == "l1norm" else 1.0)
+    p.set_source_params("moment_tensor", tr)
+    p.eval()
+    pm, pn, pg = p.get_misfits()
+    monkeypatch.setenv("KIWI_HIP_FUSE", "0")
+    q = sc.product()
+    sc.apply_setup(q, False)
+    q.set_misfit_method(method)
+    q.set_synthetics_factor(1.5 if method == "l1norm" else 1.0)
+    q.set_source_params("moment_tensor", tr)
+    q.eval()
+    qm, qn, qg = q.get_misfits()
+    assert np.all(np.abs(pm - qm) <= 1e-6 * np.maximum(np.abs(qm), 1e-6 * qn)) and np.array_equal(pn, qn)
+    m, n, g = oracle_misfits(e, 6, tr[[0, 17, 31, 59]])
+    sel = pm[[0, 17, 31, 59]]
+    assert np.all(np.abs(sel - m) <= MISFIT_RTOL * np.maximum(np.abs(m), 1e-6 * n))
