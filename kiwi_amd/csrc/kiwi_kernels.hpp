@@ -538,6 +538,91 @@ __device__ __forceinline__ void build_batch(float *__restrict__ tile0, int lds_t
     }
 }
 
+// Streamed form of build_batch for ALL components: sub-batches of two components (8 loads); two sub-batches are
+// kept in flight, the blend of sub-batch i is followed by the issue of sub-batch i + 2.  The whole group then costs
+// about one L2 round trip plus the issue time instead of one round trip per batch, with fewer registers in flight.
+template <bool BLEND, bool FAST>
+__device__ __forceinline__ void pair_issue(f4u (&v)[2][BLEND ? 4 : 1], int ig0, int p, int jb, const float *__restrict__ G,
+                                           int pitch, int ta, int tb)
+{
+    const int j = jb + p;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+#pragma unroll
+        for (int k = 0; k < (BLEND ? 4 : 1); k++) {
+            const int base = REC_I(ta, 4 * (ig0 + q) + k);
+            if constexpr (FAST) {
+                const float *rowp = G + (size_t)(unsigned)(base + jb);
+                v[q][k] = *(const f4u *)((const char *)rowp + (unsigned)(4 * p));
+            } else {
+                const int lo = REC_I(tb, 4 * (ig0 + q) + k);
+                const int idx = min(max(base + j, lo), lo + pitch - 4);
+                v[q][k] = *(const f4u *)(G + (size_t)(unsigned)idx);
+            }
+        }
+    }
+}
+
+template <bool BLEND>
+__device__ __forceinline__ void pair_finish(const f4u (&v)[2][BLEND ? 4 : 1], float *__restrict__ tile0, int lds_tile, int ig0, int p,
+                                            const GeoRec &g)
+{
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        f4u b;
+        if constexpr (BLEND) {
+            b = g.w[0] * v[q][0];             // gfdb.f90:946-949, summed in this order
+            b = b + g.w[1] * v[q][1];
+            b = b + g.w[2] * v[q][2];
+            b = b + g.w[3] * v[q][3];
+        } else {
+            b = v[q][0];
+        }
+        *(float4 *)(tile0 + (ig0 + q) * lds_tile + p) = make_float4(b.x, b.y, b.z, b.w);
+    }
+}
+
+// The halo (LDS positions TILE .. npos, at most kHalo / 4 = 16 chunks of 4 samples per component) is built by
+// one lane per (component, chunk) pair so that its loads travel in the same L2 round trip as the second main batch
+// instead of costing a round trip of their own.  Per-lane descriptors come from the lane-distributed row by
+// ds_bpermute.  halo_issue only loads; halo_finish blends and stores.
+struct HaloRegs { f4u v[4]; };
+
+template <bool BLEND, bool FAST>
+__device__ __forceinline__ HaloRegs halo_issue(bool active, int ig, int ph, int jb, const float *__restrict__ G, int pitch,
+                                               int ta, int tb)
+{
+    HaloRegs h;
+#pragma unroll
+    for (int k = 0; k < (BLEND ? 4 : 1); k++) {
+        const int base = __shfl(ta, 4 * ig + k, 64);
+        int idx = base + jb + ph;
+        if constexpr (!FAST) {
+            const int lo = __shfl(tb, 4 * ig + k, 64);
+            idx = min(max(idx, lo), lo + pitch - 4);
+        }
+        h.v[k] = f4u{ 0.f, 0.f, 0.f, 0.f };
+        if (active) h.v[k] = *(const f4u *)(G + (size_t)(unsigned)idx);
+    }
+    return h;
+}
+
+template <bool BLEND>
+__device__ __forceinline__ void halo_finish(bool active, const HaloRegs &h, float *__restrict__ tile0, int lds_tile, int ig, int ph,
+                                            const GeoRec &g)
+{
+    f4u b;
+    if constexpr (BLEND) {
+        b = g.w[0] * h.v[0];                  // gfdb.f90:946-949, summed in this order
+        b = b + g.w[1] * h.v[1];
+        b = b + g.w[2] * h.v[2];
+        b = b + g.w[3] * h.v[3];
+    } else {
+        b = h.v[0];
+    }
+    if (active) *(float4 *)(tile0 + ig * lds_tile + ph) = make_float4(b.x, b.y, b.z, b.w);
+}
+
 typedef float f2v __attribute__((ext_vector_type(2)));
 
 // (x[S], x[S+1]) out of the four aligned register pairs p[0..3] = x[0..7]: an aligned pair as it is,
@@ -678,7 +763,7 @@ __device__ __forceinline__ void centroid_apply_hd(f2v (&ar1)[2], f2v (&ar2)[2], 
 }
 
 template <int NG, int T, bool FUSE, bool RUNS>
-__global__ __launch_bounds__(T) void accumulate_grouped_kernel(
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void accumulate_grouped_kernel(
     const float *__restrict__ G, const int2 *__restrict__ span, int pitch,
     const GeoRec *__restrict__ recs, const int *__restrict__ cent_ofs, int isrc0, int nrec,
     const RecvDev *__restrict__ recv, float *__restrict__ syn, size_t syn_stride, int ntiles,
@@ -813,23 +898,62 @@ __global__ __launch_bounds__(T) void accumulate_grouped_kernel(
             for (int q = 0; q < NG - H1; q++) igB[q] = H1 + q;
             const int igH10[6] = { 0, 1, 2, 3, 4, 8 }, igD10[4] = { 5, 6, 7, 9 };      // horizontals / vertical only
             const int igH8[5] = { 0, 1, 2, 3, 4 }, igD8[3] = { 5, 6, 7 };
-            // halo chunks (LDS positions >= TILE, a handful per component): same batched form, the two
-            // component batches split over the first two waves when there are two
-            const int ph = TILE + 4 * lane;
-            const int wave = tid >> 6;
-            const bool halo = ph < npos && wave < 2;
-            if (need_h && has_d) {
-                BUILD_B(igA, 4 * tid);
-                BUILD_B(igB, 4 * tid);
-                if (halo && ((T == 64) || wave == 0)) BUILD_B(igA, ph);
-                if (halo && ((T == 64) || wave == 1)) BUILD_B(igB, ph);
-            } else if (need_h) {
-                if constexpr (NG == 10) { BUILD_B(igH10, 4 * tid); if (halo && wave == 0) BUILD_B(igH10, ph); }
-                else                    { BUILD_B(igH8, 4 * tid);  if (halo && wave == 0) BUILD_B(igH8, ph); }
-            } else {
-                if constexpr (NG == 10) { BUILD_B(igD10, 4 * tid); if (halo && wave == 0) BUILD_B(igD10, ph); }
-                else                    { BUILD_B(igD8, 4 * tid);  if (halo && wave == 0) BUILD_B(igD8, ph); }
+            // halo: pair q = (component slot, chunk) -> lanes; kHaloIter passes cover 16 * (number of components) pairs
+            constexpr int kHaloIter = (16 * NG + T - 1) / T;
+            const int ncmp = (need_h && has_d) ? NG : (need_h ? (NG == 10 ? 6 : 5) : (NG == 10 ? 4 : 3));
+            bool hact[kHaloIter];
+            int hig[kHaloIter], hph[kHaloIter];
+            HaloRegs hr[kHaloIter];
+#pragma unroll
+            for (int it = 0; it < kHaloIter; it++) {
+                const int q = tid + it * T, slot = q >> 4;
+                int ig = slot;                                            // all components: slot = component
+                if (!(need_h && has_d)) {
+                    if (need_h) ig = (slot == 5) ? 8 : slot;              // 0 1 2 3 4 8
+                    else        ig = (NG == 10 && slot == 3) ? 9 : 5 + slot;   // 5 6 7 9
+                }
+                hig[it] = min(ig, NG - 1);
+                hph[it] = TILE + 4 * (q & 15);
+                hact[it] = slot < ncmp && hph[it] < npos;
             }
+#define HALO_ISSUE() do { _Pragma("unroll") for (int it = 0; it < kHaloIter; it++) { \
+                if (fast) { if (direct) hr[it] = halo_issue<false, true>(hact[it], hig[it], hph[it], jb, G, pitch, ta, tb); \
+                            else        hr[it] = halo_issue<true, true>(hact[it], hig[it], hph[it], jb, G, pitch, ta, tb); } \
+                else      { if (direct) hr[it] = halo_issue<false, false>(hact[it], hig[it], hph[it], jb, G, pitch, ta, tb); \
+                            else        hr[it] = halo_issue<true, false>(hact[it], hig[it], hph[it], jb, G, pitch, ta, tb); } } } while (0)
+#define HALO_FINISH() do { _Pragma("unroll") for (int it = 0; it < kHaloIter; it++) { \
+                if (direct) halo_finish<false>(hact[it], hr[it], tile0, LDS_TILE, hig[it], hph[it], g0); \
+                else        halo_finish<true>(hact[it], hr[it], tile0, LDS_TILE, hig[it], hph[it], g0); } } while (0)
+            if (need_h && has_d) {
+                // streamed: NG / 2 sub-batches of two components, two in flight (see pair_issue)
+                constexpr int NP = NG / 2;
+#define STREAM(BL, FA) do { \
+                    f4u va[2][BL ? 4 : 1], vb[2][BL ? 4 : 1]; \
+                    pair_issue<BL, FA>(va, 0, 4 * tid, jb, G, pitch, ta, tb); \
+                    pair_issue<BL, FA>(vb, 2, 4 * tid, jb, G, pitch, ta, tb); \
+                    _Pragma("unroll") for (int i = 0; i < NP; i++) { \
+                        __builtin_amdgcn_sched_barrier(0); \
+                        if ((i & 1) == 0) { pair_finish<BL>(va, tile0, LDS_TILE, 2 * i, 4 * tid, g0); \
+                                            if (i + 2 < NP) pair_issue<BL, FA>(va, 2 * (i + 2), 4 * tid, jb, G, pitch, ta, tb); } \
+                        else              { pair_finish<BL>(vb, tile0, LDS_TILE, 2 * i, 4 * tid, g0); \
+                                            if (i + 2 < NP) pair_issue<BL, FA>(vb, 2 * (i + 2), 4 * tid, jb, G, pitch, ta, tb); } \
+                        if (i == NP - 3) HALO_ISSUE(); \
+                    } } while (0)
+                if (fast) { if (direct) STREAM(false, true); else STREAM(true, true); }
+                else      { if (direct) STREAM(false, false); else STREAM(true, false); }
+#undef STREAM
+                HALO_FINISH();
+            } else if (need_h) {
+                HALO_ISSUE();
+                if constexpr (NG == 10) BUILD_B(igH10, 4 * tid); else BUILD_B(igH8, 4 * tid);
+                HALO_FINISH();
+            } else {
+                HALO_ISSUE();
+                if constexpr (NG == 10) BUILD_B(igD10, 4 * tid); else BUILD_B(igD8, 4 * tid);
+                HALO_FINISH();
+            }
+#undef HALO_ISSUE
+#undef HALO_FINISH
 #undef BUILD_B
         }
         // descriptors of the NEXT group: in flight while this group is applied
