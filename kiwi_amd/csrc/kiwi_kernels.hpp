@@ -297,6 +297,23 @@ __global__ __launch_bounds__(256) void geometry_kernel(
         }
         tb[50] = jmin_h;
         tb[51] = jmin_d;
+        // per-component interpolation coefficients of THIS centroid (sparse_trace.f90:643-647 with the factors of
+        // seismogram.f90:171-250): wl = (1 - w) * factor, wr = w * factor, each rounded on its own.  Read by the grouped
+        // kernel with scalar loads, which takes them off the vector pipe.  Layout: tab[64 + 40 + 2 * i] = wl, [.. + 1] = wr
+        // for the i-th component in application order 0 1 2 8 | 3 4 | 5 6 7 9 (ng = 8: 0 1 2 | 3 4 | 5 6 7).
+        float *tf = (float *)tb + 64 + 40;
+        const float wr0 = g.wfrac, wl0 = 1.f - g.wfrac;
+        const float fh[6] = { g.f[0], g.f[1], g.f[2], g.f[5], g.f[3], g.f[4] };
+        const float fd[4] = { g.f[0] * rv.sd, g.f[1] * rv.sd, g.f[2] * rv.sd, g.f[5] * rv.sd };
+        int i = 0;
+        if (gm.ng == 10) {
+            for (int q = 0; q < 6; q++, i++) { tf[2 * i] = wl0 * fh[q]; tf[2 * i + 1] = wr0 * fh[q]; }
+            for (int q = 0; q < 4; q++, i++) { tf[2 * i] = wl0 * fd[q]; tf[2 * i + 1] = wr0 * fd[q]; }
+        } else {
+            const float fh8[5] = { g.f[0], g.f[1], g.f[2], g.f[3], g.f[4] };
+            for (int q = 0; q < 5; q++, i++) { tf[2 * i] = wl0 * fh8[q]; tf[2 * i + 1] = wr0 * fh8[q]; }
+            for (int q = 0; q < 3; q++, i++) { tf[2 * i] = wl0 * fd[q]; tf[2 * i + 1] = wr0 * fd[q]; }
+        }
     }
 }
 
@@ -655,12 +672,8 @@ __device__ __forceinline__ TileRegs tile_load(const float *__restrict__ chunk)
 // v_pk_mul_f32 / v_pk_add_f32 (two IEEE fp32 operations per lane and instruction, each rounded
 // separately exactly like the scalar form; no FMA).
 template <int R, bool TAIL>
-__device__ __forceinline__ void tile_fma(f2v (&out)[2], const TileRegs &t, int jl, int jend, float factor, float wfrac)
+__device__ __forceinline__ void tile_fma(f2v (&out)[2], const TileRegs &t, int jl, int jend, float factor, float wl, float wr)
 {
-    float wr = wfrac;
-    float wl = 1.f - wr;
-    wr = wr * factor;
-    wl = wl * factor;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         f2v c1 = { wl, wl }, c2 = { wr, wr };
@@ -681,7 +694,11 @@ __device__ __forceinline__ void tile_add(f2v (&out)[2], const float *__restrict_
                                          float factor, float wfrac)
 {
     const TileRegs t = tile_load(chunk);
-    tile_fma<R, TAIL>(out, t, jl, jend, factor, wfrac);
+    float wr = wfrac;
+    float wl = 1.f - wr;
+    wr = wr * factor;
+    wl = wl * factor;
+    tile_fma<R, TAIL>(out, t, jl, jend, factor, wl, wr);
 }
 
 // all GF components of one centroid (reference order) for one shift residue R
@@ -721,13 +738,16 @@ __device__ __forceinline__ void centroid_apply(f2v (&ar1)[2], f2v (&ar2)[2], f2v
 // of component i + kAhead are issued before the arithmetic of component i, so that a lone wave is not
 // stalled for a full LDS round trip per component (a wave can only issue every 4th cycle; with 3 waves per
 // SIMD exposed latency is what bounds this kernel).  Same operations in the same order as centroid_apply.
-template <int NG, int LDS_TILE, int R, bool TAIL>
+template <int NG, int LDS_TILE, int R, bool TAIL, bool SCOEF>
 __device__ __forceinline__ void centroid_apply_hd(f2v (&ar1)[2], f2v (&ar2)[2], f2v (&dz)[2],
                                                   const float *__restrict__ chunk0, int jl, const int (&jend)[NG],
-                                                  int flags, float wfrac, float sd,
+                                                  int flags, const float *__restrict__ coef, float wfrac, float sd,
                                                   float f0, float f1, float f2, float f3, float f4, float f5,
                                                   float cl, float sl)
 {
+    // coef: the centroid's 2 * NG interpolation coefficients (wl, wr per component in application order), computed
+    // by geometry_kernel; the pointer is wave-uniform, so these are scalar loads and the coefficients reach the
+    // packed multiplies as SGPR operands -- no vector instructions spent on them
     constexpr int kAhead = 2;
     constexpr int seq10[10] = { 0, 1, 2, 8, 3, 4, 5, 6, 7, 9 }, seq8[8] = { 0, 1, 2, 3, 4, 5, 6, 7 };
     constexpr int nH1 = (NG == 10) ? 4 : 3;      // components summed into the radial trace
@@ -736,6 +756,15 @@ __device__ __forceinline__ void centroid_apply_hd(f2v (&ar1)[2], f2v (&ar2)[2], 
     const bool rot = (flags & 2) != 0;           // seismogram.f90:160-203 vs :205-231
     f2v t1[2] = { { 0.f, 0.f }, { 0.f, 0.f } }, t2[2] = { { 0.f, 0.f }, { 0.f, 0.f } };
     if (!rot) { t1[0] = ar1[0]; t1[1] = ar1[1]; t2[0] = ar2[0]; t2[1] = ar2[1]; }
+    float cw[2 * NG];
+    if constexpr (SCOEF) {                        // scalar loads, issued together with the first LDS reads
+#pragma unroll
+        for (int i = 0; i < 2 * NG; i++) cw[i] = coef[i];
+    } else {                                      // short sources (fused variant): computed here, as centroid_apply does
+        const float wr0 = wfrac, wl0 = 1.f - wfrac;
+#pragma unroll
+        for (int i = 0; i < NG; i++) { const float f = (NG == 10) ? fac10[i] : fac8[i]; cw[2 * i] = wl0 * f; cw[2 * i + 1] = wr0 * f; }
+    }
     TileRegs tr[NG];
 #pragma unroll
     for (int i = 0; i < kAhead; i++) tr[i] = tile_load(chunk0 + ((NG == 10) ? seq10[i] : seq8[i]) * LDS_TILE);
@@ -745,9 +774,10 @@ __device__ __forceinline__ void centroid_apply_hd(f2v (&ar1)[2], f2v (&ar2)[2], 
         __builtin_amdgcn_sched_barrier(0);
         const int ig = (NG == 10) ? seq10[i] : seq8[i];
         const float fac = (NG == 10) ? fac10[i] : fac8[i];
-        if (i < nH1) tile_fma<R, TAIL>(t1, tr[i], jl, jend[ig], fac, wfrac);
-        else if (i < nH1 + 2) tile_fma<R, TAIL>(t2, tr[i], jl, jend[ig], fac, wfrac);
-        else tile_fma<R, TAIL>(dz, tr[i], jl, jend[ig], fac, wfrac);
+        const float wl = cw[2 * i], wr = cw[2 * i + 1];
+        if (i < nH1) tile_fma<R, TAIL>(t1, tr[i], jl, jend[ig], fac, wl, wr);
+        else if (i < nH1 + 2) tile_fma<R, TAIL>(t2, tr[i], jl, jend[ig], fac, wl, wr);
+        else tile_fma<R, TAIL>(dz, tr[i], jl, jend[ig], fac, wl, wr);
         if (i == nH1 + 1) {
             if (rot) {
 #pragma unroll
@@ -977,12 +1007,16 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
                         f4 = REC_F(cur, ro + 14), f5 = REC_F(cur, ro + 15);
             const float cl = REC_F(cur, ro + 16), sl = REC_F(cur, ro + 17);
             const int flags = REC_I(cur, ro + 18);
+            // wave-uniform by construction; readfirstlane tells the compiler so (-> scalar loads of the coefficients)
+            const size_t crow = ((size_t)(cent_ofs[isrc0 + js] - cb) * nrec + (size_t)r * nc + cc) * 128 + 64 + 40;
+            const unsigned clo = __builtin_amdgcn_readfirstlane((unsigned)crow), chi = __builtin_amdgcn_readfirstlane((unsigned)(crow >> 32));
+            const float *__restrict__ coef = (const float *)(tab + (((size_t)chi << 32) | clo));
             const int e = smax - ishift;                 // LDS position of lane 0's b[j-1]
             const float *chunk0 = &tiles[0][4 * (tid + (e >> 2))];
             const int jl = jb + e + 4 * tid;             // trace index of this lane's b[j-1]
             const bool tail = (jb + e + TILE) > jend_min;        // workgroup-uniform
 #define APPLY(RV, TV) do { \
-                if (need_h && has_d) centroid_apply_hd<NG, LDS_TILE, RV, TV>(ar1, ar2, dz, chunk0, jl, jend, flags, wfrac, sd, \
+                if (need_h && has_d) centroid_apply_hd<NG, LDS_TILE, RV, TV, !FUSE>(ar1, ar2, dz, chunk0, jl, jend, flags, coef, wfrac, sd, \
                                                                             f0, f1, f2, f3, f4, f5, cl, sl); \
                 else centroid_apply<NG, LDS_TILE, RV, TV>(ar1, ar2, dz, chunk0, jl, jend, need_h, has_d, flags, \
                                                           wfrac, sd, f0, f1, f2, f3, f4, f5, cl, sl); } while (0)
