@@ -842,6 +842,10 @@ int kiwi_hip_init(int device, kiwi_hip_ctx **out)
         }
         if (const char *m = std::getenv("KIWI_HIP_ACCUM")) c->accum_mode = (std::strcmp(m, "direct") == 0) ? 1 : 0;
         if (const char *m = std::getenv("KIWI_HIP_FUSE")) c->fuse_enabled = std::atoi(m);
+        if (const char *m = std::getenv("KIWI_HIP_CHUNK_MB")) {      // workspace bound per launch (default 3 GiB); tests use it
+            const long v = std::atol(m);
+            if (v > 0) c->chunk_bytes_limit = (size_t)v << 20;
+        }
         if (const char *m = std::getenv("KIWI_HIP_RUNS")) {          // 0: no tile sharing across sources; n > 1: longest run
             const int v = std::atoi(m);
             c->share_runs = v != 0;

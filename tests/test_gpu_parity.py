@@ -570,3 +570,29 @@ def test_fused_comparator_equals_separate_misfit_kernel(monkeypatch, method):
     m, n, g = oracle_misfits(e, 6, tr[[0, 17, 31, 59]])
     sel = pm[[0, 17, 31, 59]]
     assert np.all(np.abs(sel - m) <= MISFIT_RTOL * np.maximum(np.abs(m), 1e-6 * n))
+
+
+@pytest.mark.parametrize("stype", ["moment_tensor", "bilateral"])
+def test_internal_chunking_cuts_through_runs(monkeypatch, stype):
+    """A workspace bound of 1 MiB forces several launches per eval (and cuts runs of geometry-identical sources):
+    same bits as one launch."""
+    if stype == "moment_tensor":
+        sc = Scenario(nrec=5, true_type=6, true_params=synthetic.mt_sdr_grid(step=30)[17])
+        tr = synthetic.mt_sdr_grid(step=30)[:300]
+    else:
+        sc = Scenario(nrec=5)
+        tr = synthetic.bilat_strike_sweep(40, step=0.5)
+    e, p = build(sc)
+    p.set_source_params(stype, tr)
+    p.eval()
+    a = p.get_misfits()
+    monkeypatch.setenv("KIWI_HIP_CHUNK_MB", "1")
+    q = sc.product()
+    sc.apply_setup(q, False)
+    q.set_source_params(stype, tr)
+    q.eval()
+    b = q.get_misfits()
+    ms, launches = q.kernel_ms()
+    assert launches[1] >= 3
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
