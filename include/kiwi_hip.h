@@ -86,7 +86,7 @@ int kiwi_hip_switch_receiver(kiwi_hip_ctx *ctx, int irec, int enabled);
 /* set_ref_seismograms (minimizer_engine.f90:313-352; receiver.f90:746-851): one trace per receiver component */
 int kiwi_hip_set_reference(kiwi_hip_ctx *ctx, int irec, int icomp, int first, int n, const float *data);
 /* set_misfit_taper / set_misfit_filter (minimizer_engine.f90:632-698; minimizer.f90:875-1016; receiver.f90:355-389):
- * piecewise linear function control points; npts == 0 removes it */
+ * piecewise linear function control points; npts == 0 removes it; for the filter irec == 0 means every receiver (:646-661) */
 int kiwi_hip_set_taper(kiwi_hip_ctx *ctx, int irec, int npts, const float *x, const float *y);
 int kiwi_hip_set_filter(kiwi_hip_ctx *ctx, int irec, int npts, const float *x, const float *y);
 /* set_misfit_method (minimizer_engine.f90:622-630) */

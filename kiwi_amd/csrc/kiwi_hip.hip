@@ -1009,11 +1009,13 @@ int kiwi_hip_set_reference(kiwi_hip_ctx *c, int irec, int icomp, int first, int 
 
 static int set_plf(kiwi_hip_ctx *c, int irec, int npts, const float *x, const float *y, bool taper)
 {
-    if (irec < 1 || irec > (int)c->recv.size()) return fail(c, "receiver index out of range");
+    // filters: ireceiver 0 = every receiver (minimizer_engine.f90:646-661); tapers are per receiver (:684)
+    if (irec < (taper ? 1 : 0) || irec > (int)c->recv.size()) return fail(c, "receiver index out of range");
     if (npts == 1) return fail(c, "need at least two control points");
     Plf p;
     if (npts > 0) { p.x.assign(x, x + npts); p.y.assign(y, y + npts); }
-    (taper ? c->recv[irec - 1].taper : c->recv[irec - 1].filter) = p;
+    for (int ir = (irec == 0 ? 1 : irec); ir <= (irec == 0 ? (int)c->recv.size() : irec); ir++)
+        (taper ? c->recv[ir - 1].taper : c->recv[ir - 1].filter) = p;
     c->prepared = false;
     return 0;
 }

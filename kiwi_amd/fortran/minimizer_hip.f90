@@ -208,8 +208,9 @@ program minimizer_hip
         case ('get_source_crustal_thickness');       call do_get_source_crustal_thickness( ok_ )
         case ('set_ref_seismograms');       call do_set_ref_seismograms( a, ok_ )
         case ('set_misfit_method');         call do_set_misfit_method( a, ok_ )
-        case ('set_misfit_taper');          call do_set_plf( a, .true., ok_ )
-        case ('set_misfit_filter');         call do_set_plf( a, .false., ok_ )
+        case ('set_misfit_taper');          call do_set_plf( a, .true., .true., ok_ )
+        case ('set_misfit_filter');         call do_set_plf( a, .false., .false., ok_ )     ! all receivers, minimizer.f90:875-920
+        case ('set_misfit_filter_1');       call do_set_plf( a, .false., .true., ok_ )      ! one receiver, :922-968
         case ('set_synthetics_factor');     call do_set_synthetics_factor( a, ok_ )
         case ('set_floating_shiftrange');   call do_set_floating_shiftrange( a, ok_ )
         case ('shift_ref_seismogram');      call do_shift_ref_seismogram( a, ok_ )
@@ -655,17 +656,24 @@ program minimizer_hip
         evaluated = .false.
     end subroutine
 
-    subroutine do_set_plf( a, taper, ok_ )
+    subroutine do_set_plf( a, taper, with_receiver, ok_ )
         character(len=*), intent(in) :: a
-        logical, intent(in) :: taper
+        logical, intent(in) :: taper, with_receiver
         logical, intent(out) :: ok_
         integer :: n, i, ios
         integer(c_int) :: irec
         real(c_float), allocatable :: x(:), y(:)
         ok_ = .false.
-        n = (count_words( a ) - 1) / 2
-        allocate( x(max(n,1)), y(max(n,1)) )
-        read (a,*,iostat=ios) irec, (x(i), y(i), i=1,n)
+        irec = 0
+        if (with_receiver) then
+            n = (count_words( a ) - 1) / 2
+            allocate( x(max(n,1)), y(max(n,1)) )
+            read (a,*,iostat=ios) irec, (x(i), y(i), i=1,n)
+        else
+            n = count_words( a ) / 2
+            allocate( x(max(n,1)), y(max(n,1)) )
+            read (a,*,iostat=ios) (x(i), y(i), i=1,n)
+        end if
         if (ios /= 0) then
             call fail( 'failed to parse values' ); return
         end if

@@ -157,6 +157,21 @@ def test_protocol_host_matches_python_host_and_oracle(host, tmp_path):
         assert float(p.do("get_global_misfit")) <= plain * (1 + 1e-6)
         with pytest.raises(protocol.SeismosizerReturnedError, match="usage: set_floating_shiftrange"):
             p.do("set_floating_shiftrange", 1)
+        # set_misfit_filter applies to every receiver, set_misfit_filter_1 to one (minimizer.f90:875-968)
+        p.do("set_misfit_method", "l2norm")
+        p.do("set_floating_shiftrange", 0, 0, 0)
+        p.do("set_source_params", "bilateral", *["%.9g" % v for v in trials[1]])
+        unfiltered = float(p.do("get_global_misfit"))
+        p.do("set_misfit_filter", 0.01, 0, 0.02, 1, 0.1, 1, 0.2, 0)
+        filtered_all = float(p.do("get_global_misfit"))
+        assert filtered_all != unfiltered
+        p.do("set_misfit_filter")                               # no points: filter removed everywhere
+        assert float(p.do("get_global_misfit")) == unfiltered
+        p.do("set_misfit_filter_1", 2, 0.01, 0, 0.02, 1, 0.1, 1, 0.2, 0)
+        one = float(p.do("get_global_misfit"))
+        assert one != unfiltered and one != filtered_all
+        with pytest.raises(protocol.SeismosizerReturnedError, match="receiver index out of range"):
+            p.do("set_misfit_taper", 0, 0, 0, 1, 1)
     finally:
         p.close()
 
