@@ -6,4 +6,4 @@ python/tunguska/seismosizer.py, drives the Fortran engine the same way).
 """
 from .lib import build, load, KiwiHipError  # noqa: F401
 from .engine import Engine  # noqa: F401
-from . import gridsearch  # noqa: F401
+from . import gridsearch, lm  # noqa: F401
