@@ -167,6 +167,7 @@ inline int source_nparams(int type)
     switch (type) {
     case 1: return 14;   // bilateral, source_bilat.f90:32
     case 2: return 11;   // circular, source_circular.f90:32
+    case 3: return 13;   // point_lp, source_point_lp.f90:43
     case 6: return 11;   // moment_tensor, source_moment_tensor.f90:34
     }
     return -1;
@@ -334,12 +335,35 @@ inline bool discretize_circular(const float *p, float doi, DiscreteSource &out)
     return true;
 }
 
+// psm_set_point_lp + psm_to_tdsm_point_lp (source_point_lp.f90:192-337): a point source whose moment tensor follows
+// a band-limited source time function stf(t) (:408-419, default-real exp and sin), sampled every effective dt
+inline bool discretize_point_lp(const float *p, float doi, DiscreteSource &out)
+{
+    const float dur_exc = p[11], prd = p[12];
+    int nt = (int)std::floor(dur_exc / doi) + 1;
+    if (nt <= 1) nt = 2;
+    out.centroids.resize(nt);
+    const float t1 = 2.f, t2 = t1 + dur_exc - 5.f, t3 = t2 / 4.f;
+    for (int it = 1; it <= nt; it++) {
+        const float rel = (float)(it - 1) * doi, d = rel - t3;
+        const float tf = std::exp(-(d * d) / (2.f * kPi * dur_exc)) * 1.f / (1.f + std::exp(-2.f * (rel - t1))) * 1.f /
+                         (1.f + std::exp(0.5f * (rel - t2))) * std::sin(2.f * kPi / prd * rel);
+        Centroid &c = out.centroids[it - 1];
+        c.north = p[1]; c.east = p[2]; c.depth = p[3];
+        c.time = p[0] + (float)it * doi;
+        for (int k = 0; k < 6; k++) c.m[k] = p[5 + k] * tf;
+    }
+    out.moment = p[4]; out.risetime = 0.f;
+    return true;
+}
+
 // psm_to_tdsm dispatch, source_all.f90:431-465
 inline bool discretize(int type, const float *params, float doi, DiscreteSource &out)
 {
     switch (type) {
     case 1: return discretize_bilat(params, doi, out);
     case 2: return discretize_circular(params, doi, out);
+    case 3: return discretize_point_lp(params, doi, out);
     case 6: return discretize_moment_tensor(params, doi, out);
     }
     return false;

@@ -20,6 +20,8 @@ SOURCE_PARAMS = {
                    "bord-shift-y", "bord-radius", "nukl-shift-x", "nukl-shift-y", "rel-rupture-velocity", "mxx", "myy",
                    "mzz", "mxy", "mxz", "myz", "rise-time"],
     "moment_tensor": ["time", "north-shift", "east-shift", "depth", "mxx", "myy", "mzz", "mxy", "mxz", "myz", "rise-time"],
+    "point_lp": ["time", "north-shift", "east-shift", "depth", "moment", "m_xx", "m_yy", "m_zz", "m_xy", "m_xz", "m_yz",
+                 "excitation-time", "main-period"],                                     # source_point_lp.f90:110-122
 }
 
 

@@ -18,6 +18,7 @@ PARAMS_NORM = {
     "bilateral": [1., 10000., 10000., 10000., 7e18, 360., 90., 360., 360., 10000., 10000., 10000., 3000., 1.],
     "circular": [1., 10000., 10000., 10000., 7e18, 360., 90., 360., 10000., 3000., 1.],
     "moment_tensor": [1., 10000., 10000., 10000., 7e18, 7e18, 7e18, 7e18, 7e18, 7e18, 1.],
+    "point_lp": [1., 10000., 10000., 10000., 7e18, 1., 0., -1., 1., 1., 1., 20., 1.],        # source_point_lp.f90:54-55 (as is)
     "eikonal": [1., 10000., 10000., 10000., 7e18, 360., 90., 360., 10000., 10000., 10000., 360., 10000., 1., 1.],
     "mt_eikonal": [1., 10000., 10000., 10000., 7e18, 360., 90., 10000., 10000., 10000., 360., 10000., 1., 7e18, 7e18, 7e18, 7e18,
                    7e18, 7e18, 1.],

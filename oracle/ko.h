@@ -94,6 +94,7 @@ typedef struct { float north, east, depth, time, m[6]; } ko_centroid;   /* discr
 
 #define KO_SRC_BILAT 1
 #define KO_SRC_CIRCULAR 2
+#define KO_SRC_POINT_LP 3
 #define KO_SRC_MOMENT_TENSOR 6
 
 typedef struct {

@@ -16,6 +16,7 @@ int ko_psm_nparams(int sourcetype)
     case KO_SRC_BILAT: return 14;           /* source_bilat.f90:32 */
     case KO_SRC_CIRCULAR: return 11;        /* source_circular.f90:32 */
     case KO_SRC_MOMENT_TENSOR: return 11;   /* source_moment_tensor.f90:34 */
+    case KO_SRC_POINT_LP: return 13;        /* source_point_lp.f90:43 */
     }
     return -1;
 }
@@ -52,8 +53,8 @@ int ko_psm_set(ko_psm *psm, int sourcetype, const float *params)
     int n = ko_psm_nparams(sourcetype);
     if (n < 0) return -1;
     int only_moment_changed = 0;
-    if (sourcetype == KO_SRC_BILAT || sourcetype == KO_SRC_CIRCULAR) {
-        /* source_bilat.f90:206, source_circular.f90:199 */
+    if (sourcetype == KO_SRC_BILAT || sourcetype == KO_SRC_CIRCULAR || sourcetype == KO_SRC_POINT_LP) {
+        /* source_bilat.f90:206, source_circular.f90:199, source_point_lp.f90:226 */
         if (psm->inited && psm->sourcetype == sourcetype) {
             int cnt = 0;
             for (int i = 0; i < n; i++) if (params[i] != psm->params[i]) cnt++;
@@ -69,6 +70,8 @@ int ko_psm_set(ko_psm *psm, int sourcetype, const float *params)
     psm->risetime = 0.f;                                   /* parameterized_source.f90:71 */
     if (sourcetype == KO_SRC_MOMENT_TENSOR) {
         psm->moment = 1.f;                                 /* source_moment_tensor.f90:201 */
+    } else if (sourcetype == KO_SRC_POINT_LP) {
+        psm->moment = psm->params[4];                      /* source_point_lp.f90:230 */
     } else {
         psm->moment = psm->params[4];                      /* source_bilat.f90:210 */
         update_dep_params(psm);
@@ -269,9 +272,42 @@ static int to_tdsm_circular(ko_psm *psm, float shortest_doi, ko_centroid **out)
 }
 
 /* source_all.f90:431-465 dispatch */
+/* stf, source_point_lp.f90:408-419: default-real exp / sin, pi from constants.f90 */
+static float point_lp_stf(float reltime, float prd, float dur_exc)
+{
+    const float pi = 3.14159265358979f;
+    float t1 = 2.f;
+    float t2 = t1 + dur_exc - 5.f;
+    float t3 = t2 / 4.f;
+    float d = reltime - t3;
+    return expf(-(d * d) / (2.f * pi * dur_exc)) * 1.f / (1.f + expf(-2.f * (reltime - t1))) * 1.f /
+           (1.f + expf(0.5f * (reltime - t2))) * sinf(2.f * pi / prd * reltime);
+}
+
+/* psm_to_tdsm_point_lp + _table_, source_point_lp.f90:237-337 */
+static int to_tdsm_point_lp(ko_psm *psm, float shortest_doi, ko_centroid **out)
+{
+    const float *P = psm->params;
+    const float maxdt = shortest_doi, dur_exc = P[11], prd = P[12];
+    int nt = (int)floorf(dur_exc / maxdt) + 1;
+    if (nt <= 1) nt = 2;
+    ko_centroid *c = (ko_centroid *)malloc(sizeof(ko_centroid) * (size_t)nt);
+    for (int it = 1; it <= nt; it++) {
+        float rel_time = (float)(it - 1) * maxdt;
+        float tfactor = point_lp_stf(rel_time, prd, dur_exc);
+        c[it - 1].north = P[1]; c[it - 1].east = P[2]; c[it - 1].depth = P[3];
+        c[it - 1].time = P[0] + (float)it * maxdt;
+        for (int k = 0; k < 6; k++) c[it - 1].m[k] = P[5 + k] * tfactor;
+    }
+    psm->grid_size[0] = 1; psm->grid_size[1] = 1; psm->grid_size[2] = nt;
+    *out = c;
+    return nt;
+}
+
 int ko_psm_to_tdsm(ko_psm *psm, float shortest_doi, ko_centroid **out)
 {
     switch (psm->sourcetype) {
+    case KO_SRC_POINT_LP: return to_tdsm_point_lp(psm, shortest_doi, out);
     case KO_SRC_MOMENT_TENSOR: return to_tdsm_moment_tensor(psm, shortest_doi, out);
     case KO_SRC_BILAT: return to_tdsm_bilat(psm, shortest_doi, out);
     case KO_SRC_CIRCULAR: return to_tdsm_circular(psm, shortest_doi, out);

@@ -20,6 +20,7 @@ module ref_driver
     use source_moment_tensor
     use source_bilat
     use source_circular
+    use source_point_lp
     use source_eikonal
     use source_mt_eikonal
     use crust2x2
@@ -238,6 +239,10 @@ module ref_driver
             call psm_set_moment_tensor( psm, params, .false., omc )
             psm%sourcetype = psm_moment_tensor
             call psm_to_tdsm_moment_tensor( psm, tdsm, effective_dt, ok )
+        else if (sourcetype == psm_point_lp) then
+            call psm_set_point_lp( psm, params, .false., omc )
+            psm%sourcetype = psm_point_lp
+            call psm_to_tdsm_point_lp( psm, tdsm, effective_dt, ok )
         end if
         nc = -1
         if (.not. ok) return

@@ -100,7 +100,7 @@ out["or_in"] = np.stack([alat, alon, blat, blon], 1)
 out["or_dxy"] = np.stack([dx, dy], 1)
 out["or_out"] = res
 
-# ---- source discretisers (source_bilat.f90:241, source_circular.f90:235, source_moment_tensor.f90:205)
+# ---- source discretisers (source_bilat.f90:241, source_circular.f90:235, source_moment_tensor.f90:205, source_point_lp.f90:237)
 k = 0
 for st, plist in ((1, [[0., 0., 0., 10000., 1e20, 91., 87., 164., 0., 4000., 2000., 4000., 3000., 2.],
                        [0.5, 1000., -2000., 8000., 3e19, -40., 45., 90., 30., 3000., 0., 2000., 2500., 0.5],
@@ -108,7 +108,9 @@ for st, plist in ((1, [[0., 0., 0., 10000., 1e20, 91., 87., 164., 0., 4000., 200
                   (2, [[0., 0., 0., 10000., 5e19, 80., 70., 100., 3000., 3000., 1.5],
                        [1., 500., 500., 6000., 1e19, 200., 30., -60., 1200., 2800., 0.3]]),
                   (6, [[0., 0., 0., 10000., 1e18, -1e18, 0., 3e17, 0., -2e17, 1.],
-                       [2., 100., 200., 3000., 1., 2., -3., 0.5, 0.25, -0.75, 3.2]])):
+                       [2., 100., 200., 3000., 1., 2., -3., 0.5, 0.25, -0.75, 3.2]]),
+                  (3, [[0., 0., 0., 10000., 7e18, 1., 0., -1., 1., 1., 1., 20., 10.],          # point_lp, source_point_lp.f90:237-337
+                       [1.5, -300., 800., 4000., 2e17, 0.3, -0.8, 0.5, 0.1, -0.2, 0.7, 7.5, 3.0]])):
     for p in plist:
         for edt in (0.5, 1.0):
             par = np.array(p, np.float32)

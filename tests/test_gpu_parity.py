@@ -622,3 +622,16 @@ def test_minimize_lm_recovers_the_true_source_with_batched_jacobians():
     # bounds: the free parameter is clamped and the penalty keeps the optimiser inside
     res2 = lm.minimize_lm(p, "bilateral", start, [False] * 5 + [True] + [False] * 8, mins=[sc.true_params[5] + 1.0], maxs=[200.0])
     assert res2.params[5] >= sc.true_params[5] + 1.0 - 1e-3
+
+
+def test_point_lp_source():
+    """point_lp (source type 3, source_point_lp.f90): band-limited point source, ~40 time steps at one point."""
+    sc = Scenario(nrec=4)
+    e, p = build(sc)
+    trials = np.array([[0.0, 0., 0., 10000., 7e18, 1., 0., -1., 1., 1., 1., 20., 10.],
+                       [0.7, 300., -500., 9000., 3e18, 0.3, -0.8, 0.5, 0.1, -0.2, 0.7, 7.5, 3.0]], np.float32)
+    m, n, g = oracle_misfits(e, 3, trials)
+    p.set_source_params("point_lp", trials)
+    p.eval()
+    pm, pn, pg = p.get_misfits()
+    assert misfit_close(pm, m) and misfit_close(pg, g) and np.array_equal(pn[0], n[0])

@@ -262,4 +262,10 @@ def test_discretize_bitexact():
         b = ref_discretize(6, mt, edt)
         assert a[3][0] == b[3][0]
         assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+        # point_lp (source_point_lp.f90:237-337; default-real exp / sin in the source time function)
+        lp = p[:5] + list(rng.standard_normal(6)) + [rng.uniform(1, 40), rng.uniform(2, 30)]
+        a = ko.discretize(3, lp, edt)
+        b = ref_discretize(3, lp, edt)
+        assert a[3] == b[3] and a[1] == b[1] and a[2] == b[2]
+        assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
 

@@ -52,7 +52,8 @@ def test_host_discretisers_match_oracle_bitwise():
              rng.uniform(1500, 4000), rng.uniform(0, 3)]
         edt = float(rng.choice([0.5, 1.0, 2.0]))
         cases = [(1, p), (2, p[:8] + [rng.uniform(0, 1.5e4), p[12], p[13]]),
-                 (6, p[:4] + list(rng.standard_normal(6) * 1e18) + [rng.uniform(0.01, 4)])]
+                 (6, p[:4] + list(rng.standard_normal(6) * 1e18) + [rng.uniform(0.01, 4)]),
+                 (3, p[:5] + list(rng.standard_normal(6)) + [rng.uniform(1, 40), rng.uniform(2, 30)])]
         for st, par in cases:
             a, mo_a, ri_a = keng.discretize(st, par, edt)
             b, mo_b, ri_b, _ = ko.discretize(st, par, edt)
@@ -65,7 +66,9 @@ def test_discretize_rejects_bad_input():
     with pytest.raises(klib.KiwiHipError):
         keng.discretize(1, [0.0] * 5, 0.5)
     with pytest.raises(klib.KiwiHipError):
-        keng.discretize(3, [0.0] * 13, 0.5)
+        keng.discretize(3, [0.0] * 12, 0.5)
+    with pytest.raises(klib.KiwiHipError):
+        keng.discretize(7, [0.0] * 13, 0.5)
 
 
 def test_make_global_misfits_hand_vectors():
