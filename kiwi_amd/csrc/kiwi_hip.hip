@@ -144,7 +144,6 @@ struct kiwi_hip_ctx {
     DevBuf<int> fshift_d;
     int last_isrc0 = 0, last_nsrc = 0, last_chunk0 = 0, last_chunkn = 0;
     int last_proc_which = 0;
-    int group_spt = 4;                // samples per thread of the grouped kernel; env KIWI_HIP_GROUP_SPT
     int group_threads_env = 0;
     int group_threads = 128;          // workgroup size of the grouped kernel (tile = 4x); env KIWI_HIP_GROUP_THREADS
     int accum_mode = 0;               // 0 grouped (LDS-staged), 1 direct; env KIWI_HIP_ACCUM
@@ -835,10 +834,6 @@ int kiwi_hip_init(int device, kiwi_hip_ctx **out)
         if (const char *m = std::getenv("KIWI_HIP_GROUP_THREADS")) {
             const int v = std::atoi(m);
             if (v == 64 || v == 128 || v == 256) { c->group_threads = v; c->group_threads_env = 1; }
-        }
-        if (const char *m = std::getenv("KIWI_HIP_GROUP_SPT")) {
-            const int v = std::atoi(m);
-            if (v == 4 || v == 8 || v == 16) c->group_spt = v;
         }
         if (const char *m = std::getenv("KIWI_HIP_ACCUM")) c->accum_mode = (std::strcmp(m, "direct") == 0) ? 1 : 0;
         if (const char *m = std::getenv("KIWI_HIP_FUSE")) c->fuse_enabled = std::atoi(m);
