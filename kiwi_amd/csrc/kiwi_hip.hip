@@ -102,7 +102,9 @@ struct kiwi_hip_ctx {
 
     // prepared (derived) state
     bool prepared = false;
-    bool synth_only = false;              // some enabled receiver has no taper / reference yet: synthetics only
+    bool synth_only = false;              // some enabled receiver has no reference yet: synthetics only
+    bool any_untapered = false;           // some enabled receiver has references but no taper (comparator.f90:798-800)
+    DevBuf<int> spansrc_d;                // per-source strip spans of the current chunk (un-tapered receivers)
     int nmis = 0, nrec_en = 0;
     int halo = 0;
     size_t syn_stride = 0;
@@ -228,7 +230,7 @@ void natural_spans(kiwi_hip_ctx *c, std::vector<int> &sb)
         EvalParams ep{ c->bilinear, c->xus, c->zus, nrec, s0 };
         dim3 grid((unsigned)((maxnc * nrec + 255) / 256), (unsigned)n);
         hipLaunchKernelGGL(geometry_kernel, grid, dim3(256), 0, c->stream, c->cent_d.p, c->centofs_d.p, ep, c->gm,
-                           c->span.p, c->recv_d.p, (GeoRec *)nullptr, (int *)nullptr, c->spanbuf_d.p);
+                           c->span.p, c->recv_d.p, (GeoRec *)nullptr, (int *)nullptr, c->spanbuf_d.p, (int *)nullptr);
     }
     HIPCHECK(hipMemcpyAsync(sb.data(), c->spanbuf_d.p, sb.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));
@@ -259,15 +261,17 @@ void prepare(kiwi_hip_ctx *c)
     // "synthetic reference" is made, minimizer.f90:1296-1380): then every window is the natural span of the
     // synthetic strips and misfits are not available.
     c->synth_only = false;
+    c->any_untapered = false;
     for (auto &r : c->recv) {
         if (!r.enabled || r.ncomp == 0) continue;
-        if (!r.taper.defined()) c->synth_only = true;
+        if (!r.taper.defined()) c->any_untapered = true;
         for (int k = 0; k < r.ncomp; k++) if (r.ref[k].data.empty()) c->synth_only = true;
     }
+    if (c->synth_only) c->any_untapered = false;
     std::vector<int> nat;
-    if (c->synth_only) {
+    if (c->synth_only || c->any_untapered) {
         if (c->nsrc == 0) throw std::runtime_error("no source set");
-        c->floating = false;
+        if (c->synth_only) c->floating = false;
         for (int ir = 0; ir < nrec; ir++) {                 // geometry part of the receiver records only
             Receiver &r = c->recv[ir];
             RecvDev &d = rd[ir];
@@ -302,11 +306,23 @@ void prepare(kiwi_hip_ctx *c)
         }
         if (!d.enabled) continue;
         int w[2];
-        if (c->synth_only) {
+        const bool untapered = !c->synth_only && !r.taper.defined();
+        if (c->synth_only || untapered) {
+            // no taper: the window must hold every strip of the uploaded sources and, for the comparator, the
+            // references at every floating shift; the norms themselves are restricted per source in the kernels
             w[0] = std::min(nat[4 * ir], nat[4 * ir + 2]);
             w[1] = std::max(nat[4 * ir + 1], nat[4 * ir + 3]);
             if (w[1] < w[0]) { w[0] = 0; w[1] = 0; }                        // no centroid reached this receiver
             else if (hs > 0) { w[0] -= hs; w[1] += hs + 1; }                // strip_fold grows the strip, sparse_trace.f90:379-402
+            if (untapered) {
+                const int flo = c->floating ? r.float_lo : 0, fhi = c->floating ? r.float_hi : 0;
+                bool first = (nat[4 * ir + 1] < nat[4 * ir] && nat[4 * ir + 3] < nat[4 * ir + 2]);
+                for (int k = 0; k < r.ncomp; k++) {
+                    const int f0 = r.ref[k].first, f1 = f0 + (int)r.ref[k].data.size() - 1;
+                    if (first) { w[0] = f0 + flo; w[1] = f1 + fhi; first = false; }
+                    w[0] = std::min(w[0], f0 + flo); w[1] = std::max(w[1], f1 + fhi);
+                }
+            }
         } else {
             discrete_plf_span(r.taper, dt, w);                             // comparator.f90:1157-1169
             if (w[1] < w[0]) throw std::runtime_error("receiver " + std::to_string(ir + 1) + ": empty taper span");
@@ -317,7 +333,7 @@ void prepare(kiwi_hip_ctx *c)
         c->max_wlen = std::max(c->max_wlen, d.wlen);
         // taper weights: plf_taper_array applied to ones (piecewise_linear_function.f90:195-237)
         std::vector<float> tww(wlen, 1.f);
-        if (!c->synth_only) plf_taper_array(r.taper, tww.data(), w[0], w[1], dt, IP_COS);
+        if (!c->synth_only && !untapered) plf_taper_array(r.taper, tww.data(), w[0], w[1], dt, IP_COS);
         recfirst.push_back((int)c->comps.size());
         d.slot0 = (int)c->comps.size();
         for (int k = 0; k < r.ncomp; k++) {
@@ -328,18 +344,22 @@ void prepare(kiwi_hip_ctx *c)
             cd.synofs = (int)synofs; cd.halo = c->halo; cd.w0 = w[0]; cd.wlen = wlen;
             cd.refofs = (int)reft.size(); cd.rec = ir;
             cd.fl_lo = 0; cd.fl_ns = 1; cd.refxofs = 0;
+            cd.untapered = untapered ? 1 : 0;
+            cd.vertical = std::abs(r.comp[k]) == 3 ? 1 : 0;
             d.synofs[k] = (int)synofs;
             d.refofs[k] = cd.refofs;
             synofs += ((size_t)d.wlen + 3) / 4 * 4;
             // reference probe contents over the window: zeros before the data, last value repeated
             // after it (probe_set_array, comparator.f90:259-265), then tapered (:1173-1184)
             const int f0 = rf.first, f1 = rf.first + (int)rf.data.size() - 1;
+            cd.rf0 = f0; cd.rf1 = f1;
             double sum = 0.0, pk = 0.0;
             for (int t = w[0]; t <= w[1]; t++) {
                 float v = 0.f;
                 if (t >= f0) v = rf.data[std::min(t, f1) - f0] * 1.f;
                 if (t >= f0) v = v * tww[t - w[0]];                         // taper acts from dataspan(1) on
                 reft.push_back(v);
+                if (untapered && (t < f0 || t > f1)) continue;             // probe_norm without taper: the data span only, :843-845
                 switch (eval_method) {                                     // probe_norm, comparator.f90:669-697
                 case KIWI_L2NORM: sum += (double)v * (double)v; break;
                 case KIWI_L1NORM: sum += (double)std::fabs(v); break;
@@ -372,6 +392,7 @@ void prepare(kiwi_hip_ctx *c)
                     double acc = 0.0;
                     for (int t = w[0]; t <= w[1]; t++) {
                         const int ts = t - sh;
+                        if (untapered && (ts < f0 || ts > f1)) continue;
                         float v = 0.f;
                         if (ts >= f0) v = (rf.data[std::min(ts, f1) - f0] * 1.f) * tww[t - w[0]];
                         acc += eval_method == KIWI_L2NORM ? (double)v * (double)v : (double)std::fabs(v);
@@ -416,6 +437,8 @@ void prepare(kiwi_hip_ctx *c)
     c->any_filter = false;
     for (auto &r : c->recv) if (r.enabled && r.ncomp > 0 && r.filter.defined()) c->any_filter = true;
     if (c->floating && c->any_filter) throw std::runtime_error("floating norms with a misfit filter are not supported by the device comparator");
+    if (c->any_untapered && (c->any_filter || c->method == KIWI_AMPSPEC_L2NORM || c->method == KIWI_AMPSPEC_L1NORM))
+        throw std::runtime_error("spectral norms and misfit filters need a misfit taper on every enabled receiver in the device comparator");
     c->fft_needed = !c->synth_only && (c->method == KIWI_AMPSPEC_L2NORM || c->method == KIWI_AMPSPEC_L1NORM || c->any_filter);
     c->prepared = true;
 }
@@ -631,7 +654,7 @@ bool can_fuse(const kiwi_hip_ctx *c, int proc_which, int isrc0, int nsrc)
     // with ~100 centroids per source the separate misfit kernel costs less than the fused epilogue's registers
     const int ncent = nsrc > 0 ? (c->cent_ofs[isrc0 + nsrc] - c->cent_ofs[isrc0]) / nsrc : 0;
     if (c->fuse_enabled < 2 && ncent > 32) return false;               // KIWI_HIP_FUSE=2 forces it
-    return c->fuse_enabled && c->accum_mode == 0 && proc_which == 0 && !c->fft_needed && !c->floating && !c->synth_only &&
+    return c->fuse_enabled && c->accum_mode == 0 && proc_which == 0 && !c->fft_needed && !c->floating && !c->synth_only && !c->any_untapered &&
            c->halo == 0 && (c->method == KIWI_L2NORM || c->method == KIWI_L1NORM || c->method == KIWI_SCALAR_PRODUCT || c->method == KIWI_PEAK);
 }
 
@@ -650,12 +673,22 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
     if (proc_which) { c->proc_d.ensure((size_t)nsrc * c->syn_stride, &c->dev_bytes); proc = c->proc_d.p; }
 
     EvalParams ep{ c->bilinear, c->xus, c->zus, nrec, isrc0 };
+    int *spansrc = nullptr;
+    if (c->any_untapered) {                        // per-source strip spans, initialised empty
+        const size_t n = (size_t)nsrc * nrec;
+        c->spansrc_d.ensure(n * 4, &c->dev_bytes);
+        std::vector<int> init(n * 4);
+        for (size_t i = 0; i < n; i++) { init[4 * i] = init[4 * i + 2] = 0x7fffffff; init[4 * i + 1] = init[4 * i + 3] = -0x7fffffff; }
+        HIPCHECK(hipMemcpyAsync(c->spansrc_d.p, init.data(), init.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIPCHECK(hipStreamSynchronize(c->stream));
+        spansrc = c->spansrc_d.p;
+    }
     hipEvent_t e0, e1, e2, e3;
     record(c, 0, e0);
     if (maxnc > 0) {
         dim3 grid((unsigned)((maxnc * nrec + 255) / 256), (unsigned)nsrc);
         hipLaunchKernelGGL(geometry_kernel, grid, dim3(256), 0, c->stream, c->cent_d.p, c->centofs_d.p, ep, c->gm,
-                           c->span.p, c->recv_d.p, c->recs_d.p, tab, (int *)nullptr);
+                           c->span.p, c->recv_d.p, c->recs_d.p, tab, (int *)nullptr, spansrc);
     }
     record(c, 0, e1);
     int fuse_T = 0, fuse_ntiles = 0;
@@ -743,11 +776,12 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
         } else
         hipLaunchKernelGGL(misfit_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream,
                            c->syn_d.p, c->syn_stride, c->comps_d.p, c->reft_d.p, c->tw_d.p, c->moment_d.p,
-                           c->risetime_d.p, mp, c->misfit_d.p, proc_which == 3 ? nullptr : proc, c->fft_d.p, c->vt_d.p);
+                           c->risetime_d.p, mp, c->misfit_d.p, proc_which == 3 ? nullptr : proc, c->fft_d.p, c->vt_d.p,
+                           spansrc, nrec, fold_halfwidth(c->max_risetime, c->gm.dt));
         if (c->floating) {
             hipLaunchKernelGGL(floating_norm_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream,
                                c->vt_d.p, c->syn_stride, c->comps_d.p, c->refx_d.p, c->tw_d.p, fl_method, c->gm.dt,
-                               c->syn_factor, c->nmis, c->max_ns, c->partial_d.p);
+                               c->syn_factor, c->nmis, c->max_ns, c->partial_d.p, spansrc, nrec, fold_halfwidth(c->max_risetime, c->gm.dt));
             const int nth = nsrc * c->nrec_en;
             hipLaunchKernelGGL(floating_select_kernel, dim3((unsigned)((nth + 127) / 128)), dim3(128), 0, c->stream,
                                c->partial_d.p, c->comps_d.p, c->recfirst_d.p, c->nrec_en, c->nmis, c->max_ns, fl_method,
@@ -1235,7 +1269,7 @@ int kiwi_hip_set_sources(kiwi_hip_ctx *c, int nsrc, const int *cent_ofs, const f
     c->nsrc = nsrc;
     if (fold_halfwidth(maxrise, c->gm.dt) != fold_halfwidth(c->max_risetime, c->gm.dt)) c->prepared = false;
     c->max_risetime = maxrise;
-    if (c->synth_only) c->prepared = false;          // windows = natural spans of the uploaded sources
+    if (c->synth_only || c->any_untapered) c->prepared = false;   // windows follow the natural spans of the uploaded sources
     c->last_nsrc = 0;
     c->proc_which_held = 0;
     c->fft_ready = false;

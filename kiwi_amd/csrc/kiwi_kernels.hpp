@@ -93,6 +93,8 @@ struct CompDev {
     // floating norms (receiver.f90:439-510): integer shift range of the receiver and where the un-tapered
     // reference over [w0 - fl_hi, w0 + wlen - 1 - fl_lo] lives
     int fl_lo, fl_ns, refxofs;
+    // un-tapered comparator (comparator.f90:798-800): norms run over the union of the two data spans
+    int untapered, rf0, rf1, vertical;      // reference data span [rf0, rf1]; which strip span applies to the synthetic
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -116,7 +118,7 @@ struct EvalParams {
 __global__ __launch_bounds__(256) void geometry_kernel(
     const float *__restrict__ cent, const int *__restrict__ cent_ofs, EvalParams ep, GfMeta gm,
     const int2 *__restrict__ span, const RecvDev *__restrict__ recv, GeoRec *__restrict__ out,
-    int *__restrict__ tab, int *__restrict__ spanbuf)
+    int *__restrict__ tab, int *__restrict__ spanbuf, int *__restrict__ spansrc /* optional [source][receiver][4] */)
 {
     const int s = blockIdx.y;
     const int c0 = cent_ofs[ep.isrc0 + s], nc = cent_ofs[ep.isrc0 + s + 1] - c0;
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(256) void geometry_kernel(
     // natural span of the synthetic strips (seismogram.f90:102-130 + sparse_trace.f90:648-668): union over
     // centroids of [first + shift, last + shift + 1], horizontals (all share one span, :196-197) and vertical
     // separately; only needed to size the comparator's FFT (comparator.f90:464-486)
-    if (spanbuf && g.row[0] >= 0) {
+    if ((spanbuf || spansrc) && g.row[0] >= 0) {
         const int nn = (g.flags & 1) ? 1 : 4;
         int lo_h = 0x7fffffff, hi_h = -0x7fffffff, lo_d = 0x7fffffff, hi_d = -0x7fffffff;
         for (int ig = 0; ig < gm.ng; ig++) {
@@ -266,8 +268,15 @@ __global__ __launch_bounds__(256) void geometry_kernel(
             for (int k = 0; k < nn; k++) { const int2 sp = span[g.row[k] + ig]; lo = min(lo, sp.x); hi = max(hi, sp.y); }
             if (horiz) { lo_h = min(lo_h, lo); hi_h = max(hi_h, hi); } else { lo_d = min(lo_d, lo); hi_d = max(hi_d, hi); }
         }
-        if (rv.need_h) { atomicMin(&spanbuf[4 * r + 0], lo_h + g.ishift); atomicMax(&spanbuf[4 * r + 1], hi_h + g.ishift + 1); }
-        if (rv.has_d) { atomicMin(&spanbuf[4 * r + 2], lo_d + g.ishift); atomicMax(&spanbuf[4 * r + 3], hi_d + g.ishift + 1); }
+        if (spanbuf) {
+            if (rv.need_h) { atomicMin(&spanbuf[4 * r + 0], lo_h + g.ishift); atomicMax(&spanbuf[4 * r + 1], hi_h + g.ishift + 1); }
+            if (rv.has_d) { atomicMin(&spanbuf[4 * r + 2], lo_d + g.ishift); atomicMax(&spanbuf[4 * r + 3], hi_d + g.ishift + 1); }
+        }
+        if (spansrc) {                               // the same per trial source: data spans of ITS synthetic strips
+            int *sp = spansrc + ((size_t)s * ep.nrec + r) * 4;
+            if (rv.need_h) { atomicMin(&sp[0], lo_h + g.ishift); atomicMax(&sp[1], hi_h + g.ishift + 1); }
+            if (rv.has_d) { atomicMin(&sp[2], lo_d + g.ishift); atomicMax(&sp[3], hi_d + g.ishift + 1); }
+        }
     }
     if (!out) return;
     const size_t base = (size_t)(c0 - cent_ofs[ep.isrc0]) * ep.nrec + (size_t)r * nc + c;
@@ -1074,10 +1083,20 @@ __global__ __launch_bounds__(256) void misfit_kernel(
     const float *__restrict__ reft, const float *__restrict__ tw,
     const float *__restrict__ moment, const float *__restrict__ risetime, MisfitParams mp,
     float *__restrict__ misfit_out, float *__restrict__ proc /* optional [src][stride] processed synthetics */,
-    float *__restrict__ fftbuf, float *__restrict__ vt_out /* optional [src][stride] tapered synthetics */)
+    float *__restrict__ fftbuf, float *__restrict__ vt_out /* optional [src][stride] tapered synthetics */,
+    const int *__restrict__ spansrc /* per-source strip spans, un-tapered receivers only */, int nrec, int fold_grow)
 {
     const int m = blockIdx.x, s = blockIdx.y;
     const CompDev cd = comps[m];
+    // window samples that take part in the norm: all of them with a taper; without, the union of the reference's data
+    // span and the data span of this source's synthetic strip (probes_norm_timedomain, comparator.f90:798-800)
+    int i_lo = 0, i_hi = cd.wlen - 1;
+    if (cd.untapered) {
+        const int *sp = spansrc + ((size_t)s * nrec + cd.rec) * 4 + (cd.vertical ? 2 : 0);
+        int lo = cd.rf0, hi = cd.rf1;
+        if (sp[1] >= sp[0]) { lo = min(lo, sp[0] - fold_grow); hi = max(hi, sp[1] + (fold_grow ? fold_grow + 1 : 0)); }
+        i_lo = max(lo - cd.w0, 0); i_hi = min(hi - cd.w0, cd.wlen - 1);
+    }
     const float mom = moment[mp.isrc0 + s];
     const float rise = risetime[mp.isrc0 + s];
     const float *__restrict__ sy = syn + (size_t)s * syn_stride + cd.synofs + cd.halo;   // sy[i] = sample w0 + i
@@ -1140,6 +1159,7 @@ __global__ __launch_bounds__(256) void misfit_kernel(
         if (proc) proc[(size_t)s * syn_stride + cd.synofs + cd.halo + i] = mp.write_tapered == 2 ? vt : v;
         if (frow) { frow[i] = vt; continue; }
         if (mp.skip_norm) { vt_out[(size_t)s * syn_stride + cd.synofs + cd.halo + i] = vt; continue; }
+        if (i < i_lo || i > i_hi) continue;
         const float a = rt[i];
         switch (mp.method) {
         case 1: {                                 // l2norm_func, comparator.f90:650-659
@@ -1330,11 +1350,16 @@ __global__ void misfit_finish_kernel(const double *__restrict__ partial, const C
 __global__ __launch_bounds__(256) void floating_norm_kernel(
     const float *__restrict__ vt, size_t syn_stride, const CompDev *__restrict__ comps,
     const float *__restrict__ refx, const float *__restrict__ tw, int method /* 1 l2, 2 l1 */, float dt,
-    float syn_factor, int nmis, int maxns, float *__restrict__ partial)
+    float syn_factor, int nmis, int maxns, float *__restrict__ partial, const int *__restrict__ spansrc, int nrec, int fold_grow)
 {
     __shared__ double red[256];
     const int m = blockIdx.x, s = blockIdx.y;
     const CompDev cd = comps[m];
+    int s_lo = 0x7fffffff, s_hi = -0x7fffffff;          // data span of this source's synthetic strip (un-tapered only)
+    if (cd.untapered) {
+        const int *sp = spansrc + ((size_t)s * nrec + cd.rec) * 4 + (cd.vertical ? 2 : 0);
+        if (sp[1] >= sp[0]) { s_lo = sp[0] - fold_grow; s_hi = sp[1] + (fold_grow ? fold_grow + 1 : 0); }
+    }
     const float *__restrict__ sy = vt + (size_t)s * syn_stride + cd.synofs + cd.halo;
     const float *__restrict__ rx = refx + cd.refxofs;
     const float *__restrict__ tp = tw + cd.refofs;
@@ -1342,8 +1367,14 @@ __global__ __launch_bounds__(256) void floating_norm_kernel(
     for (int q = 0; q < cd.fl_ns; q++) {
         // reference value at window sample i for shift fl_lo + q: un-tapered reference at w0 + i - (fl_lo + q)
         const float *__restrict__ rq = rx + (cd.fl_ns - 1 - q);
+        int i_lo = 0, i_hi = cd.wlen - 1;
+        if (cd.untapered) {                            // union of the SHIFTED reference's data span and the strip's
+            const int sh = cd.fl_lo + q;
+            i_lo = max(min(cd.rf0 + sh, s_lo) - cd.w0, 0);
+            i_hi = min(max(cd.rf1 + sh, s_hi) - cd.w0, cd.wlen - 1);
+        }
         double acc = 0.0;
-        for (int i = threadIdx.x; i < cd.wlen; i += 256) {
+        for (int i = i_lo + threadIdx.x; i <= i_hi; i += 256) {
             const float a = rq[i] * tp[i];                 // make_array_tapered, comparator.f90:1173-1184
             const float b = sy[i];
             if (method == 1) {

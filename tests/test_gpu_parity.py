@@ -635,3 +635,49 @@ def test_point_lp_source():
     p.eval()
     pm, pn, pg = p.get_misfits()
     assert misfit_close(pm, m) and misfit_close(pg, g) and np.array_equal(pn[0], n[0])
+
+
+@pytest.mark.parametrize("method", ["l2norm", "l1norm", "floating_l1norm"])
+def test_untapered_comparator_fresh_evaluation_semantics(method):
+    """Without misfit tapers (the reference's own benchmark/kiwibench.py runs floating_l1norm that way) a norm runs over
+    the union of the reference's data span and the data span of the synthetic strip (comparator.f90:798-800).  In the
+    reference that strip never shrinks, so the span depends on the sources evaluated before; the device gives every
+    source the span of a FRESH evaluation -- compared here with a fresh oracle engine per trial source."""
+    sc = Scenario(nrec=4, comps_list=["ned", "ne", "d", "ned"])
+    e0 = sc.oracle()
+    sc.make_references(e0)
+    mid = {"l2norm": 1, "l1norm": 2, "floating_l1norm": 8}[method]
+    dt = sc.gf["dt"]
+    trials = synthetic.bilat_strike_sweep(4, step=2.0)
+    trials[:, 0] = [-1.1, 0.0, 0.6, 2.1]                    # origin times move the strips against the references
+    trials[2, 13] = 0.0                                     # and one without rise time
+    want_m, want_n, want_g, want_s = [], [], [], []
+    for t in trials:
+        e = sc.oracle()
+        for (ir, k), (lo, d) in sc.refs.items():
+            e.set_reference(ir, k, lo, d)
+        e.set_misfit_method(mid)
+        if mid == 8:
+            for ir in range(4):
+                e.set_floating_shiftrange(ir + 1, -2, 2)
+        e.set_source_params(1, t)
+        m, n, g = e.get_misfits()
+        want_m.append(m); want_n.append(n); want_g.append(g)
+        want_s.append([e.floating_shift(ir + 1) * dt for ir in range(4)])
+        e.close()
+    p = sc.product()
+    for (ir, k), (lo, d) in sc.refs.items():
+        p.set_ref_seismogram(ir, k, lo, d)
+    p.set_misfit_method(method)
+    if mid == 8:
+        p.set_floating_shiftrange(0, -2 * dt, 2 * dt)
+    p.set_source_params("bilateral", trials)
+    p.eval()
+    pm, pn, pg = p.get_misfits()
+    assert misfit_close(pm, np.array(want_m)) and misfit_close(pg, np.array(want_g, np.float32))
+    assert np.array_equal(pn, np.array(want_n))
+    if mid == 8:
+        assert np.array_equal(p.get_floating_shifts(), np.array(want_s, np.float32))
+    with pytest.raises(KiwiHipError, match="need a misfit taper"):
+        p.set_misfit_method("ampspec_l2norm")
+        p.eval()
