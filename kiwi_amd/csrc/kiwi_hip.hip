@@ -151,7 +151,7 @@ struct kiwi_hip_ctx {
     int accum_mode = 0;               // 0 grouped (LDS-staged), 1 direct; env KIWI_HIP_ACCUM
     int keep_which = 0;               // kiwi_hip_set_keep_synthetics
     int proc_chunk0 = 0, proc_chunkn = 0, proc_which_held = 0;   // what proc_d currently holds
-    size_t chunk_bytes_limit = (size_t)3 << 30;
+    size_t chunk_bytes_limit = (size_t)16 << 30;      // workspace per launch; the device has 288 GB
 
     // spectral / filtered comparator (hipFFT)
     bool fft_needed = false, fft_ready = false, any_filter = false;
@@ -871,7 +871,7 @@ int kiwi_hip_init(int device, kiwi_hip_ctx **out)
         }
         if (const char *m = std::getenv("KIWI_HIP_ACCUM")) c->accum_mode = (std::strcmp(m, "direct") == 0) ? 1 : 0;
         if (const char *m = std::getenv("KIWI_HIP_FUSE")) c->fuse_enabled = std::atoi(m);
-        if (const char *m = std::getenv("KIWI_HIP_CHUNK_MB")) {      // workspace bound per launch (default 3 GiB); tests use it
+        if (const char *m = std::getenv("KIWI_HIP_CHUNK_MB")) {      // workspace bound per launch (default 16 GiB); tests use it
             const long v = std::atol(m);
             if (v > 0) c->chunk_bytes_limit = (size_t)v << 20;
         }
