@@ -681,3 +681,31 @@ def test_untapered_comparator_fresh_evaluation_semantics(method):
     with pytest.raises(KiwiHipError, match="need a misfit taper"):
         p.set_misfit_method("ampspec_l2norm")
         p.eval()
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_odd_window_lengths_and_offsets(fused):
+    """Taper spans of arbitrary length / start (not multiples of the 4-sample lane chunks), different per receiver."""
+    sc = Scenario(nrec=5, comps_list=["ned", "ne", "d", "ned", "e"], true_type=6 if fused else 1,
+                  true_params=synthetic.mt_sdr_grid(step=30)[17] if fused else None)
+    e, p = build(sc)
+    dt = sc.gf["dt"]
+    for ir in range(5):
+        lo, d = sc.refs[(ir + 1, 1)]
+        t0, t1 = (lo + 3 + ir) * dt + 0.13, (lo + len(d) - 11 - 2 * ir) * dt - 0.21
+        x, y = [t0, t0 + 4.7, t1 - 6.1, t1], [0., 1., 1., 0.]
+        e.set_taper(ir + 1, x, y)
+        p.set_misfit_taper(ir + 1, x, y)
+    if fused:
+        trials = synthetic.mt_sdr_grid(step=30)[40:52]
+        m, n, g = oracle_misfits(e, 6, trials)
+        p.set_source_params("moment_tensor", trials)
+    else:
+        trials = synthetic.bilat_strike_sweep(5, step=1.5)
+        m, n, g = oracle_misfits(e, 1, trials)
+        p.set_source_params("bilateral", trials)
+    p.eval()
+    pm, pn, pg = p.get_misfits()
+    assert np.array_equal(pn[0], n[0]) and misfit_close(pm, m) and misfit_close(pg, g)
+    lens = {p.get_synthetics(0, ir + 1, 1, 2)[1].size for ir in range(5)}
+    assert any(v % 4 for v in lens)
