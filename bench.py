@@ -260,6 +260,10 @@ def main():
                          "kernel": "accumulate_grouped_kernel<10,256>" if os.environ.get("KIWI_HIP_ACCUM") != "direct" else "accumulate_kernel<10>", "launches": int(launches[1]),
                          "avg_launch_ms": float(ms[1]) / max(int(launches[1]), 1),
                          "algorithmic_bytes_per_eval": b_eval,
+                         "note": "achieved = no-reuse algorithmic bytes (SURVEY 8d) / kernel time; it exceeds the HBM peak because the "
+                                 "Green's function tensor is cache resident and every blended tile is reused by the time steps of a "
+                                 "sub-fault: `traffic` is what actually crossed the fabric per launch.  The kernel runs against L2->CU "
+                                 "bandwidth and VALU issue (DESIGN.md section 3, profiles/README.md)",
                          "other_kernels_ms_per_step": {"geometry": float(ms[0]) / args.steps,
                                                        "misfit": float(ms[2]) / args.steps}},
         }
