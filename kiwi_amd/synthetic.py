@@ -7,7 +7,7 @@ EARTH_R = 6371000.0
 
 
 def make_gfdb(nx=128, nz=6, ng=10, L=4096, dt=0.5, dx=4000.0, dz=2000.0, firstx=100e3, firstz=6e3,
-              variant="probe"):
+              variant="probe", center=600.0, width=400.0, vel=6000.0):
     """Returns dict(dt,dx,dz,firstx,firstz, data[nx,nz,ng,L] f32, first[nx,nz,ng] i32, nsamp[...] i32).
 
     variant "probe": the survey's probe database -- damped sinusoids, last sample forced to 0.
@@ -20,7 +20,7 @@ def make_gfdb(nx=128, nz=6, ng=10, L=4096, dt=0.5, dx=4000.0, dz=2000.0, firstx=
     i = np.arange(L)[None, None, None, :].astype(np.float64)
     x = firstx + ix * dx
     val = (1e-20 * np.sin(0.02 * i * (1 + 0.05 * ig) + 0.37 * ig + 0.11 * (iz + 1))
-           * np.exp(-((i - 600 - 40 * ig) / 400.0) ** 2) / (x / 1e5))
+           * np.exp(-((i - center - center / 15.0 * ig) / width) ** 2) / (x / 1e5))
     if variant == "static":
         ramp = 0.5 * (1 + np.tanh((i - 500.0) / 60.0))
         stat = np.zeros((1, 1, ng, 1))
@@ -32,7 +32,7 @@ def make_gfdb(nx=128, nz=6, ng=10, L=4096, dt=0.5, dx=4000.0, dz=2000.0, firstx=
     data = val.astype(np.float32)
     if variant != "static":
         data[..., -1] = 0.0
-    first = np.rint((firstx + np.arange(nx) * dx) / 6000.0 / dt).astype(np.int32)
+    first = np.rint((firstx + np.arange(nx) * dx) / vel / dt).astype(np.int32)
     first = np.broadcast_to(first[:, None, None], (nx, nz, ng)).copy()
     nsamp = np.full((nx, nz, ng), L, np.int32)
     return dict(dt=dt, dx=dx, dz=dz, firstx=firstx, firstz=firstz, data=data, first=first, nsamp=nsamp)
