@@ -132,6 +132,39 @@ static void trim_polygon_more(const polygon *in, const halfspace *hs, int nh, po
     free(temp.p);
 }
 
+/* exported for the reference's test_geometry.f90 vectors (tests/test_oracle_kats.py) */
+int ko_point_in_halfspace(const float pt[3], const float hpoint[3], const float hnormal[3])
+{
+    halfspace h;
+    memcpy(h.point, hpoint, sizeof(h.point)); memcpy(h.normal, hnormal, sizeof(h.normal));
+    return point_in_halfspace(pt, &h);
+}
+
+void ko_get_piercingpoint(const float a[3], const float b[3], const float hpoint[3], const float hnormal[3], float pp[3],
+                          int *between_ab, int *parallel)
+{
+    halfspace h;
+    memcpy(h.point, hpoint, sizeof(h.point)); memcpy(h.normal, hnormal, sizeof(h.normal));
+    get_piercingpoint(a, b, &h, pp, between_ab, parallel, NULL, NULL);
+}
+
+/* circle_to_polygon + trim_polygon with one half-space; returns the number of points written to out[][3] */
+int ko_trim_circle(const float center[3], const float transform[9], int npoints, const float hpoint[3], const float hnormal[3],
+                   float *out, int maxn)
+{
+    float tr[3][3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) tr[i][j] = transform[3 * i + j];
+    halfspace h;
+    memcpy(h.point, hpoint, sizeof(h.point)); memcpy(h.normal, hnormal, sizeof(h.normal));
+    polygon circ, trimmed;
+    circle_to_polygon(center, tr, npoints, &circ);
+    trim_polygon_one(&circ, &h, &trimmed);
+    const int n = trimmed.n < maxn ? trimmed.n : maxn;
+    memcpy(out, trimmed.p, sizeof(float[3]) * (size_t)n);
+    free(circ.p); free(trimmed.p);
+    return trimmed.n;
+}
+
 /* ---------------------------------------------------------------- heap.f90 (1-based indices kept) */
 typedef struct { int *iheap; int n, cap; } iheap;
 

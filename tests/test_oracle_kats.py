@@ -201,3 +201,74 @@ def test_plf_integrate_and_centroid():
     assert a == np.float32(1. / 8.) and abs(c - 1. / 3.) < 1e-6
     a, c = ic(0., 2.)
     assert a == np.float32(3. / 2.) and abs(c - (1. + 2. / 9.)) < 1e-6
+
+
+# ---------------------------------------------------------------- test_eikonal.f90:33-60
+def test_eikonal_uniform_speed():
+    import ctypes as C
+    L = ko.lib()
+    nx, ny = 500, 1000
+    speed = np.full((ny, nx), 2.0, np.float32)
+    delta = np.array([50. / nx, 50. / ny], np.float32)
+    origin = np.zeros(2, np.float32)
+    start = np.array([0., 25.], np.float32)
+    t = np.zeros((ny, nx), np.float32)
+    L.ko_eikonal_solver_fmm(ko._fp(speed), C.c_int(nx), C.c_int(ny), ko._fp(origin), ko._fp(delta), ko._fp(start), ko._fp(t))
+    eps = float(delta.max()) / 2.0
+    assert abs(t[0, 0] - 12.5) < eps and abs(t[ny - 1, 0] - 12.5) < eps           # times(1,1), times(1,ny)
+    assert abs(t[0, nx - 1] - 27.95) < eps and abs(t[ny - 1, nx - 1] - 27.95) < eps  # times(nx,1), times(nx,ny)
+
+
+# ---------------------------------------------------------------- test_euler.f90:25-62
+def test_euler_quarter_turns():
+    import ctypes as C
+    L = ko.lib()
+    L.ko_init_euler.argtypes = [C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float)]
+    pi = np.float32(3.14159265358979)
+    want = {"alpha": [[1, 0, 0], [0, 0, 1], [0, -1, 0]], "beta": [[0, 1, 0], [-1, 0, 0], [0, 0, 1]],
+            "gamma": [[0, 1, 0], [-1, 0, 0], [0, 0, 1]]}                            # columns = images of the unit vectors
+    for name, args in (("alpha", (pi / 2, 0, 0)), ("beta", (0, pi / 2, 0)), ("gamma", (0, 0, pi / 2))):
+        rot = np.zeros((3, 3), np.float32)
+        L.ko_init_euler(C.c_float(args[0]), C.c_float(args[1]), C.c_float(args[2]), ko._fp(rot))
+        rotsys = np.stack([rot @ np.eye(3, dtype=np.float32)[:, i] for i in range(3)])   # rotsys(:,i) as rows
+        assert np.all(np.abs(rotsys - np.array(want[name], np.float32)) < 1e-3), name
+
+
+# ---------------------------------------------------------------- test_geometry.f90:25-92
+def test_geometry_halfspace_piercing_and_trimmed_circle():
+    import ctypes as C
+    L = ko.lib()
+    fp = ko._fp
+    hp, hn = np.array([0, 0, -1], np.float32), np.array([0, -1, -1], np.float32)
+    pts = np.array([[0, 2, -1], [0, -2, -1], [0, 0, -1], [0, 0, 0]], np.float32)
+    assert [bool(L.ko_point_in_halfspace(fp(p), fp(hp), fp(hn))) for p in pts] == [True, False, True, True]
+
+    def pierce(a, b):
+        a, b = np.array(a, np.float32), np.array(b, np.float32)
+        pp = np.zeros(3, np.float32)
+        bt, par = C.c_int(), C.c_int()
+        L.ko_get_piercingpoint(fp(a), fp(b), fp(hp), fp(hn), fp(pp), C.byref(bt), C.byref(par))
+        return pp, bool(bt.value), bool(par.value)
+
+    pp, bt, par = pierce(pts[0], pts[1])
+    assert np.array_equal(pp, [0, 0, -1]) and bt and not par
+    pp, bt, par = pierce([0, 2, -1], [0, 1, -2])
+    assert np.array_equal(pp, [0, 1, -2]) and not bt and not par
+    pp, bt, par = pierce([0, 2, 5], [0, 1, 1])
+    assert np.all(np.abs(pp - [0, 0.4, -1.4]) < 1e-4) and not bt and not par
+    pp, bt, par = pierce([0, 1, 0], [0, 2, -1.0001])
+    assert np.array_equal(pp, [0, 0, 0]) and not bt and par
+    # circle of radius 3, dip = strike = 45 degrees, centre (0,0,1), 7 points, cut by z <= 0 ... expected_circ (:36-40)
+    d2r = np.float32(2.) / np.float32(360.) * np.float32(3.14159265358979)
+    rot = np.zeros((3, 3), np.float32)
+    L.ko_init_euler.argtypes = [C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float)]
+    L.ko_init_euler(C.c_float(d2r * 45), C.c_float(d2r * 45), C.c_float(0), fp(rot))
+    tr = np.ascontiguousarray(rot * np.float32(3.))
+    out = np.zeros((16, 3), np.float32)
+    L.ko_trim_circle.restype = C.c_int
+    n = L.ko_trim_circle(fp(np.array([0, 0, 1], np.float32)), fp(tr), C.c_int(7), fp(np.zeros(3, np.float32)),
+                         fp(np.array([0, 0, -1], np.float32)), fp(out), C.c_int(16))
+    expected = np.array([0.14987442, 2.4953687, 2.6585152, -1.9344299, 0.9903534, 3.0681345, -2.5620692, -1.2604182,
+                         1.9204066, -1.2604178, -2.5620692, 0.07959348, -1.1043297, -2.5185432, 0., 2.3468528,
+                         0.9326396, 0., 2.12132, 2.1213207, 1.0000004], np.float32).reshape(7, 3)
+    assert n == 7 and np.all(np.abs(out[:7] - expected) < 1e-5)
