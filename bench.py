@@ -263,6 +263,13 @@ def main():
                          "kernel": "accumulate_grouped_kernel<10,256>" if os.environ.get("KIWI_HIP_ACCUM") != "direct" else "accumulate_kernel<10>", "launches": int(launches[1]),
                          "avg_launch_ms": float(ms[1]) / max(int(launches[1]), 1),
                          "algorithmic_bytes_per_eval": b_eval,
+                         # the issue-side view: separately rounded fp32 multiplies and adds the kernel has to execute per
+                         # launch (apply: 4 per component and sample and centroid + 8 for the rotation; blend: 7 per
+                         # component and sample and sub-fault) against the packed-fp32 issue rate measured by
+                         # profiles/microbench/pk_rate.hip (256 CUs x 4 SIMDs x 16 lanes x 2 per lane x ~2.3 GHz, no FMA)
+                         "valu": {"achieved_tflops": (ncent * nrec * L * (ng * 4 + 8) + ncent / 5.0 * nrec * L * 1.0625 * ng * 7)
+                                  * args.batch * args.steps / acc_s / 1e12 if acc_s > 0 else 0.0,
+                                  "peak_tflops": 74.0, "unit": "Tflop/s fp32 mul/add, unfused"},
                          "note": "achieved = no-reuse algorithmic bytes (SURVEY 8d) / kernel time; it exceeds the HBM peak because the "
                                  "Green's function tensor is cache resident and every blended tile is reused by the time steps of a "
                                  "sub-fault: `traffic` is what actually crossed the fabric per launch.  The kernel runs against L2->CU "
