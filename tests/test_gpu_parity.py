@@ -733,3 +733,17 @@ def test_all_component_letters():
             lo_p, sp = p.get_synthetics(0, ir + 1, k + 1, 1)
             a, b = max(lo_o, lo_p), min(lo_o + len(so), lo_p + len(sp))
             assert np.max(np.abs(so[a - lo_o:b - lo_o] - sp[a - lo_p:b - lo_p])) <= SYN_RTOL * np.max(np.abs(so))
+
+
+def test_example_inversion_recovers_the_source():
+    """examples/invert_bilateral.py: grid search + bootstrap + LM on noisy synthetic data through the public API."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("invert_bilateral", os.path.join(os.path.dirname(os.path.dirname(__file__)),
+                                                                                    "examples", "invert_bilateral.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    true, grid, res = mod.main(nrec=12, L=512, verbose=False)
+    assert abs(grid.best_source[5] - true[5]) <= 3 and abs(grid.best_source[6] - true[6]) <= 3
+    assert abs(res.params[5] - true[5]) < 1.5 and abs(res.params[6] - true[6]) < 1.5 and abs(res.params[7] - true[7]) < 3
+    assert res.misfit <= grid.get_best_misfit() + 1e-6
