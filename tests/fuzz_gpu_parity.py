@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep (manual: `python tests/fuzz_gpu_parity.py [seconds] [seed]` on a GPU box): random databases,
+receiver sets, interpolation modes, source types, tapers and norms, each compared with the CPU oracle at the tolerances
+of tests/test_gpu_parity.py.  Not collected by pytest; the cases it has found are pinned as regular tests."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from kiwi_amd import synthetic  # noqa: E402
+from tests.common import Scenario, oracle_misfits  # noqa: E402
+
+FAMILIES = ["ac", "rl", "du", "ns", "ew"]            # a component and its negated twin exclude each other (receiver.f90:255-270)
+
+
+def one_case(rng, verbose):
+    ng = int(rng.choice([8, 10]))
+    L = int(rng.choice([96, 200, 256, 700, 1500, 2300]))
+    nrec = int(rng.integers(1, 7))
+    comps = ["".join(str(rng.choice(list(FAMILIES[k]))) for k in rng.choice(5, size=int(rng.integers(1, 4)), replace=False))
+             for _ in range(nrec)]
+    bil = bool(rng.integers(0, 2))
+    variant = str(rng.choice(["probe", "static"]))
+    edt = float(rng.choice([0.5, 1.0]))
+    depths = rng.choice([0., 0., 300., 900.], nrec)
+    sc = Scenario(nx=int(rng.integers(8, 14)), nz=int(rng.integers(4, 7)), ng=ng, L=L, nrec=nrec, variant=variant, bilinear=bil,
+                  effective_dt=edt, comps_list=comps, depths=depths, taper_ramp=float(rng.uniform(2, 12)),
+                  dmin=float(rng.uniform(101e3, 108e3)), dspan=float(rng.uniform(10e3, 30e3)))
+    e = sc.oracle()
+    sc.make_references(e)
+    # tapers: random sub-windows of the references
+    dt = sc.gf["dt"]
+    for ir in range(nrec):
+        lo, d = sc.refs[(ir + 1, 1)]
+        a = (lo + rng.integers(0, max(1, len(d) // 4))) * dt + rng.uniform(0, dt)
+        b = (lo + len(d) - 1 - rng.integers(0, max(1, len(d) // 4))) * dt - rng.uniform(0, dt)
+        r1, r2 = rng.uniform(0.5, 6), rng.uniform(0.5, 6)
+        if b - a > r1 + r2 + 2 * dt:
+            sc.tapers[ir + 1] = ([a, a + r1, b - r2, b], [0., 1., 1., 0.])
+    sc.apply_setup(e, True)
+    p = sc.product()
+    sc.apply_setup(p, False)
+    method = str(rng.choice(["l2norm", "l1norm", "scalar_product", "peak", "floating_l2norm", "floating_l1norm"]))
+    mid = {"l2norm": 1, "l1norm": 2, "scalar_product": 5, "peak": 6, "floating_l2norm": 7, "floating_l1norm": 8}[method]
+    e.set_misfit_method(mid)
+    p.set_misfit_method(method)
+    if mid >= 7:
+        for ir in range(nrec):
+            lo, hi = sorted(int(v) for v in rng.integers(-5, 6, 2))
+            e.set_floating_shiftrange(ir + 1, lo, hi)
+            p.set_floating_shiftrange(ir + 1, lo * dt, hi * dt)
+    if rng.random() < 0.3:
+        xus, zus = int(rng.integers(1, 3)), int(rng.integers(1, 3))
+        e.set_interpolation(bil, xus, zus)
+        p.set_spacial_undersampling(xus, zus)
+    f = float(rng.choice([1.0, 1.0, 0.7]))
+    e.set_synthetics_factor(f)
+    p.set_synthetics_factor(f)
+    stype = int(rng.choice([1, 2, 3, 6]))
+    n = int(rng.integers(1, 9))
+    base = np.array(synthetic.TRUE_BILAT, np.float32)
+    if stype == 1:
+        tr = np.tile(base, (n, 1))
+        tr[:, 5] += rng.uniform(-20, 20, n); tr[:, 6] -= rng.uniform(0, 20, n); tr[:, 3] += rng.uniform(-1500, 1500, n)
+        tr[:, 0] += rng.uniform(-2, 2, n); tr[:, 13] = rng.choice([0., 0.3, 2.], n)
+        if rng.random() < 0.3:
+            tr[:, 9:12] = 0.0                                  # point source
+    elif stype == 2:
+        tr = np.tile(np.array([0, 0, 0, 10000, 5e19, 80, 70, 100, 3000, 3000, 1.5], np.float32), (n, 1))
+        tr[:, 5] += rng.uniform(-20, 20, n); tr[:, 8] = rng.uniform(500, 4000, n)
+    elif stype == 3:
+        tr = np.tile(np.array([0, 0, 0, 10000, 7e18, 1, 0, -1, 1, 1, 1, 20, 10], np.float32), (n, 1))
+        tr[:, 5:11] += rng.standard_normal((n, 6)).astype(np.float32) * 0.3; tr[:, 11] = rng.uniform(3, 25, n)
+    else:
+        same = rng.random() < 0.6                              # runs of geometry-identical sources
+        tr = np.tile(np.array([0, 0, 0, 10000, 1, 0, 0, 0, 0, 0, 1.0], np.float32), (n, 1))
+        tr[:, 4:10] = rng.standard_normal((n, 6)) * 1e18
+        if not same:
+            tr[:, 3] += rng.uniform(-1500, 1500, n); tr[:, 10] = rng.choice([0.4, 1.0, 2.6], n)
+    m, nn, g = oracle_misfits(e, stype, tr)
+    name = {1: "bilateral", 2: "circular", 3: "point_lp", 6: "moment_tensor"}[stype]
+    p.set_source_params(name, tr)
+    p.eval()
+    pm, pn, pg = p.get_misfits()
+    scale = np.maximum(np.abs(m), 1e-6 * np.maximum(nn, 1e-30))
+    tol = 1e-6 if mid not in (5,) else 2e-6
+    bad = np.abs(pm - m) > tol * scale
+    ok = np.array_equal(pn[0], nn[0]) and not bad.any()
+    if verbose or not ok:
+        print("%s ng=%d L=%d nrec=%d comps=%s bil=%d %s edt=%.1f %s x%d method=%s factor=%.1f -> worst %.2e (median misfit / norm %.3f)"
+              % ("ok " if ok else "BAD", ng, L, nrec, comps, bil, variant, edt, name, n, method, f,
+                 float(np.max(np.abs(pm - m) / scale)), float(np.median(np.abs(m) / np.maximum(nn, 1e-30)))))
+    p.close()
+    e.close()
+    sc.odb.close()
+    return ok
+
+
+def main():
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 20261002
+    rng = np.random.default_rng(seed)
+    t0 = time.time()
+    n = nbad = 0
+    while time.time() - t0 < seconds:
+        ok = one_case(rng, verbose=(n < 5))
+        n += 1
+        nbad += 0 if ok else 1
+    print("fuzz: %d cases, %d bad, seed %d" % (n, nbad, seed))
+    sys.exit(1 if nbad else 0)
+
+
+if __name__ == "__main__":
+    main()
