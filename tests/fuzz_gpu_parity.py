@@ -58,7 +58,7 @@ def one_case(rng, verbose):
     f = float(rng.choice([1.0, 1.0, 0.7]))
     e.set_synthetics_factor(f)
     p.set_synthetics_factor(f)
-    stype = int(rng.choice([1, 2, 3, 6]))
+    stype = int(rng.choice([1, 2, 3, 4, 5, 6]))
     n = int(rng.integers(1, 9))
     base = np.array(synthetic.TRUE_BILAT, np.float32)
     if stype == 1:
@@ -79,8 +79,38 @@ def one_case(rng, verbose):
         tr[:, 4:10] = rng.standard_normal((n, 6)) * 1e18
         if not same:
             tr[:, 3] += rng.uniform(-1500, 1500, n); tr[:, 10] = rng.choice([0.4, 1.0, 2.6], n)
-    m, nn, g = oracle_misfits(e, stype, tr)
-    name = {1: "bilateral", 2: "circular", 3: "point_lp", 6: "moment_tensor"}[stype]
+    name = {1: "bilateral", 2: "circular", 3: "point_lp", 4: "eikonal", 5: "mt_eikonal", 6: "moment_tensor"}[stype]
+    if stype in (4, 5):
+        from oracle import ko
+        nz = sc.gf["data"].shape[1]
+        cp = np.array([[0, 0, 6500.], [0, 0, 6000. + (nz - 1) * 2000. - 500.]], np.float32)
+        cn = np.array([[0, 0, -1.], [0, 0, 1.]], np.float32)
+        n = min(n, 3)
+        tr = []
+        for i in range(n):
+            common = [rng.uniform(-1, 1), rng.uniform(-500, 500), rng.uniform(-500, 500), rng.uniform(8000, 11000)]
+            bord = [rng.uniform(-300, 300), rng.uniform(-300, 300), rng.uniform(1500, 4000)]
+            nukl = [rng.uniform(-400, 400), rng.uniform(-300, 300)]
+            if stype == 5:
+                tr.append(common + [1.0, rng.uniform(0, 360), rng.uniform(40, 90)] + bord + nukl + [rng.uniform(0.7, 1.0)]
+                          + list(rng.standard_normal(6) * 1e18) + [float(rng.choice([0., 1.2]))])
+            else:
+                tr.append(common + [5e18, rng.uniform(0, 360), rng.uniform(40, 90), rng.uniform(-180, 180)] + bord + nukl
+                          + [rng.uniform(0.7, 1.0), float(rng.choice([0., 1.2]))])
+        tr = np.array(tr, np.float32)
+        prof = synthetic.SYNTH_CRUST
+        oprof = ko.crust_profile(prof[0:8], prof[8:16], prof[16:24], prof[24:31])
+        p.set_source_crust(prof, prof)
+        p.set_source_constraints(cp, cn)
+        ms, ns, gs = [], [], []
+        for t in tr:
+            c, mo, ri, _ = ko.discretize_eikonal(stype, t, edt, oprof, cp, cn)
+            e.set_centroids(c, mo, ri)
+            a, b, cglob = e.get_misfits()
+            ms.append(a); ns.append(b); gs.append(cglob)
+        m, nn, g = np.array(ms), np.array(ns), np.array(gs, np.float32)
+    else:
+        m, nn, g = oracle_misfits(e, stype, tr)
     p.set_source_params(name, tr)
     p.eval()
     pm, pn, pg = p.get_misfits()
