@@ -536,6 +536,9 @@ void prepare_fft(kiwi_hip_ctx *c, const std::vector<float> &reft_host)
         if (ntr[m] < cd.wlen) ntr[m] = next_pow2(cd.wlen);
         cd.ntrans = ntr[m];
         cd.fft_row = rows_of[ntr[m]]++;
+        if (std::getenv("KIWI_HIP_DEBUG"))
+            std::fprintf(stderr, "kiwi_hip: slot %zu rec %d: ref [%d,%d] syn [%d,%d] window [%d,%d] ntrans %d\n", m, cd.rec + 1, f0, f1, s0, s1,
+                         cd.w0, cd.w0 + cd.wlen - 1, ntr[m]);
     }
     // ---- 3. groups and capacities
     c->fft_groups.clear();

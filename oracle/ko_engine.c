@@ -208,6 +208,14 @@ void ko_engine_set_floating_shiftrange(ko_engine *e, int irec1, int lo, int hi)
     e->receivers[irec1 - 1].floating_shiftrange[1] = hi;
 }
 
+/* probe bookkeeping for diagnostics: out = span(1:2), dataspan(1:2) of the reference (which = 0) or synthetic probe */
+void ko_engine_probe_spans(ko_engine *e, int irec1, int icomp1, int which, int out[4])
+{
+    ko_receiver *r = &e->receivers[irec1 - 1];
+    ko_probe *p = which ? &r->syn_probes[icomp1 - 1] : &r->ref_probes[icomp1 - 1];
+    out[0] = p->span[0]; out[1] = p->span[1]; out[2] = p->dataspan[0]; out[3] = p->dataspan[1];
+}
+
 /* receiver_shift_ref_seismogram, receiver.f90:800-814 (shift in samples) */
 void ko_engine_shift_ref_seismogram(ko_engine *e, int irec1, int ishift)
 {
