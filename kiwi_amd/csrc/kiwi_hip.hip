@@ -810,6 +810,11 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
     }
     record(c, 2, e3);
     HIPCHECK(hipGetLastError());
+    if (c->events.size() >= 3 * 2048) {               // nobody reads the timings: recycle instead of growing without bound
+        HIPCHECK(hipStreamSynchronize(c->stream));
+        for (auto &ev : c->events) { if (ev.kind == 0) c->event_pool.push_back(ev.a); c->event_pool.push_back(ev.b); }
+        c->events.clear();
+    }
     c->events.push_back({ e0, e1, 0 });
     c->events.push_back({ e1, e2, 1 });
     c->events.push_back({ e2, e3, 2 });

@@ -747,3 +747,18 @@ def test_example_inversion_recovers_the_source():
     assert abs(grid.best_source[5] - true[5]) <= 3 and abs(grid.best_source[6] - true[6]) <= 3
     assert abs(res.params[5] - true[5]) < 1.5 and abs(res.params[6] - true[6]) < 1.5 and abs(res.params[7] - true[7]) < 3
     assert res.misfit <= grid.get_best_misfit() + 1e-6
+
+
+def test_many_small_evaluations_recycle_timing_events():
+    """Thousands of evaluations without anybody reading kernel_ms(): the event list is recycled, results stay right."""
+    sc = Scenario(nrec=2, L=96)
+    e, p = build(sc)
+    trials = synthetic.bilat_strike_sweep(2, step=3.0)
+    m, n, g = oracle_misfits(e, 1, trials)
+    p.set_source_params("bilateral", trials)
+    for _ in range(2500):
+        p.eval()
+    pm, pn, pg = p.get_misfits()
+    assert misfit_close(pm, m) and misfit_close(pg, g)
+    ms, launches = p.kernel_ms()
+    assert 0 < launches[1] < 2500
