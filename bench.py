@@ -164,7 +164,7 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
                     help="BASELINE.json configs[1..4]; cfg3 (default) is the one the metric is quoted on")
     ap.add_argument("--batch", type=int, default=0,
-                    help="trial sources per GPU per step (default: 12960 cfg2, 256 cfg3/cfg5, 32 cfg4)")
+                    help="trial sources per GPU per step (default: 12960 cfg2, 256 cfg3/cfg5, 128 cfg4)")
     ap.add_argument("--samples", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -185,7 +185,7 @@ def main():
     from kiwi_amd.shard import shard_range, gather_misfits
     from kiwi_amd import synthetic
     if args.batch <= 0:
-        args.batch = {"cfg2": 12960, "cfg3": 256, "cfg4": 32, "cfg5": 256}[args.workload]
+        args.batch = {"cfg2": 12960, "cfg3": 256, "cfg4": 128, "cfg5": 256}[args.workload]
     lo, hi = shard_range(args.batch * ngpus, ngpus, rank)
     wl = synthetic.workload(args.workload, hi - lo, lo)
     p, gf, recv, refs, tapers, ncent = setup_product(local_rank, wl, args.samples)
