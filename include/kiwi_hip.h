@@ -163,6 +163,9 @@ int kiwi_hip_get_misfits(kiwi_hip_ctx *ctx, int isrc0, int nsrc, float *misfit, 
 int kiwi_hip_set_keep_synthetics(kiwi_hip_ctx *ctx, int which);
 int kiwi_hip_get_synthetics(kiwi_hip_ctx *ctx, int isrc, int irec, int icomp, int which,
                             int *first, int *n, float *out, int maxn);
+/* the reference probe the same way (output_seismograms ... references plain|tapered|filtered, receiver.f90:618-680):
+ * plain = the data as set, tapered / filtered = over the comparator window */
+int kiwi_hip_get_reference(kiwi_hip_ctx *ctx, int irec, int icomp, int which, int *first, int *n, float *out, int maxn);
 
 /* ---- measurement / inspection ---- */
 /* HIP-event durations [ms] of the last kiwi_hip_eval on the context stream:

@@ -1491,6 +1491,43 @@ int kiwi_hip_autoshift_ref_seismogram(kiwi_hip_ctx *c, int irec, float min_shift
     GUARD_END(c)
 }
 
+int kiwi_hip_get_reference(kiwi_hip_ctx *c, int irec, int icomp, int which, int *first, int *n, float *out, int maxn)
+{
+    GUARD_BEGIN
+    if (which < 1 || which > 3) throw std::runtime_error("which must be 1 (plain), 2 (tapered) or 3 (filtered)");
+    if (irec < 1 || irec > (int)c->recv.size()) throw std::runtime_error("receiver index out of range");
+    const Receiver &r = c->recv[irec - 1];
+    if (icomp < 1 || icomp > r.ncomp) throw std::runtime_error("component index out of range");
+    if (which == 1) {                                  // the data as set (and shifted), comparator.f90:350-372
+        const auto &rf = r.ref[icomp - 1];
+        if (rf.data.empty()) throw std::runtime_error("no reference seismogram set");
+        *first = rf.first; *n = (int)rf.data.size();
+        std::memcpy(out, rf.data.data(), (size_t)std::min(*n, maxn) * sizeof(float));
+        return 0;
+    }
+    HIPCHECK(hipSetDevice(c->device));
+    prepare(c);
+    if (c->synth_only) throw std::runtime_error("no reference seismogram set");
+    int slot = -1, k = 0;
+    for (size_t i = 0; i < c->comps.size(); i++) if (c->comps[i].rec == irec - 1) { if (k == icomp - 1) { slot = (int)i; break; } k++; }
+    if (slot < 0) throw std::runtime_error("receiver disabled");
+    const CompDev &cd = c->comps[slot];
+    *first = cd.w0; *n = cd.wlen;
+    const int m = std::min(cd.wlen, maxn);
+    if (which == 2) {                                  // over the comparator window, tapered (:1173-1184)
+        std::memcpy(out, c->reft_h.data() + cd.refofs, (size_t)m * sizeof(float));
+    } else {                                           // filtered and cut to the taper (:1233-1263): device pipeline output
+        if (!c->any_filter || c->method == KIWI_AMPSPEC_L2NORM || c->method == KIWI_AMPSPEC_L1NORM)
+            throw std::runtime_error("filtered references need a misfit filter and a time-domain norm");
+        if (c->nsrc == 0) throw std::runtime_error("no source set (the transform length follows the synthetics)");
+        if (!c->fft_ready) prepare_fft(c, c->reft_h);
+        HIPCHECK(hipStreamSynchronize(c->stream));
+        HIPCHECK(hipMemcpy(out, c->reffilt_d.p + cd.refofs, (size_t)m * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return 0;
+    GUARD_END(c)
+}
+
 int kiwi_hip_get_kernel_ms(kiwi_hip_ctx *c, float ms[4], int launches[3])
 {
     GUARD_BEGIN

@@ -274,6 +274,14 @@ class Engine:
                                                 _fp(out), maxn), "output_seismograms")
         return first.value, out[:n.value].copy()
 
+    def get_reference(self, irec, icomp, which=1, maxn=1 << 20):
+        """(first sample index, samples) of a reference probe: 1 plain, 2 tapered, 3 filtered."""
+        first, n = C.c_int(), C.c_int()
+        buf = np.zeros(maxn, np.float32)
+        self._ck(self.L.kiwi_hip_get_reference(self.h, irec, icomp, which, C.byref(first), C.byref(n), _fp(buf), maxn),
+                 "output_seismograms")
+        return first.value, buf[:min(n.value, maxn)].copy()
+
     def kernel_ms(self):
         ms = np.zeros(4, np.float32)
         ln = np.zeros(3, np.int32)

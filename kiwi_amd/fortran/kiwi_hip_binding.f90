@@ -259,6 +259,15 @@ module kiwi_hip_binding
             real(c_float), intent(out) :: out(*)
         end function
 
+        integer(c_int) function kiwi_hip_get_reference( ctx, irec, icomp, which, first, n, out, maxn ) &
+                bind(C, name='kiwi_hip_get_reference')
+            import :: c_int, c_ptr, c_float
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: irec, icomp, which, maxn
+            integer(c_int), intent(out) :: first, n
+            real(c_float), intent(out) :: out(*)
+        end function
+
         integer(c_int) function kiwi_hip_get_receiver_geometry( ctx, irec, azi, bazi, dist ) &
                 bind(C, name='kiwi_hip_get_receiver_geometry')
             import :: c_int, c_ptr, c_double

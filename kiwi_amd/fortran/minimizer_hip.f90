@@ -825,6 +825,7 @@ program minimizer_hip
         character(len=maxline) :: r1, r2, fmt_, probe, proc
         integer(c_int) :: which, first, n
         integer :: irec, k, unit, ios, i
+        logical :: refs
         real(c_float), allocatable :: d(:)
         ok_ = .false.
         call split_first( a, base, r1 )
@@ -833,19 +834,27 @@ program minimizer_hip
         if (trim(fmt_) /= 'table') then
             call fail( 'only the table format is available in this host' ); return
         end if
-        if (trim(probe) == 'references') then
-            call fail( 'only synthetics can be written by this host' ); return
+        refs = (trim(probe) == 'references')
+        if (.not. refs .and. trim(probe) /= 'synthetics') then
+            call fail( 'unknown probe: '//trim(probe) ); return
         end if
         which = 1
         if (trim(proc) == 'tapered') which = 2
         if (trim(proc) == 'filtered') which = 3
-        if (.not. update_misfits()) return
+        if (.not. refs .or. which == 3) then
+            if (.not. update_misfits()) return
+        end if
         allocate( d(1048576) )
         do irec = 1, nreceivers
             if (.not. enabled(irec)) cycle
             do k = 1, len_trim(components(irec))
-                if (.not. check( kiwi_hip_get_synthetics( ctx, 0_c_int, int(irec,c_int), int(k,c_int), which, first, n, &
-                                                          d, 1048576_c_int ) )) return
+                if (refs) then
+                    if (.not. check( kiwi_hip_get_reference( ctx, int(irec,c_int), int(k,c_int), which, first, n, &
+                                                             d, 1048576_c_int ) )) return
+                else
+                    if (.not. check( kiwi_hip_get_synthetics( ctx, 0_c_int, int(irec,c_int), int(k,c_int), which, first, n, &
+                                                              d, 1048576_c_int ) )) return
+                end if
                 write (fn,'(a,a,i0,a,a,a)') trim(base), '-', irec, '-', components(irec)(k:k), '.table'
                 open( newunit=unit, file=trim(fn), status='unknown', iostat=ios )
                 if (ios /= 0) then

@@ -233,6 +233,7 @@ void ko_engine_set_misfit_method(ko_engine *e, int method);
 void ko_engine_set_synthetics_factor(ko_engine *e, float f);
 void ko_engine_set_floating_shiftrange(ko_engine *e, int irec1, int lo, int hi);
 int ko_engine_get_floating_shift(ko_engine *e, int irec1);
+int ko_engine_get_reference(ko_engine *e, int irec1, int icomp1, int which, int *lo, float *out, int maxn);
 void ko_engine_probe_spans(ko_engine *e, int irec1, int icomp1, int which, int out[4]);
 void ko_engine_shift_ref_seismogram(ko_engine *e, int irec1, int ishift);
 int ko_engine_autoshift_ref_seismogram(ko_engine *e, int irec1, int lo, int hi);

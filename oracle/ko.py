@@ -377,6 +377,14 @@ class Engine:
         n = lib().ko_engine_get_synthetic(self.h, irec1, icomp1, which, C.byref(lo), _fp(out), maxn)
         return lo.value, out[:n].copy()
 
+    def reference(self, irec1, icomp1, which=1, maxn=1 << 20):
+        out = np.zeros(maxn, np.float32)
+        lo = C.c_int()
+        L = lib()
+        L.ko_engine_get_reference.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), c_float_p, C.c_int]
+        n = L.ko_engine_get_reference(self.h, irec1, icomp1, which, C.byref(lo), _fp(out), maxn)
+        return lo.value, out[:n].copy()
+
     def centroid_geometry(self, irec1, ncent, dtype):
         """GeoRec-compatible records of the current centroid table at receiver irec1."""
         out = np.zeros(ncent, dtype)

@@ -609,3 +609,9 @@ int ko_engine_get_synthetic(ko_engine *e, int irec1, int icomp1, int which, int 
 {
     return ko_probe_get(&e->receivers[irec1 - 1].syn_probes[icomp1 - 1], which, lo, out, maxn);
 }
+
+/* the reference probe the same way (receiver_output_seismogram with which_probe = REFERENCES, receiver.f90:618-680) */
+int ko_engine_get_reference(ko_engine *e, int irec1, int icomp1, int which, int *lo, float *out, int maxn)
+{
+    return ko_probe_get(&e->receivers[irec1 - 1].ref_probes[icomp1 - 1], which, lo, out, maxn);
+}

@@ -762,3 +762,31 @@ def test_many_small_evaluations_recycle_timing_events():
     assert misfit_close(pm, m) and misfit_close(pg, g)
     ms, launches = p.kernel_ms()
     assert 0 < launches[1] < 2500
+
+
+def test_reference_probes_plain_tapered_filtered():
+    """output_seismograms ... references plain|tapered|filtered (receiver.f90:618-680) against the oracle's probes."""
+    sc = Scenario(nrec=3, comps_list=["ned", "d", "ne"])
+    e, p = build(sc)
+    fx, fy = [0.02, 0.04, 0.15, 0.3], [0., 1., 1., 0.]
+    for ir in range(3):
+        e.set_filter(ir + 1, fx, fy)
+        p.set_misfit_filter(ir + 1, fx, fy)
+    trial = synthetic.bilat_strike_sweep(1, step=2.0)
+    e.set_source_params(1, trial[0])
+    e.get_misfits()
+    p.set_source_params("bilateral", trial)
+    p.eval()
+    for ir, comps in enumerate(sc.comps):
+        for k in range(len(comps)):
+            lo0, d0 = sc.refs[(ir + 1, k + 1)]
+            lo, d = p.get_reference(ir + 1, k + 1, 1)
+            assert lo == lo0 and np.array_equal(d, d0)
+            for which, tol in ((2, 0.0), (3, 2e-5)):
+                lo_p, dp = p.get_reference(ir + 1, k + 1, which)
+                lo_o, do = e.reference(ir + 1, k + 1, which)
+                a, b = max(lo_o, lo_p), min(lo_o + len(do), lo_p + len(dp))
+                assert b - a >= len(dp) - 1
+                assert np.max(np.abs(do[a - lo_o:b - lo_o] - dp[a - lo_p:b - lo_p])) <= tol * np.max(np.abs(do)) + 0.0
+    with pytest.raises(KiwiHipError):
+        p.get_reference(1, 9, 1)

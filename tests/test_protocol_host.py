@@ -172,6 +172,16 @@ def test_protocol_host_matches_python_host_and_oracle(host, tmp_path):
         assert one != unfiltered and one != filtered_all
         with pytest.raises(protocol.SeismosizerReturnedError, match="receiver index out of range"):
             p.do("set_misfit_taper", 0, 0, 0, 1, 1)
+        # the reference probes can be written too (receiver.f90:618-680)
+        p.do("output_seismograms", str(tmp_path / "refout"), "table", "references", "plain")
+        t, v = protocol.read_table(str(tmp_path / "refout-1-n.table"))
+        lo, d = sc.refs[(1, 1)]
+        assert len(v) == len(d) and np.allclose(v, d, rtol=2e-7, atol=0)       # eight significant digits in the table
+        p.do("output_seismograms", str(tmp_path / "reftap"), "table", "references", "tapered")
+        t2, v2 = protocol.read_table(str(tmp_path / "reftap-1-n.table"))
+        assert abs(v2[0]) == 0.0 and np.max(np.abs(v2)) <= np.max(np.abs(d)) * (1 + 1e-6)
+        with pytest.raises(protocol.SeismosizerReturnedError, match="unknown probe"):
+            p.do("output_seismograms", str(tmp_path / "x"), "table", "nonsense", "plain")
     finally:
         p.close()
 
