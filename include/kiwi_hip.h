@@ -138,6 +138,9 @@ int kiwi_hip_discretize_eikonal(int sourcetype, const float *params, int nparams
  * moment / risetime = psm%moment / psm%risetime per source (parameterized_source.f90:70-71) */
 int kiwi_hip_set_sources(kiwi_hip_ctx *ctx, int nsrc, const int *cent_ofs, const float *cent,
                          const float *moment, const float *risetime);
+/* the centroid table of uploaded source isrc as the engine holds it (output_source_model writes it to
+ * <base>-dsm.table, minimizer_engine.f90:947-977); cent == NULL or maxcent <= 0 only returns the count */
+int kiwi_hip_get_source_centroids(kiwi_hip_ctx *ctx, int isrc, int maxcent, int *ncent, float *cent);
 /* set_source_params for a whole batch (minimizer_engine.f90:500-523): params[nsrc][nparams] in
  * wire order; discretised on the host with the current effective dt, then uploaded */
 int kiwi_hip_set_sources_params(kiwi_hip_ctx *ctx, int sourcetype, int nsrc, const float *params);

@@ -1491,6 +1491,22 @@ int kiwi_hip_autoshift_ref_seismogram(kiwi_hip_ctx *c, int irec, float min_shift
     GUARD_END(c)
 }
 
+int kiwi_hip_get_source_centroids(kiwi_hip_ctx *c, int isrc, int maxcent, int *ncent, float *cent)
+{
+    GUARD_BEGIN
+    if (isrc < 0 || isrc >= c->nsrc) throw std::runtime_error("source index out of range");
+    HIPCHECK(hipSetDevice(c->device));
+    const int c0 = c->cent_ofs[isrc], nc = c->cent_ofs[isrc + 1] - c0;
+    *ncent = nc;
+    if (cent && maxcent > 0) {
+        if (nc > maxcent) throw std::runtime_error("centroid buffer too small");
+        HIPCHECK(hipStreamSynchronize(c->stream));
+        HIPCHECK(hipMemcpy(cent, c->cent_d.p + (size_t)c0 * 10, (size_t)nc * 10 * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return 0;
+    GUARD_END(c)
+}
+
 int kiwi_hip_get_reference(kiwi_hip_ctx *c, int irec, int icomp, int which, int *first, int *n, float *out, int maxn)
 {
     GUARD_BEGIN

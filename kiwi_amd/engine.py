@@ -274,6 +274,14 @@ class Engine:
                                                 _fp(out), maxn), "output_seismograms")
         return first.value, out[:n.value].copy()
 
+    def get_source_centroids(self, isrc=0):
+        """The discretised source the engine holds for trial `isrc`: centroids[n, 10] (`output_source_model`)."""
+        n = C.c_int()
+        self._ck(self.L.kiwi_hip_get_source_centroids(self.h, isrc, 0, C.byref(n), None), "output_source_model")
+        cent = np.zeros((n.value, 10), np.float32)
+        self._ck(self.L.kiwi_hip_get_source_centroids(self.h, isrc, n.value, C.byref(n), _fp(cent)), "output_source_model")
+        return cent
+
     def get_reference(self, irec, icomp, which=1, maxn=1 << 20):
         """(first sample index, samples) of a reference probe: 1 plain, 2 tapered, 3 filtered."""
         first, n = C.c_int(), C.c_int()

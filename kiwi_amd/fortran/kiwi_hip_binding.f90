@@ -259,6 +259,21 @@ module kiwi_hip_binding
             real(c_float), intent(out) :: out(*)
         end function
 
+        integer(c_int) function kiwi_hip_get_source_centroids( ctx, isrc, maxcent, ncent, cent ) &
+                bind(C, name='kiwi_hip_get_source_centroids')
+            import :: c_int, c_ptr, c_float
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: isrc, maxcent
+            integer(c_int), intent(out) :: ncent
+            real(c_float), intent(out) :: cent(10,*)
+        end function
+
+        integer(c_int) function kiwi_hip_get_device_bytes( ctx, bytes ) bind(C, name='kiwi_hip_get_device_bytes')
+            import :: c_int, c_ptr, c_long_long
+            type(c_ptr), value :: ctx
+            integer(c_long_long), intent(out) :: bytes
+        end function
+
         integer(c_int) function kiwi_hip_get_reference( ctx, irec, icomp, which, first, n, out, maxn ) &
                 bind(C, name='kiwi_hip_get_reference')
             import :: c_int, c_ptr, c_float

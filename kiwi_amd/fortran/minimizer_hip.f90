@@ -220,6 +220,9 @@ program minimizer_hip
         case ('get_global_misfit');         call do_get_misfits( .true., ok_ )
         case ('output_seismograms');        call do_output_seismograms( a, ok_ )
         case ('output_distances');          call do_output_distances( a, ok_ )
+        case ('output_source_model');       call do_output_source_model( a, ok_ )
+        case ('get_cached_traces_memory');  call do_get_cached_traces_memory( ok_ )
+        case ('set_cached_traces_memory_limit'); ok_ = .true.      ! the database is resident on the device: nothing to limit
         case ('eval_sources');              call do_eval_sources( a, ok_ )
         case ('set_verbose', 'set_ignore_sigint'); ok_ = .true.
         case default
@@ -890,6 +893,55 @@ program minimizer_hip
             write (unit,*) 360./2./pi*(dist/earthradius), dist, 360./2./pi*azi
         end do
         close( unit )
+        ok_ = .true.
+    end subroutine
+
+  ! output_source_model filenamebase (minimizer.f90:1226-1262, minimizer_engine.f90:947-977): <base>-tdsm.info and the
+  ! centroid table <base>-dsm.table (north east depth time mxx myy mzz mxy mxz myz)
+    subroutine do_output_source_model( a, ok_ )
+        character(len=*), intent(in) :: a
+        logical, intent(out) :: ok_
+        integer(c_int) :: nc
+        real(c_float), allocatable :: cent(:,:)
+        real(c_float) :: dummy(10,1)
+        integer :: unit, ios, i
+        ok_ = .false.
+        if (.not. need_ctx()) return
+        if (.not. source_set) then
+            call fail( 'no source set' ); return
+        end if
+        if (.not. check( kiwi_hip_get_source_centroids( ctx, 0_c_int, 0_c_int, nc, dummy ) )) return
+        allocate( cent(10,max(nc,1)) )
+        if (.not. check( kiwi_hip_get_source_centroids( ctx, 0_c_int, nc, nc, cent ) )) return
+        open( newunit=unit, file=trim(a)//'-tdsm.info', status='unknown', iostat=ios )
+        if (ios /= 0) then
+            call fail( 'failed to open output file: '//trim(a)//'-tdsm.info' ); return
+        end if
+        write (unit,'(a)') 'ncentroids'
+        write (unit,*) nc
+        write (unit,*)
+        close( unit )
+        open( newunit=unit, file=trim(a)//'-dsm.table', status='unknown', iostat=ios )
+        if (ios /= 0) then
+            call fail( 'failed to open output file: '//trim(a)//'-dsm.table' ); return
+        end if
+        do i = 1, nc
+            write (unit,'(10(1x,es15.8e2))') cent(:,i)     ! one record per centroid, nine significant digits
+        end do
+        close( unit )
+        ok_ = .true.
+    end subroutine
+
+  ! get_cached_traces_memory (minimizer.f90:1141-1163): here the bytes the engine holds on the device
+    subroutine do_get_cached_traces_memory( ok_ )
+        logical, intent(out) :: ok_
+        integer(c_long_long) :: bytes
+        character(len=32) :: buffer
+        ok_ = .false.
+        if (.not. need_ctx()) return
+        if (.not. check( kiwi_hip_get_device_bytes( ctx, bytes ) )) return
+        write (buffer,'(i0)') bytes
+        answer = trim(buffer)
         ok_ = .true.
     end subroutine
 

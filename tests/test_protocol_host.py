@@ -182,6 +182,15 @@ def test_protocol_host_matches_python_host_and_oracle(host, tmp_path):
         assert abs(v2[0]) == 0.0 and np.max(np.abs(v2)) <= np.max(np.abs(d)) * (1 + 1e-6)
         with pytest.raises(protocol.SeismosizerReturnedError, match="unknown probe"):
             p.do("output_seismograms", str(tmp_path / "x"), "table", "nonsense", "plain")
+        # output_source_model: the centroid table the engine holds (minimizer_engine.f90:947-977)
+        p.do("output_source_model", str(tmp_path / "sm"))
+        tab = np.loadtxt(str(tmp_path / "sm-dsm.table"), dtype=np.float32, ndmin=2)
+        ocent = ko.discretize(1, np.asarray(trials[1], np.float32), sc.effective_dt)[0]
+        assert tab.shape == ocent.shape and np.array_equal(tab, ocent)
+        info = open(str(tmp_path / "sm-tdsm.info")).read().split()
+        assert info[0] == "ncentroids" and int(info[1]) == len(ocent)
+        assert int(p.do("get_cached_traces_memory")) > 0
+        p.do("set_cached_traces_memory_limit", 1000000)
     finally:
         p.close()
 
