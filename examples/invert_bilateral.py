@@ -62,8 +62,8 @@ def main(nrec=24, L=1024, noise=0.05, seed=1, verbose=True):
               % (len(grid.sources), t_grid, len(grid.bootstrap_sources), best[5], best[6], best[7], grid.get_best_misfit()))
         for name, st in grid.stats.items():
             print("   %-10s best %7.2f   bootstrap mean %7.2f +- %.2f" % (name, st.best, st.mean, st.std))
-        print("LM:   %d forward evaluations in %d device batches, %.3f s; strike/dip/rake/depth %.2f/%.2f/%.2f/%.0f, misfit %.4f"
-              % (res.iterations, res.nbatches, t_lm, res.params[5], res.params[6], res.params[7], res.params[3], res.misfit))
+        print("LM:   %d forward evaluations (Jacobians batched), %.3f s; strike/dip/rake/depth %.2f/%.2f/%.2f/%.0f, misfit %.4f"
+              % (res.iterations, t_lm, res.best[5], res.best[6], res.best[7], res.best[3], res.misfit))
         print("true: strike/dip/rake/depth %.2f/%.2f/%.2f/%.0f" % (true[5], true[6], true[7], true[3]))
     e.close()
     return true, grid, res

@@ -145,6 +145,23 @@ int kiwi_hip_get_source_centroids(kiwi_hip_ctx *ctx, int isrc, int maxcent, int 
  * wire order; discretised on the host with the current effective dt, then uploaded */
 int kiwi_hip_set_sources_params(kiwi_hip_ctx *ctx, int sourcetype, int nsrc, const float *params);
 
+/* minimize_lm (minimizer_engine.f90:728-874; sminpack/lmdif.f in fp32 with the reference's settings: ftol = xtol =
+ * sqrt(spmpar(1)), gtol = 0, maxfev = 500 (n + 1), mode 2 with diag = 1, factor 0.01) over the parameters with
+ * mask[i] != 0 (set_source_params_mask), starting at params[nparams].  mins / maxs: limits of the FREE parameters in
+ * physical units or both NULL (set_source_subparams_limits, :580-611; :820-842).  Each forward-difference Jacobian is
+ * ONE batched evaluation of n sources.  On return params = the source of the LAST forward step -- what the reference
+ * leaves in psm and reports through get_source_subparams --, misfit = its global misfit, iterations = forward steps,
+ * info as lmdif (8 reported as 4, :796); best (may be NULL) = lmdif's accepted iterate in physical units. */
+int kiwi_hip_minimize_lm(kiwi_hip_ctx *ctx, int sourcetype, float *params, const int *mask, const float *mins,
+                         const float *maxs, int *info, int *iterations, float *misfit, float *best);
+
+/* The optimiser underneath, usable with any residual function: sminpack/lmdif.f in fp32, the n forward differences of
+ * a Jacobian requested as ONE call.  fcn gets k points xs[k][n] (it may modify them in place, as lm_forward_step clamps
+ * its argument) and fills fv[k][m]; a negative return aborts and becomes *info.  No device involved. */
+typedef int (*kiwi_hip_residual_fn)(void *user, int k, int m, int n, float *xs, float *fv);
+int kiwi_hip_lmdif(kiwi_hip_residual_fn fcn, void *user, int m, int n, float *x, float *fvec, float ftol, float xtol,
+                   float gtol, int maxfev, float epsfcn, float *diag, int mode, float factor, int *info, int *nfev);
+
 /* ---- the hot path: calculate_seismograms + scale_seismograms + calculate_misfits for
  * sources [isrc0, isrc0+nsrc) of the uploaded batch.  Asynchronous on the context's HIP
  * stream; results stay on the device until fetched. */

@@ -7,6 +7,7 @@
 #include "../../include/kiwi_hip.h"
 #include "kiwi_host.hpp"
 #include "kiwi_host_eikonal.hpp"
+#include "kiwi_host_lm.hpp"
 #include "kiwi_kernels.hpp"
 
 #include <hip/hip_runtime.h>
@@ -1321,6 +1322,106 @@ int kiwi_hip_set_sources_params(kiwi_hip_ctx *c, int sourcetype, int nsrc, const
         mom[s] = ds[s].moment; rise[s] = ds[s].risetime;
     }
     return kiwi_hip_set_sources(c, nsrc, ofs.data(), cent.data(), mom.data(), rise.data());
+    GUARD_END(c)
+}
+
+// psm_params_norm_* (source_bilat.f90:45-46, source_circular.f90:44-45, source_point_lp.f90:54-55, source_eikonal.f90:48-49,
+// source_mt_eikonal.f90:48-50, source_moment_tensor.f90:42-43)
+static const std::vector<float> &params_norm(int sourcetype)
+{
+    static const std::vector<float> none, norm[7] = {
+        {},
+        { 1.f, 10000.f, 10000.f, 10000.f, 7e18f, 360.f, 90.f, 360.f, 360.f, 10000.f, 10000.f, 10000.f, 3000.f, 1.f },
+        { 1.f, 10000.f, 10000.f, 10000.f, 7e18f, 360.f, 90.f, 360.f, 10000.f, 3000.f, 1.f },
+        { 1.f, 10000.f, 10000.f, 10000.f, 7e18f, 1.f, 0.f, -1.f, 1.f, 1.f, 1.f, 20.f, 1.f },
+        { 1.f, 10000.f, 10000.f, 10000.f, 7e18f, 360.f, 90.f, 360.f, 10000.f, 10000.f, 10000.f, 360.f, 10000.f, 1.f, 1.f },
+        { 1.f, 10000.f, 10000.f, 10000.f, 7e18f, 360.f, 90.f, 10000.f, 10000.f, 10000.f, 360.f, 10000.f, 1.f, 7e18f, 7e18f,
+          7e18f, 7e18f, 7e18f, 7e18f, 1.f },
+        { 1.f, 10000.f, 10000.f, 10000.f, 7e18f, 7e18f, 7e18f, 7e18f, 7e18f, 7e18f, 1.f },
+    };
+    return sourcetype >= 1 && sourcetype <= 6 ? norm[sourcetype] : none;
+}
+
+int kiwi_hip_lmdif(kiwi_hip_residual_fn fcn, void *user, int m, int n, float *x, float *fvec, float ftol, float xtol, float gtol,
+                   int maxfev, float epsfcn, float *diag, int mode, float factor, int *info, int *nfev)
+{
+    try {
+        lm::Fcn f = [&](int k, float *xs, float *fv) { return fcn(user, k, m, n, xs, fv); };
+        *info = lm::lmdif(f, m, n, x, fvec, ftol, xtol, gtol, maxfev, epsfcn, diag, mode, factor, *nfev);
+        return 0;
+    } catch (...) { return -1; }
+}
+
+// minimize_lm (minimizer_engine.f90:728-874): lmdif over the masked, normalised parameters; every forward step is
+// lm_forward_step (:806-872): clamp to the limits with a penalty factor on the residuals, psm_set_subparams through the
+// normalised copy of ALL parameters (source_all.f90:377-425, so unmasked ones go through (p / norm) * norm as well),
+// update_misfits.  The n forward steps of a Jacobian are one batch on the device.
+int kiwi_hip_minimize_lm(kiwi_hip_ctx *c, int sourcetype, float *params, const int *mask, const float *mins, const float *maxs,
+                         int *info, int *iterations, float *misfit, float *best)
+{
+    GUARD_BEGIN
+    const int np = nparams_any(sourcetype);
+    if (np < 0) throw std::runtime_error("source type not supported by the host discretiser");
+    const std::vector<float> &norm = params_norm(sourcetype);
+    std::vector<int> idx;
+    for (int i = 0; i < np; i++) if (mask[i]) idx.push_back(i);
+    const int n = (int)idx.size();
+    int m = 0;
+    if (int rc = kiwi_hip_nmisfits(c, &m)) return rc;
+    if (n <= 0 || m < n) throw std::runtime_error("minimize_lm needs at least one free parameter and at least as many misfits");
+    if ((mins == nullptr) != (maxs == nullptr)) throw std::runtime_error("parameter limits need both minima and maxima");
+    std::vector<float> cur(params, params + np), x(n), fvec(m), diag(n, 1.0f), rows, mis, glob;
+    int nsteps = 0;
+    float last_global = 0.0f;
+    lm::Fcn fcn = [&](int k, float *xs, float *fv) -> int {
+        rows.resize((size_t)k * np); mis.resize((size_t)k * m); glob.resize(k);
+        std::vector<float> factor(k);
+        for (int s = 0; s < k; s++) {
+            float *sub = xs + (size_t)s * n;
+            float penalty = 0.0f;
+            if (mins)
+                for (int i = 0; i < n; i++) {
+                    const float nrm = norm[idx[i]];
+                    if (sub[i] * nrm < mins[i]) {
+                        penalty = penalty + fabsf(sub[i] * nrm - mins[i]) / fabsf(maxs[i] - mins[i]);
+                        sub[i] = mins[i] / nrm;
+                    }
+                    if (sub[i] * nrm > maxs[i]) {
+                        penalty = penalty + fabsf(sub[i] * nrm - maxs[i]) / fabsf(maxs[i] - mins[i]);
+                        sub[i] = maxs[i] / nrm;
+                    }
+                }
+            factor[s] = 1.0f + penalty;
+            std::vector<float> copy(np);
+            for (int i = 0; i < np; i++) copy[i] = cur[i] / norm[i];
+            for (int i = 0; i < n; i++) copy[idx[i]] = sub[i];
+            for (int i = 0; i < np; i++) cur[i] = copy[i] * norm[i];
+            std::copy(cur.begin(), cur.end(), rows.begin() + (size_t)s * np);
+        }
+        if (kiwi_hip_set_sources_params(c, sourcetype, k, rows.data())) return -2;
+        if (kiwi_hip_eval(c, 0, k)) return -2;
+        if (kiwi_hip_get_misfits(c, 0, k, mis.data(), nullptr, glob.data())) return -2;
+        for (int s = 0; s < k; s++)
+            for (int i = 0; i < m; i++) fv[(size_t)s * m + i] = mis[(size_t)s * m + i] * factor[s];
+        nsteps += k;
+        last_global = glob[k - 1];
+        return 0;
+    };
+    for (int i = 0; i < n; i++) x[i] = cur[idx[i]] / norm[idx[i]];
+    const float tol = sqrtf(lm::kEpsMch);
+    int nfev = 0;
+    int rc = lm::lmdif(fcn, m, n, x.data(), fvec.data(), tol, tol, 0.0f, 500 * (n + 1), 0.0f, diag.data(), 2, 0.01f, nfev);
+    if (rc == -2) return -1;                         // the engine call has set the error text
+    if (rc == 8) rc = 4;
+    *info = rc; *iterations = nsteps; *misfit = last_global;
+    std::copy(cur.begin(), cur.end(), params);       // the source the engine is left with: the LAST forward step
+    if (best) {
+        std::vector<float> copy(np);
+        for (int i = 0; i < np; i++) copy[i] = cur[i] / norm[i];
+        for (int i = 0; i < n; i++) copy[idx[i]] = x[i];
+        for (int i = 0; i < np; i++) best[i] = copy[i] * norm[i];
+    }
+    return 0;
     GUARD_END(c)
 }
 

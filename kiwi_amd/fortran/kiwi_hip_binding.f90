@@ -259,6 +259,19 @@ module kiwi_hip_binding
             real(c_float), intent(out) :: out(*)
         end function
 
+        integer(c_int) function kiwi_hip_minimize_lm( ctx, sourcetype, params, mask, mins, maxs, info, iterations, misfit, best ) &
+                bind(C, name='kiwi_hip_minimize_lm')
+            import :: c_int, c_ptr, c_float
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: sourcetype
+            real(c_float), intent(inout) :: params(*)
+            integer(c_int), intent(in) :: mask(*)
+            type(c_ptr), value :: mins, maxs                 ! real(c_float) arrays or c_null_ptr
+            integer(c_int), intent(out) :: info, iterations
+            real(c_float), intent(out) :: misfit
+            real(c_float), intent(out) :: best(*)
+        end function
+
         integer(c_int) function kiwi_hip_get_source_centroids( ctx, isrc, maxcent, ncent, cent ) &
                 bind(C, name='kiwi_hip_get_source_centroids')
             import :: c_int, c_ptr, c_float

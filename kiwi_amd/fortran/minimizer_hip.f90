@@ -4,22 +4,29 @@
 ! one command per line, '#' starts a comment, blanks collapse; answers are "<cmd>: ok",
 ! "<cmd>: ok >" + answer line, "<cmd>: nok" or "<cmd>: nok >" + error line, flushed after each.
 !
-! Commands (the subset SURVEY.md 8b lists for the hot path):
-!   set_database <base>                    reads <base>.kiwiflat (flat dense GFDB, see read_flat_gfdb)
+! Commands (SURVEY.md 8b's subset for the hot path, widened to most of minimizer.f90:1729-1811):
+!   set_database <base>                    <base>.kiwiflat (flat dense GFDB) or the reference's HDF5 <base>.index + chunks
 !   set_effective_dt <dt>
 !   set_local_interpolation nearest_neighbor|bilinear
 !   set_spacial_undersampling <nx> <nz>
 !   set_receivers <file> [has_depth]       lines: lat lon [depth] components
 !   switch_receiver <i> on|off
 !   set_source_location <lat> <lon> <reftime>
-!   set_source_params <type> p1 .. pn      bilateral | circular | moment_tensor
+!   set_source_crust, set_source_constraints, set_source_crustal_thickness_limit, get_source_crustal_thickness
+!   set_source_params <type> p1 .. pn      bilateral | circular | point_lp | eikonal | mt_eikonal | moment_tensor
+!   set_source_params_mask T|F ..;  set_source_subparams v ..;  set_source_subparams_limits mins .. maxs ..;
+!   get_source_subparams;  minimize_lm     answers "info iterations misfit"; Jacobians are batched on the device
 !   set_ref_seismograms <base> table       files <base>-<irec>-<comp>.table (time value)
-!   set_misfit_method <name>;  set_misfit_taper <i> x y ..;  set_misfit_filter <i> x y ..
+!   shift_ref_seismogram, autoshift_ref_seismogram
+!   set_misfit_method <name>;  set_misfit_taper <i> x y ..;  set_misfit_filter x y ..;  set_misfit_filter_1 <i> x y ..
+!   set_floating_shiftrange <i> lo hi;  get_floating_shifts
 !   set_synthetics_factor <f>
 !   get_misfits;  get_global_misfit
-!   output_seismograms <base> table synthetics [plain|tapered|filtered]
-!   output_distances <file>
-!   set_verbose, set_ignore_sigint         accepted, no effect
+!   output_seismograms <base> table synthetics|references [plain|tapered|filtered]
+!   output_distances <file>;  output_source_model <base>
+!   get_cached_traces_memory;  set_cached_traces_memory_limit, set_verbose, set_ignore_sigint   accepted, no effect
+! Not provided: get_arias_intensities, get_peak_amplitudes, get_principal_axes, output_cross_correlations,
+!   output_seismogram_spectra (diagnostics beside the inversion loop) and mseed / sac file formats.
 ! Batch extension (SURVEY.md 8f-1), one pipe round trip for a whole grid:
 !   eval_sources <type> <paramfile> <outfile>   one parameter vector per line in; per source
 !                                               "global m1 n1 m2 n2 .." out; answers the number of sources
@@ -47,6 +54,11 @@ program minimizer_hip
     real(c_float) :: effective_dt = 1.
     logical :: source_set = .false., evaluated = .false.
     integer(c_int) :: cur_bilinear = 0, cur_xus = 1, cur_zus = 1
+  ! the current source as psm holds it: type, parameters, mask and limits of the masked ones (minimize_lm)
+    integer(c_int) :: cur_st = 0
+    real(c_float), allocatable :: cur_params(:)
+    real(c_float), allocatable, target :: sub_mins(:), sub_maxs(:)
+    integer(c_int), allocatable :: cur_mask(:)
 
     ctx = c_null_ptr
     have_ctx = .false.
@@ -202,6 +214,11 @@ program minimizer_hip
         case ('switch_receiver');           call do_switch_receiver( a, ok_ )
         case ('set_source_location');       call do_set_source_location( a, ok_ )
         case ('set_source_params');         call do_set_source_params( a, ok_ )
+        case ('set_source_params_mask');    call do_set_source_params_mask( a, ok_ )
+        case ('set_source_subparams');      call do_set_source_subparams( a, ok_ )
+        case ('set_source_subparams_limits'); call do_set_source_subparams_limits( a, ok_ )
+        case ('get_source_subparams');      call do_get_source_subparams( ok_ )
+        case ('minimize_lm');               call do_minimize_lm( ok_ )
         case ('set_source_crust');          call do_set_source_crust( a, ok_ )
         case ('set_source_constraints');    call do_set_source_constraints( a, ok_ )
         case ('set_source_crustal_thickness_limit'); call do_set_source_crustal_thickness_limit( a, ok_ )
@@ -588,6 +605,142 @@ program minimizer_hip
         ok_ = check( kiwi_hip_set_sources_params( ctx, int(st,c_int), 1_c_int, p ) )
         source_set = ok_
         evaluated = .false.
+        if (.not. ok_) return
+        if (st /= cur_st .or. .not. allocated(cur_mask)) then        ! psm_set, source_all.f90:249-253: new type, mask all true
+            if (allocated(cur_mask)) deallocate( cur_mask )
+            allocate( cur_mask(np) )
+            cur_mask = 1
+        end if
+        cur_st = st
+        cur_params = p
+    end subroutine
+
+  ! set_source_params_mask mask ... (minimizer.f90:694-736, minimizer_engine.f90:525-543): T / F per parameter
+    subroutine do_set_source_params_mask( a, ok_ )
+        character(len=*), intent(in) :: a
+        logical, intent(out) :: ok_
+        logical, allocatable :: m(:)
+        integer :: n, ios
+        ok_ = .false.
+        if (.not. source_set) then
+            call fail( 'no source set' ); return
+        end if
+        n = count_words( a )
+        allocate( m(n) )
+        read (a,*,iostat=ios) m
+        if (ios > 0) then
+            call fail( 'failed to parse source parameter mask' ); return
+        end if
+        if (n /= size(cur_params)) then
+            call fail( 'wrong number of elements in mask' ); return
+        end if
+        cur_mask = merge( 1_c_int, 0_c_int, m )
+        if (allocated(sub_mins)) deallocate( sub_mins )            ! reset_subparam_limits
+        if (allocated(sub_maxs)) deallocate( sub_maxs )
+        ok_ = .true.
+    end subroutine
+
+  ! set_source_subparams subparams ... (minimizer.f90:738-770, minimizer_engine.f90:545-566)
+    subroutine do_set_source_subparams( a, ok_ )
+        character(len=*), intent(in) :: a
+        logical, intent(out) :: ok_
+        real(c_float), allocatable :: sub(:), p(:)
+        integer :: n, ios, i, isub
+        ok_ = .false.
+        n = count_words( a )
+        allocate( sub(n) )
+        read (a,*,iostat=ios) sub
+        if (ios > 0) then
+            call fail( 'failed to parse source parameters' ); return
+        end if
+        if (.not. source_set) then
+            call fail( 'source parameters must be set prior to setting parameter subset' ); return
+        end if
+        if (count(cur_mask /= 0) /= n) then
+            call fail( 'wrong number of subparams' ); return
+        end if
+        p = cur_params
+        isub = 1
+        do i = 1, size(p)
+            if (cur_mask(i) /= 0) then
+                p(i) = sub(isub)
+                isub = isub + 1
+            end if
+        end do
+        ok_ = check( kiwi_hip_set_sources_params( ctx, cur_st, 1_c_int, p ) )
+        evaluated = .false.
+        if (ok_) cur_params = p
+    end subroutine
+
+  ! set_source_subparams_limits mins ... maxs ... (minimizer.f90:772-810, minimizer_engine.f90:580-611)
+    subroutine do_set_source_subparams_limits( a, ok_ )
+        character(len=*), intent(in) :: a
+        logical, intent(out) :: ok_
+        real(c_float), allocatable :: temp(:)
+        integer :: n, ios
+        ok_ = .false.
+        n = count_words( a ) / 2
+        allocate( temp(2*n) )
+        read (a,*,iostat=ios) temp
+        if (ios > 0) then
+            call fail( 'failed to parse source parameter minimums' ); return
+        end if
+        if (.not. allocated(cur_mask)) then
+            call fail( 'wrong number of subparam_mins' ); return
+        end if
+        if (count(cur_mask /= 0) /= n) then
+            call fail( 'wrong number of subparam_mins' ); return
+        end if
+        sub_mins = temp(1:n)
+        sub_maxs = temp(n+1:2*n)
+        ok_ = .true.
+    end subroutine
+
+  ! get_source_subparams (minimizer.f90:1199-1224)
+    subroutine do_get_source_subparams( ok_ )
+        logical, intent(out) :: ok_
+        character(len=32) :: buffer
+        integer :: i
+        ok_ = .false.
+        if (.not. source_set) then
+            call fail( 'must set source parameters before retrieving them' ); return
+        end if
+        answer = ''
+        do i = 1, size(cur_params)
+            if (cur_mask(i) /= 0) then
+                write (buffer,*) cur_params(i)
+                if (len(answer) > 0) answer = answer//' '
+                answer = answer//trim(adjustl(buffer))
+            end if
+        end do
+        ok_ = .true.
+    end subroutine
+
+  ! minimize_lm (minimizer.f90:1048-1083): answers "info iterations misfit"; the current source afterwards is the one
+  ! of the last forward step, as in the reference
+    subroutine do_minimize_lm( ok_ )
+        logical, intent(out) :: ok_
+        integer(c_int) :: info, iterations
+        real(c_float) :: misfit_
+        real(c_float), allocatable :: best(:)
+        character(len=96) :: buffer
+        ok_ = .false.
+        if (.not. source_set) then
+            call fail( 'no source set' ); return
+        end if
+        allocate( best(size(cur_params)) )
+        if (allocated(sub_mins)) then
+            rc = kiwi_hip_minimize_lm( ctx, cur_st, cur_params, cur_mask, c_loc(sub_mins), c_loc(sub_maxs), info, iterations, &
+                                       misfit_, best )
+        else
+            rc = kiwi_hip_minimize_lm( ctx, cur_st, cur_params, cur_mask, c_null_ptr, c_null_ptr, info, iterations, misfit_, best )
+        end if
+        if (.not. check( rc )) return
+        evaluated = .false.
+        write (buffer,*) info, iterations, misfit_
+        call reduce_whitespace( buffer )
+        answer = trim(adjustl(buffer))
+        ok_ = .true.
     end subroutine
 
   ! table format: two columns time [s], value (seismogram_io.f90:231-245); first = nint((t0-reftime)/dt)+1

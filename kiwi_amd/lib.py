@@ -19,6 +19,10 @@ class KiwiHipError(RuntimeError):
     (the reference's '<cmd>: nok >' line, minimizer.f90:1689-1696)."""
 
 
+# kiwi_hip_residual_fn: (user, k, m, n, xs[k][n], fv[k][m]) -> int
+RESIDUAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float))
+
+
 def build(force=False):
     """Compile kiwi_amd/csrc for gfx950 into kiwi_amd/libkiwi_hip.so (hipcc cross-compiles without a GPU)."""
     if force and os.path.exists(LIB_PATH):
@@ -88,6 +92,9 @@ def load():
         "kiwi_hip_get_geometry": [vp, C.c_int, C.c_int, C.c_int, c_int_p, vp],
         "kiwi_hip_get_receiver_geometry": [vp, C.c_int, c_double_p, c_double_p, c_double_p],
         "kiwi_hip_get_device_bytes": [vp, C.POINTER(C.c_longlong)],
+        "kiwi_hip_minimize_lm": [vp, C.c_int, c_float_p, c_int_p, c_float_p, c_float_p, c_int_p, c_int_p, c_float_p, c_float_p],
+        "kiwi_hip_lmdif": [RESIDUAL_FN, vp, C.c_int, C.c_int, c_float_p, c_float_p, C.c_float, C.c_float, C.c_float, C.c_int,
+                           C.c_float, c_float_p, C.c_int, C.c_float, c_int_p, c_int_p],
     }
     for name, argtypes in sig.items():
         f = getattr(L, name)

@@ -30,7 +30,41 @@ module ref_driver
 
     implicit none
 
+    abstract interface
+        function lm_cfcn_t( m, n, x, fvec ) bind(C) result(iflag)
+            import :: c_int, c_float
+            integer(c_int), value :: m, n
+            real(c_float) :: x(*), fvec(*)
+            integer(c_int) :: iflag
+        end function
+    end interface
+    procedure(lm_cfcn_t), pointer, save :: lm_cfcn => null()
+
   contains
+
+  ! sminpack/lmdif.f (the reference's single-precision MINPACK, compiled as it is) with a C residual callback
+    subroutine ref_lmdif( cfcn, m, n, x, fvec, ftol, xtol, gtol, maxfev, epsfcn, diag, mode, factor, info, nfev ) &
+                          bind(C, name='ref_lmdif')
+        type(c_funptr), value :: cfcn
+        integer(c_int), value :: m, n, maxfev, mode
+        real(c_float), value :: ftol, xtol, gtol, epsfcn, factor
+        real(c_float) :: x(n), fvec(m), diag(n)
+        integer(c_int), intent(out) :: info, nfev
+        real :: fjac(m,n), qtf(n), wa1(n), wa2(n), wa3(n), wa4(m)
+        integer :: ipvt(n)
+        external lmdif
+        call c_f_procpointer( cfcn, lm_cfcn )
+        call lmdif( lm_trampoline, m, n, x, fvec, ftol, xtol, gtol, maxfev, epsfcn, diag, mode, factor, 0, info, nfev, &
+                    fjac, m, ipvt, qtf, wa1, wa2, wa3, wa4 )
+    end subroutine
+
+    subroutine lm_trampoline( m, n, x, fvec, iflag )
+        integer :: m, n, iflag
+        real :: x(n), fvec(m)
+        integer :: rc
+        rc = lm_cfcn( m, n, x, fvec )
+        if (rc < 0) iflag = rc
+    end subroutine
 
   ! trace_pack (sparse_trace.f90:443): returns number of strips and their spans
     subroutine ref_trace_pack( lo, n, data, maxstrips, nstrips, spans, tspan ) bind(C, name='ref_trace_pack')

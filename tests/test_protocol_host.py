@@ -104,6 +104,49 @@ def test_protocol_host_matches_python_host_and_oracle(host, tmp_path):
         out = np.loadtxt(tmp_path / "out.txt")
         assert out.shape == (3, 1 + 2 * m.shape[1])
         assert np.allclose(out[:, 0], g, rtol=2e-5)
+        # masked parameters and minimize_lm (minimizer.f90:694-810,1048-1083,1199-1224) against the Python face of the
+        # same C-ABI call, fed with the reference traces as they read back from the text files
+        from kiwi_amd import lm
+        start = trials[0].copy()
+        start[5] += 3.0
+        start[3] += 400.0
+        p.do("set_source_params", "bilateral", *["%.9g" % v for v in start])
+        with pytest.raises(protocol.SeismosizerReturnedError, match="wrong number of elements in mask"):
+            p.do("set_source_params_mask", "T", "F")
+        p.do("set_source_params_mask", *["T" if i in (3, 5, 6) else "F" for i in range(14)])
+        assert np.array_equal(np.array(p.do("get_source_subparams").split(), np.float32), start[[3, 5, 6]])
+        with pytest.raises(protocol.SeismosizerReturnedError, match="wrong number of subparams"):
+            p.do("set_source_subparams", 1.0)
+        p.do("set_source_subparams", "%.9g" % (start[3] + 100), "%.9g" % start[5], "%.9g" % start[6])
+        start[3] += 100
+        assert np.array_equal(np.array(p.do("get_source_subparams").split(), np.float32), start[[3, 5, 6]])
+        g_start = float(p.do("get_global_misfit"))
+        pp = sc.product()
+        for (ir, k) in sc.refs:
+            t, v = protocol.read_table(str(tmp_path / ("ref-%d-%s.table" % (ir, sc.comps[ir - 1][k - 1]))))
+            pp.set_ref_seismogram(ir, k, int(round(t[0] / dt)) + 1, v.astype(np.float32))
+        for ir, (x, y) in sc.tapers.items():
+            pp.set_misfit_taper(ir, x, y)
+        pp.set_misfit_method("l2norm")
+        for lim in (None, ([8000.0, float(trials[0][5]) + 1.0, 50.0], [14000.0, 120.0, 95.0])):
+            p.do("set_source_subparams", *["%.9g" % v for v in start[[3, 5, 6]]])
+            if lim:
+                with pytest.raises(protocol.SeismosizerReturnedError, match="wrong number of subparam_mins"):
+                    p.do("set_source_subparams_limits", 1, 2)
+                p.do("set_source_subparams_limits", *(lim[0] + lim[1]))
+            info, iters, mis = p.do("minimize_lm").split()
+            res = lm.minimize_lm(pp, "bilateral", start, [i in (3, 5, 6) for i in range(14)], *(lim or (None, None)))
+            # (the traces reach the two engines through different text parsers; at the noise floor of a perfect fit the
+            # runs may differ in the last digits, not in their course)
+            assert int(info) in (1, 2, 3, 4) and res.info in (1, 2, 3, 4) and abs(int(iters) - res.iterations) <= 8
+            assert abs(float(mis) - res.misfit) < 1e-4 * g_start and float(mis) < (0.9 if lim else 0.5) * g_start
+            assert np.allclose(np.array(p.do("get_source_subparams").split(), np.float32), res.params[[3, 5, 6]], rtol=1e-4)
+            assert np.float32(p.do("get_global_misfit")) == np.float32(mis)       # the engine holds the last forward step
+            if lim:
+                assert res.best[5] >= lim[0][1] - 1e-3
+        pp.close()
+        p.do("set_source_params_mask", *["T"] * 14)
+        p.do("set_source_params", "bilateral", *["%.9g" % v for v in trials[0]])
         # inspection commands
         p.do("output_distances", str(tmp_path / "dist.txt"))
         d = np.loadtxt(tmp_path / "dist.txt")
