@@ -654,10 +654,9 @@ void prepare_fft(kiwi_hip_ctx *c, const std::vector<float> &reft_host)
 // may this evaluation compare inside the accumulate kernel (no synthetics in memory)?
 bool can_fuse(const kiwi_hip_ctx *c, int proc_which, int isrc0, int nsrc)
 {
-    // it pays where writing and re-reading the synthetics is a large share of the work (point sources, few centroids);
-    // with ~100 centroids per source the separate misfit kernel costs less than the fused epilogue's registers
-    const int ncent = nsrc > 0 ? (c->cent_ofs[isrc0 + nsrc] - c->cent_ofs[isrc0]) / nsrc : 0;
-    if (c->fuse_enabled < 2 && ncent > 32) return false;               // KIWI_HIP_FUSE=2 forces it
+    // whenever nothing needs the synthetics themselves: saves writing and re-reading them (a third of the time for point
+    // sources; 0.2 ms of 12 per 256 sources of 100 centroids, where the epilogue's registers cost the main loop 1 %)
+    (void)isrc0; (void)nsrc;
     return c->fuse_enabled && c->accum_mode == 0 && proc_which == 0 && !c->fft_needed && !c->floating && !c->synth_only && !c->any_untapered &&
            c->halo == 0 && (c->method == KIWI_L2NORM || c->method == KIWI_L1NORM || c->method == KIWI_SCALAR_PRODUCT || c->method == KIWI_PEAK);
 }

@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
             const int jl = jb + e + 4 * tid;             // trace index of this lane's b[j-1]
             const bool tail = (jb + e + TILE) > jend_min;        // workgroup-uniform
 #define APPLY(RV, TV) do { \
-                if (need_h && has_d) centroid_apply_hd<NG, LDS_TILE, RV, TV, !FUSE>(ar1, ar2, dz, chunk0, jl, jend, flags, coef, wfrac, sd, \
+                if (need_h && has_d) centroid_apply_hd<NG, LDS_TILE, RV, TV, !(FUSE && RUNS)>(ar1, ar2, dz, chunk0, jl, jend, flags, coef, wfrac, sd, \
                                                                             f0, f1, f2, f3, f4, f5, cl, sl); \
                 else centroid_apply<NG, LDS_TILE, RV, TV>(ar1, ar2, dz, chunk0, jl, jend, need_h, has_d, flags, \
                                                           wfrac, sd, f0, f1, f2, f3, f4, f5, cl, sl); } while (0)
