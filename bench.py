@@ -148,12 +148,41 @@ def cpu_baseline(wl, gf, recv, refs, tapers, gpu_global, budget_s=20.0):
     gl = np.array([one(trials[i]) for i in range(n)])
     dtm = time.perf_counter() - t0
     err = float(np.max(np.abs(gpu_global[:n] - gl) / np.abs(gl)))
+    # the same on ONE core (SURVEY 8d asks for both), two sources
+    e.set_nthreads(1)
+    t0 = time.perf_counter()
+    n1 = 2
+    for i in range(n1):
+        one(trials[i])
+    v1 = n1 / (time.perf_counter() - t0)
     e.close()
     db.close()
     return {"value": n / dtm, "unit": "evals/s", "cores": cores, "kind": "port",
             "sample": "%d of the timed trial sources, oracle/libko.so, OpenMP over the %d receivers (host has %d hardware threads)"
                       % (n, wl["nrec"], os.cpu_count() or 1),
+            "value_1core": v1,
+            "reference_in_dev_container": "the reference itself (amdflang -O2, 135 centroids, 8 vCPU Xeon 2.1 GHz): 0.76 evals/s "
+                                          "on 8 threads, 0.11 on one (BASELINE.md section 2); this port there: 6.2 on 8 threads",
             "max_rel_misfit_diff_vs_gpu": err}
+
+
+def measured_copy_bandwidth(torch, device):
+    """What a plain device-to-device copy reaches on this box (read + written bytes per second): the practical HBM
+    ceiling next to the nominal 8 TB/s."""
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=device)
+    b = torch.empty(n, dtype=torch.uint8, device=device)
+    for _ in range(3):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    ev0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    ev1.record()
+    torch.cuda.synchronize()
+    return 2.0 * n * reps / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
 
 
 def main():
@@ -247,6 +276,10 @@ def main():
                     traffic = tb["total"] * args.batch / tb["batch"]
         except Exception:
             traffic = None
+        try:
+            copy_gbs = measured_copy_bandwidth(torch, torch.device("cuda", local_rank))
+        except Exception:
+            copy_gbs = None
         out = {
             "metric": "trial-source misfit evals/s", "value": value, "unit": "evals/s",
             "n_gpus": ngpus, "steps": args.steps, "warmup": args.warmup,
@@ -260,6 +293,7 @@ def main():
                        "parallelism": "trial-source shard x%d, all-gather of global misfits" % ngpus},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "peak_measured_copy": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs if copy_gbs else None,
                          "kernel": "accumulate_grouped_kernel<10,256>" if os.environ.get("KIWI_HIP_ACCUM") != "direct" else "accumulate_kernel<10>", "launches": int(launches[1]),
                          "avg_launch_ms": float(ms[1]) / max(int(launches[1]), 1),
                          "algorithmic_bytes_per_eval": b_eval,
