@@ -188,6 +188,16 @@ int kiwi_hip_get_synthetics(kiwi_hip_ctx *ctx, int isrc, int irec, int icomp, in
 int kiwi_hip_get_reference(kiwi_hip_ctx *ctx, int irec, int icomp, int which, int *first, int *n, float *out, int maxn);
 
 /* ---- measurement / inspection ---- */
+/* get_peak_amplitudes (minimizer_engine.f90:1174-1212; receiver.f90:544-574; comparator.f90:519-589): per ENABLED
+ * receiver the maximum over the misfit window (taper span; without taper the union of the synthetic strips' data spans)
+ * of the vector norm of the once (differentiate = 1, velocity) or twice (2, acceleration) differenced synthetics of
+ * uploaded source isrc -- vertical + the horizontal pair a/c + r/l or else n/s + e/w, whatever of them the receiver has.
+ * get_arias_intensities (:1214-1246; receiver.f90:576-594; comparator.f90:591-625) likewise.  Tapered synthetics where
+ * the receiver has a taper; not available while a misfit filter is set.  Without a taper the span is that of THIS
+ * source's strips (the reference's strips remember earlier sources).  out[number of enabled receivers]. */
+int kiwi_hip_get_peak_amplitudes(kiwi_hip_ctx *ctx, int isrc, int differentiate, float *out);
+int kiwi_hip_get_arias_intensities(kiwi_hip_ctx *ctx, int isrc, float *out);
+
 /* HIP-event durations [ms] of the last kiwi_hip_eval on the context stream:
  * ms[0] geometry kernel, ms[1] accumulate kernel(s), ms[2] misfit kernels, ms[3] whole eval;
  * launches[0..2] = number of launches of each in that eval.  Synchronises. */

@@ -106,6 +106,7 @@ struct kiwi_hip_ctx {
     bool synth_only = false;              // some enabled receiver has no reference yet: synthetics only
     bool any_untapered = false;           // some enabled receiver has references but no taper (comparator.f90:798-800)
     DevBuf<int> spansrc_d;                // per-source strip spans of the current chunk (un-tapered receivers)
+    bool want_spansrc = false;            // a diagnostic needs them although no misfit does (shake_impl)
     int nmis = 0, nrec_en = 0;
     int halo = 0;
     size_t syn_stride = 0;
@@ -677,7 +678,7 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
 
     EvalParams ep{ c->bilinear, c->xus, c->zus, nrec, isrc0 };
     int *spansrc = nullptr;
-    if (c->any_untapered) {                        // per-source strip spans, initialised empty
+    if (c->any_untapered || c->want_spansrc) {     // per-source strip spans, initialised empty
         const size_t n = (size_t)nsrc * nrec;
         c->spansrc_d.ensure(n * 4, &c->dev_bytes);
         std::vector<int> init(n * 4);
@@ -1502,6 +1503,81 @@ int kiwi_hip_get_synthetics(kiwi_hip_ctx *c, int isrc, int irec, int icomp, int 
     const int m = std::min(cd.wlen, maxn);
     HIPCHECK(hipMemcpy(out, c->proc_d.p + srcofs + cd.synofs + cd.halo, (size_t)m * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
+    GUARD_END(c)
+}
+
+// get_peak_amplitudes (minimizer_engine.f90:1174-1212) / get_arias_intensities (:1214-1246) of uploaded source isrc
+static int shake_impl(kiwi_hip_ctx *c, int isrc, int kind, float *out)
+{
+    if (isrc < 0 || isrc >= c->nsrc) throw std::runtime_error("source index out of range");
+    prepare(c);
+    if (c->any_filter) throw std::runtime_error("peak amplitudes / Arias intensities are not available with a misfit filter set");
+    std::vector<ShakeRec> recs;
+    bool spans = false;
+    for (size_t ir = 0; ir < c->recv.size(); ir++) {
+        const Receiver &r = c->recv[ir];
+        if (!r.enabled) continue;
+        int iver = 0, ih1 = 0, ih2 = 0;                           // get_component_ids, receiver.f90:512-542
+        for (int k = 0; k < r.ncomp; k++) {
+            const int ict = std::abs(r.comp[k]);
+            if (ict == 1) ih1 = k + 1;
+            if (ict == 2) ih2 = k + 1;
+            if (ict == 3) iver = k + 1;
+        }
+        if (ih1 == 0 || ih2 == 0)
+            for (int k = 0; k < r.ncomp; k++) {
+                const int ict = std::abs(r.comp[k]);
+                if (ict == 4) ih1 = k + 1;
+                if (ict == 5) ih2 = k + 1;
+            }
+        if (ih1 == 0 || ih2 == 0) { ih1 = 0; ih2 = 0; }
+        ShakeRec sr;
+        std::memset(&sr, 0, sizeof(sr));
+        sr.rec = (int)ir;
+        sr.untapered = r.taper.defined() ? 0 : 1;
+        int slot0 = -1;
+        for (size_t i = 0; i < c->comps.size(); i++) if (c->comps[i].rec == (int)ir) { slot0 = (int)i; break; }
+        auto use = [&](int k1) { if (k1 && slot0 >= 0) sr.slot[sr.np++] = slot0 + k1 - 1; };
+        if (kind != 3) { use(iver); use(ih1); use(ih2); }        // receiver_get_maxabs, receiver.f90:544-574
+        else if (iver && ih1 && ih2) { use(iver); use(ih1); use(ih2); }     // receiver_get_arias_intensity, :576-594
+        else if (ih1 && ih2) { use(ih1); use(ih2); }
+        else if (iver) use(iver);
+        if (sr.untapered && sr.np) spans = true;
+        recs.push_back(sr);
+    }
+    if (recs.empty()) return 0;
+    c->want_spansrc = spans;
+    try { eval_impl(c, isrc, 1, 2); } catch (...) { c->want_spansrc = false; throw; }
+    c->want_spansrc = false;
+    DevBuf<ShakeRec> recs_d;
+    DevBuf<float> out_d;
+    recs_d.ensure(recs.size(), nullptr);
+    out_d.ensure(recs.size(), nullptr);
+    HIPCHECK(hipMemcpyAsync(recs_d.p, recs.data(), recs.size() * sizeof(ShakeRec), hipMemcpyHostToDevice, c->stream));
+    std::vector<float> rise(1);
+    HIPCHECK(hipMemcpyAsync(rise.data(), c->risetime_d.p + isrc, sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    hipLaunchKernelGGL(shake_kernel, dim3((unsigned)recs.size()), dim3(256), 0, c->stream, c->proc_d.p, c->comps_d.p, recs_d.p,
+                       spans ? c->spansrc_d.p : (const int *)nullptr, kind, c->gm.dt, c->syn_factor, fold_halfwidth(rise[0], c->gm.dt), out_d.p);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(out, out_d.p, recs.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int kiwi_hip_get_peak_amplitudes(kiwi_hip_ctx *c, int isrc, int differentiate, float *out)
+{
+    GUARD_BEGIN
+    if (differentiate != 1 && differentiate != 2)
+        throw std::runtime_error("differentiate argument must be 1 for velocity or 2 for acceleration");
+    return shake_impl(c, isrc, differentiate, out);
+    GUARD_END(c)
+}
+
+int kiwi_hip_get_arias_intensities(kiwi_hip_ctx *c, int isrc, float *out)
+{
+    GUARD_BEGIN
+    return shake_impl(c, isrc, 3, out);
     GUARD_END(c)
 }
 

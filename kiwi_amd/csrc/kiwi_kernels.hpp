@@ -97,6 +97,15 @@ struct CompDev {
     int untapered, rf0, rf1, vertical;      // reference data span [rf0, rf1]; which strip span applies to the synthetic
 };
 
+// Shake-map diagnostics of one source (get_peak_amplitudes / get_arias_intensities): the components a receiver's value
+// is made of, in the reference's order (receiver.f90:544-594)
+struct ShakeRec {
+    int slot[3];     // misfit slots (CompDev indices) of the probes, np of them used
+    int np;
+    int untapered;   // no taper: the norm runs over the union of the synthetic strips' data spans (comparator.f90:733-736)
+    int rec;
+};
+
 // ------------------------------------------------------------------------------------------------
 // geometry
 
@@ -355,6 +364,59 @@ __global__ __launch_bounds__(256) void geometry_kernel(
     if (tab && g.row[0] >= 0) {
         if (gm.ng == 10) write_tab<10>(tab + base * 128, g, span, gm.pitch, rv.sd);
         else write_tab<8>(tab + base * 128, g, span, gm.pitch, rv.sd);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// get_peak_amplitudes / get_arias_intensities: block per enabled receiver over the processed synthetics of ONE source
+// (moment, fold and taper applied by misfit_kernel).  kind 1: max_vecnorm_d1 (comparator.f90:519-553), 2: max_vecnorm_d2
+// (:555-589), 3: arias_intensity (:591-625); fp32 differences, fp64 squares and sums as there.
+__global__ __launch_bounds__(256) void shake_kernel(const float *__restrict__ proc, const CompDev *__restrict__ comps,
+                                                    const ShakeRec *__restrict__ recs, const int *__restrict__ spansrc,
+                                                    int kind, float dt, float factor, int fold_grow, float *__restrict__ out)
+{
+    const ShakeRec sr = recs[blockIdx.x];
+    __shared__ double red[256];
+    if (sr.np == 0) { if (threadIdx.x == 0) out[blockIdx.x] = 0.f; return; }
+    const CompDev c0 = comps[sr.slot[0]];
+    int i_lo = 0, i_hi = c0.wlen - 1;
+    if (sr.untapered) {
+        int lo = 0x7fffffff, hi = -0x7fffffff;
+        for (int k = 0; k < sr.np; k++) {
+            const int *sp = spansrc + (size_t)sr.rec * 4 + (comps[sr.slot[k]].vertical ? 2 : 0);
+            if (sp[1] >= sp[0]) { lo = min(lo, sp[0] - fold_grow); hi = max(hi, sp[1] + (fold_grow ? fold_grow + 1 : 0)); }
+        }
+        i_lo = max(lo - c0.w0, 0); i_hi = min(hi - c0.w0, c0.wlen - 1);
+        if (hi < lo) { if (threadIdx.x == 0) out[blockIdx.x] = 0.f; return; }
+    }
+    const float *x[3];
+    for (int k = 0; k < 3; k++) { const CompDev cd = comps[sr.slot[k < sr.np ? k : 0]]; x[k] = proc + cd.synofs + cd.halo; }
+    const int n = i_hi - i_lo + 1, m = kind == 1 ? n - 1 : n - 2;
+    const double f2 = (double)(factor * factor);
+    double acc = kind == 3 ? 0.0 : -HUGE_VAL;
+    for (int i = threadIdx.x; i < m; i += 256) {
+        double v = 0.0;
+        for (int k = 0; k < sr.np; k++) {
+            const float *a = x[k] + i_lo + i;
+            const float d = kind == 1 ? a[0] - a[1] : a[0] - 2.0f * a[1] + a[2];
+            const double t = f2 * ((double)d * (double)d);
+            v = k == 0 ? t : v + t;
+        }
+        if (kind == 3) acc += v; else acc = fmax(acc, v);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] = kind == 3 ? red[threadIdx.x] + red[threadIdx.x + st] : fmax(red[threadIdx.x], red[threadIdx.x + st]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float pi = 3.14159265358979f;                         // constants.f90:21
+        float res;
+        if (kind == 1) res = (float)(sqrt(red[0]) / (double)dt);
+        else if (kind == 2) res = (float)(sqrt(red[0]) / (double)(dt * dt));
+        else res = (float)((double)(pi / (2.f * 9.81f) * dt) * red[0] / (double)(dt * dt));
+        out[blockIdx.x] = res;
     }
 }
 

@@ -274,6 +274,18 @@ class Engine:
                                                 _fp(out), maxn), "output_seismograms")
         return first.value, out[:n.value].copy()
 
+    def get_peak_amplitudes(self, differentiate, isrc=0):
+        """`get_peak_amplitudes`: per enabled receiver the peak vector norm of the velocity (1) or acceleration (2)."""
+        out = np.zeros(sum(1 for e in self.enabled if e), np.float32)
+        self._ck(self.L.kiwi_hip_get_peak_amplitudes(self.h, isrc, differentiate, _fp(out)), "get_peak_amplitudes")
+        return out
+
+    def get_arias_intensities(self, isrc=0):
+        """`get_arias_intensities` per enabled receiver."""
+        out = np.zeros(sum(1 for e in self.enabled if e), np.float32)
+        self._ck(self.L.kiwi_hip_get_arias_intensities(self.h, isrc, _fp(out)), "get_arias_intensities")
+        return out
+
     def get_source_centroids(self, isrc=0):
         """The discretised source the engine holds for trial `isrc`: centroids[n, 10] (`output_source_model`)."""
         n = C.c_int()

@@ -259,6 +259,21 @@ module kiwi_hip_binding
             real(c_float), intent(out) :: out(*)
         end function
 
+        integer(c_int) function kiwi_hip_get_peak_amplitudes( ctx, isrc, differentiate, out ) &
+                bind(C, name='kiwi_hip_get_peak_amplitudes')
+            import :: c_int, c_ptr, c_float
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: isrc, differentiate
+            real(c_float), intent(out) :: out(*)
+        end function
+
+        integer(c_int) function kiwi_hip_get_arias_intensities( ctx, isrc, out ) bind(C, name='kiwi_hip_get_arias_intensities')
+            import :: c_int, c_ptr, c_float
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: isrc
+            real(c_float), intent(out) :: out(*)
+        end function
+
         integer(c_int) function kiwi_hip_minimize_lm( ctx, sourcetype, params, mask, mins, maxs, info, iterations, misfit, best ) &
                 bind(C, name='kiwi_hip_minimize_lm')
             import :: c_int, c_ptr, c_float

@@ -25,8 +25,9 @@
 !   output_seismograms <base> table synthetics|references [plain|tapered|filtered]
 !   output_distances <file>;  output_source_model <base>
 !   get_cached_traces_memory;  set_cached_traces_memory_limit, set_verbose, set_ignore_sigint   accepted, no effect
-! Not provided: get_arias_intensities, get_peak_amplitudes, get_principal_axes, output_cross_correlations,
-!   output_seismogram_spectra (diagnostics beside the inversion loop) and mseed / sac file formats.
+!   get_peak_amplitudes 1|2;  get_arias_intensities
+! Not provided: get_principal_axes, output_cross_correlations, output_seismogram_spectra (diagnostics beside the
+!   inversion loop) and mseed / sac file formats.
 ! Batch extension (SURVEY.md 8f-1), one pipe round trip for a whole grid:
 !   eval_sources <type> <paramfile> <outfile>   one parameter vector per line in; per source
 !                                               "global m1 n1 m2 n2 .." out; answers the number of sources
@@ -219,6 +220,8 @@ program minimizer_hip
         case ('set_source_subparams_limits'); call do_set_source_subparams_limits( a, ok_ )
         case ('get_source_subparams');      call do_get_source_subparams( ok_ )
         case ('minimize_lm');               call do_minimize_lm( ok_ )
+        case ('get_peak_amplitudes');       call do_get_shake( a, .true., ok_ )
+        case ('get_arias_intensities');     call do_get_shake( a, .false., ok_ )
         case ('set_source_crust');          call do_set_source_crust( a, ok_ )
         case ('set_source_constraints');    call do_set_source_constraints( a, ok_ )
         case ('set_source_crustal_thickness_limit'); call do_set_source_crustal_thickness_limit( a, ok_ )
@@ -713,6 +716,38 @@ program minimizer_hip
                 answer = answer//trim(adjustl(buffer))
             end if
         end do
+        ok_ = .true.
+    end subroutine
+
+  ! get_peak_amplitudes differentiate (minimizer.f90:1305-1343) / get_arias_intensities (:1345-1372): one value per
+  ! enabled receiver, list-directed
+    subroutine do_get_shake( a, peak, ok_ )
+        character(len=*), intent(in) :: a
+        logical, intent(in) :: peak
+        logical, intent(out) :: ok_
+        integer :: differentiate, ios, nen, i
+        real(c_float), allocatable :: vals(:)
+        character(len=:), allocatable :: buffer
+        ok_ = .false.
+        if (.not. need_ctx()) return
+        if (.not. source_set) then
+            call fail( 'no source set' ); return
+        end if
+        nen = count( enabled )
+        allocate( vals(max(nen,1)) )
+        if (peak) then
+            read (a,*,iostat=ios) differentiate
+            if (ios /= 0) then
+                call fail( 'failed to parse number' ); return
+            end if
+            if (.not. check( kiwi_hip_get_peak_amplitudes( ctx, 0_c_int, int(differentiate,c_int), vals ) )) return
+        else
+            if (.not. check( kiwi_hip_get_arias_intensities( ctx, 0_c_int, vals ) )) return
+        end if
+        allocate( character(len=32*max(nen,1)) :: buffer )
+        write (buffer,*) (vals(i), i=1,nen)
+        answer = trim(buffer)
+        evaluated = .false.
         ok_ = .true.
     end subroutine
 

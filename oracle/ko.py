@@ -101,6 +101,8 @@ def lib():
         L.ko_engine_get_floating_shift.argtypes = [C.c_void_p, C.c_int]
         L.ko_engine_get_floating_shift.restype = C.c_int
         L.ko_engine_set_nthreads.argtypes = [C.c_void_p, C.c_int]
+        L.ko_engine_shake.argtypes = [C.c_void_p, C.c_int, c_float_p]
+        L.ko_engine_shake.restype = C.c_int
         for f in ("calculate_seismograms", "scale_seismograms", "calculate_misfits"):
             getattr(L, "ko_engine_" + f).argtypes = [C.c_void_p]
         L.ko_engine_get_misfits.argtypes = [C.c_void_p, c_float_p, c_float_p, C.c_int]
@@ -350,6 +352,18 @@ class Engine:
 
     def set_nthreads(self, n):
         lib().ko_engine_set_nthreads(self.h, n)
+
+    def peak_amplitudes(self, differentiate):
+        """get_peak_amplitudes: peak velocity (1) / acceleration (2) vector norm per enabled receiver (update_syn_probes first)."""
+        self.calculate_seismograms()
+        self.scale_seismograms()
+        out = np.zeros(len(self.ncomp), np.float32)
+        n = lib().ko_engine_shake(self.h, differentiate, _fp(out))
+        return out[:n]
+
+    def arias_intensities(self):
+        """get_arias_intensities per enabled receiver."""
+        return self.peak_amplitudes(0)
 
     def calculate_seismograms(self):
         lib().ko_engine_calculate_seismograms(self.h)

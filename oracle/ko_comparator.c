@@ -444,6 +444,85 @@ void ko_probes_windowed_cross_corr(ko_probe *a, ko_probe *b, int shift_lo, int s
     ko_probe_shift(b, -shift_hi);
 }
 
+/* probes_adjust_spans_3, comparator.f90:488-516 */
+static void probes_adjust_spans_3(ko_probe *a, ko_probe *b, ko_probe *c)
+{
+    int t[2], u[2], newspan[2];
+    span_union(a->dataspan, b->dataspan, t);
+    span_union(t, c->dataspan, u);
+    int minlength = imax(imax((int)ceilf((float)slen(a->dataspan) * a->paddingfactor),
+                              (int)ceilf((float)slen(b->dataspan) * b->paddingfactor)),
+                         (int)ceilf((float)slen(c->dataspan) * c->paddingfactor));
+    ko_allowed_span(u, minlength, newspan);
+    if (a->span[0] == b->span[0] && a->span[1] == b->span[1] && a->span[0] == c->span[0] && a->span[1] == c->span[1] &&
+        slen(a->span) == slen(newspan) &&
+        containing(a->span, b->dataspan) && containing(b->span, a->dataspan) &&
+        containing(a->span, c->dataspan) && containing(c->span, a->dataspan) &&
+        containing(b->span, c->dataspan) && containing(c->span, b->dataspan)) return;
+    probe_extend_span(a, newspan);
+    probe_extend_span(b, newspan);
+    probe_extend_span(c, newspan);
+}
+
+/* max_vecnorm_d1_{1,2,3} (kind 1), max_vecnorm_d2_{1,2,3} (kind 2), arias_intensity_{1,2,3} (kind 3), comparator.f90:519-625 */
+static float shake_apply(int kind, const float *const *x, const float *f, int np, int n, float dt)
+{
+    const float pi = 3.14159265358979f;                           /* constants.f90:21 */
+    const int m = kind == 1 ? n - 1 : n - 2;
+    double mx = -HUGE_VAL, sum = 0.0;
+    for (int i = 0; i < m; i++) {
+        double v = 0.0;
+        for (int k = 0; k < np; k++) {
+            const float *a = x[k];
+            const float d = kind == 1 ? a[i] - a[i + 1] : a[i] - 2.0f * a[i + 1] + a[i + 2];
+            const double t = (double)(f[k] * f[k]) * ((double)d * (double)d);
+            v = k == 0 ? t : v + t;
+        }
+        if (v > mx) mx = v;
+        sum += v;
+    }
+    if (kind == 1) return (float)(sqrt(mx) / (double)dt);
+    if (kind == 2) return (float)(sqrt(mx) / (double)(dt * dt));
+    return (float)((double)(pi / (2.f * 9.81f) * dt) * sum / (double)(dt * dt));
+}
+
+/* probes_max_vecnorm_{1,2,3} / probes_arias_intensity_{1,2,3} (comparator.f90:1012-1058) through
+ * probe_norm_timedomain (:824-859), probes_norm_timedomain (:770-822) and probes_norm_timedomain_3 (:700-766) */
+float ko_probes_shake(ko_probe **p, int np, int kind)
+{
+    int span[2], ps[2], t[3][2];
+    int all_taper = 1, all_filter = 1;
+    for (int k = 0; k < np; k++) { if (p[k]->taper.n <= 0) all_taper = 0; if (p[k]->filter.n <= 0) all_filter = 0; }
+    if (np == 1) {
+        if (all_taper) { ko_discrete_plf_span(&p[0]->taper, p[0]->dt, ps); span_isect(ps, p[0]->span, span); }
+        else { span[0] = p[0]->dataspan[0]; span[1] = p[0]->dataspan[1]; }
+    } else {
+        if (np == 2) probes_adjust_spans(p[0], p[1]); else probes_adjust_spans_3(p[0], p[1], p[2]);
+        if (all_taper) {
+            for (int k = 0; k < np; k++) { ko_discrete_plf_span(&p[k]->taper, p[k]->dt, ps); span_isect(ps, p[k]->span, t[k]); }
+            if (t[0][0] > t[0][1]) { span[0] = t[1][0]; span[1] = t[1][1]; }
+            else if (t[1][0] > t[1][1]) { span[0] = t[0][0]; span[1] = t[0][1]; }
+            else if (np == 3 && t[2][0] > t[2][1]) { span[0] = t[2][0]; span[1] = t[2][1]; }     /* as the reference has it */
+            else { span_union(t[0], t[1], span); if (np == 3) { int u[2] = { span[0], span[1] }; span_union(u, t[2], span); } }
+        } else {
+            span_union(p[0]->dataspan, p[1]->dataspan, span);
+            if (np == 3) { int u[2] = { span[0], span[1] }; span_union(u, p[2]->dataspan, span); }
+        }
+        if (span[0] > span[1]) return 0.f;
+    }
+    const float *x[3];
+    float f[3];
+    for (int k = 0; k < np; k++) {
+        const float *src;
+        if (all_filter) { update_array_filtered(p[k]); src = p[k]->array_filtered; }
+        else if (all_taper) { update_array_tapered(p[k]); src = p[k]->array_tapered; }
+        else src = p[k]->array;
+        x[k] = src + (span[0] - p[k]->span[0]);
+        f[k] = p[k]->factor;
+    }
+    return shake_apply(kind, x, f, np, slen(span), p[0]->dt);
+}
+
 /* probe_get_plain/tapered/filtered, comparator.f90:350-420 */
 int ko_probe_get(ko_probe *p, int which, int *lo, float *out, int maxn)
 {

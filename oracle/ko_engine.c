@@ -216,6 +216,54 @@ void ko_engine_probe_spans(ko_engine *e, int irec1, int icomp1, int which, int o
     out[0] = p->span[0]; out[1] = p->span[1]; out[2] = p->dataspan[0]; out[3] = p->dataspan[1];
 }
 
+/* get_component_ids, receiver.f90:512-542 (1-based component indices, 0 = none) */
+static void get_component_ids(const ko_receiver *r, int *iver, int *ihor1, int *ihor2)
+{
+    *ihor1 = 0; *ihor2 = 0; *iver = 0;
+    for (int k = 0; k < r->ncomponents; k++) {
+        const int ict = abs(r->components[k]);
+        if (ict == 1) *ihor1 = k + 1;
+        if (ict == 2) *ihor2 = k + 1;
+        if (ict == 3) *iver = k + 1;
+    }
+    if (*ihor1 == 0 || *ihor2 == 0)
+        for (int k = 0; k < r->ncomponents; k++) {
+            const int ict = abs(r->components[k]);
+            if (ict == 4) *ihor1 = k + 1;
+            if (ict == 5) *ihor2 = k + 1;
+        }
+    if (*ihor1 == 0 || *ihor2 == 0) { *ihor1 = 0; *ihor2 = 0; }
+}
+
+/* get_peak_amplitudes (minimizer_engine.f90:1174-1212, receiver_get_maxabs receiver.f90:544-574) for differentiate = 1, 2
+ * and get_arias_intensities (:1214-1246, receiver_get_arias_intensity receiver.f90:576-594) for differentiate = 0:
+ * one value per ENABLED receiver; the synthetic probes must be current.  Returns the count. */
+int ko_engine_shake(ko_engine *e, int differentiate, float *out)
+{
+    int n = 0;
+    for (int ir = 0; ir < e->nreceivers; ir++) {
+        ko_receiver *r = &e->receivers[ir];
+        if (!r->enabled) continue;
+        int iver, ih1, ih2;
+        get_component_ids(r, &iver, &ih1, &ih2);
+        ko_probe *p[3];
+        int np = 0;
+        float val = 0.f;
+        if (differentiate) {
+            const int ic[3] = { iver, ih1, ih2 };
+            for (int i = 0; i < 3; i++) if (ic[i]) p[np++] = &r->syn_probes[ic[i] - 1];
+            if (np) val = ko_probes_shake(p, np, differentiate);
+        } else {
+            if (iver && ih1 && ih2) { p[0] = &r->syn_probes[iver - 1]; p[1] = &r->syn_probes[ih1 - 1]; p[2] = &r->syn_probes[ih2 - 1]; np = 3; }
+            else if (ih1 && ih2) { p[0] = &r->syn_probes[ih1 - 1]; p[1] = &r->syn_probes[ih2 - 1]; np = 2; }
+            else if (iver) { p[0] = &r->syn_probes[iver - 1]; np = 1; }
+            if (np) val = ko_probes_shake(p, np, 3);
+        }
+        out[n++] = val;
+    }
+    return n;
+}
+
 /* receiver_shift_ref_seismogram, receiver.f90:800-814 (shift in samples) */
 void ko_engine_shift_ref_seismogram(ko_engine *e, int irec1, int ishift)
 {

@@ -694,6 +694,51 @@ def test_minimize_lm_is_the_reference_minpack_run_with_batched_jacobians(limits)
     assert np.max(np.abs(last_o - res.params) / scale) < 2e-3 and abs(glob_o - res.misfit) < 1e-3 * g0 + 1e-5
 
 
+@pytest.mark.parametrize("mode", ["tapered", "untapered", "synthesis_only"])
+def test_peak_amplitudes_and_arias_intensities(mode):
+    """get_peak_amplitudes / get_arias_intensities (receiver.f90:512-594, comparator.f90:519-625): per enabled receiver the
+    peak velocity / acceleration vector norm and the Arias intensity of the (tapered) synthetics.  The values are built on
+    sample differences, so the synthetics' tolerance shows amplified: 1e-4 relative."""
+    comps = ["ned", "d", "ar", "nd", "une", "rau"]
+    sc = Scenario(nrec=6, comps_list=comps)
+    e = sc.oracle()
+    p = sc.product()
+    if mode != "synthesis_only":
+        sc.make_references(e)
+        if mode == "untapered":
+            sc.tapers = {}
+        sc.apply_setup(e, True)
+        sc.apply_setup(p, False)
+    for rise, factor in ((0.0, 1.0), (2.0, 0.7)):
+        e.set_synthetics_factor(factor)
+        p.set_synthetics_factor(factor)
+        trials = synthetic.bilat_strike_sweep(3, step=4.0)
+        trials[:, 13] = rise
+        p.set_source_params("bilateral", trials)
+        for i in (2, 0):
+            if mode != "tapered":              # strip spans remember earlier sources in the reference: fresh engine each time
+                e.close()
+                e = sc.oracle()
+                sc.apply_setup(e, True)
+                e.set_synthetics_factor(factor)
+            e.set_source_params(1, trials[i])
+            for want, got in ((e.peak_amplitudes(1), p.get_peak_amplitudes(1, i)), (e.peak_amplitudes(2), p.get_peak_amplitudes(2, i)),
+                              (e.arias_intensities(), p.get_arias_intensities(i))):
+                assert len(got) == len(want) == 6 and np.all(want > 0)
+                assert np.allclose(got, want, rtol=1e-4, atol=0), (mode, rise, i, got, want)
+    if mode == "tapered":                     # misfits are unaffected by the diagnostic evaluations in between
+        m, n, g = oracle_misfits(e, 1, trials)
+        p.eval()
+        assert misfit_close(p.get_misfits()[2], g)
+        p.switch_receiver(2, False)
+        assert len(p.get_arias_intensities(1)) == 5
+        with pytest.raises(KiwiHipError, match="differentiate argument must be 1"):
+            p.get_peak_amplitudes(0)
+        p.set_misfit_filter(1, [0.01, 0.02, 0.1, 0.2], [0, 1, 1, 0])
+        with pytest.raises(KiwiHipError, match="not available with a misfit filter"):
+            p.get_arias_intensities(0)
+
+
 def test_point_lp_source():
     """point_lp (source type 3, source_point_lp.f90): band-limited point source, ~40 time steps at one point."""
     sc = Scenario(nrec=4)

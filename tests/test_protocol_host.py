@@ -225,6 +225,15 @@ def test_protocol_host_matches_python_host_and_oracle(host, tmp_path):
         assert abs(v2[0]) == 0.0 and np.max(np.abs(v2)) <= np.max(np.abs(d)) * (1 + 1e-6)
         with pytest.raises(protocol.SeismosizerReturnedError, match="unknown probe"):
             p.do("output_seismograms", str(tmp_path / "x"), "table", "nonsense", "plain")
+        # shake-map diagnostics over the wire (minimizer.f90:1305-1372)
+        p.do("set_misfit_filter")
+        e.set_source_params(1, trials[1])
+        for cmd, want in (("get_peak_amplitudes 1", e.peak_amplitudes(1)), ("get_peak_amplitudes 2", e.peak_amplitudes(2)),
+                          ("get_arias_intensities", e.arias_intensities())):
+            got = np.array(p.do(*cmd.split()).split(), np.float32)
+            assert got.shape == want.shape and np.allclose(got, want, rtol=2e-4)
+        with pytest.raises(protocol.SeismosizerReturnedError, match="differentiate argument must be 1"):
+            p.do("get_peak_amplitudes", 3)
         # output_source_model: the centroid table the engine holds (minimizer_engine.f90:947-977)
         p.do("output_source_model", str(tmp_path / "sm"))
         tab = np.loadtxt(str(tmp_path / "sm-dsm.table"), dtype=np.float32, ndmin=2)
