@@ -188,6 +188,12 @@ int kiwi_hip_get_synthetics(kiwi_hip_ctx *ctx, int isrc, int irec, int icomp, in
 int kiwi_hip_get_reference(kiwi_hip_ctx *ctx, int irec, int icomp, int which, int *first, int *n, float *out, int maxn);
 
 /* ---- measurement / inspection ---- */
+/* output_cross_correlations (minimizer_engine.f90:1283-1306; receiver.f90:597-616; comparator.f90:1061-1090): for one
+ * receiver cc[component][shift] = scalar product of the tapered synthetic of source isrc with the reference pulled
+ * through its fixed taper, for the integer shifts nint(min/dt) .. nint(max/dt) (first_shift, nshift; nshift = 0 for a
+ * disabled receiver).  Set-up-time helper like autoshift: evaluated on the host from one device evaluation. */
+int kiwi_hip_get_cross_correlations(kiwi_hip_ctx *ctx, int isrc, int irec, float min_shift, float max_shift,
+                                    int *first_shift, int *nshift, float *cc, int maxn);
 /* get_peak_amplitudes (minimizer_engine.f90:1174-1212; receiver.f90:544-574; comparator.f90:519-589): per ENABLED
  * receiver the maximum over the misfit window (taper span; without taper the union of the synthetic strips' data spans)
  * of the vector norm of the once (differentiate = 1, velocity) or twice (2, acceleration) differenced synthetics of

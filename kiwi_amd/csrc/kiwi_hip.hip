@@ -1594,6 +1594,68 @@ int kiwi_hip_shift_ref_seismogram(kiwi_hip_ctx *c, int irec, float shift)
     GUARD_END(c)
 }
 
+// receiver_calculate_cross_correlations (receiver.f90:597-616): cc[k][q] = scalar product of the tapered synthetic of
+// component k (host copy `syn` of one evaluated source block) with the reference shifted by lo + q samples inside its
+// fixed taper (probes_windowed_cross_corr, comparator.f90:1061-1090; scalar_product_2, :627-637)
+static void receiver_cross_correlations(kiwi_hip_ctx *c, int ir, const std::vector<float> &syn, int lo, int ns, std::vector<float> &cc)
+{
+    const Receiver &r = c->recv[ir];
+    const float dt = c->gm.dt;
+    int w[2];
+    discrete_plf_span(r.taper, dt, w);
+    const int wlen = w[1] - w[0] + 1;
+    std::vector<float> tww(wlen, 1.f);
+    plf_taper_array(r.taper, tww.data(), w[0], w[1], dt, IP_COS);
+    cc.assign((size_t)ns * r.ncomp, 0.f);
+    int slot0 = -1;
+    for (size_t i = 0; i < c->comps.size(); i++) if (c->comps[i].rec == ir) { slot0 = (int)i; break; }
+    for (int k = 0; k < r.ncomp; k++) {
+        const CompDev &cd = c->comps[slot0 + k];
+        const float *a = syn.data() + cd.synofs + cd.halo;               // tapered synthetic over the window
+        const auto &rf = r.ref[k];
+        const int f0 = rf.first, f1 = f0 + (int)rf.data.size() - 1;
+        for (int q = 0; q < ns; q++) {
+            const int sh = lo + q;
+            double acc = 0.0;
+            for (int t = w[0]; t <= w[1]; t++) {
+                const int ts = t - sh;
+                float b = 0.f;
+                if (ts >= f0) b = (rf.data[std::min(ts, f1) - f0] * 1.f) * tww[t - w[0]];
+                const float av = a[t - w[0]];
+                acc += (c->syn_factor == 1.f) ? (double)(av * b) : (double)(av * c->syn_factor * b * 1.f);
+            }
+            cc[(size_t)k * ns + q] = (float)acc;
+        }
+    }
+}
+
+// output_cross_correlations (minimizer_engine.f90:1283-1306): the table of one receiver
+int kiwi_hip_get_cross_correlations(kiwi_hip_ctx *c, int isrc, int irec, float min_shift, float max_shift, int *first_shift,
+                                    int *nshift, float *cc_out, int maxn)
+{
+    GUARD_BEGIN
+    if (irec < 1 || irec > (int)c->recv.size()) throw std::runtime_error("receiver index out of range");
+    if (isrc < 0 || isrc >= c->nsrc) throw std::runtime_error("source index out of range");
+    HIPCHECK(hipSetDevice(c->device));
+    prepare(c);
+    const Receiver &r = c->recv[irec - 1];
+    if (c->synth_only || !r.taper.defined()) throw std::runtime_error("cross-correlations need reference seismograms and misfit tapers");
+    const float dt = c->gm.dt;
+    const int lo = (int)std::lround(min_shift / dt), hi = (int)std::lround(max_shift / dt), ns = hi - lo + 1;      // :1298
+    if (ns < 1) throw std::runtime_error("empty shift range");
+    *first_shift = lo; *nshift = ns;
+    if (!r.enabled || r.ncomp == 0) { *nshift = 0; return 0; }
+    if ((long long)ns * r.ncomp > maxn) throw std::runtime_error("cross-correlation buffer too small");
+    eval_impl(c, isrc, 1, 2);
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    std::vector<float> syn(c->syn_stride), cc;
+    HIPCHECK(hipMemcpy(syn.data(), c->proc_d.p, c->syn_stride * sizeof(float), hipMemcpyDeviceToHost));
+    receiver_cross_correlations(c, irec - 1, syn, lo, ns, cc);
+    std::copy(cc.begin(), cc.end(), cc_out);
+    return 0;
+    GUARD_END(c)
+}
+
 int kiwi_hip_autoshift_ref_seismogram(kiwi_hip_ctx *c, int irec, float min_shift, float max_shift, int isrc, float *shifts)
 {
     GUARD_BEGIN
@@ -1616,34 +1678,10 @@ int kiwi_hip_autoshift_ref_seismogram(kiwi_hip_ctx *c, int irec, float min_shift
         Receiver &r = c->recv[ir];
         int ishift = 0;
         if (r.enabled && r.ncomp > 0) {                                          // receiver.f90:816-832
-            int w[2];
-            discrete_plf_span(r.taper, dt, w);
-            const int wlen = w[1] - w[0] + 1;
-            std::vector<float> tww(wlen, 1.f);
-            plf_taper_array(r.taper, tww.data(), w[0], w[1], dt, IP_COS);
-            std::vector<float> cc((size_t)ns * r.ncomp);
-            int slot0 = -1;
-            for (size_t i = 0; i < c->comps.size(); i++) if (c->comps[i].rec == ir) { slot0 = (int)i; break; }
+            std::vector<float> cc;
+            receiver_cross_correlations(c, ir, syn, lo, ns, cc);
             float ccmax = -std::numeric_limits<float>::infinity();
-            for (int k = 0; k < r.ncomp; k++) {
-                const CompDev &cd = c->comps[slot0 + k];
-                const float *a = syn.data() + cd.synofs + cd.halo;               // tapered synthetic over the window
-                const auto &rf = r.ref[k];
-                const int f0 = rf.first, f1 = f0 + (int)rf.data.size() - 1;
-                for (int q = 0; q < ns; q++) {                                   // probes_windowed_cross_corr, comparator.f90:1061-1090
-                    const int sh = lo + q;
-                    double acc = 0.0;
-                    for (int t = w[0]; t <= w[1]; t++) {
-                        const int ts = t - sh;
-                        float b = 0.f;
-                        if (ts >= f0) b = (rf.data[std::min(ts, f1) - f0] * 1.f) * tww[t - w[0]];
-                        const float av = a[t - w[0]];
-                        acc += (c->syn_factor == 1.f) ? (double)(av * b) : (double)(av * c->syn_factor * b * 1.f);   // scalar_product_2, :627-637
-                    }
-                    cc[(size_t)k * ns + q] = (float)acc;
-                    ccmax = std::max(ccmax, (float)acc);
-                }
-            }
+            for (float v : cc) ccmax = std::max(ccmax, v);
             // imax = maxloc( sum( max(cc / max(1, maxval(cc)), 0)**2, over components ) ), first maximum
             const float den = std::max(1.f, ccmax);
             int imax = 0;

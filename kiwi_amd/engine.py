@@ -274,6 +274,17 @@ class Engine:
                                                 _fp(out), maxn), "output_seismograms")
         return first.value, out[:n.value].copy()
 
+    def get_cross_correlations(self, irec, min_shift, max_shift, isrc=0):
+        """`output_cross_correlations` for one receiver: (first shift in samples, cc[ncomp, nshift])."""
+        dt = self.dt
+        ns = int(round(max_shift / dt)) - int(round(min_shift / dt)) + 1
+        nc = len(self.components[irec - 1])
+        out = np.zeros(max(ns, 1) * max(nc, 1), np.float32)
+        first, n = C.c_int(), C.c_int()
+        self._ck(self.L.kiwi_hip_get_cross_correlations(self.h, isrc, irec, min_shift, max_shift, C.byref(first), C.byref(n),
+                                                        _fp(out), len(out)), "output_cross_correlations")
+        return first.value, out[:nc * n.value].reshape(nc, n.value) if n.value else np.zeros((0, 0), np.float32)
+
     def get_peak_amplitudes(self, differentiate, isrc=0):
         """`get_peak_amplitudes`: per enabled receiver the peak vector norm of the velocity (1) or acceleration (2)."""
         out = np.zeros(sum(1 for e in self.enabled if e), np.float32)

@@ -259,6 +259,16 @@ module kiwi_hip_binding
             real(c_float), intent(out) :: out(*)
         end function
 
+        integer(c_int) function kiwi_hip_get_cross_correlations( ctx, isrc, irec, min_shift, max_shift, first_shift, nshift, &
+                                                                  cc, maxn ) bind(C, name='kiwi_hip_get_cross_correlations')
+            import :: c_int, c_ptr, c_float
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: isrc, irec, maxn
+            real(c_float), value :: min_shift, max_shift
+            integer(c_int), intent(out) :: first_shift, nshift
+            real(c_float), intent(out) :: cc(*)
+        end function
+
         integer(c_int) function kiwi_hip_get_peak_amplitudes( ctx, isrc, differentiate, out ) &
                 bind(C, name='kiwi_hip_get_peak_amplitudes')
             import :: c_int, c_ptr, c_float

@@ -25,8 +25,8 @@
 !   output_seismograms <base> table synthetics|references [plain|tapered|filtered]
 !   output_distances <file>;  output_source_model <base>
 !   get_cached_traces_memory;  set_cached_traces_memory_limit, set_verbose, set_ignore_sigint   accepted, no effect
-!   get_peak_amplitudes 1|2;  get_arias_intensities
-! Not provided: get_principal_axes, output_cross_correlations, output_seismogram_spectra (diagnostics beside the
+!   get_peak_amplitudes 1|2;  get_arias_intensities;  output_cross_correlations <base> <shift-min> <shift-max>
+! Not provided: get_principal_axes, output_seismogram_spectra (diagnostics beside the
 !   inversion loop) and mseed / sac file formats.
 ! Batch extension (SURVEY.md 8f-1), one pipe round trip for a whole grid:
 !   eval_sources <type> <paramfile> <outfile>   one parameter vector per line in; per source
@@ -220,6 +220,7 @@ program minimizer_hip
         case ('set_source_subparams_limits'); call do_set_source_subparams_limits( a, ok_ )
         case ('get_source_subparams');      call do_get_source_subparams( ok_ )
         case ('minimize_lm');               call do_minimize_lm( ok_ )
+        case ('output_cross_correlations'); call do_output_cross_correlations( a, ok_ )
         case ('get_peak_amplitudes');       call do_get_shake( a, .true., ok_ )
         case ('get_arias_intensities');     call do_get_shake( a, .false., ok_ )
         case ('set_source_crust');          call do_set_source_crust( a, ok_ )
@@ -716,6 +717,49 @@ program minimizer_hip
                 answer = answer//trim(adjustl(buffer))
             end if
         end do
+        ok_ = .true.
+    end subroutine
+
+  ! output_cross_correlations filenamebase shift-min shift-max (minimizer.f90:1442-1482, minimizer_engine.f90:1283-1306,
+  ! receiver.f90:710-744): per enabled receiver and component <base>-<irec>-<comp>.table with lines "shift [s]  value"
+    subroutine do_output_cross_correlations( a, ok_ )
+        character(len=*), intent(in) :: a
+        logical, intent(out) :: ok_
+        character(len=1024) :: base, fn
+        character(len=maxline) :: rest
+        real(c_float) :: smin, smax
+        integer(c_int) :: first, ns
+        integer :: ios, irec, k, q, unit, nc
+        real(c_float), allocatable :: cc(:)
+        ok_ = .false.
+        call split_first( a, base, rest )
+        read (rest,*,iostat=ios) smin, smax
+        if (ios /= 0) then
+            call fail( 'usage: output_cross_correlations filenamebase shift-min shift-max' ); return
+        end if
+        if (.not. need_ctx()) return
+        if (.not. source_set) then
+            call fail( 'no source set' ); return
+        end if
+        allocate( cc(1048576) )
+        do irec = 1, nreceivers
+            if (.not. enabled(irec)) cycle
+            nc = len_trim(components(irec))
+            if (.not. check( kiwi_hip_get_cross_correlations( ctx, 0_c_int, int(irec,c_int), smin, smax, first, ns, cc, &
+                                                              1048576_c_int ) )) return
+            do k = 1, nc
+                write (fn,'(a,a,i0,a,a,a)') trim(base), '-', irec, '-', components(irec)(k:k), '.table'
+                open( newunit=unit, file=trim(fn), status='unknown', iostat=ios )
+                if (ios /= 0) then
+                    call fail( 'failed to write output file: '//trim(fn) ); return
+                end if
+                do q = 1, ns
+                    write (unit,*) real(first,8) * real(db_dt,8) + (q - 1) * db_dt, cc((k-1)*ns + q)
+                end do
+                close( unit )
+            end do
+        end do
+        evaluated = .false.
         ok_ = .true.
     end subroutine
 

@@ -238,6 +238,7 @@ int ko_engine_get_reference(ko_engine *e, int irec1, int icomp1, int which, int 
 void ko_engine_probe_spans(ko_engine *e, int irec1, int icomp1, int which, int out[4]);
 void ko_engine_shift_ref_seismogram(ko_engine *e, int irec1, int ishift);
 int ko_engine_autoshift_ref_seismogram(ko_engine *e, int irec1, int lo, int hi);
+int ko_engine_cross_correlations(ko_engine *e, int irec1, int lo, int hi, float *cc);
 int ko_engine_shake(ko_engine *e, int differentiate, float *out);   /* get_peak_amplitudes (1, 2) / get_arias_intensities (0) */
 void ko_engine_set_nthreads(ko_engine *e, int n);
 /* the three private engine steps (minimizer_engine.f90:885-945) */

@@ -101,6 +101,8 @@ def lib():
         L.ko_engine_get_floating_shift.argtypes = [C.c_void_p, C.c_int]
         L.ko_engine_get_floating_shift.restype = C.c_int
         L.ko_engine_set_nthreads.argtypes = [C.c_void_p, C.c_int]
+        L.ko_engine_cross_correlations.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, c_float_p]
+        L.ko_engine_cross_correlations.restype = C.c_int
         L.ko_engine_shake.argtypes = [C.c_void_p, C.c_int, c_float_p]
         L.ko_engine_shake.restype = C.c_int
         for f in ("calculate_seismograms", "scale_seismograms", "calculate_misfits"):
@@ -352,6 +354,14 @@ class Engine:
 
     def set_nthreads(self, n):
         lib().ko_engine_set_nthreads(self.h, n)
+
+    def cross_correlations(self, irec1, lo, hi):
+        """receiver_calculate_cross_correlations for integer shifts lo..hi: cc[ncomp, nshift] (update_misfits first)."""
+        self.get_misfits()
+        ns = hi - lo + 1
+        out = np.zeros(5 * ns, np.float32)
+        nc = lib().ko_engine_cross_correlations(self.h, irec1, lo, hi, _fp(out))
+        return out[:nc * ns].reshape(nc, ns)
 
     def peak_amplitudes(self, differentiate):
         """get_peak_amplitudes: peak velocity (1) / acceleration (2) vector norm per enabled receiver (update_syn_probes first)."""

@@ -271,6 +271,18 @@ void ko_engine_shift_ref_seismogram(ko_engine *e, int irec1, int ishift)
     for (int k = 0; k < r->ncomponents; k++) ko_probe_shift(&r->ref_probes[k], ishift);
 }
 
+/* receiver_calculate_cross_correlations, receiver.f90:597-616: cc[k][q] for shifts lo..hi (samples); returns ncomponents
+ * (0 for a disabled receiver).  The synthetic probes must be current. */
+int ko_engine_cross_correlations(ko_engine *e, int irec1, int lo, int hi, float *cc)
+{
+    ko_receiver *r = &e->receivers[irec1 - 1];
+    if (!r->enabled) return 0;
+    const int ns = hi - lo + 1;
+    for (int k = 0; k < r->ncomponents; k++)
+        ko_probes_windowed_cross_corr(&r->syn_probes[k], &r->ref_probes[k], lo, hi, cc + (size_t)k * ns);
+    return r->ncomponents;
+}
+
 /* receiver_autoshift_ref_seismogram, receiver.f90:816-832 (range in samples; synthetics must be current).
  * Returns the shift applied. */
 int ko_engine_autoshift_ref_seismogram(ko_engine *e, int irec1, int lo, int hi)

@@ -499,6 +499,12 @@ def test_shift_and_autoshift_of_reference_seismograms():
     p.eval()
     pm, pn, pg = p.get_misfits()
     assert misfit_close(pm, m) and np.array_equal(pn[0], n[0])
+    # the cross-correlations autoshift is built on (output_cross_correlations, receiver.f90:597-616)
+    for ir in (1, 3):
+        want_cc = e.cross_correlations(ir, -5, 5)
+        first, cc = p.get_cross_correlations(ir, -5 * dt, 5 * dt)
+        assert first == -5 and cc.shape == want_cc.shape == (len(sc.comps[ir - 1]), 11)
+        assert np.allclose(cc, want_cc, rtol=1e-5, atol=1e-6 * np.max(np.abs(want_cc)))
     # autoshift all receivers within [-5, +5] samples against the current source
     want = [e.autoshift_ref_seismogram(ir + 1, -5, 5) * dt for ir in range(4)]
     got = p.autoshift_ref_seismogram(0, -5 * dt, 5 * dt, isrc=0)

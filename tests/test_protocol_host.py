@@ -234,6 +234,11 @@ def test_protocol_host_matches_python_host_and_oracle(host, tmp_path):
             assert got.shape == want.shape and np.allclose(got, want, rtol=2e-4)
         with pytest.raises(protocol.SeismosizerReturnedError, match="differentiate argument must be 1"):
             p.do("get_peak_amplitudes", 3)
+        p.do("output_cross_correlations", str(tmp_path / "cc"), -2 * dt, 2 * dt)
+        t, v = protocol.read_table(str(tmp_path / "cc-3-e.table"))
+        e.get_misfits()
+        want_cc = e.cross_correlations(3, -2, 2)[sc.comps[2].index("e")]
+        assert np.allclose(t, np.arange(-2, 3) * dt) and np.allclose(v, want_cc, rtol=1e-4, atol=1e-5 * np.max(np.abs(want_cc)))
         # output_source_model: the centroid table the engine holds (minimizer_engine.f90:947-977)
         p.do("output_source_model", str(tmp_path / "sm"))
         tab = np.loadtxt(str(tmp_path / "sm-dsm.table"), dtype=np.float32, ndmin=2)
