@@ -188,6 +188,10 @@ int kiwi_hip_get_synthetics(kiwi_hip_ctx *ctx, int isrc, int irec, int icomp, in
 int kiwi_hip_get_reference(kiwi_hip_ctx *ctx, int irec, int icomp, int which, int *first, int *n, float *out, int maxn);
 
 /* ---- measurement / inspection ---- */
+/* get_principal_axes (minimizer_engine.f90:1248-1258): P and T axis (azimuth, polar angle in degrees, lower hemisphere)
+ * of a bilateral source as psm_update_dep_params_bilat derives them (source_bilat.f90:216-239); the reference sets them
+ * for no other source type: returns -1 for those.  Host only. */
+int kiwi_hip_principal_axes(int sourcetype, const float *params, float *pax, float *tax);
 /* output_cross_correlations (minimizer_engine.f90:1283-1306; receiver.f90:597-616; comparator.f90:1061-1090): for one
  * receiver cc[component][shift] = scalar product of the tapered synthetic of source isrc with the reference pulled
  * through its fixed taper, for the integer shifts nint(min/dt) .. nint(max/dt) (first_shift, nshift; nshift = 0 for a

@@ -1565,6 +1565,13 @@ static int shake_impl(kiwi_hip_ctx *c, int isrc, int kind, float *out)
     return 0;
 }
 
+int kiwi_hip_principal_axes(int sourcetype, const float *params, float *pax, float *tax)
+{
+    if (sourcetype != KIWI_SRC_BILAT) return -1;          // only psm_update_dep_params_bilat sets them (source_bilat.f90:233-237)
+    principal_axes_bilat(params, pax, tax);
+    return 0;
+}
+
 int kiwi_hip_get_peak_amplitudes(kiwi_hip_ctx *c, int isrc, int differentiate, float *out)
 {
     GUARD_BEGIN

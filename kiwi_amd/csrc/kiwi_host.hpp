@@ -28,6 +28,7 @@ struct GeoCoords { double lat = 0, lon = 0; };   // orthodrome.f90:32-34, radian
 // d2r for real*8 / real (orthodrome.f90:313-338): the factor 2./360.*pi is a default-real constant
 inline double d2r(double deg) { return (double)((2.f / 360.f) * kPi) * deg; }
 inline float  d2r(float deg)  { return ((2.f / 360.f) * kPi) * deg; }
+inline float  r2d(float rad)  { return ((360.f / 2.f) / kPi) * rad; }          // r2d_r, orthodrome.f90:319-326
 
 // cosdelta, orthodrome.f90:284-293
 inline double cosdelta(const GeoCoords &a, const GeoCoords &b)
@@ -261,6 +262,29 @@ inline bool discretize_moment_tensor(const float *p, float doi, DiscreteSource &
     }
     out.moment = 1.f; out.risetime = 0.f;
     return true;
+}
+
+// P and T axes of a bilateral source (psm_update_dep_params_bilat, source_bilat.f90:216-239, with polar / domeshot / wrap
+// :565-593): (azimuth, polar angle) in degrees of R_slip (+-sqrt 2, 0, -sqrt 2), folded onto the lower hemisphere
+inline void principal_axes_bilat(const float *p, float pax[2], float tax[2])
+{
+    float R[3][3];
+    const float strike = d2r(p[5]), dip = d2r(p[6]), rake = d2r(p[7]);
+    init_euler(dip, strike, -rake, R);
+    const float s2 = std::sqrt(2.f);
+    auto wrap = [](float x, float mi, float ma) { return x - std::floor((x - mi) / (ma - mi)) * (ma - mi); };
+    auto axis = [&](float vx, float out[2]) {
+        float xyz[3], pol[3];
+        for (int i = 0; i < 3; i++) xyz[i] = detail::dot3(R[i], vx, 0.f, -s2);
+        pol[0] = std::sqrt((xyz[0] * xyz[0] + xyz[1] * xyz[1]) + xyz[2] * xyz[2]);
+        pol[1] = std::atan2(xyz[1], xyz[0]);
+        pol[2] = std::acos(xyz[2] / pol[0]);
+        float d1 = wrap(pol[1], kPi, -kPi), d2 = wrap(pol[2], kPi, -kPi);
+        if (d2 > kPi / 2.f) { d1 = wrap(d1 + kPi, -kPi, kPi); d2 = kPi - d2; }
+        out[0] = r2d(d1); out[1] = r2d(d2);
+    };
+    axis(s2, pax);
+    axis(-s2, tax);
 }
 
 // psm_set_bilat + psm_to_tdsm_bilat, source_bilat.f90:173-459

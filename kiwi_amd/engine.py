@@ -46,6 +46,16 @@ def discretize(sourcetype, params, effective_dt):
     return cent, mo.value, ri.value
 
 
+def principal_axes(sourcetype, params):
+    """`get_principal_axes`: ((P azimuth, P polar angle), (T azimuth, T polar angle)) in degrees; bilateral sources only."""
+    L = _lib.load()
+    p = np.ascontiguousarray(params, np.float32)
+    pax, tax = np.zeros(2, np.float32), np.zeros(2, np.float32)
+    if L.kiwi_hip_principal_axes(SOURCE_TYPES[sourcetype], _fp(p), _fp(pax), _fp(tax)) != 0:
+        raise KiwiHipError("principal axes are defined for bilateral sources only")
+    return pax, tax
+
+
 def pack_crust_profile(vp, vs, rho, thickness):
     """t_crust2x2_1d_profile (crust2x2.f90:45-50) as the 31 floats the C-ABI takes."""
     out = np.concatenate([np.asarray(vp, np.float32), np.asarray(vs, np.float32), np.asarray(rho, np.float32),

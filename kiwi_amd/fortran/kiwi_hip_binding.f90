@@ -259,6 +259,13 @@ module kiwi_hip_binding
             real(c_float), intent(out) :: out(*)
         end function
 
+        integer(c_int) function kiwi_hip_principal_axes( sourcetype, params, pax, tax ) bind(C, name='kiwi_hip_principal_axes')
+            import :: c_int, c_float
+            integer(c_int), value :: sourcetype
+            real(c_float), intent(in) :: params(*)
+            real(c_float), intent(out) :: pax(2), tax(2)
+        end function
+
         integer(c_int) function kiwi_hip_get_cross_correlations( ctx, isrc, irec, min_shift, max_shift, first_shift, nshift, &
                                                                   cc, maxn ) bind(C, name='kiwi_hip_get_cross_correlations')
             import :: c_int, c_ptr, c_float

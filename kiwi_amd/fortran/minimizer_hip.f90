@@ -26,7 +26,8 @@
 !   output_distances <file>;  output_source_model <base>
 !   get_cached_traces_memory;  set_cached_traces_memory_limit, set_verbose, set_ignore_sigint   accepted, no effect
 !   get_peak_amplitudes 1|2;  get_arias_intensities;  output_cross_correlations <base> <shift-min> <shift-max>
-! Not provided: get_principal_axes, output_seismogram_spectra (diagnostics beside the
+!   get_principal_axes                     bilateral sources
+! Not provided: output_seismogram_spectra (diagnostics beside the
 !   inversion loop) and mseed / sac file formats.
 ! Batch extension (SURVEY.md 8f-1), one pipe round trip for a whole grid:
 !   eval_sources <type> <paramfile> <outfile>   one parameter vector per line in; per source
@@ -221,6 +222,7 @@ program minimizer_hip
         case ('get_source_subparams');      call do_get_source_subparams( ok_ )
         case ('minimize_lm');               call do_minimize_lm( ok_ )
         case ('output_cross_correlations'); call do_output_cross_correlations( a, ok_ )
+        case ('get_principal_axes');        call do_get_principal_axes( ok_ )
         case ('get_peak_amplitudes');       call do_get_shake( a, .true., ok_ )
         case ('get_arias_intensities');     call do_get_shake( a, .false., ok_ )
         case ('set_source_crust');          call do_set_source_crust( a, ok_ )
@@ -717,6 +719,24 @@ program minimizer_hip
                 answer = answer//trim(adjustl(buffer))
             end if
         end do
+        ok_ = .true.
+    end subroutine
+
+  ! get_principal_axes (minimizer.f90:1374-1402): "p-azimuth p-polar t-azimuth t-polar" in degrees
+    subroutine do_get_principal_axes( ok_ )
+        logical, intent(out) :: ok_
+        real(c_float) :: pax(2), tax(2)
+        character(len=128) :: buffer
+        ok_ = .false.
+        if (.not. source_set) then
+            call fail( 'no source set' ); return
+        end if
+        if (kiwi_hip_principal_axes( cur_st, cur_params, pax, tax ) /= 0) then
+            call fail( 'principal axes are defined for bilateral sources only' ); return
+        end if
+        write (buffer,*) pax(1), pax(2), tax(1), tax(2)
+        call reduce_whitespace( buffer )
+        answer = trim(adjustl(buffer))
         ok_ = .true.
     end subroutine
 

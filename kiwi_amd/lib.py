@@ -99,6 +99,8 @@ def load():
         "kiwi_hip_lmdif": [RESIDUAL_FN, vp, C.c_int, C.c_int, c_float_p, c_float_p, C.c_float, C.c_float, C.c_float, C.c_int,
                            C.c_float, c_float_p, C.c_int, C.c_float, c_int_p, c_int_p],
     }
+    L.kiwi_hip_principal_axes.argtypes = [C.c_int, c_float_p, c_float_p, c_float_p]
+    L.kiwi_hip_principal_axes.restype = C.c_int
     for name, argtypes in sig.items():
         f = getattr(L, name)
         f.argtypes = argtypes

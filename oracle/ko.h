@@ -113,6 +113,8 @@ int ko_psm_nparams(int sourcetype);
 int ko_psm_set(ko_psm *psm, int sourcetype, const float *params);
 /* discretise; *out is malloc'ed (caller frees), returns ncentroids (<0 on error) */
 int ko_psm_to_tdsm(ko_psm *psm, float shortest_doi, ko_centroid **out);
+/* psm%pax, psm%tax of a bilateral source (get_principal_axes) */
+void ko_principal_axes_bilat(const float *params, float pax[2], float tax[2]);
 
 /* ---------------- source_eikonal.f90 / source_mt_eikonal.f90 (+ eikonal, heap, geometry) ---------------- */
 #define KO_SRC_EIKONAL 4

@@ -314,3 +314,28 @@ int ko_psm_to_tdsm(ko_psm *psm, float shortest_doi, ko_centroid **out)
     }
     return -1;
 }
+
+/* P and T axes of a bilateral source: psm_update_dep_params_bilat (source_bilat.f90:216-239) with polar, domeshot and wrap
+ * (:565-593); (azimuth, polar angle) in degrees, lower hemisphere */
+static float wrapf_(float x, float mi, float ma) { return x - floorf((x - mi) / (ma - mi)) * (ma - mi); }
+
+void ko_principal_axes_bilat(const float *params, float pax[2], float tax[2])
+{
+    const float pi = 3.14159265358979f;
+    const float d2r = 2.f / 360.f * pi, r2d = 360.f / 2.f / pi;
+    float R[3][3];
+    ko_init_euler(d2r * params[6], d2r * params[5], -(d2r * params[7]), R);
+    const float s2 = sqrtf(2.f);
+    for (int a = 0; a < 2; a++) {
+        const float v[3] = { a == 0 ? s2 : -s2, 0.f, -s2 };
+        float xyz[3], pol[3];
+        for (int i = 0; i < 3; i++) xyz[i] = (R[i][0] * v[0] + R[i][1] * v[1]) + R[i][2] * v[2];
+        pol[0] = sqrtf((xyz[0] * xyz[0] + xyz[1] * xyz[1]) + xyz[2] * xyz[2]);
+        pol[1] = atan2f(xyz[1], xyz[0]);
+        pol[2] = acosf(xyz[2] / pol[0]);
+        float d1 = wrapf_(pol[1], pi, -pi), d2 = wrapf_(pol[2], pi, -pi);
+        if (d2 > pi / 2.f) { d1 = wrapf_(d1 + pi, -pi, pi); d2 = pi - d2; }
+        float *out = a == 0 ? pax : tax;
+        out[0] = r2d * d1; out[1] = r2d * d2;
+    }
+}

@@ -247,6 +247,18 @@ module ref_driver
 
   ! psm_set_<type> + psm_to_tdsm_<type> (source_bilat.f90:173,241; source_circular.f90:165,235;
   ! source_moment_tensor.f90:163,205).  sourcetype ids as parameterized_source.f90:45-50.
+  ! psm_set_bilat -> psm%pax, psm%tax (source_bilat.f90:216-239): P and T axis of a bilateral source
+    subroutine ref_principal_axes_bilat( params, pax, tax ) bind(C, name='ref_principal_axes_bilat')
+        real(c_float), intent(in) :: params(14)
+        real(c_float), intent(out) :: pax(2), tax(2)
+        type(t_psm), save :: psm
+        logical :: omc
+        call psm_destroy( psm )
+        call psm_set_bilat( psm, params, .false., omc )
+        pax = psm%pax
+        tax = psm%tax
+    end subroutine
+
     subroutine ref_discretize( sourcetype, np, params, effective_dt, maxc, nc, cent, moment, risetime, &
                                grid_size ) bind(C, name='ref_discretize')
         integer(c_int), value :: sourcetype, np, maxc

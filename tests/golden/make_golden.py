@@ -125,6 +125,20 @@ for st, plist in ((1, [[0., 0., 0., 10000., 1e20, 91., 87., 164., 0., 4000., 200
             k += 1
 out["ds_n"] = np.array(k)
 
+# ---- P / T axes of bilateral sources (psm_update_dep_params_bilat, source_bilat.f90:216-239)
+pa_rng = np.random.default_rng(77)
+pa_in = np.zeros((40, 14), np.float32)
+pa_in[:, 5] = pa_rng.uniform(-360, 360, 40)
+pa_in[:, 6] = pa_rng.uniform(0, 90, 40)
+pa_in[:, 7] = pa_rng.uniform(-180, 180, 40)
+pa_in[:4, 5:8] = [[0, 90, 0], [90, 45, 90], [30, 0, -90], [180, 90, 180]]
+pa_out = np.zeros((40, 4), np.float32)
+for i in range(40):
+    pax, tax = np.zeros(2, np.float32), np.zeros(2, np.float32)
+    R.ref_principal_axes_bilat(fp(pa_in[i]), fp(pax), fp(tax))
+    pa_out[i] = [pax[0], pax[1], tax[0], tax[1]]
+out["pa_in"], out["pa_out"] = pa_in, pa_out
+
 # ---- strip_fold (sparse_trace.f90:379): 20 cases
 for i in range(20):
     n = int(rng.integers(5, 80))

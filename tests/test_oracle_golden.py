@@ -90,3 +90,20 @@ def test_taper_weights_golden():
         arr = np.ones(hi - lo + 1, np.float32)
         L.ko_plf_taper_array_r(C.byref(p), fp(arr), C.c_int(lo), C.c_int(hi), C.c_float(float(G["tp%d_dx" % i])), C.c_int(0))
         assert biteq(arr, G["tp%d_o" % i]), i
+
+
+def test_principal_axes_golden():
+    """psm%pax / psm%tax of bilateral sources (source_bilat.f90:216-239): oracle and product host, bit for bit."""
+    from kiwi_amd import engine
+    L = ko.lib()
+    L.ko_principal_axes_bilat.restype = None
+    for p, want in zip(G["pa_in"], G["pa_out"]):
+        pax, tax = np.zeros(2, np.float32), np.zeros(2, np.float32)
+        L.ko_principal_axes_bilat(fp(np.ascontiguousarray(p)), fp(pax), fp(tax))
+        assert biteq(np.concatenate([pax, tax]), want)
+        ppax, ptax = engine.principal_axes("bilateral", p)
+        assert biteq(np.concatenate([ppax, ptax]), want)
+    import pytest
+    from kiwi_amd import KiwiHipError
+    with pytest.raises(KiwiHipError):
+        engine.principal_axes("circular", np.zeros(11, np.float32))

@@ -234,6 +234,9 @@ def test_protocol_host_matches_python_host_and_oracle(host, tmp_path):
             assert got.shape == want.shape and np.allclose(got, want, rtol=2e-4)
         with pytest.raises(protocol.SeismosizerReturnedError, match="differentiate argument must be 1"):
             p.do("get_peak_amplitudes", 3)
+        from kiwi_amd import engine as kengine
+        axes = np.array(p.do("get_principal_axes").split(), np.float32)
+        assert np.array_equal(axes, np.concatenate(kengine.principal_axes("bilateral", trials[1])))
         p.do("output_cross_correlations", str(tmp_path / "cc"), -2 * dt, 2 * dt)
         t, v = protocol.read_table(str(tmp_path / "cc-3-e.table"))
         e.get_misfits()
