@@ -913,7 +913,10 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
     // SOURCE index fastest in dispatch order: the workgroups resident at any moment are the same
     // (tile, receiver) of many neighbouring trial sources, which read (nearly) the same GF rows at
     // the same time, and blocks b, b+8, ... share an XCD and therefore its L2 (dispatch is
-    // round-robin over the 8 XCDs; speed only, never correctness).
+    // round-robin over the 8 XCDs; speed only, never correctness).  Measured alternative: giving each XCD a
+    // contiguous eighth of this order (all sources of one (tile, receiver) on ONE XCD, eight different
+    // (tile, receiver) sets in flight) is 4 % slower at cfg3 and 6 % at cfg4 -- eight L2s holding the same few rows
+    // cost nothing, eight times as many distinct rows in flight load the Infinity Fabric.
     const int s = RUNS ? run_first[blockIdx.x] : (int)blockIdx.x;               // first (or only) source of this workgroup
     const int s_end = RUNS ? run_first[blockIdx.x + 1] : s + 1;
     const bool multi = RUNS && s_end - s > 1;
