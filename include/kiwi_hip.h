@@ -188,6 +188,13 @@ int kiwi_hip_get_synthetics(kiwi_hip_ctx *ctx, int isrc, int irec, int icomp, in
 int kiwi_hip_get_reference(kiwi_hip_ctx *ctx, int irec, int icomp, int which, int *first, int *n, float *out, int maxn);
 
 /* ---- measurement / inspection ---- */
+/* output_seismogram_spectra (minimizer_engine.f90:1012-1039; probe_get_amp_spectrum, comparator.f90:333-354): amplitude
+ * spectrum of the reference (which_probe 0) or of the synthetic of source isrc (1) of one receiver component:
+ * |r2c| of the tapered window, n = ntrans / 2 + 1 bins at spacing df, transform length as the spectral comparator sizes
+ * the reference / synthetic pair (in the reference it follows the probes' span history); filtered != 0: times the
+ * frequency filter where the receiver has one.  Needs references and tapers. */
+int kiwi_hip_get_amp_spectrum(kiwi_hip_ctx *ctx, int isrc, int irec, int icomp, int which_probe, int filtered,
+                              float *df, int *n, float *out, int maxn);
 /* get_principal_axes (minimizer_engine.f90:1248-1258): P and T axis (azimuth, polar angle in degrees, lower hemisphere)
  * of a bilateral source as psm_update_dep_params_bilat derives them (source_bilat.f90:216-239); the reference sets them
  * for no other source type: returns -1 for those.  Host only. */

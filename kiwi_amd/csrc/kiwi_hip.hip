@@ -1565,6 +1565,57 @@ static int shake_impl(kiwi_hip_ctx *c, int isrc, int kind, float *out)
     return 0;
 }
 
+// output_seismogram_spectra (minimizer_engine.f90:1012-1039; probe_get_amp_spectrum, comparator.f90:333-354): the amplitude
+// spectrum of one probe as the spectral comparator sees it -- |r2c| of the tapered window, transform length as
+// probes_adjust_spans sizes the reference / synthetic pair; filtered = times the frequency filter where one is set.
+// Runs the engine's own spectral pipeline once with the method switched to ampspec_l2norm for the duration of the call.
+int kiwi_hip_get_amp_spectrum(kiwi_hip_ctx *c, int isrc, int irec, int icomp, int which_probe, int filtered, float *df, int *n,
+                              float *out, int maxn)
+{
+    GUARD_BEGIN
+    if (irec < 1 || irec > (int)c->recv.size()) throw std::runtime_error("receiver index out of range");
+    if (which_probe && (isrc < 0 || isrc >= c->nsrc)) throw std::runtime_error("source index out of range");
+    HIPCHECK(hipSetDevice(c->device));
+    const int method0 = c->method;
+    const Plf filter0 = c->recv[irec - 1].filter;
+    c->method = KIWI_AMPSPEC_L2NORM;
+    if (!filtered) c->recv[irec - 1].filter = Plf();              // plain: as if this receiver had no filter
+    c->prepared = false;
+    std::string err;
+    try {
+        prepare(c);
+        if (c->synth_only) throw std::runtime_error("spectra need reference seismograms and misfit tapers");
+        int slot = -1, k = 0;
+        for (size_t i = 0; i < c->comps.size(); i++)
+            if (c->comps[i].rec == irec - 1) { if (k == icomp - 1) { slot = (int)i; break; } k++; }
+        if (slot < 0) throw std::runtime_error("receiver disabled or component index out of range");
+        if (which_probe) eval_impl(c, isrc, 1, 0);
+        else if (!c->fft_ready) prepare_fft(c, c->reft_h);
+        HIPCHECK(hipStreamSynchronize(c->stream));
+        const CompDev cd = c->comps[slot];
+        const int nb = cd.ntrans / 2 + 1;
+        *df = 1.f / ((float)cd.ntrans * c->gm.dt);
+        *n = nb;
+        if (nb > maxn) throw std::runtime_error("spectrum buffer too small");
+        std::vector<float> fw(nb, 1.f);
+        const bool has_filter = c->recv[irec - 1].filter.defined();
+        if (has_filter) HIPCHECK(hipMemcpy(fw.data(), c->filtw_d.p + cd.specofs, nb * sizeof(float), hipMemcpyDeviceToHost));
+        if (which_probe) {
+            std::vector<float2> z(nb);
+            HIPCHECK(hipMemcpy(z.data(), c->spec_d.p + cd.spec_base + (size_t)cd.fft_row * nb, nb * sizeof(float2), hipMemcpyDeviceToHost));
+            for (int i = 0; i < nb; i++) out[i] = hypotf(z[i].x, z[i].y) * ((filtered && has_filter) ? fw[i] : 1.f);
+        } else {
+            HIPCHECK(hipMemcpy(out, c->refamp_d.p + cd.specofs, nb * sizeof(float), hipMemcpyDeviceToHost));   // |spec| x filter weights
+        }
+    } catch (const std::exception &e) { err = e.what(); }
+    c->method = method0;
+    c->recv[irec - 1].filter = filter0;
+    c->prepared = false;
+    if (!err.empty()) throw std::runtime_error(err);
+    return 0;
+    GUARD_END(c)
+}
+
 int kiwi_hip_principal_axes(int sourcetype, const float *params, float *pax, float *tax)
 {
     if (sourcetype != KIWI_SRC_BILAT) return -1;          // only psm_update_dep_params_bilat sets them (source_bilat.f90:233-237)

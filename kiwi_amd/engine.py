@@ -284,6 +284,14 @@ class Engine:
                                                 _fp(out), maxn), "output_seismograms")
         return first.value, out[:n.value].copy()
 
+    def get_amp_spectrum(self, irec, icomp, probe="synthetics", filtered=False, isrc=0, maxn=1 << 20):
+        """`output_seismogram_spectra` for one receiver component: (df, amplitudes[ntrans / 2 + 1])."""
+        out = np.zeros(maxn, np.float32)
+        df, n = C.c_float(), C.c_int()
+        self._ck(self.L.kiwi_hip_get_amp_spectrum(self.h, isrc, irec, icomp, 0 if probe == "references" else 1, int(bool(filtered)),
+                                                  C.byref(df), C.byref(n), _fp(out), maxn), "output_seismogram_spectra")
+        return float(df.value), out[:n.value].copy()
+
     def get_cross_correlations(self, irec, min_shift, max_shift, isrc=0):
         """`output_cross_correlations` for one receiver: (first shift in samples, cc[ncomp, nshift])."""
         dt = self.dt

@@ -259,6 +259,16 @@ module kiwi_hip_binding
             real(c_float), intent(out) :: out(*)
         end function
 
+        integer(c_int) function kiwi_hip_get_amp_spectrum( ctx, isrc, irec, icomp, which_probe, filtered, df, n, out, maxn ) &
+                bind(C, name='kiwi_hip_get_amp_spectrum')
+            import :: c_int, c_ptr, c_float
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: isrc, irec, icomp, which_probe, filtered, maxn
+            real(c_float), intent(out) :: df
+            integer(c_int), intent(out) :: n
+            real(c_float), intent(out) :: out(*)
+        end function
+
         integer(c_int) function kiwi_hip_principal_axes( sourcetype, params, pax, tax ) bind(C, name='kiwi_hip_principal_axes')
             import :: c_int, c_float
             integer(c_int), value :: sourcetype

@@ -27,7 +27,8 @@
 !   get_cached_traces_memory;  set_cached_traces_memory_limit, set_verbose, set_ignore_sigint   accepted, no effect
 !   get_peak_amplitudes 1|2;  get_arias_intensities;  output_cross_correlations <base> <shift-min> <shift-max>
 !   get_principal_axes                     bilateral sources
-! Not provided: output_seismogram_spectra (diagnostics beside the
+!   output_seismogram_spectra <base> synthetics|references plain|filtered
+! Not provided: (diagnostics beside the
 !   inversion loop) and mseed / sac file formats.
 ! Batch extension (SURVEY.md 8f-1), one pipe round trip for a whole grid:
 !   eval_sources <type> <paramfile> <outfile>   one parameter vector per line in; per source
@@ -222,6 +223,7 @@ program minimizer_hip
         case ('get_source_subparams');      call do_get_source_subparams( ok_ )
         case ('minimize_lm');               call do_minimize_lm( ok_ )
         case ('output_cross_correlations'); call do_output_cross_correlations( a, ok_ )
+        case ('output_seismogram_spectra'); call do_output_seismogram_spectra( a, ok_ )
         case ('get_principal_axes');        call do_get_principal_axes( ok_ )
         case ('get_peak_amplitudes');       call do_get_shake( a, .true., ok_ )
         case ('get_arias_intensities');     call do_get_shake( a, .false., ok_ )
@@ -719,6 +721,49 @@ program minimizer_hip
                 answer = answer//trim(adjustl(buffer))
             end if
         end do
+        ok_ = .true.
+    end subroutine
+
+  ! output_seismogram_spectra filenamebase (synthetics|references) (plain|filtered) (minimizer.f90:1102-1149,
+  ! receiver.f90:666-708): <base>-<irec>-<comp>.table with lines "frequency [Hz]  amplitude"
+    subroutine do_output_seismogram_spectra( a, ok_ )
+        character(len=*), intent(in) :: a
+        logical, intent(out) :: ok_
+        character(len=1024) :: base, fn
+        character(len=maxline) :: r1, probe, proc
+        integer(c_int) :: which_probe, filtered, n
+        real(c_float) :: df
+        integer :: irec, k, i, unit, ios
+        real(c_float), allocatable :: d(:)
+        ok_ = .false.
+        call split_first( a, base, r1 )
+        call split_first( r1, probe, proc )
+        which_probe = 1
+        if (trim(probe) == 'references') which_probe = 0
+        filtered = 0
+        if (trim(proc) == 'filtered') filtered = 1
+        if (.not. need_ctx()) return
+        if (which_probe == 1 .and. .not. source_set) then
+            call fail( 'no source set' ); return
+        end if
+        allocate( d(1048576) )
+        do irec = 1, nreceivers
+            if (.not. enabled(irec)) cycle
+            do k = 1, len_trim(components(irec))
+                if (.not. check( kiwi_hip_get_amp_spectrum( ctx, 0_c_int, int(irec,c_int), int(k,c_int), which_probe, filtered, &
+                                                            df, n, d, 1048576_c_int ) )) return
+                write (fn,'(a,a,i0,a,a,a)') trim(base), '-', irec, '-', components(irec)(k:k), '.table'
+                open( newunit=unit, file=trim(fn), status='unknown', iostat=ios )
+                if (ios /= 0) then
+                    call fail( 'failed to write output file: '//trim(fn) ); return
+                end if
+                do i = 1, n
+                    write (unit,*) (i - 1) * df, d(i)
+                end do
+                close( unit )
+            end do
+        end do
+        evaluated = .false.
         ok_ = .true.
     end subroutine
 

@@ -178,6 +178,7 @@ void  ko_probe_set_taper(ko_probe *p, const ko_plf *plf);
 void  ko_probe_set_filter(ko_probe *p, const ko_plf *plf);
 float ko_probes_norm(ko_probe *a, ko_probe *b, int method);
 float ko_probe_norm(ko_probe *a, int method);
+int   ko_probe_get_amp_spectrum(ko_probe *p, int filtered, float *df, float *out, int maxn);
 float ko_probes_shake(ko_probe **p, int np, int kind);   /* 1 peak velocity, 2 peak acceleration, 3 Arias intensity */
 void  ko_probes_windowed_cross_corr(ko_probe *a, ko_probe *b, int shift_lo, int shift_hi, float *cc);
 int   ko_next_power_of_two(int n);
@@ -241,6 +242,7 @@ void ko_engine_probe_spans(ko_engine *e, int irec1, int icomp1, int which, int o
 void ko_engine_shift_ref_seismogram(ko_engine *e, int irec1, int ishift);
 int ko_engine_autoshift_ref_seismogram(ko_engine *e, int irec1, int lo, int hi);
 int ko_engine_cross_correlations(ko_engine *e, int irec1, int lo, int hi, float *cc);
+int ko_engine_amp_spectrum(ko_engine *e, int irec1, int icomp1, int synthetic, int filtered, float *df, float *out, int maxn);
 int ko_engine_shake(ko_engine *e, int differentiate, float *out);   /* get_peak_amplitudes (1, 2) / get_arias_intensities (0) */
 void ko_engine_set_nthreads(ko_engine *e, int n);
 /* the three private engine steps (minimizer_engine.f90:885-945) */

@@ -101,6 +101,8 @@ def lib():
         L.ko_engine_get_floating_shift.argtypes = [C.c_void_p, C.c_int]
         L.ko_engine_get_floating_shift.restype = C.c_int
         L.ko_engine_set_nthreads.argtypes = [C.c_void_p, C.c_int]
+        L.ko_engine_amp_spectrum.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, C.c_int]
+        L.ko_engine_amp_spectrum.restype = C.c_int
         L.ko_engine_cross_correlations.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, c_float_p]
         L.ko_engine_cross_correlations.restype = C.c_int
         L.ko_engine_shake.argtypes = [C.c_void_p, C.c_int, c_float_p]
@@ -354,6 +356,13 @@ class Engine:
 
     def set_nthreads(self, n):
         lib().ko_engine_set_nthreads(self.h, n)
+
+    def amp_spectrum(self, irec1, icomp1, synthetic=True, filtered=False, maxn=1 << 20):
+        """probe_get_amp_spectrum of a synthetic or reference probe as it stands: (df, amplitudes)."""
+        out = np.zeros(maxn, np.float32)
+        df = C.c_float()
+        n = lib().ko_engine_amp_spectrum(self.h, irec1, icomp1, int(synthetic), int(filtered), C.byref(df), _fp(out), maxn)
+        return float(df.value), out[:n].copy()
 
     def cross_correlations(self, irec1, lo, hi):
         """receiver_calculate_cross_correlations for integer shifts lo..hi: cc[ncomp, nshift] (update_misfits first)."""

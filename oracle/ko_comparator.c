@@ -523,6 +523,18 @@ float ko_probes_shake(ko_probe **p, int np, int kind)
     return shake_apply(kind, x, f, np, slen(span), p[0]->dt);
 }
 
+/* probe_get_amp_spectrum, comparator.f90:333-354: returns the number of bins */
+int ko_probe_get_amp_spectrum(ko_probe *p, int filtered, float *df, float *out, int maxn)
+{
+    if (!p->array) return 0;
+    update_spectrum_filtered(p);
+    *df = p->df;
+    const float *src = (p->filter.n > 0 && filtered) ? p->amp_spectrum_filtered : p->amp_spectrum;
+    const int n = p->nspec < maxn ? p->nspec : maxn;
+    memcpy(out, src, sizeof(float) * (size_t)n);
+    return p->nspec;
+}
+
 /* probe_get_plain/tapered/filtered, comparator.f90:350-420 */
 int ko_probe_get(ko_probe *p, int which, int *lo, float *out, int maxn)
 {

@@ -271,6 +271,14 @@ void ko_engine_shift_ref_seismogram(ko_engine *e, int irec1, int ishift)
     for (int k = 0; k < r->ncomponents; k++) ko_probe_shift(&r->ref_probes[k], ishift);
 }
 
+/* receiver_output_seismogram_spectra, receiver.f90:666-708 (one probe; the data instead of a file) */
+int ko_engine_amp_spectrum(ko_engine *e, int irec1, int icomp1, int synthetic, int filtered, float *df, float *out, int maxn)
+{
+    ko_receiver *r = &e->receivers[irec1 - 1];
+    ko_probe *p = synthetic ? &r->syn_probes[icomp1 - 1] : &r->ref_probes[icomp1 - 1];
+    return ko_probe_get_amp_spectrum(p, filtered, df, out, maxn);
+}
+
 /* receiver_calculate_cross_correlations, receiver.f90:597-616: cc[k][q] for shifts lo..hi (samples); returns ncomponents
  * (0 for a disabled receiver).  The synthetic probes must be current. */
 int ko_engine_cross_correlations(ko_engine *e, int irec1, int lo, int hi, float *cc)

@@ -321,6 +321,40 @@ def test_spectral_norms(method, with_filter):
     assert np.allclose(pg, g, rtol=SPEC_RTOL)
 
 
+@pytest.mark.parametrize("method", ["ampspec_l2norm", "l2norm"])
+def test_amplitude_spectra_output(method):
+    """output_seismogram_spectra (receiver.f90:666-708, probe_get_amp_spectrum comparator.f90:333-354): amplitude spectra of
+    synthetic and reference probes, plain and filtered, sized as the comparator sizes the pair (a fresh reference engine
+    after one misfit evaluation), under a spectral and under a time-domain method."""
+    sc = Scenario(nrec=4)
+    e, p = build(sc)
+    mid = {"ampspec_l2norm": 3, "l2norm": 1}[method]
+    e.set_misfit_method(mid)
+    p.set_misfit_method(method)
+    fx, fy = [0.01, 0.03, 0.25, 0.4], [0., 1., 1., 0.]
+    for ir in (1, 3):                                   # receivers 2 and 4 stay without filter
+        e.set_filter(ir, fx, fy)
+        p.set_misfit_filter(ir, fx, fy)
+    trials = synthetic.bilat_strike_sweep(2, step=3.0)
+    p.set_source_params("bilateral", trials)
+    p.eval()
+    before = p.get_misfits()[0].copy()
+    e.set_source_params(1, trials[1])
+    e.get_misfits()
+    for ir in (1, 2, 3):
+        for k in (1, 3):
+            for synth in (True, False):
+                for filt in (False, True):
+                    odf, want = e.amp_spectrum(ir, k, synth, filt)
+                    df, got = p.get_amp_spectrum(ir, k, "synthetics" if synth else "references", filt, isrc=1)
+                    assert abs(df - odf) <= 1e-7 * odf and got.shape == want.shape
+                    assert np.allclose(got, want, rtol=SPEC_RTOL, atol=2e-6 * want.max()), (ir, k, synth, filt)
+                    if filt and ir in (1, 3):
+                        assert got[0] == 0.0 and got[-1] == 0.0 and not np.array_equal(got, p.get_amp_spectrum(ir, k, "synthetics" if synth else "references", False, isrc=1)[1])
+    p.eval()                                            # the engine's own state (method, filters) is as before
+    assert np.array_equal(p.get_misfits()[0], before)
+
+
 @pytest.mark.parametrize("method", ["l2norm", "l1norm"])
 def test_time_domain_norms_with_frequency_filter(method):
     """comparator.f90:810-813,1233-1263: r2c -> cosine PLF filter -> c2r / ntrans -> zero outside the taper."""

@@ -237,6 +237,10 @@ def test_protocol_host_matches_python_host_and_oracle(host, tmp_path):
         from kiwi_amd import engine as kengine
         axes = np.array(p.do("get_principal_axes").split(), np.float32)
         assert np.array_equal(axes, np.concatenate(kengine.principal_axes("bilateral", trials[1])))
+        p.do("output_seismogram_spectra", str(tmp_path / "spec"), "synthetics", "plain")
+        f, v = protocol.read_table(str(tmp_path / "spec-2-d.table"))
+        odf, want_spec = e.amp_spectrum(2, sc.comps[1].index("d") + 1, True, False)
+        assert len(v) == len(want_spec) and abs(f[1] - odf) < 1e-6 * odf and np.allclose(v, want_spec, rtol=1e-4, atol=1e-5 * want_spec.max())
         p.do("output_cross_correlations", str(tmp_path / "cc"), -2 * dt, 2 * dt)
         t, v = protocol.read_table(str(tmp_path / "cc-3-e.table"))
         e.get_misfits()
