@@ -221,11 +221,13 @@ def main():
     nrec = wl["nrec"]
     nmis = p.nmisfits()
 
+    counts = [shard_range(args.batch * ngpus, ngpus, r)[1] - shard_range(args.batch * ngpus, ngpus, r)[0] for r in range(ngpus)]
+
     def step():
         p.eval()
         p.sync()
         _, _, g = p.get_misfits()
-        return gather_misfits(g, dist, local_rank)
+        return gather_misfits(g, dist, local_rank, counts)
 
     if dist is not None:                             # RCCL sets itself up lazily at the first collective: not in the timed region
         dist.barrier()

@@ -32,6 +32,14 @@ def _worker(rank, world, port, nsrc, q):
     local_mis = np.stack([idx, idx * 2.0, idx * 3.0], 1).astype(np.float32)
     g = gather_misfits(local_global, dist)
     m = gather_misfits(local_mis, dist)
+    # with the share sizes given (what bench.py does): one collective, same result
+    counts = [shard_range(nsrc, world, r)[1] - shard_range(nsrc, world, r)[0] for r in range(world)]
+    assert np.array_equal(gather_misfits(local_global, dist, counts=counts), g)
+    try:
+        gather_misfits(local_global, dist, counts=[1] * world)
+        raise AssertionError("wrong counts accepted")
+    except ValueError:
+        pass
     if rank == 0:
         q.put((g, m))
     dist.barrier()
