@@ -259,6 +259,35 @@ module kiwi_hip_binding
             real(c_float), intent(out) :: out(*)
         end function
 
+        integer(c_int) function kiwi_hip_get_kernel_ms( ctx, ms, launches ) bind(C, name='kiwi_hip_get_kernel_ms')
+            import :: c_int, c_ptr, c_float
+            type(c_ptr), value :: ctx
+            real(c_float), intent(out) :: ms(4)
+            integer(c_int), intent(out) :: launches(3)
+        end function
+
+        integer(c_int) function kiwi_hip_get_geometry( ctx, isrc, irec, maxcent, ncent, records ) &
+                bind(C, name='kiwi_hip_get_geometry')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: isrc, irec, maxcent
+            integer(c_int), intent(out) :: ncent
+            type(c_ptr), value :: records                    ! maxcent records of 80 bytes (kiwi_kernels.hpp, GeoRec)
+        end function
+
+      ! fcn: a bind(C) function  integer(c_int) f( user, k, m, n, xs, fv )  with value arguments user (c_ptr), k, m, n and
+      ! arrays xs(n,k), fv(m,k); pass c_funloc(f)
+        integer(c_int) function kiwi_hip_lmdif( fcn, user, m, n, x, fvec, ftol, xtol, gtol, maxfev, epsfcn, diag, mode, factor, &
+                                                info, nfev ) bind(C, name='kiwi_hip_lmdif')
+            import :: c_int, c_ptr, c_funptr, c_float
+            type(c_funptr), value :: fcn
+            type(c_ptr), value :: user
+            integer(c_int), value :: m, n, maxfev, mode
+            real(c_float), value :: ftol, xtol, gtol, epsfcn, factor
+            real(c_float), intent(inout) :: x(*), fvec(*), diag(*)
+            integer(c_int), intent(out) :: info, nfev
+        end function
+
         integer(c_int) function kiwi_hip_get_amp_spectrum( ctx, isrc, irec, icomp, which_probe, filtered, df, n, out, maxn ) &
                 bind(C, name='kiwi_hip_get_amp_spectrum')
             import :: c_int, c_ptr, c_float

@@ -22,3 +22,13 @@ def test_fortran_program_calls_c_abi():
     assert int(line[1]) > 0
     assert abs(float(line[3]) + 1.0) < 0.01
     assert abs(float(line[5]) - 1.0) < 1e-6
+
+
+def test_binding_module_covers_the_header():
+    """every function include/kiwi_hip.h declares has an interface in kiwi_hip_binding.f90"""
+    import re
+    from kiwi_amd import lib as klib
+    text = open(os.path.join(FDIR, "kiwi_hip_binding.f90")).read()
+    bound = set(re.findall(r"name='(kiwi_hip_[a-z_0-9]+)'", text))
+    missing = [name for name in klib.declared_symbols() if name not in bound]
+    assert not missing, missing
