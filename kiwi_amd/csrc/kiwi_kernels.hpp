@@ -745,74 +745,78 @@ __device__ __forceinline__ void halo_finish(bool active, const HaloRegs &h, floa
 
 typedef float f2v __attribute__((ext_vector_type(2)));
 
-// (x[S], x[S+1]) out of the four aligned register pairs p[0..3] = x[0..7]: an aligned pair as it is,
-// a straddling one assembled with one v_pk_mov_b32
-template <int S>
-__device__ __forceinline__ f2v pair_at(const f2v (&p)[4])
+// Apply-phase mapping of samples to lanes: lane l of wave w owns the four tile samples 256 w + l + 64 q, q = 0..3 (stride
+// 64, not four consecutive ones).  The two blended samples an output needs, b[j-1] and b[j], then sit at LDS dwords
+// base + 64 q and base + 64 q + 1 of the lane: consecutive lanes read consecutive dwords (no bank conflicts whatever the
+// shift), the compiler fuses the reads of two q into one ds_read2st64_b32 whose result IS the aligned register pair a
+// packed multiply wants -- for every shift residue alike, so no v_pk_mov assemblies and no per-residue code variants.
+// LDS_TILE is a multiple of 64 dwords, which puts all components and q of a centroid within the instruction's offsets.
+struct TileRegs { f2v lo[2], hi[2]; };          // (q0, q1), (q2, q3): b[j-1] and b[j] of the lane's four outputs
+
+// The lane's two LDS base addresses of a centroid: b[j-1] and b[j] of its output q = 0 in component 0.  The second is
+// the first plus one dword, but hidden from the compiler: it would otherwise pair the adjacent dwords (b[j-1], b[j]) of
+// ONE output into a ds_read2_b32 and then shuffle registers, instead of pairing the same quantity of TWO outputs.
+struct TileBase { const __attribute__((address_space(3))) float *lo, *hi; };
+
+__device__ __forceinline__ TileBase tile_base(const float *__restrict__ p)
 {
-    if constexpr ((S & 1) == 0) return p[S / 2];
-    else return __builtin_shufflevector(p[S / 2], p[S / 2 + 1], 1, 2);
+    typedef const __attribute__((address_space(3))) float *lds_fp;
+    TileBase b;
+    b.lo = (lds_fp)p;
+    unsigned a = (unsigned)(size_t)(b.lo + 1);
+    asm volatile("" : "+v"(a));
+    b.hi = (lds_fp)(size_t)a;
+    return b;
 }
 
-// the lane's 8 blended samples around its 4 output samples, as four aligned register pairs
-struct TileRegs { f2v p[4]; };
-
-__device__ __forceinline__ TileRegs tile_load(const float *__restrict__ chunk)
+__device__ __forceinline__ TileRegs tile_load(const TileBase &b, int ofs)
 {
-    // volatile: keeps the two loads whole ds_read_b128 (conflict-free at 16 B per lane); left alone the
-    // compiler narrows them to the 5 elements used (ds_read2_b32 / ds_read_b64), which at a 16-byte
-    // lane stride are 4-way bank conflicts
-    typedef float f4a __attribute__((ext_vector_type(4)));
-    typedef const volatile __attribute__((address_space(3))) f4a *lds_f4p;      // explicit LDS address space
-    const f4a A = *(lds_f4p)(const __attribute__((address_space(3))) float *)chunk;
-    const f4a B = *(lds_f4p)(const __attribute__((address_space(3))) float *)(chunk + 4);
     TileRegs t;
-    t.p[0] = A.xy; t.p[1] = A.zw; t.p[2] = B.xy; t.p[3] = B.zw;
+    t.lo[0] = f2v{ b.lo[ofs], b.lo[ofs + 64] };   t.lo[1] = f2v{ b.lo[ofs + 128], b.lo[ofs + 192] };
+    t.hi[0] = f2v{ b.hi[ofs], b.hi[ofs + 64] };   t.hi[1] = f2v{ b.hi[ofs + 128], b.hi[ofs + 192] };
     return t;
 }
 
 // The lane's 4 output samples are held as two register pairs so that the multiplies and adds are
 // v_pk_mul_f32 / v_pk_add_f32 (two IEEE fp32 operations per lane and instruction, each rounded
 // separately exactly like the scalar form; no FMA).
-template <int R, bool TAIL>
+template <bool TAIL>
 __device__ __forceinline__ void tile_fma(f2v (&out)[2], const TileRegs &t, int jl, int jend, float factor, float wl, float wr)
 {
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         f2v c1 = { wl, wl }, c2 = { wr, wr };
-        if (TAIL) {                               // sparse_trace.f90:698-703, jl = trace index of this lane's b[j-1]
-            const bool t0 = (jl + 2 * h + 1) > jend, t1 = (jl + 2 * h + 2) > jend;
+        if (TAIL) {                               // sparse_trace.f90:698-703, jl = trace index of b[j-1] of the lane's output q = 0
+            const bool t0 = (jl + 128 * h + 1) > jend, t1 = (jl + 128 * h + 64 + 1) > jend;
             c1.x = t0 ? factor : wl; c2.x = t0 ? 0.f : wr;
             c1.y = t1 ? factor : wl; c2.y = t1 ? 0.f : wr;
         }
-        const f2v hi = (h == 0) ? pair_at<R + 1>(t.p) : pair_at<(R + 3 < 7 ? R + 3 : 6)>(t.p);
-        const f2v lo = (h == 0) ? pair_at<R>(t.p) : pair_at<R + 2>(t.p);
-        out[h] = out[h] + c1 * hi;
-        out[h] = out[h] + c2 * lo;
+        out[h] = out[h] + c1 * t.hi[h];
+        out[h] = out[h] + c2 * t.lo[h];
     }
 }
 
-template <int R, bool TAIL>
-__device__ __forceinline__ void tile_add(f2v (&out)[2], const float *__restrict__ chunk, int jl, int jend,
+template <bool TAIL>
+__device__ __forceinline__ void tile_add(f2v (&out)[2], const TileBase &b, int ofs, int jl, int jend,
                                          float factor, float wfrac)
 {
-    const TileRegs t = tile_load(chunk);
+    const TileRegs t = tile_load(b, ofs);
     float wr = wfrac;
     float wl = 1.f - wr;
     wr = wr * factor;
     wl = wl * factor;
-    tile_fma<R, TAIL>(out, t, jl, jend, factor, wl, wr);
+    tile_fma<TAIL>(out, t, jl, jend, factor, wl, wr);
 }
 
-// all GF components of one centroid (reference order) for one shift residue R
-template <int NG, int LDS_TILE, int R, bool TAIL>
+// all GF components of one centroid (reference order)
+template <int NG, int LDS_TILE, bool TAIL>
 __device__ __forceinline__ void centroid_apply(f2v (&ar1)[2], f2v (&ar2)[2], f2v (&dz)[2],
-                                               const float *__restrict__ chunk0, int jl, const int (&jend)[NG],
+                                               const TileBase &chunk0, int jl, const int (&jend)[NG],
                                                bool need_h, bool has_d, int flags, float wfrac, float sd,
                                                float f0, float f1, float f2, float f3, float f4, float f5,
                                                float cl, float sl)
 {
-#define TADD(acc, ig, fac) tile_add<R, TAIL>(acc, chunk0 + (ig) * LDS_TILE, jl, jend[ig], fac, wfrac)
+#define TADD(acc, ig, fac) tile_add<TAIL>(acc, chunk0, (ig) * LDS_TILE, jl, jend[ig], fac, wfrac)
     if (need_h) {
         if (flags & 2) {                         // seismogram.f90:160-203
             f2v t1[2] = { { 0.f, 0.f }, { 0.f, 0.f } }, t2[2] = { { 0.f, 0.f }, { 0.f, 0.f } };
@@ -841,9 +845,9 @@ __device__ __forceinline__ void centroid_apply(f2v (&ar1)[2], f2v (&ar2)[2], f2v
 // of component i + kAhead are issued before the arithmetic of component i, so that a lone wave is not
 // stalled for a full LDS round trip per component (a wave can only issue every 4th cycle; with 3 waves per
 // SIMD exposed latency is what bounds this kernel).  Same operations in the same order as centroid_apply.
-template <int NG, int LDS_TILE, int R, bool TAIL, bool SCOEF>
+template <int NG, int LDS_TILE, bool TAIL, bool SCOEF>
 __device__ __forceinline__ void centroid_apply_hd(f2v (&ar1)[2], f2v (&ar2)[2], f2v (&dz)[2],
-                                                  const float *__restrict__ chunk0, int jl, const int (&jend)[NG],
+                                                  const TileBase &chunk0, int jl, const int (&jend)[NG],
                                                   int flags, const float *__restrict__ coef, float wfrac, float sd,
                                                   float f0, float f1, float f2, float f3, float f4, float f5,
                                                   float cl, float sl)
@@ -870,17 +874,17 @@ __device__ __forceinline__ void centroid_apply_hd(f2v (&ar1)[2], f2v (&ar2)[2], 
     }
     TileRegs tr[NG];
 #pragma unroll
-    for (int i = 0; i < kAhead; i++) tr[i] = tile_load(chunk0 + ((NG == 10) ? seq10[i] : seq8[i]) * LDS_TILE);
+    for (int i = 0; i < kAhead; i++) tr[i] = tile_load(chunk0, ((NG == 10) ? seq10[i] : seq8[i]) * LDS_TILE);
 #pragma unroll
     for (int i = 0; i < NG; i++) {
-        if (i + kAhead < NG) tr[i + kAhead] = tile_load(chunk0 + ((NG == 10) ? seq10[i + kAhead] : seq8[i + kAhead]) * LDS_TILE);
+        if (i + kAhead < NG) tr[i + kAhead] = tile_load(chunk0, ((NG == 10) ? seq10[i + kAhead] : seq8[i + kAhead]) * LDS_TILE);
         __builtin_amdgcn_sched_barrier(0);
         const int ig = (NG == 10) ? seq10[i] : seq8[i];
         const float fac = (NG == 10) ? fac10[i] : fac8[i];
         const float wl = cw[2 * i], wr = cw[2 * i + 1];
-        if (i < nH1) tile_fma<R, TAIL>(t1, tr[i], jl, jend[ig], fac, wl, wr);
-        else if (i < nH1 + 2) tile_fma<R, TAIL>(t2, tr[i], jl, jend[ig], fac, wl, wr);
-        else tile_fma<R, TAIL>(dz, tr[i], jl, jend[ig], fac, wl, wr);
+        if (i < nH1) tile_fma<TAIL>(t1, tr[i], jl, jend[ig], fac, wl, wr);
+        else if (i < nH1 + 2) tile_fma<TAIL>(t2, tr[i], jl, jend[ig], fac, wl, wr);
+        else tile_fma<TAIL>(dz, tr[i], jl, jend[ig], fac, wl, wr);
         if (i == nH1 + 1) {
             if (rot) {
 #pragma unroll
@@ -936,7 +940,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
     f2v ar1[2] = { { 0.f, 0.f }, { 0.f, 0.f } }, ar2[2] = { { 0.f, 0.f }, { 0.f, 0.f } }, dz[2] = { { 0.f, 0.f }, { 0.f, 0.f } };
     // rotation to N/E, signs and store of one source's accumulators (seismogram.f90:256-283)
     auto store = [&](int js) {
-        const int tl = tile * TILE + 4 * tid;
+        const int tl = tile * TILE + 4 * (tid & ~63) + lane;     // window sample of the lane's output q = 0; q-th: + 64 q
         if (!FUSE && tl >= rv.wlen) return;
         float *__restrict__ so = syn + (size_t)js * syn_stride + tl;
         const float a1[4] = { ar1[0].x, ar1[0].y, ar1[1].x, ar1[1].y }, a2[4] = { ar2[0].x, ar2[0].y, ar2[1].x, ar2[1].y },
@@ -958,7 +962,9 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
                 }
             }
             if constexpr (!FUSE) {
-                *(float4 *)(so + rv.synofs[k]) = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (tl + 64 * i < rv.wlen) so[rv.synofs[k] + 64 * i] = o[i];      // 256 contiguous bytes per wave and store
                 continue;
             }
             // ---- fused comparator: what misfit_kernel does per sample (comparator.f90:264,1173-1184,627-667), then a
@@ -967,10 +973,10 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
             const float *__restrict__ rt = fp.reft + rv.refofs[k] + tl, *__restrict__ tp = fp.tw + rv.refofs[k] + tl;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                if (tl + i >= rv.wlen) break;
+                if (tl + 64 * i >= rv.wlen) break;
                 const float v = o[i] * mom;
-                const float vt = v * tp[i];
-                const float a = rt[i];
+                const float vt = v * tp[64 * i];
+                const float a = rt[64 * i];
                 switch (fp.method) {
                 case 1: { const float d = unit ? (a - vt) : (1.f * a - fp.syn_factor * vt); acc += (double)d * (double)d; break; }
                 case 2: { const float d = unit ? fabsf(a - vt) : fabsf(1.f * a - fp.syn_factor * vt); acc += (double)d; break; }
@@ -1117,30 +1123,17 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
             const size_t crow = ((size_t)(cent_ofs[isrc0 + js] - cb) * nrec + (size_t)r * nc + cc) * 128 + 64 + 40;
             const unsigned clo = __builtin_amdgcn_readfirstlane((unsigned)crow), chi = __builtin_amdgcn_readfirstlane((unsigned)(crow >> 32));
             const float *__restrict__ coef = (const float *)(tab + (((size_t)chi << 32) | clo));
-            const int e = smax - ishift;                 // LDS position of lane 0's b[j-1]
-            const float *chunk0 = &tiles[0][4 * (tid + (e >> 2))];
-            const int jl = jb + e + 4 * tid;             // trace index of this lane's b[j-1]
+            const int e = smax - ishift;                 // LDS position of b[j-1] of the tile's first sample
+            const int u0 = 4 * (tid & ~63) + lane;       // this lane's first tile sample (the others: + 64 q)
+            const TileBase chunk0 = tile_base(&tiles[0][e + u0]);
+            const int jl = jb + e + u0;                  // trace index of b[j-1] of the lane's output q = 0
             const bool tail = (jb + e + TILE) > jend_min;        // workgroup-uniform
-#define APPLY(RV, TV) do { \
-                if (need_h && has_d) centroid_apply_hd<NG, LDS_TILE, RV, TV, !(FUSE && RUNS)>(ar1, ar2, dz, chunk0, jl, jend, flags, coef, wfrac, sd, \
+#define APPLY(TV) do { \
+                if (need_h && has_d) centroid_apply_hd<NG, LDS_TILE, TV, !(FUSE && RUNS)>(ar1, ar2, dz, chunk0, jl, jend, flags, coef, wfrac, sd, \
                                                                             f0, f1, f2, f3, f4, f5, cl, sl); \
-                else centroid_apply<NG, LDS_TILE, RV, TV>(ar1, ar2, dz, chunk0, jl, jend, need_h, has_d, flags, \
-                                                          wfrac, sd, f0, f1, f2, f3, f4, f5, cl, sl); } while (0)
-            if (!tail) {
-                switch (e & 3) {
-                case 0: APPLY(0, false); break;
-                case 1: APPLY(1, false); break;
-                case 2: APPLY(2, false); break;
-                default: APPLY(3, false); break;
-                }
-            } else {
-                switch (e & 3) {
-                case 0: APPLY(0, true); break;
-                case 1: APPLY(1, true); break;
-                case 2: APPLY(2, true); break;
-                default: APPLY(3, true); break;
-                }
-            }
+                else centroid_apply<NG, LDS_TILE, TV>(ar1, ar2, dz, chunk0, jl, jend, need_h, has_d, flags, \
+                                                      wfrac, sd, f0, f1, f2, f3, f4, f5, cl, sl); } while (0)
+            if (!tail) APPLY(false); else APPLY(true);
 #undef APPLY
             cur = nxt;
         }
