@@ -848,10 +848,16 @@ __device__ __forceinline__ void centroid_apply(f2v (&ar1)[2], f2v (&ar2)[2], f2v
 template <int NG, int LDS_TILE, bool TAIL, bool SCOEF>
 __device__ __forceinline__ void centroid_apply_hd(f2v (&ar1)[2], f2v (&ar2)[2], f2v (&dz)[2],
                                                   const TileBase &chunk0, int jl, const int (&jend)[NG],
-                                                  int flags, const float *__restrict__ coef, float wfrac, float sd,
-                                                  float f0, float f1, float f2, float f3, float f4, float f5,
+                                                  int flags, const float *__restrict__ coef, int rec, float sd,
                                                   float cl, float sl)
 {
+    // rec: the lane-distributed record of the centroid; its weights and interpolation fraction are fetched only where
+    // the variant needs them (the tail rule's `factor`, or coefficients computed in registers)
+    float wfrac = 0.f, f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f, f4 = 0.f, f5 = 0.f;
+    if constexpr (TAIL || !SCOEF) {
+        wfrac = REC_F(rec, 9);
+        f0 = REC_F(rec, 10); f1 = REC_F(rec, 11); f2 = REC_F(rec, 12); f3 = REC_F(rec, 13); f4 = REC_F(rec, 14); f5 = REC_F(rec, 15);
+    }
     // coef: the centroid's 2 * NG interpolation coefficients (wl, wr per component in application order), computed
     // by geometry_kernel; the pointer is wave-uniform, so these are scalar loads and the coefficients reach the
     // packed multiplies as SGPR operands -- no vector instructions spent on them
@@ -1114,9 +1120,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
             const int nxt = rec_load(rcj, cc + 1, nc, lane);     // prefetch the next record
             constexpr int ro = 0;
             const int ishift = REC_I(cur, ro + 8);
-            const float wfrac = REC_F(cur, ro + 9);
-            const float f0 = REC_F(cur, ro + 10), f1 = REC_F(cur, ro + 11), f2 = REC_F(cur, ro + 12), f3 = REC_F(cur, ro + 13),
-                        f4 = REC_F(cur, ro + 14), f5 = REC_F(cur, ro + 15);
+            // (the interpolation fraction and the six weights are read from the record only by the variants that use them:
+            // with scalar-loaded coefficients and no tail rule they are not needed at all)
             const float cl = REC_F(cur, ro + 16), sl = REC_F(cur, ro + 17);
             const int flags = REC_I(cur, ro + 18);
             // wave-uniform by construction; readfirstlane tells the compiler so (-> scalar loads of the coefficients)
@@ -1129,10 +1134,10 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
             const int jl = jb + e + u0;                  // trace index of b[j-1] of the lane's output q = 0
             const bool tail = (jb + e + TILE) > jend_min;        // workgroup-uniform
 #define APPLY(TV) do { \
-                if (need_h && has_d) centroid_apply_hd<NG, LDS_TILE, TV, !(FUSE && RUNS)>(ar1, ar2, dz, chunk0, jl, jend, flags, coef, wfrac, sd, \
-                                                                            f0, f1, f2, f3, f4, f5, cl, sl); \
+                if (need_h && has_d) centroid_apply_hd<NG, LDS_TILE, TV, !(FUSE && RUNS)>(ar1, ar2, dz, chunk0, jl, jend, flags, coef, cur, sd, cl, sl); \
                 else centroid_apply<NG, LDS_TILE, TV>(ar1, ar2, dz, chunk0, jl, jend, need_h, has_d, flags, \
-                                                      wfrac, sd, f0, f1, f2, f3, f4, f5, cl, sl); } while (0)
+                                                      REC_F(cur, 9), sd, REC_F(cur, 10), REC_F(cur, 11), REC_F(cur, 12), REC_F(cur, 13), \
+                                                      REC_F(cur, 14), REC_F(cur, 15), cl, sl); } while (0)
             if (!tail) APPLY(false); else APPLY(true);
 #undef APPLY
             cur = nxt;
