@@ -1116,6 +1116,11 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
             if (js + 1 < s_end) cur_next_src = rec_load(recs + ((size_t)(cent_ofs[isrc0 + js + 1] - cb) * nrec + (size_t)r * nc), c, nc, lane);
             ar1[0] = ar1[1] = ar2[0] = ar2[1] = dz[0] = dz[1] = f2v{ 0.f, 0.f };
         }
+        // coefficient rows of the group's centroids: wave-uniform by construction; readfirstlane tells the compiler so
+        // (-> scalar address arithmetic and scalar loads of the coefficients)
+        const size_t crow = ((size_t)(cent_ofs[isrc0 + js] - cb) * nrec + (size_t)r * nc + c) * 128 + 64 + 40;
+        const unsigned clo = __builtin_amdgcn_readfirstlane((unsigned)crow), chi = __builtin_amdgcn_readfirstlane((unsigned)(crow >> 32));
+        const float *__restrict__ coef_grp = (const float *)(tab + (((size_t)chi << 32) | clo));
         for (int cc = c; cc < cend; cc++) {
             const int nxt = rec_load(rcj, cc + 1, nc, lane);     // prefetch the next record
             constexpr int ro = 0;
@@ -1124,10 +1129,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
             // with scalar-loaded coefficients and no tail rule they are not needed at all)
             const float cl = REC_F(cur, ro + 16), sl = REC_F(cur, ro + 17);
             const int flags = REC_I(cur, ro + 18);
-            // wave-uniform by construction; readfirstlane tells the compiler so (-> scalar loads of the coefficients)
-            const size_t crow = ((size_t)(cent_ofs[isrc0 + js] - cb) * nrec + (size_t)r * nc + cc) * 128 + 64 + 40;
-            const unsigned clo = __builtin_amdgcn_readfirstlane((unsigned)crow), chi = __builtin_amdgcn_readfirstlane((unsigned)(crow >> 32));
-            const float *__restrict__ coef = (const float *)(tab + (((size_t)chi << 32) | clo));
+            const float *__restrict__ coef = coef_grp + (size_t)(cc - c) * 128;
             const int e = smax - ishift;                 // LDS position of b[j-1] of the tile's first sample
             const int u0 = 4 * (tid & ~63) + lane;       // this lane's first tile sample (the others: + 64 q)
             const TileBase chunk0 = tile_base(&tiles[0][e + u0]);
