@@ -203,7 +203,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    # KIWI_BENCH_FORCE_DIST=1: go through RCCL even with one rank (self-test of the collective path on a 1-GPU box)
+    force_dist = bool(os.environ.get("KIWI_BENCH_FORCE_DIST"))
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -227,7 +229,7 @@ def main():
         p.eval()
         p.sync()
         _, _, g = p.get_misfits()
-        return gather_misfits(g, dist, local_rank, counts)
+        return gather_misfits(g, dist, local_rank, counts, force=force_dist)
 
     if dist is not None:                             # RCCL sets itself up lazily at the first collective: not in the timed region
         dist.barrier()

@@ -16,13 +16,13 @@ def shard_range(nsrc, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_misfits(local, dist=None, device_index=None, counts=None):
+def gather_misfits(local, dist=None, device_index=None, counts=None, force=False):
     """All-gather per-source values (1-D or [n, k]) from every rank, restoring global source order.
     `dist` is torch.distributed (initialised) or None for a single process.  `counts`: the ranks' share sizes when the
     caller knows them (shard_range), which saves the exchange of the counts -- one collective per call instead of two."""
     local = np.ascontiguousarray(local, np.float32)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return local
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
+        return local                                  # force: run the collective even for one rank (self-test)
     import torch
     world = dist.get_world_size()
     use_cuda = dist.get_backend() == "nccl"

@@ -127,3 +127,27 @@ def test_cfg5_spectral_comparator_with_filter():
     p.eval(0, 5); p.eval(5, 11)
     m2, _, g2 = p.get_misfits()
     assert np.array_equal(m, m2) and np.array_equal(g, g2)
+
+
+def test_bench_line_through_rccl_with_one_rank():
+    """bench.py under torch.distributed.run with the collective path forced on (KIWI_BENCH_FORCE_DIST): RCCL init bound to
+    the device, barrier, all-gather of the global misfits, all-reduce of the elapsed time -- what the N > 1 runs do,
+    exercised with the one GPU a test box has.  Checks the contract fields of the JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KIWI_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                          "127.0.0.1", "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3",
+                          "--warmup", "1", "--batch", "16", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600,
+                         env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
