@@ -1345,6 +1345,7 @@ static const std::vector<float> &params_norm(int sourcetype)
 int kiwi_hip_lmdif(kiwi_hip_residual_fn fcn, void *user, int m, int n, float *x, float *fvec, float ftol, float xtol, float gtol,
                    int maxfev, float epsfcn, float *diag, int mode, float factor, int *info, int *nfev)
 {
+    if (!fcn || !x || !fvec || !diag || !info || !nfev) return -1;
     try {
         lm::Fcn f = [&](int k, float *xs, float *fv) { return fcn(user, k, m, n, xs, fv); };
         *info = lm::lmdif(f, m, n, x, fvec, ftol, xtol, gtol, maxfev, epsfcn, diag, mode, factor, *nfev);
@@ -1360,6 +1361,7 @@ int kiwi_hip_minimize_lm(kiwi_hip_ctx *c, int sourcetype, float *params, const i
                          int *info, int *iterations, float *misfit, float *best)
 {
     GUARD_BEGIN
+    if (!params || !mask || !info || !iterations || !misfit) throw std::runtime_error("null argument");
     const int np = nparams_any(sourcetype);
     if (np < 0) throw std::runtime_error("source type not supported by the host discretiser");
     const std::vector<float> &norm = params_norm(sourcetype);
@@ -1509,6 +1511,7 @@ int kiwi_hip_get_synthetics(kiwi_hip_ctx *c, int isrc, int irec, int icomp, int 
 // get_peak_amplitudes (minimizer_engine.f90:1174-1212) / get_arias_intensities (:1214-1246) of uploaded source isrc
 static int shake_impl(kiwi_hip_ctx *c, int isrc, int kind, float *out)
 {
+    if (!out) throw std::runtime_error("null argument");
     if (isrc < 0 || isrc >= c->nsrc) throw std::runtime_error("source index out of range");
     prepare(c);
     if (c->any_filter) throw std::runtime_error("peak amplitudes / Arias intensities are not available with a misfit filter set");
@@ -1573,6 +1576,7 @@ int kiwi_hip_get_amp_spectrum(kiwi_hip_ctx *c, int isrc, int irec, int icomp, in
                               float *out, int maxn)
 {
     GUARD_BEGIN
+    if (!df || !n || !out) throw std::runtime_error("null argument");
     if (irec < 1 || irec > (int)c->recv.size()) throw std::runtime_error("receiver index out of range");
     if (which_probe && (isrc < 0 || isrc >= c->nsrc)) throw std::runtime_error("source index out of range");
     HIPCHECK(hipSetDevice(c->device));
@@ -1618,7 +1622,7 @@ int kiwi_hip_get_amp_spectrum(kiwi_hip_ctx *c, int isrc, int irec, int icomp, in
 
 int kiwi_hip_principal_axes(int sourcetype, const float *params, float *pax, float *tax)
 {
-    if (sourcetype != KIWI_SRC_BILAT) return -1;          // only psm_update_dep_params_bilat sets them (source_bilat.f90:233-237)
+    if (sourcetype != KIWI_SRC_BILAT || !params || !pax || !tax) return -1;          // only psm_update_dep_params_bilat sets them (source_bilat.f90:233-237)
     principal_axes_bilat(params, pax, tax);
     return 0;
 }
@@ -1692,6 +1696,7 @@ int kiwi_hip_get_cross_correlations(kiwi_hip_ctx *c, int isrc, int irec, float m
                                     int *nshift, float *cc_out, int maxn)
 {
     GUARD_BEGIN
+    if (!first_shift || !nshift || !cc_out) throw std::runtime_error("null argument");
     if (irec < 1 || irec > (int)c->recv.size()) throw std::runtime_error("receiver index out of range");
     if (isrc < 0 || isrc >= c->nsrc) throw std::runtime_error("source index out of range");
     HIPCHECK(hipSetDevice(c->device));
@@ -1766,6 +1771,7 @@ int kiwi_hip_autoshift_ref_seismogram(kiwi_hip_ctx *c, int irec, float min_shift
 int kiwi_hip_get_source_centroids(kiwi_hip_ctx *c, int isrc, int maxcent, int *ncent, float *cent)
 {
     GUARD_BEGIN
+    if (!ncent) throw std::runtime_error("null argument");
     if (isrc < 0 || isrc >= c->nsrc) throw std::runtime_error("source index out of range");
     HIPCHECK(hipSetDevice(c->device));
     const int c0 = c->cent_ofs[isrc], nc = c->cent_ofs[isrc + 1] - c0;
