@@ -670,7 +670,12 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
     for (int s = isrc0; s < isrc0 + nsrc; s++) maxnc = std::max(maxnc, c->cent_ofs[s + 1] - c->cent_ofs[s]);
     c->recs_d.ensure((size_t)(cend - cbeg) * nrec, &c->dev_bytes);
     int *tab = nullptr;
-    if (c->accum_mode == 0) { c->tab_d.ensure((size_t)(cend - cbeg) * nrec * 128, &c->dev_bytes); tab = c->tab_d.p; }
+    if (c->accum_mode == 0) {
+        c->tab_d.ensure((size_t)(cend - cbeg) * nrec * 128, &c->dev_bytes); tab = c->tab_d.p;
+        // KIWI_HIP_POISON=1 (tests): rows keep nothing from earlier evaluations -- a descriptor line the kernel reads but
+        // geometry_kernel did not write shows as a wild address instead of passing by accident
+        if (std::getenv("KIWI_HIP_POISON")) HIPCHECK(hipMemsetAsync(tab, 0x7f, (size_t)(cend - cbeg) * nrec * 128 * sizeof(int), c->stream));
+    }
     const bool fuse = c->fuse_now;
     if (!fuse) c->syn_d.ensure((size_t)nsrc * c->syn_stride, &c->dev_bytes);
     float *proc = nullptr;

@@ -124,6 +124,42 @@ struct EvalParams {
     int isrc0;
 };
 
+// Length of the centroid group that accumulate_grouped_kernel forms when a group STARTS at centroid c of a source: the
+// following centroids at this same point whose integer shifts stay within the LDS halo (also returns the shift range).
+__device__ __forceinline__ int group_len(const float *__restrict__ cent, int c0, int nc, int c, float dt, int &smin, int &smax)
+{
+    const float *ce = cent + (size_t)(c0 + c) * 10;
+    const float dnorth = ce[0], deast = ce[1], depth = ce[2];
+    int len = 1;
+    smin = smax = (int)floorf(ce[3] / dt);
+    for (int k = c + 1; k < nc && len < kMaxGroup; k++) {
+        const float *ne = cent + (size_t)(c0 + k) * 10;
+        if (!(ne[0] == dnorth && ne[1] == deast && ne[2] == depth)) break;
+        const int sh = (int)floorf(ne[3] / dt);
+        const int nmin = min(smin, sh), nmax = max(smax, sh);
+        if (nmax - nmin > kHalo - 10) break;
+        smin = nmin; smax = nmax; len++;
+    }
+    return len;
+}
+
+// Does the grouped kernel start a group at centroid c?  Groups never span two points, so the first centroid of a
+// same-point run always starts one; inside a run the starts follow from the group lengths (all centroids of a run share
+// their GF rows, so they are stored or missing together and the kernel's skipping of missing ones does not interfere).
+__device__ __forceinline__ bool starts_group(const float *__restrict__ cent, int c0, int nc, int c, float dt)
+{
+    const float *ce = cent + (size_t)(c0 + c) * 10;
+    int r0 = c;
+    while (r0 > 0) {
+        const float *pe = cent + (size_t)(c0 + r0 - 1) * 10;
+        if (!(pe[0] == ce[0] && pe[1] == ce[1] && pe[2] == ce[2])) break;
+        r0--;
+    }
+    int pos = r0, lo, hi;
+    while (pos < c) pos += group_len(cent, c0, nc, pos, dt, lo, hi);
+    return pos == c;
+}
+
 // Load descriptors for accumulate_grouped_kernel, 128 ints per record, laid out so that one coalesced load per wave
 // brings them in lane-distributed: for component ig and node k
 //   tab[4*ig + k]      = row*pitch + kRowPad - first   (float index of trace sample 0, minus... + j)
@@ -138,11 +174,15 @@ struct EvalParams {
 // out as consecutive 16-byte stores, so that a line is complete in L2 before it leaves it (interleaving the stores
 // with the look-ups left every line open for microseconds: partial-line write-backs, 0.32 ms per 1.3 M records).
 template <int NG>
-__device__ __forceinline__ void write_tab(int *__restrict__ tb, const GeoRec &g, const int2 *__restrict__ span, int pitch, float sd)
+__device__ __forceinline__ void write_tab(int *__restrict__ tb, const GeoRec &g, const int2 *__restrict__ span, int pitch, float sd,
+                                          bool full)
 {
+    // full: this centroid starts a group and the kernel reads the whole row; otherwise only its coefficients (they
+    // share the row's last 128-byte line with the clamp floors of components 9 and 10, which are then not needed)
     const int nn = (g.flags & 1) ? 1 : 4;
     int bases[NG][4], floors[NG][4], jend[12];
     int jmin_h = 0x7fffffff, jmin_d = 0x7fffffff;
+    if (full) {
 #pragma unroll
     for (int ig = 0; ig < NG; ig++) {
         int je = -0x7fffffff;
@@ -162,6 +202,7 @@ __device__ __forceinline__ void write_tab(int *__restrict__ tb, const GeoRec &g,
     for (int ig = NG; ig < 10; ig++) jend[ig] = 0;
     jend[10] = jmin_h;
     jend[11] = jmin_d;
+    }
     float cf[20];
     {
         const float wr0 = g.wfrac, wl0 = 1.f - g.wfrac;
@@ -184,12 +225,14 @@ __device__ __forceinline__ void write_tab(int *__restrict__ tb, const GeoRec &g,
         }
     }
     int4 *t4 = reinterpret_cast<int4 *>(tb);
+    if (full) {
 #pragma unroll
-    for (int ig = 0; ig < NG; ig++) t4[ig] = make_int4(bases[ig][0], bases[ig][1], bases[ig][2], bases[ig][3]);
+        for (int ig = 0; ig < NG; ig++) t4[ig] = make_int4(bases[ig][0], bases[ig][1], bases[ig][2], bases[ig][3]);
 #pragma unroll
-    for (int q = 0; q < 3; q++) t4[10 + q] = make_int4(jend[4 * q], jend[4 * q + 1], jend[4 * q + 2], jend[4 * q + 3]);
+        for (int q = 0; q < 3; q++) t4[10 + q] = make_int4(jend[4 * q], jend[4 * q + 1], jend[4 * q + 2], jend[4 * q + 3]);
 #pragma unroll
-    for (int ig = 0; ig < NG; ig++) t4[16 + ig] = make_int4(floors[ig][0], floors[ig][1], floors[ig][2], floors[ig][3]);
+        for (int ig = 0; ig < NG; ig++) t4[16 + ig] = make_int4(floors[ig][0], floors[ig][1], floors[ig][2], floors[ig][3]);
+    }
     float4 *f4 = reinterpret_cast<float4 *>(tb);
 #pragma unroll
     for (int q = 0; q < (NG == 10 ? 5 : 4); q++) f4[26 + q] = make_float4(cf[4 * q], cf[4 * q + 1], cf[4 * q + 2], cf[4 * q + 3]);
@@ -323,16 +366,7 @@ __global__ __launch_bounds__(256) void geometry_kernel(
     // the spread of those shifts.  pad = len | (smax - ishift) << 8 | (ishift - smin) << 16
     {
         int len = 1, smin = g.ishift, smax = g.ishift;
-        if (g.row[0] >= 0) {
-            for (int k = c + 1; k < nc && len < kMaxGroup; k++) {
-                const float *ne = cent + (size_t)(c0 + k) * 10;
-                if (!(ne[0] == dnorth && ne[1] == deast && ne[2] == depth)) break;
-                const int sh = (int)floorf(ne[3] / gm.dt);
-                const int nmin = min(smin, sh), nmax = max(smax, sh);
-                if (nmax - nmin > kHalo - 10) break;
-                smin = nmin; smax = nmax; len++;
-            }
-        }
+        if (g.row[0] >= 0) len = group_len(cent, c0, nc, c, gm.dt, smin, smax);
         g.pad = len | ((smax - g.ishift) << 8) | ((g.ishift - smin) << 16);
     }
     // natural span of the synthetic strips (seismogram.f90:102-130 + sparse_trace.f90:648-668): union over
@@ -362,8 +396,9 @@ __global__ __launch_bounds__(256) void geometry_kernel(
     const size_t base = (size_t)(c0 - cent_ofs[ep.isrc0]) * ep.nrec + (size_t)r * nc + c;
     out[base] = g;
     if (tab && g.row[0] >= 0) {
-        if (gm.ng == 10) write_tab<10>(tab + base * 128, g, span, gm.pitch, rv.sd);
-        else write_tab<8>(tab + base * 128, g, span, gm.pitch, rv.sd);
+        const bool full = !(g.flags & 4) || starts_group(cent, c0, nc, c, gm.dt);
+        if (gm.ng == 10) write_tab<10>(tab + base * 128, g, span, gm.pitch, rv.sd, full);
+        else write_tab<8>(tab + base * 128, g, span, gm.pitch, rv.sd, full);
     }
 }
 

@@ -779,6 +779,32 @@ def test_peak_amplitudes_and_arias_intensities(mode):
             p.get_arias_intensities(0)
 
 
+def test_descriptor_rows_of_group_starts_only(monkeypatch):
+    """geometry_kernel writes the full descriptor row only where accumulate_grouped_kernel starts a group and just the
+    coefficient line elsewhere.  With the table poisoned before every evaluation (KIWI_HIP_POISON) a wrong prediction of
+    the group starts would show as a wild address; the sources here have same-point runs that split into several groups:
+    80 time steps at one point (shift spread beyond the LDS halo, more than 64 centroids) and a bilateral source."""
+    monkeypatch.setenv("KIWI_HIP_POISON", "1")
+    sc = Scenario(nrec=5, L=700)
+    e, p = build(sc)
+    mt = np.array([[0.3, 200., -300., 9000., 1e18, -5e17, 2e17, 3e17, -1e17, 4e17, 40.0],      # rise time 40 s: 81 time steps
+                   [0.0, 0., 0., 10000., 1e18, 1e18, -2e18, 0., 0., 0., 33.3]], np.float32)
+    from oracle import ko
+    assert len(ko.discretize(6, mt[0], sc.effective_dt)[0]) > 70
+    m, n, g = oracle_misfits(e, 6, mt)
+    p.set_source_params("moment_tensor", mt)
+    p.eval()
+    pm, pn, pg = p.get_misfits()
+    assert misfit_close(pm, m) and misfit_close(pg, g)
+    trials = synthetic.bilat_strike_sweep(4, step=5.0)
+    trials[:, 13] = 6.0                                  # longer rise time: more time steps per sub-fault
+    m, n, g = oracle_misfits(e, 1, trials)
+    p.set_source_params("bilateral", trials)
+    p.eval()
+    pm, pn, pg = p.get_misfits()
+    assert misfit_close(pm, m) and misfit_close(pg, g)
+
+
 def test_point_lp_source():
     """point_lp (source type 3, source_point_lp.f90): band-limited point source, ~40 time steps at one point."""
     sc = Scenario(nrec=4)
