@@ -185,9 +185,32 @@ def measured_copy_bandwidth(torch, device):
     return 2.0 * n * reps / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
 
 
+def launch_ranks(n):
+    """Parent of a multi-GPU run: one child process per GPU through torch.distributed.run (RCCL rendezvous on 127.0.0.1).
+    Nothing is retried or restarted in place: a failing rank ends the run with a non-zero status."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()                 # counts devices without initialising the runtime in this process
+    if have < n:
+        print("bench.py: --gpus %d requested but only %d GPU(s) are visible" % (n, have), file=sys.stderr)
+        return 2
+    with socket.socket() as so:                      # a free rendezvous port
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), "--max-restarts", "0",
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks = GPUs of this node (default: WORLD_SIZE when started by a launcher, else 1)")
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
@@ -198,8 +221,20 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus is None:
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: this process becomes the launcher.  It starts N ranks (one per
+        # GPU) under torch.distributed.run BEFORE anything here has touched the GPU (device_count() only counts), relays
+        # their output -- rank 0 prints the JSON line -- and exits with their status.
+        sys.exit(launch_ranks(args.gpus))
+
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None

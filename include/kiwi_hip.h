@@ -142,8 +142,17 @@ int kiwi_hip_set_sources(kiwi_hip_ctx *ctx, int nsrc, const int *cent_ofs, const
  * <base>-dsm.table, minimizer_engine.f90:947-977); cent == NULL or maxcent <= 0 only returns the count */
 int kiwi_hip_get_source_centroids(kiwi_hip_ctx *ctx, int isrc, int maxcent, int *ncent, float *cent);
 /* set_source_params for a whole batch (minimizer_engine.f90:500-523): params[nsrc][nparams] in
- * wire order; discretised on the host with the current effective dt, then uploaded */
+ * wire order; discretised on the host with the current effective dt, then uploaded.
+ * A trial source the discretiser rejects ("Empty rupture area", source_eikonal.f90:286; nucleation point outside of the
+ * rupture region, :428) does not fail the batch: it is recorded (kiwi_hip_get_source_status) and skipped, its misfits,
+ * norm factors and global misfit read as zeros -- python/tunguska/seismosizer.py:703-720 (`failings`).  The call
+ * returns non-zero only when NO source of the batch could be discretised (a batch of one: the reference's
+ * `set_source_params: nok > Empty rupture area`); the statuses stay readable then too. */
 int kiwi_hip_set_sources_params(kiwi_hip_ctx *ctx, int sourcetype, int nsrc, const float *params);
+/* status[nsrc] of uploaded sources isrc0 ..: 0 discretised, 5 "Empty rupture area", 6 "position of nucleation point is
+ * outside of rupture region" (the codes kiwi_hip_discretize_eikonal returns); message text of a code */
+int kiwi_hip_get_source_status(kiwi_hip_ctx *ctx, int isrc0, int nsrc, int *status);
+int kiwi_hip_source_status_message(int code, char *buf, int buflen);
 
 /* minimize_lm (minimizer_engine.f90:728-874; sminpack/lmdif.f in fp32 with the reference's settings: ftol = xtol =
  * sqrt(spmpar(1)), gtol = 0, maxfev = 500 (n + 1), mode 2 with diag = 1, factor 0.01) over the parameters with

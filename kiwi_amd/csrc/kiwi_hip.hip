@@ -125,6 +125,12 @@ struct kiwi_hip_ctx {
     float max_risetime = 0.f;
     DevBuf<float> cent_d, moment_d, risetime_d;
     DevBuf<int> centofs_d;
+    // per uploaded source: 0 = discretised, 5 = "Empty rupture area", 6 = "position of nucleation point is outside of
+    // rupture region" (source_eikonal.f90:286,428).  A failed trial source stays in the batch with no centroids, its
+    // misfits, norm factors and global misfit read as zeros (seismosizer.py:703-720: skipped, arrays keep zeros)
+    std::vector<int> src_status;
+    bool any_failed = false;
+    DevBuf<int> status_d;
     // runs of consecutive sources with identical centroid geometry (points and times), single group each: the
     // grouped kernel builds their blended tiles once (env KIWI_HIP_RUNS=0 switches the sharing off)
     std::vector<unsigned long long> geo_hash;
@@ -147,6 +153,7 @@ struct kiwi_hip_ctx {
     DevBuf<float> refx_d, vt_d, partial_d;
     DevBuf<int> fshift_d;
     int last_isrc0 = 0, last_nsrc = 0, last_chunk0 = 0, last_chunkn = 0;
+    std::vector<char> evaluated;      // per uploaded source: misfit_d / global_d hold its results (cleared by set_sources and prepare)
     int last_proc_which = 0;
     int group_threads_env = 0;
     int group_threads = 128;          // workgroup size of the grouped kernel (tile = 4x); env KIWI_HIP_GROUP_THREADS
@@ -242,6 +249,7 @@ void prepare(kiwi_hip_ctx *c)
 {
     if (c->prepared) return;
     c->proc_which_held = 0;
+    c->evaluated.assign((size_t)c->nsrc, 0);
     if (!c->have_db) throw std::runtime_error("no database set");
     if (!c->have_origin) throw std::runtime_error("no source location set");
     if (c->recv.empty()) throw std::runtime_error("no receivers set");
@@ -812,7 +820,8 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
             }
         }
         hipLaunchKernelGGL(global_kernel, dim3((unsigned)((nsrc + 127) / 128)), dim3(128), 0, c->stream,
-                           c->misfit_d.p, c->norm_d.p, c->recfirst_d.p, c->nrec_en, c->nmis, isrc0, nsrc, c->global_d.p);
+                           c->misfit_d.p, c->norm_d.p, c->recfirst_d.p, c->nrec_en, c->nmis, isrc0, nsrc, c->global_d.p,
+                           c->any_failed ? c->status_d.p : (const int *)nullptr);
     }
     record(c, 2, e3);
     HIPCHECK(hipGetLastError());
@@ -857,6 +866,8 @@ int eval_impl(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
         s += n;
     }
     c->last_isrc0 = isrc0; c->last_nsrc = nsrc; c->last_proc_which = proc_which;
+    c->evaluated.resize((size_t)c->nsrc, 0);
+    std::fill(c->evaluated.begin() + isrc0, c->evaluated.begin() + isrc0 + nsrc, 1);
     return 0;
 }
 
@@ -974,13 +985,19 @@ int kiwi_hip_set_gfdb(kiwi_hip_ctx *c, int nx, int nz, int ng, int L, float dt, 
 
 int kiwi_hip_set_interp(kiwi_hip_ctx *c, int bilinear, int xus, int zus)
 {
+    if (!c) return fail(nullptr, "null context");
     if (xus < 1 || zus < 1) return fail(c, "undersampling must be >= 1");
     c->bilinear = bilinear ? 1 : 0; c->xus = xus; c->zus = zus;
+    // set_local_interpolation / set_spacial_undersampling dirty the seismograms (minimizer_engine.f90:1483-1493):
+    // natural-span windows, transform lengths and any kept synthetics are stale
+    c->prepared = false;
+    c->proc_which_held = 0;
     return 0;
 }
 
 int kiwi_hip_set_effective_dt(kiwi_hip_ctx *c, float edt)
 {
+    if (!c) return fail(nullptr, "null context");
     if (!(edt > 0.f)) return fail(c, "effective dt must be positive");
     c->effective_dt = edt;
     return 0;
@@ -1281,6 +1298,13 @@ int kiwi_hip_set_sources(kiwi_hip_ctx *c, int nsrc, const int *cent_ofs, const f
     HIPCHECK(hipMemcpy(c->moment_d.p, moment, (size_t)nsrc * sizeof(float), hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(c->risetime_d.p, risetime, (size_t)nsrc * sizeof(float), hipMemcpyHostToDevice));
     c->nsrc = nsrc;
+    c->src_status.assign((size_t)nsrc, 0);
+    c->any_failed = false;
+    c->evaluated.assign((size_t)nsrc, 0);
+    if (c->prepared) {                 // results of the new batch have their place before anything reads them
+        c->misfit_d.ensure((size_t)nsrc * c->nmis, &c->dev_bytes);
+        c->global_d.ensure((size_t)nsrc, &c->dev_bytes);
+    }
     if (fold_halfwidth(maxrise, c->gm.dt) != fold_halfwidth(c->max_risetime, c->gm.dt)) c->prepared = false;
     c->max_risetime = maxrise;
     if (c->synth_only || c->any_untapered) c->prepared = false;   // windows follow the natural spans of the uploaded sources
@@ -1300,7 +1324,8 @@ int kiwi_hip_set_sources_params(kiwi_hip_ctx *c, int sourcetype, int nsrc, const
     const bool eikonal = source_nparams_eikonal(sourcetype) > 0;
     if (eikonal && !c->have_crust) throw std::runtime_error("eikonal sources need the crust profiles (kiwi_hip_set_source_crust)");
     std::vector<DiscreteSource> ds((size_t)nsrc);
-    int bad = -1;
+    std::vector<int> status((size_t)nsrc, 0);
+    int bad = -1, nbad = 0;
     std::string why = "source discretisation failed";
     // a few threads only: the discretisers take microseconds per source, and idle OpenMP workers spin for their
     // block time after the loop, competing with the HIP runtime's own threads for the caller's next calls
@@ -1314,11 +1339,15 @@ int kiwi_hip_set_sources_params(kiwi_hip_ctx *c, int sourcetype, int nsrc, const
         if (eikonal) err = discretize_eikonal(sourcetype, params + (size_t)s * np, c->effective_dt, c->rupture_profile, c->constraints, ds[s]);
         else if (!discretize(sourcetype, params + (size_t)s * np, c->effective_dt, ds[s])) err = why;
         if (!err.empty()) {
+            status[s] = !eikonal ? 3 : (err[0] == 'E' ? 5 : 6);
+            ds[s].centroids.clear(); ds[s].moment = 0.f; ds[s].risetime = 0.f;
 #pragma omp critical
-            if (bad < 0 || s < bad) { bad = s; why = err; }
+            { nbad++; if (bad < 0 || s < bad) { bad = s; why = err; } }
         }
     }
-    if (bad >= 0) throw std::runtime_error(why + " (source " + std::to_string(bad + 1) + ")");
+    // wrong type / parameter count is the caller's error for the whole batch; a source the discretiser rejects
+    // ("Empty rupture area", ...) is recorded and skipped like seismosizer.py:703-720 does (failings)
+    if (bad >= 0 && !eikonal) throw std::runtime_error(why + " (source " + std::to_string(bad + 1) + ")");
     std::vector<int> ofs((size_t)nsrc + 1, 0);
     for (int s = 0; s < nsrc; s++) ofs[s + 1] = ofs[s] + (int)ds[s].centroids.size();
     std::vector<float> cent((size_t)ofs[nsrc] * 10), mom((size_t)nsrc), rise((size_t)nsrc);
@@ -1326,8 +1355,45 @@ int kiwi_hip_set_sources_params(kiwi_hip_ctx *c, int sourcetype, int nsrc, const
         std::memcpy(cent.data() + (size_t)ofs[s] * 10, ds[s].centroids.data(), ds[s].centroids.size() * sizeof(Centroid));
         mom[s] = ds[s].moment; rise[s] = ds[s].risetime;
     }
-    return kiwi_hip_set_sources(c, nsrc, ofs.data(), cent.data(), mom.data(), rise.data());
+    if (int rc = kiwi_hip_set_sources(c, nsrc, ofs.data(), cent.data(), mom.data(), rise.data())) return rc;
+    if (nbad > 0) {
+        c->src_status = status;
+        c->any_failed = true;
+        c->status_d.ensure((size_t)nsrc, &c->dev_bytes);
+        HIPCHECK(hipMemcpy(c->status_d.p, status.data(), (size_t)nsrc * sizeof(int), hipMemcpyHostToDevice));
+        // no source of the batch could be discretised (a batch of one: the reference's `set_source_params: nok >`)
+        if (nbad == nsrc) throw std::runtime_error(why + " (source " + std::to_string(bad + 1) + ")");
+    }
+    return 0;
     GUARD_END(c)
+}
+
+static const char *status_message(int code)
+{
+    switch (code) {
+    case 0: return "";
+    case 5: return "Empty rupture area";                                              // source_eikonal.f90:286
+    case 6: return "position of nucleation point is outside of rupture region";       // source_eikonal.f90:428
+    default: return "source discretisation failed";
+    }
+}
+
+int kiwi_hip_get_source_status(kiwi_hip_ctx *c, int isrc0, int nsrc, int *status)
+{
+    GUARD_BEGIN
+    if (!c) return fail(nullptr, "null context");
+    if (!status) throw std::runtime_error("null argument");
+    if (isrc0 < 0 || nsrc < 0 || isrc0 + nsrc > c->nsrc) throw std::runtime_error("source range out of bounds");
+    for (int s = 0; s < nsrc; s++) status[s] = c->src_status[(size_t)isrc0 + s];
+    return 0;
+    GUARD_END(c)
+}
+
+int kiwi_hip_source_status_message(int code, char *buf, int buflen)
+{
+    if (!buf || buflen <= 0) return 1;
+    std::snprintf(buf, (size_t)buflen, "%s", status_message(code));
+    return 0;
 }
 
 // psm_params_norm_* (source_bilat.f90:45-46, source_circular.f90:44-45, source_point_lp.f90:54-55, source_eikonal.f90:48-49,
@@ -1406,6 +1472,8 @@ int kiwi_hip_minimize_lm(kiwi_hip_ctx *c, int sourcetype, float *params, const i
             std::copy(cur.begin(), cur.end(), rows.begin() + (size_t)s * np);
         }
         if (kiwi_hip_set_sources_params(c, sourcetype, k, rows.data())) return -2;
+        for (int s = 0; s < k; s++)                 // update_misfits( ok ) false -> iflag = -2, minimizer_engine.f90:853-857
+            if (c->src_status[s]) { c->err = std::string(status_message(c->src_status[s])) + " (forward step " + std::to_string(nsteps + s + 1) + ")"; return -2; }
         if (kiwi_hip_eval(c, 0, k)) return -2;
         if (kiwi_hip_get_misfits(c, 0, k, mis.data(), nullptr, glob.data())) return -2;
         for (int s = 0; s < k; s++)
@@ -1471,11 +1539,17 @@ int kiwi_hip_get_misfits(kiwi_hip_ctx *c, int isrc0, int nsrc, float *misfit, fl
     if (c->synth_only) throw std::runtime_error("misfits need a reference seismogram and a misfit taper for every enabled receiver component "
                                                 "(the device comparator evaluates norms over the taper span, comparator.f90:782-792)");
     if (isrc0 < 0 || nsrc < 0 || isrc0 + nsrc > c->nsrc) throw std::runtime_error("source range out of bounds");
+    for (int s = isrc0; s < isrc0 + nsrc; s++)
+        if ((size_t)s >= c->evaluated.size() || !c->evaluated[s])
+            throw std::runtime_error("nothing evaluated yet for source " + std::to_string(s + 1) + " of the uploaded batch");
     HIPCHECK(hipStreamSynchronize(c->stream));
     if (misfit)
         HIPCHECK(hipMemcpy(misfit, c->misfit_d.p + (size_t)isrc0 * c->nmis, (size_t)nsrc * c->nmis * sizeof(float), hipMemcpyDeviceToHost));
     if (norm)
-        for (int s = 0; s < nsrc; s++) std::memcpy(norm + (size_t)s * c->nmis, c->norm_h.data(), (size_t)c->nmis * sizeof(float));
+        for (int s = 0; s < nsrc; s++) {
+            if (c->src_status[(size_t)isrc0 + s]) std::memset(norm + (size_t)s * c->nmis, 0, (size_t)c->nmis * sizeof(float));
+            else std::memcpy(norm + (size_t)s * c->nmis, c->norm_h.data(), (size_t)c->nmis * sizeof(float));
+        }
     if (global)
         HIPCHECK(hipMemcpy(global, c->global_d.p + isrc0, (size_t)nsrc * sizeof(float), hipMemcpyDeviceToHost));
     return 0;

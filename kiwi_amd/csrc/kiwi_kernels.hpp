@@ -1065,7 +1065,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
             float *tile0 = &tiles[0][0];
             // all 40 rows of the group cover [jb, jb + LDS_TILE) inside their padded storage?  (lane l < 40 holds
             // row l's descriptors; workgroup-uniform because every wave holds the same table)
-            const bool lane_ok = lane >= 40 || (ta + jb >= tb && ta + jb + LDS_TILE <= tb + pitch);
+            const bool lane_ok = lane >= 4 * NG || (ta + jb >= tb && ta + jb + LDS_TILE <= tb + pitch);
             const bool fast = __builtin_amdgcn_ballot_w64(lane_ok) == ~0ull;
 #define BUILD_B(IGS, P) do { \
                 if (fast) { if (direct) build_batch<false, true>(tile0, LDS_TILE, IGS, P, jb, G, pitch, ta, tb, g0); \
@@ -1556,12 +1556,18 @@ __global__ void floating_select_kernel(const float *__restrict__ partial, const 
 }
 
 // minimizer_engine.f90:936-942: per receiver sum of squares in fp32, receivers in order
-__global__ void global_kernel(const float *__restrict__ misfit, const float *__restrict__ norm,
+__global__ void global_kernel(float *misfit, const float *__restrict__ norm,
                               const int *__restrict__ rec_first /*[nrec_en+1]*/, int nrec_en, int nmis,
-                              int isrc0, int nsrc, float *__restrict__ global_out)
+                              int isrc0, int nsrc, float *__restrict__ global_out, const int *__restrict__ status)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsrc) return;
+    if (status && status[isrc0 + s]) {               // a trial source the discretiser rejected: zeros (seismosizer.py:703-720)
+        float *mz = misfit + (size_t)(isrc0 + s) * nmis;
+        for (int k = 0; k < nmis; k++) mz[k] = 0.f;
+        global_out[isrc0 + s] = 0.f;
+        return;
+    }
     const float *m = misfit + (size_t)(isrc0 + s) * nmis;
     float mis = 0.f, nf = 0.f;
     for (int r = 0; r < nrec_en; r++) {

@@ -248,8 +248,20 @@ class Engine:
         st = SOURCE_TYPES.get(sourcetype, sourcetype)
         if p.shape[1] != self.L.kiwi_hip_source_nparams(st):
             raise KiwiHipError("set_source_params: wrong number of source parameters")
+        self.nsrc = p.shape[0]          # the batch is uploaded even when the call reports that no source could be discretised
         self._ck(self.L.kiwi_hip_set_sources_params(self.h, st, p.shape[0], _fp(p)), "set_source_params")
-        self.nsrc = p.shape[0]
+
+    def get_source_status(self, isrc0=0, nsrc=None):
+        """Per uploaded source: 0 discretised, else the discretiser's error code (see source_status_message)."""
+        nsrc = self.nsrc - isrc0 if nsrc is None else nsrc
+        st = np.zeros(nsrc, np.int32)
+        self._ck(self.L.kiwi_hip_get_source_status(self.h, isrc0, nsrc, _ip(st)), "set_source_params")
+        return st
+
+    def source_status_message(self, code):
+        buf = C.create_string_buffer(256)
+        self.L.kiwi_hip_source_status_message(int(code), buf, 256)
+        return buf.value.decode()
 
     # ------------------------------------------------------------------ hot path
     def eval(self, isrc0=0, nsrc=None):
@@ -357,10 +369,17 @@ class Engine:
 
     # ------------------------------------------------------------------ seismosizer.py counterparts
     def make_misfits_for_sources(self, sourcetype=None, params=None):
-        """seismosizer.py:682-722: returns (misfits_by_src[N_s,N_r,N_k], norms_by_src[...]) as float64,
-        receivers in file order, components in string order, disabled receivers as zeros."""
+        """seismosizer.py:682-722: returns (misfits_by_src[N_s,N_r,N_k], norms_by_src[...], failings) -- float64 arrays,
+        receivers in file order, components in string order, disabled receivers as zeros; `failings` lists the indices of
+        the trial sources the engine rejected (`SeismosizersReturnedErrors` there, :716-717), whose rows stay zero."""
         if params is not None:
-            self.set_source_params(sourcetype, params)
+            try:
+                self.set_source_params(sourcetype, params)
+            except KiwiHipError:
+                # "no source of the batch could be discretised": every trial is a failing, not an error of the sweep
+                if self.nsrc != len(np.atleast_2d(params)) or not np.all(self.get_source_status() != 0):
+                    raise
+        failings = [int(i) for i in np.nonzero(self.get_source_status())[0]]
         self.eval()
         m, n, _ = self.get_misfits()
         nrec = len(self.components)
@@ -375,7 +394,7 @@ class Engine:
             mis[:, ir, :k] = m[:, j:j + k]
             nor[:, ir, :k] = n[:, j:j + k]
             j += k
-        return mis, nor
+        return mis, nor, failings
 
 
 def make_global_misfits(misfits_by_src, norms_by_src, outer_norm="l2norm", receiver_weights=None, receiver_mask=None,

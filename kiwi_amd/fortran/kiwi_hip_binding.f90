@@ -219,6 +219,21 @@ module kiwi_hip_binding
             real(c_float), intent(in) :: params(*)        ! (nparams, nsrc)
         end function
 
+        integer(c_int) function kiwi_hip_get_source_status( ctx, isrc0, nsrc, status ) &
+                bind(C, name='kiwi_hip_get_source_status')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: isrc0, nsrc          ! isrc0 is 0-based
+            integer(c_int), intent(out) :: status(*)      ! 0 ok, 5 empty rupture area, 6 nucleation point outside
+        end function
+
+        integer(c_int) function kiwi_hip_source_status_message( code, buf, buflen ) &
+                bind(C, name='kiwi_hip_source_status_message')
+            import :: c_int, c_char
+            integer(c_int), value :: code, buflen
+            character(kind=c_char), intent(out) :: buf(*)
+        end function
+
         integer(c_int) function kiwi_hip_eval( ctx, isrc0, nsrc ) bind(C, name='kiwi_hip_eval')
             import :: c_int, c_ptr
             type(c_ptr), value :: ctx

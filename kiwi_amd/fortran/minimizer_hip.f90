@@ -32,7 +32,8 @@
 !   inversion loop) and mseed / sac file formats.
 ! Batch extension (SURVEY.md 8f-1), one pipe round trip for a whole grid:
 !   eval_sources <type> <paramfile> <outfile>   one parameter vector per line in; per source
-!                                               "global m1 n1 m2 n2 .." out; answers the number of sources
+!                                               "global m1 n1 m2 n2 .." out; answers the number of sources, followed by
+!                                               "failed i1 i2 .." when the discretiser rejected some (their rows: zeros)
 
 program minimizer_hip
 
@@ -1251,6 +1252,7 @@ program minimizer_hip
         character(len=maxline) :: r1, r2, str
         integer :: st, np, unit, ios, nsrc, i, s
         integer(c_int) :: nmis
+        integer(c_int), allocatable :: status(:)
         real(c_float), allocatable :: p(:), m(:), n(:), g(:)
         ok_ = .false.
         call split_first( a, tname, r1 )
@@ -1292,7 +1294,20 @@ program minimizer_hip
         end do
         close( unit )
         if (.not. need_ctx()) return
-        if (.not. check( kiwi_hip_set_sources_params( ctx, int(st,c_int), int(nsrc,c_int), p ) )) return
+      ! trial sources the discretiser rejects do not fail the sweep (seismosizer.py:703-720): they are listed in the
+      ! answer and their rows are zeros.  The call itself reports an error when NO source could be discretised.
+        allocate( status(nsrc) )
+        rc = kiwi_hip_set_sources_params( ctx, int(st,c_int), int(nsrc,c_int), p )
+        if (rc /= 0) then
+            if (kiwi_hip_get_source_status( ctx, 0_c_int, int(nsrc,c_int), status ) /= 0) then
+                ok_ = check( rc ); return
+            end if
+            if (any(status == 0) .or. nsrc == 1) then
+                ok_ = check( rc ); return
+            end if
+        else
+            if (.not. check( kiwi_hip_get_source_status( ctx, 0_c_int, int(nsrc,c_int), status ) )) return
+        end if
         source_set = .true.
         if (.not. check( kiwi_hip_eval( ctx, 0_c_int, int(nsrc,c_int) ) )) return
         if (.not. check( kiwi_hip_nmisfits( ctx, nmis ) )) return
@@ -1309,6 +1324,15 @@ program minimizer_hip
         evaluated = .true.         ! source 0 of the batch is the "current" source
         write (str,'(i0)') nsrc
         answer = trim(str)
+        if (any(status /= 0)) then              ! "<nsrc> failed <i1> <i2> ..." (1-based, in trial order)
+            answer = answer//' failed'
+            do s = 1, nsrc
+                if (status(s) /= 0) then
+                    write (str,'(i0)') s
+                    answer = answer//' '//trim(str)
+                end if
+            end do
+        end if
         ok_ = .true.
     end subroutine
 

@@ -90,6 +90,7 @@ class MisfitGrid:
         self.sources = source_grid(sourcetype, self.base_params, self.param_values, source_constraints)
         self.sourceparams = [p for p, _ in self.param_values]
         self.misfits_by_src = self.norms_by_src = None
+        self.failings = []
         self.best_source = self.misfits_by_s = self.misfits_by_r = self.variability_by_r = None
         self.bootstrap_sources = self.stats = None
 
@@ -101,12 +102,15 @@ class MisfitGrid:
         if len(self.sources):
             if dist is not None:
                 from .shard import sharded_misfits_for_sources
-                self.misfits_by_src, self.norms_by_src = sharded_misfits_for_sources(engine, self.sourcetype, self.sources,
-                                                                                    dist, device)
+                self.misfits_by_src, self.norms_by_src, self.failings = sharded_misfits_for_sources(
+                    engine, self.sourcetype, self.sources, dist, device)
             else:
-                self.misfits_by_src, self.norms_by_src = engine.make_misfits_for_sources(self.sourcetype, self.sources)
-        self.ref_misfits_by_src, self.ref_norms_by_src = engine.make_misfits_for_sources(self.sourcetype,
-                                                                                       self.ref_params[None, :])
+                self.misfits_by_src, self.norms_by_src, self.failings = engine.make_misfits_for_sources(self.sourcetype,
+                                                                                                      self.sources)
+        # sources the engine rejected keep zero misfits AND zero norms: their global misfit comes out as NaN and
+        # nanargmin passes over them (gridsearch.py:172-178 drops `failings` the same way)
+        self.ref_misfits_by_src, self.ref_norms_by_src, _ = engine.make_misfits_for_sources(self.sourcetype,
+                                                                                          self.ref_params[None, :])
         self.best_source = None
 
     def _best_source(self, **cfg):

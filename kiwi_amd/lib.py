@@ -80,6 +80,8 @@ def load():
                                         c_float_p, c_float_p, C.c_int, c_int_p, c_float_p, c_float_p],
         "kiwi_hip_set_sources": [vp, C.c_int, c_int_p, c_float_p, c_float_p, c_float_p],
         "kiwi_hip_set_sources_params": [vp, C.c_int, C.c_int, c_float_p],
+        "kiwi_hip_get_source_status": [vp, C.c_int, C.c_int, c_int_p],
+        "kiwi_hip_source_status_message": [C.c_int, C.c_char_p, C.c_int],
         "kiwi_hip_eval": [vp, C.c_int, C.c_int],
         "kiwi_hip_sync": [vp],
         "kiwi_hip_set_keep_synthetics": [vp, C.c_int],

@@ -45,6 +45,12 @@ class MinimizerProcess:
             raise SeismosizerReturnedError("%s: %s" % (cmd, answer))
         return answer
 
+    def eval_sources(self, sourcetype, paramfile, outfile):
+        """`eval_sources`: (number of sources, failings) -- failings 0-based like seismosizer.py:716-717."""
+        words = self.do("eval_sources", sourcetype, paramfile, outfile).split()
+        failings = [int(w) - 1 for w in words[2:]] if len(words) > 1 and words[1] == "failed" else []
+        return int(words[0]), failings
+
     def close(self):
         if self.p.poll() is None:
             self.p.stdin.close()

@@ -58,18 +58,23 @@ def sharded_misfits_for_sources(engine, sourcetype, params, dist=None, device_in
     """`Seismosizer.make_misfits_for_sources` (seismosizer.py:682-722) over all ranks: this rank evaluates its
     contiguous share of `params` on its own GPU, then the [n, N_r, N_k] misfit and norm arrays are
     all-gathered so that every rank holds the full, ordered result (what MisfitGrid's outer norm and bootstrap
-    need: N_s * N_r * N_k * 2 floats)."""
+    need: N_s * N_r * N_k * 2 floats).  Returns (misfits_by_src, norms_by_src, failings) with
+    `failings` in global source indices (seismosizer.py:716-717)."""
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
     lo, hi = shard_range(len(params), world, rank)
     if hi > lo:
-        m, n = engine.make_misfits_for_sources(sourcetype, params[lo:hi])
+        m, n, fails = engine.make_misfits_for_sources(sourcetype, params[lo:hi])
     else:
         nrec = len(engine.components)
         nk = max([len(c) for c in engine.components] + [1])
         m = n = np.zeros((0, nrec, nk))
+        fails = []
     shape = m.shape[1:]
-    both = np.concatenate([m.reshape(len(m), -1), n.reshape(len(n), -1)], 1)
+    failed = np.zeros((len(m), 1))
+    failed[list(fails)] = 1.0
+    both = np.concatenate([m.reshape(len(m), -1), n.reshape(len(n), -1), failed], 1)
     allb = gather_misfits(both, dist, device_index).astype(np.float64)
-    k = allb.shape[1] // 2
-    return allb[:, :k].reshape((-1,) + shape), allb[:, k:].reshape((-1,) + shape)
+    k = (allb.shape[1] - 1) // 2
+    failings = [int(i) for i in np.nonzero(allb[:, 2 * k])[0]]
+    return allb[:, :k].reshape((-1,) + shape), allb[:, k:2 * k].reshape((-1,) + shape), failings

@@ -211,8 +211,8 @@ def test_edge_cases_components_depth_disabled_outofrange():
     assert np.array_equal(pn[0], n[0])
     assert misfit_close(pm, m)
     assert misfit_close(pg, g)
-    mis, nor = p.make_misfits_for_sources()
-    assert mis.shape == (4, 6, 3) and np.all(mis[:, 3] == 0)
+    mis, nor, failings = p.make_misfits_for_sources()
+    assert mis.shape == (4, 6, 3) and np.all(mis[:, 3] == 0) and failings == []
 
 
 def test_chunked_eval_equals_single_launch():
@@ -437,6 +437,31 @@ def test_eikonal_sources_with_risetime_fold(stype):
     p.set_source_params(stype, trials[:1])
     p.eval()
     assert misfit_close(p.get_misfits()[0][0], pm[0])
+    # ... and inside a batch it is skipped, not fatal (seismosizer.py:703-720): a grid with two "Empty rupture area"
+    # points and one nucleation point outside of the rupture region
+    grid = np.concatenate([trials[:2], bad, trials[2:3], bad, trials[3:]], 0)
+    grid[4, 3] = 300.0
+    out = trials[1:2].copy()
+    out[0, (10 if st == 5 else 11)] = 9000.0            # nukl-shift-x far outside the 2.9 km bounding circle
+    grid = np.concatenate([grid, out], 0)
+    p.set_source_params(stype, grid)
+    status = p.get_source_status()
+    assert list(status) == [0, 0, 5, 0, 5, 0, 6]
+    assert p.source_status_message(5) == "Empty rupture area"
+    assert p.source_status_message(6) == "position of nucleation point is outside of rupture region"
+    mis, nor, failings = p.make_misfits_for_sources()
+    assert failings == [2, 4, 6]
+    gm, gn, gg = p.get_misfits()
+    good = [0, 1, 3, 5]
+    assert np.array_equal(gm[good], pm) and np.array_equal(gn[good], pn) and np.array_equal(gg[good], pg)
+    assert np.all(gm[failings] == 0) and np.all(gn[failings] == 0) and np.all(gg[failings] == 0)
+    assert np.all(mis[failings] == 0) and np.all(nor[failings] == 0) and np.all(mis[good][:, 0] != 0)
+    from kiwi_amd.engine import make_global_misfits
+    gl, _ = make_global_misfits(mis, nor)
+    assert np.all(np.isnan(gl[failings])) and np.all(np.isfinite(gl[good]))
+    # the same through the sweep API when every trial fails: all failings, no exception
+    mis, nor, failings = p.make_misfits_for_sources(stype, np.concatenate([bad, bad], 0))
+    assert failings == [0, 1] and np.all(mis == 0) and np.all(nor == 0)
 
 
 @pytest.mark.parametrize("method", ["floating_l2norm", "floating_l1norm"])

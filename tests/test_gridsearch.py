@@ -73,6 +73,7 @@ class FakeEngine:
     """Stands in for kiwi_amd.Engine: misfit = |strike - 30| + |dip - 2| per receiver-component."""
     components = ["ned", "d", "ne"]
     enabled = [True, False, True]
+    reject = False
 
     def make_misfits_for_sources(self, sourcetype, params):
         p = np.atleast_2d(params)
@@ -82,7 +83,10 @@ class FakeEngine:
         for ir, k in ((0, 3), (2, 2)):
             m[:, ir, :k] = base[:, None] * (1 + 0.1 * ir)
             n[:, ir, :k] = 10.
-        return m, n
+        fails = [int(i) for i in np.nonzero(p[:, 5] == 20.)[0]] if self.reject else []   # "Empty rupture area" stand-ins
+        m[fails] = 0.
+        n[fails] = 0.
+        return m, n, fails
 
 
 def test_misfit_grid_finds_minimum_and_bootstraps():
@@ -95,6 +99,15 @@ def test_misfit_grid_finds_minimum_and_bootstraps():
     assert mg.get_best_misfit() == 0.0 and len(mg.bootstrap_sources) == 50
     assert mg.stats["strike"].best == 30. and mg.stats["strike"].converged() and mg.stats["dip"].mean == 2.
     assert mg.misfits_by_r.shape == (3,) and mg.variability_by_r.shape == (3,)
+    assert mg.failings == []
+    # trial sources the engine rejects (seismosizer.py:703-720): listed, zero rows, NaN global misfit, never the best
+    fe = FakeEngine()
+    fe.reject = True
+    mf = gs.MisfitGrid("bilateral", BASE, param_ranges=[("strike", 10, 50, 10), ("dip", 1, 3, 1)])
+    mf.compute(fe)
+    mf.postprocess(bootstrap_iterations=5, rng=np.random.default_rng(1), outer_norm="l2norm")
+    assert mf.failings == [3, 4, 5] and np.all(mf.misfits_by_src[3:6] == 0) and np.all(np.isnan(mf.misfits_by_s[3:6]))
+    assert mf.ibest == 7
     # reference source misfit (gridsearch.py:266-271): base strike 91, dip 87
     assert mg.ref_misfit > 1.
     # empty grid falls back to the base source (gridsearch.py:204-209)

@@ -83,7 +83,10 @@ class _FakeEngine:
         n = np.ones((len(p), 2, 3))
         m[:, 0, :] = p[:, :1] * np.array([1., 2., 3.])
         m[:, 1, :1] = p[:, :1] + 0.5
-        return m, n
+        fails = [int(i) for i in np.nonzero(p[:, 0] == 5.0)[0]]       # the trial with parameter 5 "fails": zeros, listed
+        m[fails] = 0.0
+        n[fails] = 0.0
+        return m, n, fails
 
 
 def _grid_worker(rank, world, port, q):
@@ -92,8 +95,8 @@ def _grid_worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     params = np.arange(7, dtype=np.float32)[:, None] * np.ones((1, 4), np.float32)
-    m, n = sharded_misfits_for_sources(_FakeEngine(), "x", params, dist)
-    q.put((rank, m, n))
+    m, n, fails = sharded_misfits_for_sources(_FakeEngine(), "x", params, dist)
+    q.put((rank, m, n, fails))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -113,6 +116,8 @@ def test_two_rank_sharded_misfits_for_sources():
         p.join(120)
         assert p.exitcode == 0
     params = np.arange(7, dtype=np.float32)[:, None] * np.ones((1, 4), np.float32)
-    m0, n0 = _FakeEngine().make_misfits_for_sources("x", params)
-    for rank, m, n in res:                     # every rank ends up with the full ordered arrays
+    m0, n0, f0 = _FakeEngine().make_misfits_for_sources("x", params)
+    assert f0 == [5]
+    for rank, m, n, fails in res:              # every rank ends up with the full ordered arrays and the global failings
         assert m.shape == (7, 2, 3) and np.array_equal(m, m0) and np.array_equal(n, n0)
+        assert fails == [5] and np.all(m[5] == 0) and np.all(n[5] == 0)
