@@ -38,7 +38,9 @@ struct GeoRec {
     float f[6];       // make_weights                                          seismogram.f90:329-334
     float cl, sl;     // cos / sin (bazi - bazi_orig)                          seismogram.f90:164-165
     int   flags;      // bit0: exactly on a node -> no blend (gfdb.f90:890-893); bit1: rotate (seismogram.f90:160);
-                      // bit2: same position as the previous centroid
+                      // bit2: same position as the previous centroid; bit3: some needed trace is not stored and the
+                      // reference `cycle`s there (seismogram.f90:171-250): only the first (flags >> 8 & 15) horizontal and
+                      // (flags >> 12 & 15) vertical components IN APPLICATION ORDER are added, see geometry_kernel
     int   pad;        // group hint: len | (smax-ishift)<<8 | (ishift-smin)<<16, see geometry_kernel
 };
 static_assert(sizeof(GeoRec) == 80, "GeoRec layout");
@@ -345,20 +347,39 @@ __global__ __launch_bounds__(256) void geometry_kernel(
     bool ok = inrange(ix0, iz0);
     if (!direct) ok = ok && inrange(ix0, iz1) && inrange(ix1, iz0) && inrange(ix1, iz1);
     g.row[0] = g.row[1] = g.row[2] = g.row[3] = -1;
+    int nlim_h = 0, nlim_d = 0;                    // components of the horizontal / vertical block that are added
     if (ok) {
         g.row[0] = rowof(ix0, iz0);
         if (!direct) { g.row[1] = rowof(ix0, iz1); g.row[2] = rowof(ix1, iz0); g.row[3] = rowof(ix1, iz1); }
         else { g.row[1] = g.row[2] = g.row[3] = g.row[0]; }
-        // a trace that is not stored makes gfdb_get_trace return null and the centroid is
-        // skipped (seismogram.f90:172 ...); checked here for every component this receiver needs
+        // A trace that is not stored makes gfdb_get_trace[_bilin] return null (gfdb.f90:899-903,1003) and the reference
+        // leaves the centroid AT THAT COMPONENT (`if (.not. associated(tracep)) cycle`, seismogram.f90:171-250): what was
+        // added before stays, the rest -- including the vertical block when the gap is in the horizontal one -- is not
+        // added.  In the rotate branch the horizontals are collected in temporaries that are only added after the last of
+        // them (:196-203), so there a gap drops all of them.  Components in application order: 1 2 3 [9] 4 5 | 6 7 8 [10].
         const int nn = direct ? 1 : 4;
-        for (int k = 0; k < nn && ok; k++)
-            for (int ig = 0; ig < gm.ng && ok; ig++) {
-                const bool horiz = (ig <= 4) || (ig == 8);
-                if ((horiz && !rv.need_h) || (!horiz && !rv.has_d)) continue;
-                const int2 sp = span[g.row[k] + ig];
-                if (sp.y < sp.x) ok = false;
-            }
+        const int nH = gm.ng == 10 ? 6 : 5, nD = gm.ng == 10 ? 4 : 3;
+        auto stored = [&](int ig) {
+            for (int k = 0; k < nn; k++) { const int2 sp = span[g.row[k] + ig]; if (sp.y < sp.x) return false; }
+            return true;
+        };
+        bool hfull = true;
+        if (rv.need_h) {
+            int k = 0;
+            for (; k < nH; k++) if (!stored(gm.ng == 10 ? (k < 3 ? k : (k == 3 ? 8 : k - 1)) : k)) break;
+            hfull = (k == nH);
+            nlim_h = hfull ? nH : ((g.flags & 2) ? 0 : k);
+        }
+        if (rv.has_d && hfull) {
+            int k = 0;
+            for (; k < nD; k++) if (!stored(k < 3 ? 5 + k : 9)) break;
+            nlim_d = k;
+        }
+        const bool complete = (!rv.need_h || nlim_h == nH) && (!rv.has_d || nlim_d == nD);
+        if (!complete) {
+            if (nlim_h == 0 && nlim_d == 0) ok = false;                  // nothing of this centroid is added
+            else g.flags |= 8 | (nlim_h << 8) | (nlim_d << 12);
+        }
         if (!ok) g.row[0] = -1;
     }
     // group hint (used by accumulate_grouped_kernel when a group STARTS at this centroid): how many
@@ -375,21 +396,22 @@ __global__ __launch_bounds__(256) void geometry_kernel(
     if ((spanbuf || spansrc) && g.row[0] >= 0) {
         const int nn = (g.flags & 1) ? 1 : 4;
         int lo_h = 0x7fffffff, hi_h = -0x7fffffff, lo_d = 0x7fffffff, hi_d = -0x7fffffff;
-        for (int ig = 0; ig < gm.ng; ig++) {
-            const bool horiz = (ig <= 4) || (ig == 8);
-            if ((horiz && !rv.need_h) || (!horiz && !rv.has_d)) continue;
+        for (int i = 0; i < nlim_h + nlim_d; i++) {   // the components that are added (all of the needed ones, normally)
+            const bool horiz = i < nlim_h;
+            const int q = horiz ? i : i - nlim_h;
+            const int ig = horiz ? (gm.ng == 10 ? (q < 3 ? q : (q == 3 ? 8 : q - 1)) : q) : (q < 3 ? 5 + q : 9);
             int lo = 0x7fffffff, hi = -0x7fffffff;
             for (int k = 0; k < nn; k++) { const int2 sp = span[g.row[k] + ig]; lo = min(lo, sp.x); hi = max(hi, sp.y); }
             if (horiz) { lo_h = min(lo_h, lo); hi_h = max(hi_h, hi); } else { lo_d = min(lo_d, lo); hi_d = max(hi_d, hi); }
         }
         if (spanbuf) {
-            if (rv.need_h) { atomicMin(&spanbuf[4 * r + 0], lo_h + g.ishift); atomicMax(&spanbuf[4 * r + 1], hi_h + g.ishift + 1); }
-            if (rv.has_d) { atomicMin(&spanbuf[4 * r + 2], lo_d + g.ishift); atomicMax(&spanbuf[4 * r + 3], hi_d + g.ishift + 1); }
+            if (nlim_h) { atomicMin(&spanbuf[4 * r + 0], lo_h + g.ishift); atomicMax(&spanbuf[4 * r + 1], hi_h + g.ishift + 1); }
+            if (nlim_d) { atomicMin(&spanbuf[4 * r + 2], lo_d + g.ishift); atomicMax(&spanbuf[4 * r + 3], hi_d + g.ishift + 1); }
         }
         if (spansrc) {                               // the same per trial source: data spans of ITS synthetic strips
             int *sp = spansrc + ((size_t)s * ep.nrec + r) * 4;
-            if (rv.need_h) { atomicMin(&sp[0], lo_h + g.ishift); atomicMax(&sp[1], hi_h + g.ishift + 1); }
-            if (rv.has_d) { atomicMin(&sp[2], lo_d + g.ishift); atomicMax(&sp[3], hi_d + g.ishift + 1); }
+            if (nlim_h) { atomicMin(&sp[0], lo_h + g.ishift); atomicMax(&sp[1], hi_h + g.ishift + 1); }
+            if (nlim_d) { atomicMin(&sp[2], lo_d + g.ishift); atomicMax(&sp[3], hi_d + g.ishift + 1); }
         }
     }
     if (!out) return;
@@ -525,8 +547,12 @@ __device__ __forceinline__ void centroid_add(float (&ar1)[4], float (&ar2)[4], f
                                              const float *__restrict__ G, const int2 *__restrict__ span, int pitch,
                                              const GeoRec &g, const RecvDev &rv, int j0)
 {
-    if (rv.need_h) {
-        if (g.flags & 2) {                       // seismogram.f90:160-203
+    // components that are added, in application order (all of them unless a trace is missing: geometry_kernel)
+    const int nlh = (g.flags & 8) ? (g.flags >> 8) & 15 : 15, nld = (g.flags & 8) ? (g.flags >> 12) & 15 : 15;
+    constexpr int o9 = (NG == 10) ? 1 : 0;       // position shift behind the optional near-field component
+#define GA(acc, pos, lim, ig, fac) do { if ((pos) < (lim)) gf_add<BLEND>(acc, G, span, pitch, g, ig, fac, j0); } while (0)
+    if (rv.need_h && nlh > 0) {
+        if (g.flags & 2) {                       // seismogram.f90:160-203 (a missing trace leaves before the sums are added)
             float t1[4] = { 0.f, 0.f, 0.f, 0.f }, t2[4] = { 0.f, 0.f, 0.f, 0.f };
             gf_add<BLEND>(t1, G, span, pitch, g, 0, g.f[0], j0);
             gf_add<BLEND>(t1, G, span, pitch, g, 1, g.f[1], j0);
@@ -540,20 +566,21 @@ __device__ __forceinline__ void centroid_add(float (&ar1)[4], float (&ar2)[4], f
                 ar2[i] = ar2[i] + g.cl * t2[i] + g.sl * t1[i];
             }
         } else {                                 // seismogram.f90:205-231
-            gf_add<BLEND>(ar1, G, span, pitch, g, 0, g.f[0], j0);
-            gf_add<BLEND>(ar1, G, span, pitch, g, 1, g.f[1], j0);
-            gf_add<BLEND>(ar1, G, span, pitch, g, 2, g.f[2], j0);
-            if (NG == 10) gf_add<BLEND>(ar1, G, span, pitch, g, 8, g.f[5], j0);
-            gf_add<BLEND>(ar2, G, span, pitch, g, 3, g.f[3], j0);
-            gf_add<BLEND>(ar2, G, span, pitch, g, 4, g.f[4], j0);
+            GA(ar1, 0, nlh, 0, g.f[0]);
+            GA(ar1, 1, nlh, 1, g.f[1]);
+            GA(ar1, 2, nlh, 2, g.f[2]);
+            if (NG == 10) GA(ar1, 3, nlh, 8, g.f[5]);
+            GA(ar2, 3 + o9, nlh, 3, g.f[3]);
+            GA(ar2, 4 + o9, nlh, 4, g.f[4]);
         }
     }
     if (rv.has_d) {                              // seismogram.f90:236-253
-        gf_add<BLEND>(dz, G, span, pitch, g, 5, g.f[0] * rv.sd, j0);
-        gf_add<BLEND>(dz, G, span, pitch, g, 6, g.f[1] * rv.sd, j0);
-        gf_add<BLEND>(dz, G, span, pitch, g, 7, g.f[2] * rv.sd, j0);
-        if (NG == 10) gf_add<BLEND>(dz, G, span, pitch, g, 9, g.f[5] * rv.sd, j0);
+        GA(dz, 0, nld, 5, g.f[0] * rv.sd);
+        GA(dz, 1, nld, 6, g.f[1] * rv.sd);
+        GA(dz, 2, nld, 7, g.f[2] * rv.sd);
+        if (NG == 10) GA(dz, 3, nld, 9, g.f[5] * rv.sd);
     }
+#undef GA
 }
 
 template <int NG>
@@ -851,8 +878,12 @@ __device__ __forceinline__ void centroid_apply(f2v (&ar1)[2], f2v (&ar2)[2], f2v
                                                float f0, float f1, float f2, float f3, float f4, float f5,
                                                float cl, float sl)
 {
+    // components that are added, in application order (all of them unless a trace is missing: geometry_kernel)
+    const int nlh = (flags & 8) ? (flags >> 8) & 15 : 15, nld = (flags & 8) ? (flags >> 12) & 15 : 15;
+    constexpr int o9 = (NG == 10) ? 1 : 0;
 #define TADD(acc, ig, fac) tile_add<TAIL>(acc, chunk0, (ig) * LDS_TILE, jl, jend[ig], fac, wfrac)
-    if (need_h) {
+#define TADDL(acc, pos, lim, ig, fac) do { if ((pos) < (lim)) TADD(acc, ig, fac); } while (0)
+    if (need_h && nlh > 0) {
         if (flags & 2) {                         // seismogram.f90:160-203
             f2v t1[2] = { { 0.f, 0.f }, { 0.f, 0.f } }, t2[2] = { { 0.f, 0.f }, { 0.f, 0.f } };
             TADD(t1, 0, f0); TADD(t1, 1, f1); TADD(t1, 2, f2);
@@ -864,15 +895,16 @@ __device__ __forceinline__ void centroid_apply(f2v (&ar1)[2], f2v (&ar2)[2], f2v
                 ar2[i] = ar2[i] + cl * t2[i] + sl * t1[i];
             }
         } else {                                 // seismogram.f90:205-231
-            TADD(ar1, 0, f0); TADD(ar1, 1, f1); TADD(ar1, 2, f2);
-            if constexpr (NG == 10) TADD(ar1, 8, f5);
-            TADD(ar2, 3, f3); TADD(ar2, 4, f4);
+            TADDL(ar1, 0, nlh, 0, f0); TADDL(ar1, 1, nlh, 1, f1); TADDL(ar1, 2, nlh, 2, f2);
+            if constexpr (NG == 10) TADDL(ar1, 3, nlh, 8, f5);
+            TADDL(ar2, 3 + o9, nlh, 3, f3); TADDL(ar2, 4 + o9, nlh, 4, f4);
         }
     }
     if (has_d) {                                 // seismogram.f90:236-253
-        TADD(dz, 5, f0 * sd); TADD(dz, 6, f1 * sd); TADD(dz, 7, f2 * sd);
-        if constexpr (NG == 10) TADD(dz, 9, f5 * sd);
+        TADDL(dz, 0, nld, 5, f0 * sd); TADDL(dz, 1, nld, 6, f1 * sd); TADDL(dz, 2, nld, 7, f2 * sd);
+        if constexpr (NG == 10) TADDL(dz, 3, nld, 9, f5 * sd);
     }
+#undef TADDL
 #undef TADD
 }
 
@@ -1171,7 +1203,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
             const int jl = jb + e + u0;                  // trace index of b[j-1] of the lane's output q = 0
             const bool tail = (jb + e + TILE) > jend_min;        // workgroup-uniform
 #define APPLY(TV) do { \
-                if (need_h && has_d) centroid_apply_hd<NG, LDS_TILE, TV, !(FUSE && RUNS)>(ar1, ar2, dz, chunk0, jl, jend, flags, coef, cur, sd, cl, sl); \
+                if (need_h && has_d && !(flags & 8)) centroid_apply_hd<NG, LDS_TILE, TV, !(FUSE && RUNS)>(ar1, ar2, dz, chunk0, jl, jend, flags, coef, cur, sd, cl, sl); \
                 else centroid_apply<NG, LDS_TILE, TV>(ar1, ar2, dz, chunk0, jl, jend, need_h, has_d, flags, \
                                                       REC_F(cur, 9), sd, REC_F(cur, 10), REC_F(cur, 11), REC_F(cur, 12), REC_F(cur, 13), \
                                                       REC_F(cur, 14), REC_F(cur, 15), cl, sl); } while (0)

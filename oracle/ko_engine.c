@@ -379,15 +379,27 @@ void ko_engine_centroid_geometry(ko_engine *e, int irec1, int icent0, void *out2
     int direct = (dix == 0.f && diz == 0.f);
     int need_h = component_index(rec, C_AWAY) || component_index(rec, C_RIGHT) || component_index(rec, C_NORTH) || component_index(rec, C_EAST);
     int has_d = component_index(rec, C_DOWN) != 0;
-    int ok = 1;
-    for (int a = 0; a < (direct ? 1 : 2) && ok; a++)
-        for (int b = 0; b < (direct ? 1 : 2) && ok; b++)
-            for (int ig = 1; ig <= db->ng && ok; ig++) {
-                int horiz = (ig <= 5) || (ig == 9);
-                if ((horiz && !need_h) || (!horiz && !has_d)) continue;
-                int sp[2];
-                if (!ko_gfdb_trace_span(db, ix[a], iz[b], ig, sp)) ok = 0;
-            }
+    /* row = -1: nothing of this centroid is added -- the first trace make_seismogram asks for (ig 1, or 6 for a
+     * vertical-only receiver) is missing at one of the nodes, or the horizontals of the rotate branch are dropped and with
+     * them the vertical block (seismogram.f90:171-250) */
+    double lambda0 = bazi - bazi_orig;
+    static const int seq_h10[6] = { 1, 2, 3, 9, 4, 5 }, seq_h8[5] = { 1, 2, 3, 4, 5 }, seq_d[4] = { 6, 7, 8, 10 };
+    int nH = db->ng == 10 ? 6 : 5, nD = db->ng == 10 ? 4 : 3, nlh = 0, nld = 0, hfull = 1;
+#define STORED(ig, res) do { res = 1; for (int a = 0; a < (direct ? 1 : 2); a++) for (int b = 0; b < (direct ? 1 : 2); b++) { \
+        int sp[2]; if (!ko_gfdb_trace_span(db, ix[a], iz[b], (ig), sp)) res = 0; } } while (0)
+    if (need_h) {
+        int k = 0, st;
+        for (; k < nH; k++) { STORED(db->ng == 10 ? seq_h10[k] : seq_h8[k], st); if (!st) break; }
+        hfull = (k == nH);
+        nlh = hfull ? nH : (lambda0 != 0. ? 0 : k);
+    }
+    if (has_d && hfull) {
+        int k = 0, st;
+        for (; k < nD; k++) { STORED(seq_d[k], st); if (!st) break; }
+        nld = k;
+    }
+#undef STORED
+    int ok = (nlh > 0 || nld > 0);
 #define ROW(a, b) (((ix[a] - 1) * db->nz + (iz[b] - 1)) * db->ng)
     if (!ok) { oi[0] = oi[1] = oi[2] = oi[3] = -1; }
     else if (direct) { oi[0] = oi[1] = oi[2] = oi[3] = ROW(0, 0); }

@@ -464,6 +464,96 @@ def test_eikonal_sources_with_risetime_fold(stype):
     assert failings == [0, 1] and np.all(mis == 0) and np.all(nor == 0)
 
 
+def _knock_out(sc, holes):
+    """Mark single traces (ix, iz, ig; 0-based) of the scenario's database as not stored (nsamp = 0: the chunk index holds no
+    reference for them, gfdb.f90:1003)."""
+    for ix, iz, ig in holes:
+        sc.gf["nsamp"][ix, iz, ig] = 0
+
+
+@pytest.mark.parametrize("bilinear", [True, False])
+@pytest.mark.parametrize("accum", ["grouped", "direct"])
+def test_cycle_at_the_first_missing_trace(monkeypatch, bilinear, accum):
+    """seismogram.f90:171-250: `if (.not. associated(tracep)) cycle` leaves a centroid at the first trace that is not
+    stored -- what was added before stays (non-rotating branch, vertical block), horizontals collected for the rotation
+    are dropped, and a gap among the horizontals also skips the vertical block.  Database with single (ix, iz, ig)
+    traces unset at nodes the sources use; point source at the origin (no rotation) and extended ones (rotation)."""
+    if accum == "direct":
+        monkeypatch.setenv("KIWI_HIP_ACCUM", "direct")
+    comps = ["ned", "d", "ne", "ar", "ned", "u", "ned", "ned"]
+    sc = Scenario(nrec=8, comps_list=comps, nx=10, nz=5)
+    holes = []
+    for iz in range(5):
+        holes += [(1, iz, 2), (2, iz, 8), (3, iz, 4), (4, iz, 6), (5, iz, 9), (6, iz, 0), (7, iz, 5)]
+    holes += [(0, 1, 3), (0, 2, 7)]
+    e = sc.oracle()
+    sc.make_references(e)             # references from the complete database
+    sc.apply_setup(e, True)
+    _knock_out(sc, holes)
+    e = sc.oracle()
+    sc.apply_setup(e, True)
+    p = sc.product()
+    sc.apply_setup(p, False)
+    nmissing = int((sc.gf["nsamp"] == 0).sum())
+    assert nmissing == len(holes)
+    # (a) moment tensor point sources at the origin: lambda == 0, partial sums stay
+    mt = np.array([[0., 0., 0., 10000.] + synthetic.mt_from_sdr(30. * i, 60., -90. + 20 * i) + [1.0] for i in range(4)], np.float32)
+    m, n, g = oracle_misfits(e, 6, mt)
+    p.set_source_params("moment_tensor", mt)
+    p.eval()
+    pm, pn, pg = p.get_misfits()
+    assert np.array_equal(pn[0], n[0])
+    assert misfit_close(pm, m), np.max(np.abs(pm - m) / np.abs(m))
+    # the partial rule is really exercised: some centroid has bit 3 set, and dropping it changes the answer
+    flags = np.concatenate([p.get_geometry(0, ir)["flags"] for ir in range(1, 9)])
+    rows = np.concatenate([p.get_geometry(0, ir)["row"][:, 0] for ir in range(1, 9)])
+    assert np.any(flags & 8) and np.any(rows < 0) and np.any((rows >= 0) & ((flags & 8) == 0))
+    # (b) extended sources: rotation branch for every sub-fault off the origin
+    trials = synthetic.bilat_strike_sweep(5, step=7.0)
+    trials[:, 3] = [9000., 10000., 11000., 8000., 12000.]
+    m, n, g = oracle_misfits(e, 1, trials)
+    p.set_source_params("bilateral", trials)
+    p.eval()
+    pm, pn, pg = p.get_misfits()
+    assert misfit_close(pm, m), np.max(np.abs(pm - m) / np.abs(m))
+    assert misfit_close(pg, g)
+    flags = np.concatenate([p.get_geometry(0, ir)["flags"] for ir in range(1, 9)])
+    assert np.any((flags & 8) != 0) and np.any((flags & 10) == 2)
+    # sample for sample on one source
+    e.set_source_params(1, trials[2])
+    e.get_misfits()
+    for ir in range(1, 9):
+        for k in range(1, len(comps[ir - 1]) + 1):
+            lo_o, so = e.synthetic(ir, k, 1)
+            lo_p, sp = p.get_synthetics(2, ir, k, 1)
+            a, b = max(lo_o, lo_p), min(lo_o + len(so), lo_p + len(sp))
+            assert b - a > 150
+            assert np.max(np.abs(so[a - lo_o:b - lo_o] - sp[a - lo_p:b - lo_p])) <= SYN_RTOL * max(np.max(np.abs(so)), 1e-30)
+
+
+def test_grouped_and_direct_accumulate_are_bit_identical(monkeypatch):
+    """The LDS-staged kernel only moves where the blended traces are read from: its synthetics equal the direct kernel's
+    bit for bit (also with traces missing from the database and the static variant's repeated end values)."""
+    sc = Scenario(nrec=6, comps_list=["ned", "d", "ne", "ar", "ned", "u"], variant="static")
+    _knock_out(sc, [(2, iz, 8) for iz in range(5)] + [(4, iz, 6) for iz in range(5)] + [(3, 2, 1)])
+    res = {}
+    for mode in ("grouped", "direct"):
+        if mode == "direct":
+            monkeypatch.setenv("KIWI_HIP_ACCUM", "direct")
+        e = sc.oracle()
+        p = sc.product()
+        trials = np.vstack([synthetic.bilat_strike_sweep(3, step=5.0)])
+        p.set_source_params("bilateral", trials)
+        p.set_keep_synthetics(1)
+        p.eval()
+        res[mode] = [p.get_synthetics(s, ir, k, 1)[1] for s in range(3) for ir in range(1, 7) for k in range(1, len(sc.comps[ir - 1]) + 1)]
+        p.close()
+    assert len(res["grouped"]) == len(res["direct"]) > 30
+    for a, b in zip(res["grouped"], res["direct"]):
+        assert a.tobytes() == b.tobytes()
+    assert any(np.any(a != 0) for a in res["grouped"])
+
+
 @pytest.mark.parametrize("method", ["floating_l2norm", "floating_l1norm"])
 def test_floating_norms(method):
     """A15 (receiver.f90:439-510): argmin over integer shifts of the reference, per receiver."""
