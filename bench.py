@@ -37,7 +37,11 @@ def setup_product(device, wl, L):
     gf = synthetic.make_gfdb(nx=wl["nx"], L=L)
     lat, lon, depth, comps, dist = synthetic.make_receivers(nrec)
     p = Engine(device)
-    p.set_database(gf["dt"], gf["dx"], gf["dz"], gf["firstx"], gf["firstz"], gf["data"], gf["first"], gf["nsamp"])
+    # the engine gets the traces as a database reader delivers them: gap-compressed spans (trace_pack), which is also
+    # how the CPU oracle stores the same array -- the comparator's transform lengths follow these spans
+    pk = synthetic.pack_gfdb(gf)
+    p.set_database(gf["dt"], gf["dx"], gf["dz"], gf["firstx"], gf["firstz"], pk["data"], pk["first"], pk["nsamp"])
+    del pk
     p.set_receivers(lat, lon, depth, comps)
     p.set_source_location(40.0, 30.0, 0.0)
     p.set_effective_dt(0.5)
@@ -86,9 +90,12 @@ def setup_product(device, wl, L):
     return p, gf, (lat, lon, depth, comps), refs, tapers, float(np.mean(nc))
 
 
-def oracle_engine(wl, gf, recv, refs, tapers, cores):
+def oracle_engine(wl, gf, recv, refs, tapers, cores, fresh=False):
     """The CPU oracle set up exactly like the product in setup_product; returns (engine, db, evaluate) where
-    evaluate(params) = set_source_params + get_misfits (seismosizer.py:703-718) -> (misfits, norms, global)."""
+    evaluate(params) = set_source_params + get_misfits (seismosizer.py:703-718) -> (misfits, norms, global).
+    fresh=True: every evaluation runs on a NEW engine over the same database -- probes and strips of the reference
+    never shrink, so its spans (and with them the spectral comparator's transform lengths) remember every source
+    evaluated before; the product gives each trial source what a fresh engine gives it."""
     from oracle import ko
     from kiwi_amd.engine import SOURCE_TYPES
     nx, nz, ng, L = gf["data"].shape
@@ -97,32 +104,42 @@ def oracle_engine(wl, gf, recv, refs, tapers, cores):
         for iz in range(nz):
             for ig in range(ng):
                 db.set_trace(ix + 1, iz + 1, ig + 1, int(gf["first"][ix, iz, ig]), gf["data"][ix, iz, ig])
-    e = ko.Engine(db)
     lat, lon, depth, comps = recv
-    e.set_receivers(lat, lon, depth, comps)
-    e.set_source_location(40.0, 30.0, 0.0)
-    e.set_effective_dt(0.5)
-    e.set_interpolation(True)
-    e.set_nthreads(cores)
-    e.set_misfit_method(NORM_ID[wl["method"]])
-    for (ir, k), (lo, d) in refs.items():
-        e.set_reference(ir, k, lo, d)
-    for ir, (x, y) in tapers.items():
-        e.set_taper(ir, x, y)
-        if wl["filter"] is not None:
-            e.set_filter(ir, *wl["filter"])
+
+    def make():
+        e = ko.Engine(db)
+        e.set_receivers(lat, lon, depth, comps)
+        e.set_source_location(40.0, 30.0, 0.0)
+        e.set_effective_dt(0.5)
+        e.set_interpolation(True)
+        e.set_nthreads(cores)
+        e.set_misfit_method(NORM_ID[wl["method"]])
+        for (ir, k), (lo, d) in refs.items():
+            e.set_reference(ir, k, lo, d)
+        for ir, (x, y) in tapers.items():
+            e.set_taper(ir, x, y)
+            if wl["filter"] is not None:
+                e.set_filter(ir, *wl["filter"])
+        return e
+
+    e = make()
     st = SOURCE_TYPES[wl["sourcetype"]]
     if wl["crust"] is not None:
         c = wl["crust"]
         prof = ko.crust_profile(c[0:8], c[8:16], c[16:24], c[24:31])
 
     def evaluate(t):
-        if wl["crust"] is not None:
-            cent, mo, ri, _ = ko.discretize_eikonal(st, t, 0.5, prof, *wl["constraints"])
-            e.set_centroids(cent, mo, ri)
-        else:
-            e.set_source_params(st, t)
-        return e.get_misfits()
+        eng = make() if fresh else e
+        try:
+            if wl["crust"] is not None:
+                cent, mo, ri, _ = ko.discretize_eikonal(st, t, 0.5, prof, *wl["constraints"])
+                eng.set_centroids(cent, mo, ri)
+            else:
+                eng.set_source_params(st, t)
+            return eng.get_misfits()
+        finally:
+            if fresh:
+                eng.close()
 
     return e, db, evaluate
 

@@ -12,6 +12,7 @@
 
 #include <hip/hip_runtime.h>
 #include <hipfft/hipfft.h>
+#include <algorithm>
 #include <map>
 #include <tuple>
 #include <cstdio>
@@ -162,16 +163,27 @@ struct kiwi_hip_ctx {
     int proc_chunk0 = 0, proc_chunkn = 0, proc_which_held = 0;   // what proc_d currently holds
     size_t chunk_bytes_limit = (size_t)16 << 30;      // workspace per launch; the device has 288 GB
 
-    // spectral / filtered comparator (hipFFT)
+    // spectral / filtered comparator (hipFFT).  The transform length belongs to the (trial source, slot) pair
+    // (fft_size_kernel); the reference-side data that depend on it -- amplitude spectrum, filter weights per bin,
+    // filtered reference, norm factor -- are kept per (slot, ntrans) VARIANT and made when a length first occurs.
     bool fft_needed = false, fft_ready = false, any_filter = false;
     int fft_cap = 0;                        // sources per chunk the FFT buffers are sized for
-    size_t fft_floats_per_src = 0, spec_cplx_per_src = 0;
-    struct FftGroup { int ntrans, nrow; long long fft_base, spec_base; };
-    std::vector<FftGroup> fft_groups;
+    size_t fft_floats_per_src = 0, spec_cplx_per_src = 0;      // capacity per source: every slot at its longest transform
+    struct FftVariant { int ntrans, specofs, filtofs; float norm; };
+    std::map<std::pair<int, int>, FftVariant> variants;         // (slot, ntrans) ->
+    std::vector<float> refamp_h, filtw_h, reffilt_h;            // host mirrors of the variant tables (re-uploaded when they grow)
     std::vector<int> slot_has_filter;
-    DevBuf<int> spanbuf_d;
-    DevBuf<float> fft_d, refamp_d, filtw_d, reffilt_d, zmask_d;
+    DevBuf<int> spanbuf_d, ntr_d;
+    DevBuf<float> fft_d, refamp_d, filtw_d, reffilt_d, zmask_d, normsrc_d;
     DevBuf<float2> spec_d;
+    DevBuf<FftPair> pairs_d;
+    int *ntr_pin = nullptr; size_t ntr_pin_n = 0;               // pinned staging: transform lengths down, pair table up
+    FftPair *pairs_pin = nullptr; size_t pairs_pin_n = 0;
+    std::vector<FftPair> last_pairs;                             // pair table of the last chunk (diagnostic getters)
+    std::vector<float> norm_src_h;                               // norm factors per (uploaded source, slot)
+    struct FftBucket { int ntrans; long long count, fft_base, spec_base; };
+    std::vector<FftBucket> buckets;                              // of the chunk being evaluated
+    hipEvent_t size_event = nullptr;
     std::map<std::tuple<int, int, int>, hipfftHandle> plans;     // (ntrans, batch, type) -> plan
 
     std::vector<EventPair> events;
@@ -480,166 +492,209 @@ hipfftHandle get_plan(kiwi_hip_ctx *c, int ntrans, int batch, hipfftType type)
     return h;
 }
 
-void fft_forward(kiwi_hip_ctx *c, int nsrc)
+// Batched transforms of `count` contiguous rows, issued as plans of power-of-two batch sizes: the bucket sizes change
+// from chunk to chunk, the set of plans stays small (log2 of the largest bucket per length).
+void fft_rows(kiwi_hip_ctx *c, int ntrans, long long count, long long fft_base, long long spec_base, bool forward)
 {
-    for (auto &g : c->fft_groups)
-        FFTCHECK(hipfftExecR2C(get_plan(c, g.ntrans, nsrc * g.nrow, HIPFFT_R2C), c->fft_d.p + g.fft_base,
-                               (hipfftComplex *)(c->spec_d.p + g.spec_base)));
+    const long long nb = ntrans / 2 + 1;
+    long long done = 0;
+    for (int bit = 30; bit >= 0; bit--) {
+        const long long b = 1ll << bit;
+        if (!(count & b)) continue;
+        if (forward)
+            FFTCHECK(hipfftExecR2C(get_plan(c, ntrans, (int)b, HIPFFT_R2C), c->fft_d.p + fft_base + done * ntrans,
+                                   (hipfftComplex *)(c->spec_d.p + spec_base + done * nb)));
+        else
+            FFTCHECK(hipfftExecC2R(get_plan(c, ntrans, (int)b, HIPFFT_C2R), (hipfftComplex *)(c->spec_d.p + spec_base + done * nb),
+                                   c->fft_d.p + fft_base + done * ntrans));
+        done += b;
+    }
 }
 
-void fft_backward(kiwi_hip_ctx *c, int nsrc)
+void fft_buckets(kiwi_hip_ctx *c, bool forward)
 {
-    for (auto &g : c->fft_groups)
-        FFTCHECK(hipfftExecC2R(get_plan(c, g.ntrans, nsrc * g.nrow, HIPFFT_C2R), (hipfftComplex *)(c->spec_d.p + g.spec_base),
-                               c->fft_d.p + g.fft_base));
+    for (auto &b : c->buckets) fft_rows(c, b.ntrans, b.count, b.fft_base, b.spec_base, forward);
 }
 
 int next_pow2(int n) { int m = 1; while (m < n) m *= 2; return m; }      // comparator.f90:1111-1118 (integer form)
 
-__global__ void ref_amp_kernel(const float2 *__restrict__ spec, const CompDev *__restrict__ comps,
+__global__ void ref_amp_kernel(const float2 *__restrict__ spec, const FftPair *__restrict__ pairs,
                                const float *__restrict__ filtw, float *__restrict__ refamp)
 {
-    const CompDev cd = comps[blockIdx.x];
-    const int nb = cd.ntrans / 2 + 1;
-    const float2 *row = spec + cd.spec_base + (size_t)cd.fft_row * nb;
+    const FftPair pr = pairs[blockIdx.x];
+    const int nb = pr.ntrans / 2 + 1;
+    const float2 *row = spec + pr.spec_ofs;
     for (int k = threadIdx.x; k < nb; k += blockDim.x) {
         const float2 z = row[k];
-        refamp[cd.specofs + k] = hypotf(z.x, z.y) * filtw[cd.specofs + k];
+        refamp[pr.specofs + k] = hypotf(z.x, z.y) * filtw[pr.specofs + k];
     }
 }
 
-__global__ void ref_filt_kernel(const float *__restrict__ fftbuf, const CompDev *__restrict__ comps,
+__global__ void ref_filt_kernel(const float *__restrict__ fftbuf, const FftPair *__restrict__ pairs, const CompDev *__restrict__ comps,
                                 const float *__restrict__ zmask, float *__restrict__ ref_filt)
 {
-    const CompDev cd = comps[blockIdx.x];
-    const float *row = fftbuf + cd.fft_base + (size_t)cd.fft_row * cd.ntrans;
+    const FftPair pr = pairs[blockIdx.x];
+    const CompDev cd = comps[pr.slot];
+    const float *row = fftbuf + pr.fft_ofs;
     for (int i = threadIdx.x; i < cd.wlen; i += blockDim.x)
-        ref_filt[cd.refofs + i] = (row[i] / (float)cd.ntrans) * zmask[cd.refofs + i];
+        ref_filt[pr.filtofs + i] = (row[i] / (float)pr.ntrans) * zmask[cd.refofs + i];
 }
 
-// Sizes the transforms (natural synthetic spans of the whole batch, comparator.f90:464-486), lays the
-// slots out in batched groups and pushes the REFERENCE probes through the same device pipeline.
+template <class T> void pin_ensure(T *&p, size_t &have, size_t want)
+{
+    if (want <= have) return;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; have = 0;
+    HIPCHECK(hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault));
+    have = want;
+}
+
+// Capacity of the FFT buffers and the slot-level tables.  The longest transform a slot can need in this batch follows
+// from the natural spans of the synthetic strips over ALL uploaded sources (a source's own span lies inside); the
+// lengths actually used are per source (fft_size_kernel).
 void prepare_fft(kiwi_hip_ctx *c, const std::vector<float> &reft_host)
 {
     const float dt = c->gm.dt;
-    // ---- 1. spans of the synthetic strips over all uploaded sources
     std::vector<int> sb;
     natural_spans(c, sb);
     const int hs = fold_halfwidth(c->max_risetime, dt);
-    // ---- 2. transform length per slot
-    std::vector<int> ntr(c->comps.size());
-    std::map<int, int> rows_of;          // ntrans -> rows so far
+    c->fft_floats_per_src = 0; c->spec_cplx_per_src = 0;
+    c->slot_has_filter.assign(c->comps.size(), 0);
     for (size_t m = 0; m < c->comps.size(); m++) {
         CompDev &cd = c->comps[m];
-        const Receiver &r = c->recv[cd.rec];
-        int k = 0;
-        for (size_t q = 0; q < m; q++) if (c->comps[q].rec == cd.rec) k++;
-        const int f0 = r.ref[k].first, f1 = f0 + (int)r.ref[k].data.size() - 1;
-        const bool vertical = std::abs(r.comp[k]) == 3;
-        int s0 = sb[4 * cd.rec + (vertical ? 2 : 0)], s1 = sb[4 * cd.rec + (vertical ? 3 : 1)];
+        const int f0 = cd.rf0, f1 = cd.rf1;
+        int s0 = sb[4 * cd.rec + (cd.vertical ? 2 : 0)], s1 = sb[4 * cd.rec + (cd.vertical ? 3 : 1)];
         if (s1 < s0) { s0 = f0; s1 = f0; }                          // no centroid contributed
         if (hs > 0) { s0 -= hs; s1 += hs + 1; }                     // strip_fold grows the strip
         const int len_ref = f1 - f0 + 1, len_syn = s1 - s0 + 1;
         const int len_u = std::max(f1, s1) - std::min(f0, s0) + 1;
         const int minlength = std::max((int)std::ceil(len_ref * 2.f), (int)std::ceil(len_syn * 2.f));
-        ntr[m] = next_pow2(std::max(len_u, minlength));
-        if (ntr[m] < cd.wlen) ntr[m] = next_pow2(cd.wlen);
-        cd.ntrans = ntr[m];
-        cd.fft_row = rows_of[ntr[m]]++;
-        if (std::getenv("KIWI_HIP_DEBUG"))
-            std::fprintf(stderr, "kiwi_hip: slot %zu rec %d: ref [%d,%d] syn [%d,%d] window [%d,%d] ntrans %d\n", m, cd.rec + 1, f0, f1, s0, s1,
-                         cd.w0, cd.w0 + cd.wlen - 1, ntr[m]);
-    }
-    // ---- 3. groups and capacities
-    c->fft_groups.clear();
-    c->fft_floats_per_src = 0; c->spec_cplx_per_src = 0;
-    for (auto &kv : rows_of) {
-        c->fft_floats_per_src += (size_t)kv.second * kv.first;
-        c->spec_cplx_per_src += (size_t)kv.second * (kv.first / 2 + 1);
+        cd.ntrans_max = next_pow2(std::max(std::max(len_u, minlength), cd.wlen));
+        cd.has_filter = c->recv[cd.rec].filter.defined() ? 1 : 0;
+        c->slot_has_filter[m] = cd.has_filter;
+        c->fft_floats_per_src += (size_t)cd.ntrans_max;
+        c->spec_cplx_per_src += (size_t)cd.ntrans_max / 2 + 1;
     }
     const size_t per_src = c->fft_floats_per_src * 4 + c->spec_cplx_per_src * 8;
     c->fft_cap = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(c->nsrc, 1), c->chunk_bytes_limit / per_src));
-    long long fb = 0, sbase = 0;
-    for (auto &kv : rows_of) {
-        c->fft_groups.push_back({ kv.first, kv.second, fb, sbase });
-        fb += (long long)c->fft_cap * kv.second * kv.first;
-        sbase += (long long)c->fft_cap * kv.second * (kv.first / 2 + 1);
-    }
-    int specofs = 0;
-    c->slot_has_filter.assign(c->comps.size(), 0);
-    for (size_t m = 0; m < c->comps.size(); m++) {
-        CompDev &cd = c->comps[m];
-        for (auto &g : c->fft_groups) if (g.ntrans == cd.ntrans) { cd.fft_nrow = g.nrow; cd.fft_base = g.fft_base; cd.spec_base = g.spec_base; }
-        cd.specofs = specofs;
-        specofs += cd.ntrans / 2 + 1;
-        c->slot_has_filter[m] = c->recv[cd.rec].filter.defined() ? 1 : 0;
-    }
-    c->fft_d.ensure((size_t)fb, &c->dev_bytes);
-    c->spec_d.ensure((size_t)sbase, &c->dev_bytes);
-    // ---- 4. filter weights per bin (plf_taper_array on ones, abscissa j*df, comparator.f90:1224-1228),
-    //         zero/one mask of the taper over the window (:1254-1258), reference FFT input
-    std::vector<float> fw((size_t)specofs, 1.f), zm(reft_host.size(), 1.f);
-    std::vector<float> fin((size_t)c->fft_floats_per_src * 1, 0.f);       // one "source": rows of all groups
-    // host image of the single-source FFT input uses cap = fft_cap bases, so build per group then copy rows
+    c->fft_d.ensure((size_t)c->fft_cap * c->fft_floats_per_src, &c->dev_bytes);
+    c->spec_d.ensure((size_t)c->fft_cap * c->spec_cplx_per_src, &c->dev_bytes);
+    // zero/one mask of the taper over the window (comparator.f90:1254-1258)
+    std::vector<float> zm(reft_host.size(), 1.f);
     for (size_t m = 0; m < c->comps.size(); m++) {
         const CompDev &cd = c->comps[m];
-        const Receiver &r = c->recv[cd.rec];
-        const int nb = cd.ntrans / 2 + 1;
-        if (r.filter.defined()) {
-            const float df = 1.f / ((float)cd.ntrans * dt);
-            plf_taper_array(r.filter, fw.data() + cd.specofs, 0, nb - 1, df, IP_COS);
-        }
-        plf_taper_array(r.taper, zm.data() + cd.refofs, cd.w0, cd.w0 + cd.wlen - 1, dt, IP_ZERO_ONE);
+        plf_taper_array(c->recv[cd.rec].taper, zm.data() + cd.refofs, cd.w0, cd.w0 + cd.wlen - 1, dt, IP_ZERO_ONE);
     }
-    c->filtw_d.ensure(fw.size(), &c->dev_bytes);
     c->zmask_d.ensure(zm.size(), &c->dev_bytes);
-    c->refamp_d.ensure(fw.size(), &c->dev_bytes);
-    c->reffilt_d.ensure(zm.size(), &c->dev_bytes);
-    HIPCHECK(hipMemcpyAsync(c->filtw_d.p, fw.data(), fw.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIPCHECK(hipMemcpyAsync(c->zmask_d.p, zm.data(), zm.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIPCHECK(hipMemcpyAsync(c->comps_d.p, c->comps.data(), c->comps.size() * sizeof(CompDev), hipMemcpyHostToDevice, c->stream));
-    // reference rows: source index 0 of every group
-    for (size_t m = 0; m < c->comps.size(); m++) {
-        const CompDev &cd = c->comps[m];
-        std::vector<float> row((size_t)cd.ntrans, 0.f);
-        for (int i = 0; i < cd.wlen; i++) row[i] = reft_host[cd.refofs + i];
-        HIPCHECK(hipMemcpyAsync(c->fft_d.p + cd.fft_base + (size_t)cd.fft_row * cd.ntrans, row.data(),
-                                row.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
-        HIPCHECK(hipStreamSynchronize(c->stream));      // 'row' is reused
-    }
-    fft_forward(c, 1);
-    hipLaunchKernelGGL(ref_amp_kernel, dim3((unsigned)c->nmis), dim3(256), 0, c->stream, c->spec_d.p, c->comps_d.p,
-                       c->filtw_d.p, c->refamp_d.p);
-    std::vector<float> ra(fw.size()), rf(zm.size());
-    if (c->any_filter) {
-        SpecParams sp{ c->method, dt, c->syn_factor, c->nmis, 0, 1 };
-        (void)sp;
-        hipLaunchKernelGGL(spec_filter_kernel, dim3((unsigned)c->nmis, 1u), dim3(256), 0, c->stream, c->spec_d.p,
-                           c->comps_d.p, c->filtw_d.p);
-        fft_backward(c, 1);
-        hipLaunchKernelGGL(ref_filt_kernel, dim3((unsigned)c->nmis), dim3(256), 0, c->stream, c->fft_d.p, c->comps_d.p,
-                           c->zmask_d.p, c->reffilt_d.p);
-        HIPCHECK(hipMemcpyAsync(rf.data(), c->reffilt_d.p, rf.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    }
-    HIPCHECK(hipMemcpyAsync(ra.data(), c->refamp_d.p, ra.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));
-    // ---- 5. norm factors of the reference (probe_norm, comparator.f90:954-996)
+    c->variants.clear();
+    c->refamp_h.clear(); c->filtw_h.clear(); c->reffilt_h.clear();
+    c->norm_src_h.assign((size_t)c->nsrc * c->nmis, 0.f);
+    c->normsrc_d.ensure(std::max<size_t>(1, (size_t)c->nsrc * c->nmis), &c->dev_bytes);
+    if (!c->size_event) HIPCHECK(hipEventCreateWithFlags(&c->size_event, hipEventDisableTiming));
+    c->fft_ready = true;
+}
+
+// The reference probes of the (slot, ntrans) pairs in `want` that have not been seen yet go through the device
+// pipeline (r2c -> |.| x filter; filter -> c2r / ntrans -> zero outside the taper), their norm factors (probe_norm,
+// comparator.f90:954-996) are taken on the host.  Uses the FFT buffers as scratch: stream-ordered before the chunk's rows.
+void make_variants(kiwi_hip_ctx *c, const std::vector<std::pair<int, int>> &want)
+{
+    std::vector<std::pair<int, int>> fresh;
+    for (auto &w : want) if (!c->variants.count(w)) { bool dup = false; for (auto &f : fresh) if (f == w) dup = true; if (!dup) fresh.push_back(w); }
+    if (fresh.empty()) return;
+    const float dt = c->gm.dt;
     const bool spectral = (c->method == KIWI_AMPSPEC_L2NORM || c->method == KIWI_AMPSPEC_L1NORM);
-    for (size_t m = 0; m < c->comps.size(); m++) {
-        const CompDev &cd = c->comps[m];
+    std::vector<FftPair> prs;
+    long long fofs = 0, sofs = 0;
+    std::sort(fresh.begin(), fresh.end(), [](const std::pair<int, int> &a, const std::pair<int, int> &b) { return a.second != b.second ? a.second < b.second : a.first < b.first; });
+    for (auto &f : fresh) {
+        const CompDev &cd = c->comps[f.first];
+        const int ntr = f.second, nb = ntr / 2 + 1;
+        FftPair pr;
+        pr.fft_ofs = fofs; pr.spec_ofs = sofs; pr.ntrans = ntr; pr.slot = f.first;
+        pr.specofs = (int)c->refamp_h.size(); pr.filtofs = (int)c->reffilt_h.size();
+        c->refamp_h.resize(c->refamp_h.size() + nb, 0.f);
+        c->filtw_h.resize(c->filtw_h.size() + nb, 1.f);
+        c->reffilt_h.resize(c->reffilt_h.size() + cd.wlen, 0.f);
+        // filter weights per bin: plf_taper_array on ones, abscissa j * df (comparator.f90:1224-1228)
+        const Receiver &r = c->recv[cd.rec];
+        if (r.filter.defined()) {
+            const float df = 1.f / ((float)ntr * dt);
+            plf_taper_array(r.filter, c->filtw_h.data() + pr.specofs, 0, nb - 1, df, IP_COS);
+        }
+        prs.push_back(pr);
+        fofs += ntr; sofs += nb;
+    }
+    c->fft_d.ensure((size_t)fofs, &c->dev_bytes);
+    c->spec_d.ensure((size_t)sofs, &c->dev_bytes);
+    c->refamp_d.ensure(c->refamp_h.size(), &c->dev_bytes);
+    c->filtw_d.ensure(c->filtw_h.size(), &c->dev_bytes);
+    c->reffilt_d.ensure(c->reffilt_h.size(), &c->dev_bytes);
+    DevBuf<FftPair> prs_d;
+    prs_d.ensure(prs.size(), nullptr);
+    HIPCHECK(hipMemcpyAsync(prs_d.p, prs.data(), prs.size() * sizeof(FftPair), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(c->filtw_d.p, c->filtw_h.data(), c->filtw_h.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    // FFT input rows: the tapered reference over the window, zero padded
+    {
+        std::vector<float> rows((size_t)fofs, 0.f);
+        for (auto &pr : prs) {
+            const CompDev &cd = c->comps[pr.slot];
+            std::memcpy(rows.data() + pr.fft_ofs, c->reft_h.data() + cd.refofs, (size_t)cd.wlen * sizeof(float));
+        }
+        HIPCHECK(hipMemcpyAsync(c->fft_d.p, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIPCHECK(hipStreamSynchronize(c->stream));
+    }
+    // rows of equal length are contiguous (sorted): one batched transform per length
+    auto for_each_length = [&](bool forward) {
+        size_t i = 0;
+        while (i < prs.size()) {
+            size_t j = i;
+            while (j < prs.size() && prs[j].ntrans == prs[i].ntrans) j++;
+            fft_rows(c, prs[i].ntrans, (long long)(j - i), prs[i].fft_ofs, prs[i].spec_ofs, forward);
+            i = j;
+        }
+    };
+    for_each_length(true);
+    hipLaunchKernelGGL(ref_amp_kernel, dim3((unsigned)prs.size()), dim3(256), 0, c->stream, c->spec_d.p, prs_d.p, c->filtw_d.p, c->refamp_d.p);
+    if (c->any_filter && !spectral) {
+        hipLaunchKernelGGL(spec_filter_kernel, dim3((unsigned)prs.size()), dim3(256), 0, c->stream, c->spec_d.p, prs_d.p, c->comps_d.p, c->filtw_d.p);
+        for_each_length(false);
+        hipLaunchKernelGGL(ref_filt_kernel, dim3((unsigned)prs.size()), dim3(256), 0, c->stream, c->fft_d.p, prs_d.p, c->comps_d.p,
+                           c->zmask_d.p, c->reffilt_d.p);
+    }
+    HIPCHECK(hipGetLastError());
+    // results of the fresh variants down to the host mirrors (the device arrays were re-allocated if they grew: the
+    // mirrors are the master copy and go up again as a whole)
+    for (auto &pr : prs) {
+        const CompDev &cd = c->comps[pr.slot];
+        const int nb = pr.ntrans / 2 + 1;
+        HIPCHECK(hipMemcpyAsync(c->refamp_h.data() + pr.specofs, c->refamp_d.p + pr.specofs, nb * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        if (c->any_filter && !spectral)
+            HIPCHECK(hipMemcpyAsync(c->reffilt_h.data() + pr.filtofs, c->reffilt_d.p + pr.filtofs, cd.wlen * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    HIPCHECK(hipMemcpyAsync(c->refamp_d.p, c->refamp_h.data(), c->refamp_h.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(c->reffilt_d.p, c->reffilt_h.data(), c->reffilt_h.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    // norm factors of the reference (probe_norm, comparator.f90:954-996)
+    for (auto &pr : prs) {
+        const CompDev &cd = c->comps[pr.slot];
         double sum = 0.0, pk = 0.0;
+        float nf = c->norm_h[pr.slot];                        // time-domain norm of a slot without filter: unchanged
         if (spectral) {
-            const int nb = cd.ntrans / 2 + 1;
-            const float df = 1.f / ((float)cd.ntrans * dt);
+            const int nb = pr.ntrans / 2 + 1;
+            const float df = 1.f / ((float)pr.ntrans * dt);
             for (int k = 0; k < nb; k++) {
-                const float a = ra[cd.specofs + k];
+                const float a = c->refamp_h[pr.specofs + k];
                 sum += (c->method == KIWI_AMPSPEC_L2NORM) ? (double)a * (double)a : (double)std::fabs(a);
             }
-            c->norm_h[m] = (c->method == KIWI_AMPSPEC_L2NORM) ? 1.f * (float)std::sqrt((double)df * sum)
-                                                               : 1.f * (float)((double)df * sum);
-        } else if (c->slot_has_filter[m]) {
+            nf = (c->method == KIWI_AMPSPEC_L2NORM) ? 1.f * (float)std::sqrt((double)df * sum) : 1.f * (float)((double)df * sum);
+        } else if (c->slot_has_filter[pr.slot]) {
             for (int i = 0; i < cd.wlen; i++) {
-                const float a = rf[cd.refofs + i];
+                const float a = c->reffilt_h[pr.filtofs + i];
                 switch (c->method) {
                 case KIWI_L2NORM: sum += (double)a * (double)a; break;
                 case KIWI_L1NORM: sum += (double)std::fabs(a); break;
@@ -648,16 +703,67 @@ void prepare_fft(kiwi_hip_ctx *c, const std::vector<float> &reft_host)
                 }
             }
             switch (c->method) {
-            case KIWI_L2NORM: c->norm_h[m] = 1.f * (float)std::sqrt((double)dt * sum); break;
-            case KIWI_L1NORM: c->norm_h[m] = 1.f * (float)((double)dt * sum); break;
-            case KIWI_SCALAR_PRODUCT: c->norm_h[m] = (1.f * 1.f) * (float)sum; break;
-            default: c->norm_h[m] = 1.f * (float)pk; break;
+            case KIWI_L2NORM: nf = 1.f * (float)std::sqrt((double)dt * sum); break;
+            case KIWI_L1NORM: nf = 1.f * (float)((double)dt * sum); break;
+            case KIWI_SCALAR_PRODUCT: nf = (1.f * 1.f) * (float)sum; break;
+            default: nf = 1.f * (float)pk; break;
             }
         }
+        c->variants[std::make_pair(pr.slot, pr.ntrans)] = kiwi_hip_ctx::FftVariant{ pr.ntrans, pr.specofs, pr.filtofs, nf };
     }
-    HIPCHECK(hipMemcpyAsync(c->norm_d.p, c->norm_h.data(), c->norm_h.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    HIPCHECK(hipStreamSynchronize(c->stream));
-    c->fft_ready = true;
+}
+
+// Host half of the per-pair sizing: transform lengths of the chunk (already on their way down) -> buckets of equal
+// length with contiguous rows, reference variants, the pair table for the kernels, norm factors per (source, slot).
+void layout_fft_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc)
+{
+    HIPCHECK(hipEventSynchronize(c->size_event));
+    const size_t np = (size_t)nsrc * c->nmis;
+    const int *ntr = c->ntr_pin;
+    std::map<int, long long> count;
+    std::vector<std::pair<int, int>> want;
+    {
+        std::vector<int> seen((size_t)c->nmis, 0);               // last length seen per slot: most pairs repeat it
+        for (size_t i = 0; i < np; i++) {
+            const int m = (int)(i % c->nmis);
+            count[ntr[i]]++;
+            if (seen[m] != ntr[i]) { seen[m] = ntr[i]; want.emplace_back(m, ntr[i]); }
+        }
+        std::sort(want.begin(), want.end());
+        want.erase(std::unique(want.begin(), want.end()), want.end());
+    }
+    make_variants(c, want);
+    c->buckets.clear();
+    std::map<int, size_t> bucket_of;
+    long long fb = 0, sbase = 0;
+    for (auto &kv : count) {
+        bucket_of[kv.first] = c->buckets.size();
+        c->buckets.push_back({ kv.first, 0, fb, sbase });
+        fb += kv.second * kv.first;
+        sbase += kv.second * (kv.first / 2 + 1);
+    }
+    c->fft_d.ensure((size_t)fb, &c->dev_bytes);                 // within the capacity prepare_fft laid out; grows only if not
+    c->spec_d.ensure((size_t)sbase, &c->dev_bytes);
+    pin_ensure(c->pairs_pin, c->pairs_pin_n, np);
+    c->norm_src_h.resize((size_t)c->nsrc * c->nmis, 0.f);
+    int last_ntr = -1; size_t last_b = 0;
+    for (size_t i = 0; i < np; i++) {
+        const int m = (int)(i % c->nmis);
+        if (ntr[i] != last_ntr) { last_ntr = ntr[i]; last_b = bucket_of[last_ntr]; }
+        auto &b = c->buckets[last_b];
+        const auto &v = c->variants[std::make_pair(m, ntr[i])];
+        FftPair &pr = c->pairs_pin[i];
+        pr.fft_ofs = b.fft_base + b.count * b.ntrans;
+        pr.spec_ofs = b.spec_base + b.count * (b.ntrans / 2 + 1);
+        pr.ntrans = b.ntrans; pr.specofs = v.specofs; pr.filtofs = v.filtofs; pr.slot = m;
+        b.count++;
+        c->norm_src_h[(size_t)isrc0 * c->nmis + i] = v.norm;
+    }
+    c->pairs_d.ensure(np, &c->dev_bytes);
+    HIPCHECK(hipMemcpyAsync(c->pairs_d.p, c->pairs_pin, np * sizeof(FftPair), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(c->normsrc_d.p + (size_t)isrc0 * c->nmis, c->norm_src_h.data() + (size_t)isrc0 * c->nmis, np * sizeof(float),
+                            hipMemcpyHostToDevice, c->stream));
+    c->last_pairs.assign(c->pairs_pin, c->pairs_pin + np);
 }
 
 // may this evaluation compare inside the accumulate kernel (no synthetics in memory)?
@@ -691,13 +797,10 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
 
     EvalParams ep{ c->bilinear, c->xus, c->zus, nrec, isrc0 };
     int *spansrc = nullptr;
-    if (c->any_untapered || c->want_spansrc) {     // per-source strip spans, initialised empty
+    if (c->any_untapered || c->want_spansrc || c->fft_needed) {     // per-source strip spans, initialised empty
         const size_t n = (size_t)nsrc * nrec;
         c->spansrc_d.ensure(n * 4, &c->dev_bytes);
-        std::vector<int> init(n * 4);
-        for (size_t i = 0; i < n; i++) { init[4 * i] = init[4 * i + 2] = 0x7fffffff; init[4 * i + 1] = init[4 * i + 3] = -0x7fffffff; }
-        HIPCHECK(hipMemcpyAsync(c->spansrc_d.p, init.data(), init.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-        HIPCHECK(hipStreamSynchronize(c->stream));
+        hipLaunchKernelGGL(span_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->spansrc_d.p, n);
         spansrc = c->spansrc_d.p;
     }
     hipEvent_t e0, e1, e2, e3;
@@ -706,6 +809,17 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
         dim3 grid((unsigned)((maxnc * nrec + 255) / 256), (unsigned)nsrc);
         hipLaunchKernelGGL(geometry_kernel, grid, dim3(256), 0, c->stream, c->cent_d.p, c->centofs_d.p, ep, c->gm,
                            c->span.p, c->recv_d.p, c->recs_d.p, tab, (int *)nullptr, spansrc);
+    }
+    if (c->fft_needed) {
+        // transform length of every (source, slot) pair from the source's own strip spans; the lengths travel to the host
+        // while the accumulate kernel runs
+        const size_t np = (size_t)nsrc * c->nmis;
+        c->ntr_d.ensure(np, &c->dev_bytes);
+        pin_ensure(c->ntr_pin, c->ntr_pin_n, np);
+        hipLaunchKernelGGL(fft_size_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, c->stream, spansrc, c->comps_d.p, c->nmis,
+                           nsrc, nrec, fold_halfwidth(c->max_risetime, c->gm.dt), c->ntr_d.p);
+        HIPCHECK(hipMemcpyAsync(c->ntr_pin, c->ntr_d.p, np * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(hipEventRecord(c->size_event, c->stream));
     }
     record(c, 0, e1);
     int fuse_T = 0, fuse_ntiles = 0;
@@ -773,12 +887,15 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
         }
     }
     record(c, 1, e2);
+    if (c->fft_needed) layout_fft_chunk(c, isrc0, nsrc);
     {
         const bool spectral = (c->method == KIWI_AMPSPEC_L2NORM || c->method == KIWI_AMPSPEC_L1NORM);
         const int fl_method = c->method == KIWI_FLOATING_L2NORM ? KIWI_L2NORM : KIWI_L1NORM;
         const int td_method = spectral ? KIWI_L2NORM : (c->floating ? fl_method : c->method);
         const int fft_mode = !c->fft_needed ? 0 : (spectral ? 3 : 1);        // bit0 write FFT input, bit1 skip the norm
-        MisfitParams mp{ td_method, c->gm.dt, c->syn_factor, c->nmis, isrc0, proc_which == 3 ? 0 : proc_which, fft_mode, nsrc,
+        // kept synthetics "filtered" (3): slots without a filter keep their tapered trace, the others are overwritten by
+        // filtered_norm_kernel
+        MisfitParams mp{ td_method, c->gm.dt, c->syn_factor, c->nmis, isrc0, proc_which == 3 ? 2 : proc_which, fft_mode, nsrc,
                          c->floating ? 1 : 0 };
         if (c->floating) {
             c->vt_d.ensure((size_t)nsrc * c->syn_stride, &c->dev_bytes);
@@ -793,8 +910,8 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
         } else
         hipLaunchKernelGGL(misfit_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream,
                            c->syn_d.p, c->syn_stride, c->comps_d.p, c->reft_d.p, c->tw_d.p, c->moment_d.p,
-                           c->risetime_d.p, mp, c->misfit_d.p, proc_which == 3 ? nullptr : proc, c->fft_d.p, c->vt_d.p,
-                           spansrc, nrec, fold_halfwidth(c->max_risetime, c->gm.dt));
+                           c->risetime_d.p, mp, c->misfit_d.p, proc, c->fft_d.p, c->vt_d.p,
+                           spansrc, nrec, fold_halfwidth(c->max_risetime, c->gm.dt), c->pairs_d.p);
         if (c->floating) {
             hipLaunchKernelGGL(floating_norm_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream,
                                c->vt_d.p, c->syn_stride, c->comps_d.p, c->refx_d.p, c->tw_d.p, fl_method, c->gm.dt,
@@ -806,22 +923,23 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
         }
         if (c->fft_needed) {
             SpecParams sp{ c->method, c->gm.dt, c->syn_factor, c->nmis, isrc0, c->any_filter ? 1 : 0 };
-            fft_forward(c, nsrc);
+            fft_buckets(c, true);
             if (spectral) {
                 hipLaunchKernelGGL(spec_norm_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream,
-                                   c->spec_d.p, c->comps_d.p, c->refamp_d.p, c->filtw_d.p, sp, c->misfit_d.p);
+                                   c->spec_d.p, c->pairs_d.p, c->refamp_d.p, c->filtw_d.p, sp, c->misfit_d.p);
             } else {
-                hipLaunchKernelGGL(spec_filter_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream,
-                                   c->spec_d.p, c->comps_d.p, c->filtw_d.p);
-                fft_backward(c, nsrc);
+                hipLaunchKernelGGL(spec_filter_kernel, dim3((unsigned)(c->nmis * nsrc)), dim3(256), 0, c->stream,
+                                   c->spec_d.p, c->pairs_d.p, c->comps_d.p, c->filtw_d.p);
+                fft_buckets(c, false);
                 hipLaunchKernelGGL(filtered_norm_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream,
-                                   c->fft_d.p, c->comps_d.p, c->reffilt_d.p, c->zmask_d.p, sp, c->misfit_d.p,
+                                   c->fft_d.p, c->comps_d.p, c->pairs_d.p, c->reffilt_d.p, c->zmask_d.p, sp, c->misfit_d.p,
                                    proc_which == 3 ? proc : nullptr, c->syn_stride);
             }
         }
         hipLaunchKernelGGL(global_kernel, dim3((unsigned)((nsrc + 127) / 128)), dim3(128), 0, c->stream,
                            c->misfit_d.p, c->norm_d.p, c->recfirst_d.p, c->nrec_en, c->nmis, isrc0, nsrc, c->global_d.p,
-                           c->any_failed ? c->status_d.p : (const int *)nullptr);
+                           c->any_failed ? c->status_d.p : (const int *)nullptr,
+                           c->fft_needed ? c->normsrc_d.p : (const float *)nullptr);
     }
     record(c, 2, e3);
     HIPCHECK(hipGetLastError());
@@ -924,6 +1042,9 @@ int kiwi_hip_destroy(kiwi_hip_ctx *c)
     }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     for (auto &kv : c->plans) (void)hipfftDestroy(kv.second);
+    if (c->ntr_pin) (void)hipHostFree(c->ntr_pin);
+    if (c->pairs_pin) (void)hipHostFree(c->pairs_pin);
+    if (c->size_event) (void)hipEventDestroy(c->size_event);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -1548,6 +1669,8 @@ int kiwi_hip_get_misfits(kiwi_hip_ctx *c, int isrc0, int nsrc, float *misfit, fl
     if (norm)
         for (int s = 0; s < nsrc; s++) {
             if (c->src_status[(size_t)isrc0 + s]) std::memset(norm + (size_t)s * c->nmis, 0, (size_t)c->nmis * sizeof(float));
+            else if (c->fft_needed)      // spectral norms / filtered traces: the norm factor follows the pair's transform length
+                std::memcpy(norm + (size_t)s * c->nmis, c->norm_src_h.data() + ((size_t)isrc0 + s) * c->nmis, (size_t)c->nmis * sizeof(float));
             else std::memcpy(norm + (size_t)s * c->nmis, c->norm_h.data(), (size_t)c->nmis * sizeof(float));
         }
     if (global)
@@ -1672,23 +1795,32 @@ int kiwi_hip_get_amp_spectrum(kiwi_hip_ctx *c, int isrc, int irec, int icomp, in
         for (size_t i = 0; i < c->comps.size(); i++)
             if (c->comps[i].rec == irec - 1) { if (k == icomp - 1) { slot = (int)i; break; } k++; }
         if (slot < 0) throw std::runtime_error("receiver disabled or component index out of range");
-        if (which_probe) eval_impl(c, isrc, 1, 0);
-        else if (!c->fft_ready) prepare_fft(c, c->reft_h);
+        // the probe pair is sized for uploaded source isrc (the pair's transform length follows ITS strips); without a
+        // source the reference probe keeps the span probe_set_array gave it: twice its data length, padded to a power of two
+        FftPair pr;
+        if (isrc >= 0 && isrc < c->nsrc) {
+            eval_impl(c, isrc, 1, 0);
+            pr = c->last_pairs[(size_t)slot];
+        } else {
+            if (!c->fft_ready) prepare_fft(c, c->reft_h);
+            const CompDev &cd0 = c->comps[slot];
+            const int ntr = next_pow2(std::max(2 * (cd0.rf1 - cd0.rf0 + 1), cd0.wlen));
+            make_variants(c, { std::make_pair(slot, ntr) });
+            const auto &v = c->variants[std::make_pair(slot, ntr)];
+            pr = FftPair{ 0, 0, ntr, v.specofs, v.filtofs, slot };
+        }
         HIPCHECK(hipStreamSynchronize(c->stream));
-        const CompDev cd = c->comps[slot];
-        const int nb = cd.ntrans / 2 + 1;
-        *df = 1.f / ((float)cd.ntrans * c->gm.dt);
+        const int nb = pr.ntrans / 2 + 1;
+        *df = 1.f / ((float)pr.ntrans * c->gm.dt);
         *n = nb;
         if (nb > maxn) throw std::runtime_error("spectrum buffer too small");
-        std::vector<float> fw(nb, 1.f);
         const bool has_filter = c->recv[irec - 1].filter.defined();
-        if (has_filter) HIPCHECK(hipMemcpy(fw.data(), c->filtw_d.p + cd.specofs, nb * sizeof(float), hipMemcpyDeviceToHost));
         if (which_probe) {
             std::vector<float2> z(nb);
-            HIPCHECK(hipMemcpy(z.data(), c->spec_d.p + cd.spec_base + (size_t)cd.fft_row * nb, nb * sizeof(float2), hipMemcpyDeviceToHost));
-            for (int i = 0; i < nb; i++) out[i] = hypotf(z[i].x, z[i].y) * ((filtered && has_filter) ? fw[i] : 1.f);
+            HIPCHECK(hipMemcpy(z.data(), c->spec_d.p + pr.spec_ofs, nb * sizeof(float2), hipMemcpyDeviceToHost));
+            for (int i = 0; i < nb; i++) out[i] = hypotf(z[i].x, z[i].y) * ((filtered && has_filter) ? c->filtw_h[pr.specofs + i] : 1.f);
         } else {
-            HIPCHECK(hipMemcpy(out, c->refamp_d.p + cd.specofs, nb * sizeof(float), hipMemcpyDeviceToHost));   // |spec| x filter weights
+            std::memcpy(out, c->refamp_h.data() + pr.specofs, nb * sizeof(float));     // |spec| x filter weights
         }
     } catch (const std::exception &e) { err = e.what(); }
     c->method = method0;
@@ -1893,9 +2025,15 @@ int kiwi_hip_get_reference(kiwi_hip_ctx *c, int irec, int icomp, int which, int 
         if (!c->any_filter || c->method == KIWI_AMPSPEC_L2NORM || c->method == KIWI_AMPSPEC_L1NORM)
             throw std::runtime_error("filtered references need a misfit filter and a time-domain norm");
         if (c->nsrc == 0) throw std::runtime_error("no source set (the transform length follows the synthetics)");
-        if (!c->fft_ready) prepare_fft(c, c->reft_h);
+        if (!c->slot_has_filter.empty() && c->fft_ready && !c->slot_has_filter[slot]) {
+            std::memcpy(out, c->reft_h.data() + cd.refofs, (size_t)m * sizeof(float));      // no filter at this receiver
+            return 0;
+        }
+        eval_impl(c, 0, 1, 0);             // the probe pair of the current source (source 0 of the batch) sizes the transform
         HIPCHECK(hipStreamSynchronize(c->stream));
-        HIPCHECK(hipMemcpy(out, c->reffilt_d.p + cd.refofs, (size_t)m * sizeof(float), hipMemcpyDeviceToHost));
+        const FftPair pr = c->last_pairs[(size_t)slot];
+        if (!c->slot_has_filter[slot]) std::memcpy(out, c->reft_h.data() + cd.refofs, (size_t)m * sizeof(float));
+        else std::memcpy(out, c->reffilt_h.data() + pr.filtofs, (size_t)m * sizeof(float));
     }
     return 0;
     GUARD_END(c)

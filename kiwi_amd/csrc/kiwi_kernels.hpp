@@ -85,19 +85,31 @@ struct CompDev {
     int w0, wlen;    // misfit window first sample, length
     int refofs;      // offset into reft / tw arrays
     int rec;
-    // spectral / filtered comparator (comparator.f90:1186-1263): transform length of this probe pair and
-    // where its rows live in the FFT buffers (slots with equal ntrans form one batched plan)
-    int ntrans;
-    int fft_row, fft_nrow;       // row of this slot inside its group, rows per source in the group
-    long long fft_base;          // float offset of the group in the real buffer (per chunk: x nsrc rows)
-    long long spec_base;         // complex offset of the group in the spectrum buffer
-    int specofs;                 // offset of this slot's reference amplitude spectrum / filter weights
+    // spectral / filtered comparator (comparator.f90:1186-1263): the transform length belongs to the (trial source, slot)
+    // PAIR (FftPair below); per slot only whether the receiver has a frequency filter and the longest transform any source
+    // of the batch can need (buffer capacity)
+    int has_filter;
+    int ntrans_max;
     // floating norms (receiver.f90:439-510): integer shift range of the receiver and where the un-tapered
     // reference over [w0 - fl_hi, w0 + wlen - 1 - fl_lo] lives
     int fl_lo, fl_ns, refxofs;
     // un-tapered comparator (comparator.f90:798-800): norms run over the union of the two data spans
     int untapered, rf0, rf1, vertical;      // reference data span [rf0, rf1]; which strip span applies to the synthetic
 };
+
+// Spectral / filtered comparator, one record per (trial source of the chunk, misfit slot) -- or per reference variant
+// when the reference probes are pushed through the same pipeline.  The transform length of a probe pair is what a fresh
+// reference engine gives THIS source (comparator.f90:222-271,464-486, see fft_size_kernel); pairs of equal length form
+// one batched hipFFT plan, their rows are contiguous in the FFT buffers.
+struct FftPair {
+    long long fft_ofs;     // float offset of the pair's row (ntrans reals) in the real buffer
+    long long spec_ofs;    // complex offset of its row (ntrans / 2 + 1 bins) in the spectrum buffer
+    int ntrans;
+    int specofs;           // reference amplitude spectrum / filter weights of (slot, ntrans): offset into refamp / filtw
+    int filtofs;           // filtered reference of (slot, ntrans) over the window: offset into ref_filt
+    int slot;
+};
+static_assert(sizeof(FftPair) == 32, "FftPair layout");
 
 // Shake-map diagnostics of one source (get_peak_amplitudes / get_arias_intensities): the components a receiver's value
 // is made of, in the reference's order (receiver.f90:544-594)
@@ -1248,7 +1260,8 @@ __global__ __launch_bounds__(256) void misfit_kernel(
     const float *__restrict__ moment, const float *__restrict__ risetime, MisfitParams mp,
     float *__restrict__ misfit_out, float *__restrict__ proc /* optional [src][stride] processed synthetics */,
     float *__restrict__ fftbuf, float *__restrict__ vt_out /* optional [src][stride] tapered synthetics */,
-    const int *__restrict__ spansrc /* per-source strip spans, un-tapered receivers only */, int nrec, int fold_grow)
+    const int *__restrict__ spansrc /* per-source strip spans, un-tapered receivers only */, int nrec, int fold_grow,
+    const FftPair *__restrict__ pairs /* [source][slot], fft_mode only */)
 {
     const int m = blockIdx.x, s = blockIdx.y;
     const CompDev cd = comps[m];
@@ -1300,9 +1313,14 @@ __global__ __launch_bounds__(256) void misfit_kernel(
     double acc = 0.0;
     double peak = 0.0;
     float *__restrict__ frow = nullptr;
-    if (mp.fft_mode) {
-        frow = fftbuf + cd.fft_base + ((size_t)s * cd.fft_nrow + cd.fft_row) * cd.ntrans;
-        for (int i = cd.wlen + threadIdx.x; i < cd.ntrans; i += 256) frow[i] = 0.f;      // zero padding
+    // fft_mode bit0: the tapered synthetic goes, zero-padded to the pair's transform length, into the FFT buffer; a slot
+    // without a frequency filter under a time-domain method is compared right here (probes_norm_timedomain takes the
+    // plain tapered arrays then, comparator.f90:806-813)
+    const bool to_fft = mp.fft_mode && (cd.has_filter || (mp.fft_mode & 2));
+    if (to_fft) {
+        const FftPair pr = pairs[(size_t)s * mp.nmis + m];
+        frow = fftbuf + pr.fft_ofs;
+        for (int i = cd.wlen + threadIdx.x; i < pr.ntrans; i += 256) frow[i] = 0.f;      // zero padding
     }
     for (int i = threadIdx.x; i < cd.wlen; i += 256) {
         float v;
@@ -1339,7 +1357,7 @@ __global__ __launch_bounds__(256) void misfit_kernel(
             peak = fmax(peak, sqrt(x * x + y * y)); break; }
         }
     }
-    if (mp.fft_mode || mp.skip_norm) return;
+    if (to_fft || mp.skip_norm) return;
     red[threadIdx.x] = (mp.method == 6) ? peak : acc;
     __syncthreads();
     for (int st = 128; st > 0; st >>= 1) {
@@ -1386,16 +1404,16 @@ __device__ __forceinline__ double block_sum(double v, double *red)
 }
 
 __global__ __launch_bounds__(256) void spec_norm_kernel(
-    const float2 *__restrict__ spec, const CompDev *__restrict__ comps, const float *__restrict__ refamp,
+    const float2 *__restrict__ spec, const FftPair *__restrict__ pairs, const float *__restrict__ refamp,
     const float *__restrict__ filtw, SpecParams sp, float *__restrict__ misfit_out)
 {
     __shared__ double red[256];
     const int m = blockIdx.x, s = blockIdx.y;
-    const CompDev cd = comps[m];
-    const int nb = cd.ntrans / 2 + 1;
-    const float2 *__restrict__ row = spec + cd.spec_base + ((size_t)s * cd.fft_nrow + cd.fft_row) * nb;
-    const float *__restrict__ ra = refamp + cd.specofs;
-    const float *__restrict__ fw = filtw + cd.specofs;
+    const FftPair pr = pairs[(size_t)s * sp.nmis + m];
+    const int nb = pr.ntrans / 2 + 1;
+    const float2 *__restrict__ row = spec + pr.spec_ofs;
+    const float *__restrict__ ra = refamp + pr.specofs;
+    const float *__restrict__ fw = filtw + pr.specofs;
     const bool unit = (sp.syn_factor == 1.f);
     double acc = 0.0;
     for (int k = threadIdx.x; k < nb; k += 256) {
@@ -1413,21 +1431,22 @@ __global__ __launch_bounds__(256) void spec_norm_kernel(
     }
     const double tot = block_sum(acc, red);
     if (threadIdx.x == 0) {
-        const float df = 1.f / ((float)cd.ntrans * sp.dt);               // comparator.f90:1215
+        const float df = 1.f / ((float)pr.ntrans * sp.dt);               // comparator.f90:1215
         misfit_out[(size_t)(sp.isrc0 + s) * sp.nmis + m] =
             (sp.method == 3) ? (float)sqrt((double)df * tot) : (float)((double)df * tot);
     }
 }
 
-// spectrum_filtered = spectrum * filter(j df) (comparator.f90:1224-1225), in place, before the c2r
-__global__ __launch_bounds__(256) void spec_filter_kernel(float2 *__restrict__ spec, const CompDev *__restrict__ comps,
-                                                          const float *__restrict__ filtw)
+// spectrum_filtered = spectrum * filter(j df) (comparator.f90:1224-1225), in place, before the c2r; block per entry of
+// `pairs` (trial-source pairs of a chunk, or reference variants)
+__global__ __launch_bounds__(256) void spec_filter_kernel(float2 *__restrict__ spec, const FftPair *__restrict__ pairs,
+                                                          const CompDev *__restrict__ comps, const float *__restrict__ filtw)
 {
-    const int m = blockIdx.x, s = blockIdx.y;
-    const CompDev cd = comps[m];
-    const int nb = cd.ntrans / 2 + 1;
-    float2 *__restrict__ row = spec + cd.spec_base + ((size_t)s * cd.fft_nrow + cd.fft_row) * nb;
-    const float *__restrict__ fw = filtw + cd.specofs;
+    const FftPair pr = pairs[blockIdx.x];
+    if (!comps[pr.slot].has_filter) return;
+    const int nb = pr.ntrans / 2 + 1;
+    float2 *__restrict__ row = spec + pr.spec_ofs;
+    const float *__restrict__ fw = filtw + pr.specofs;
     for (int k = threadIdx.x; k < nb; k += 256) {
         float2 z = row[k];
         z.x = z.x * fw[k]; z.y = z.y * fw[k];
@@ -1438,20 +1457,22 @@ __global__ __launch_bounds__(256) void spec_filter_kernel(float2 *__restrict__ s
 // time-domain norms on the filtered traces (comparator.f90:810-813,1233-1263): c2r output / ntrans, zeroed
 // where the taper is zero (ip_zero_one mask), against the reference processed the same way
 __global__ __launch_bounds__(256) void filtered_norm_kernel(
-    const float *__restrict__ fftbuf, const CompDev *__restrict__ comps, const float *__restrict__ ref_filt,
-    const float *__restrict__ zmask, SpecParams sp, float *__restrict__ misfit_out, float *__restrict__ proc,
-    size_t syn_stride)
+    const float *__restrict__ fftbuf, const CompDev *__restrict__ comps, const FftPair *__restrict__ pairs,
+    const float *__restrict__ ref_filt, const float *__restrict__ zmask, SpecParams sp, float *__restrict__ misfit_out,
+    float *__restrict__ proc, size_t syn_stride)
 {
     __shared__ double red[256];
     const int m = blockIdx.x, s = blockIdx.y;
     const CompDev cd = comps[m];
-    const float *__restrict__ row = fftbuf + cd.fft_base + ((size_t)s * cd.fft_nrow + cd.fft_row) * cd.ntrans;
-    const float *__restrict__ rf = ref_filt + cd.refofs;
+    if (!cd.has_filter) return;                           // compared by misfit_kernel on the plain tapered arrays
+    const FftPair pr = pairs[(size_t)s * sp.nmis + m];
+    const float *__restrict__ row = fftbuf + pr.fft_ofs;
+    const float *__restrict__ rf = ref_filt + pr.filtofs;
     const float *__restrict__ zm = zmask + cd.refofs;
     const bool unit = (sp.syn_factor == 1.f);
     double acc = 0.0, peak = 0.0;
     for (int i = threadIdx.x; i < cd.wlen; i += 256) {
-        float v = row[i] / (float)cd.ntrans;              // normalize result, comparator.f90:1251
+        float v = row[i] / (float)pr.ntrans;              // normalize result, comparator.f90:1251
         v = v * zm[i];                                    // :1254-1258
         if (proc) proc[(size_t)s * syn_stride + cd.synofs + cd.halo + i] = v;
         const float a = rf[i];
@@ -1483,6 +1504,39 @@ __global__ __launch_bounds__(256) void filtered_norm_kernel(
         }
         misfit_out[(size_t)(sp.isrc0 + s) * sp.nmis + m] = res;
     }
+}
+
+// Transform length of every (trial source, slot) pair of a chunk, as a FRESH reference engine sizes it for this source:
+// the synthetic probe is set from the source's own strip (probe_set_array, comparator.f90:222-271: data span = strip
+// span, padded to a power of two of at least twice the data length), then probes_adjust_spans (:464-486) gives both
+// probes the span allowed_span(union of the two data spans, max of the two minimum lengths) (:1092-1109) -- so
+// ntrans = next_power_of_two(max(length of the union, 2 len_ref, 2 len_syn)).  spansrc: per (source, receiver) data spans
+// of the horizontal / vertical strips, reduced by geometry_kernel; fold_grow: strip_fold's growth (sparse_trace.f90:379-402).
+__global__ void fft_size_kernel(const int *__restrict__ spansrc, const CompDev *__restrict__ comps, int nmis, int nsrc, int nrec,
+                                int fold_grow, int *__restrict__ ntr_out)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nsrc * nmis) return;
+    const int s = idx / nmis, m = idx - s * nmis;
+    const CompDev cd = comps[m];
+    const int *sp = spansrc + ((size_t)s * nrec + cd.rec) * 4 + (cd.vertical ? 2 : 0);
+    int s0 = sp[0], s1 = sp[1];
+    if (s1 < s0) { s0 = cd.rf0; s1 = cd.rf0; }                       // no centroid reached this receiver
+    if (fold_grow > 0) { s0 -= fold_grow; s1 += fold_grow + 1; }
+    const int len_ref = cd.rf1 - cd.rf0 + 1, len_syn = s1 - s0 + 1;
+    const int len_u = max(cd.rf1, s1) - min(cd.rf0, s0) + 1;
+    const int minlength = max((int)ceilf((float)len_ref * 2.f), (int)ceilf((float)len_syn * 2.f));
+    int need = max(max(len_u, minlength), cd.wlen);
+    int n = 1;
+    while (n < need) n *= 2;                                         // next_power_of_two, comparator.f90:1111-1118
+    ntr_out[idx] = n;
+}
+
+// empty spans for the per-source reduction of geometry_kernel
+__global__ void span_init_kernel(int *__restrict__ spansrc, size_t n4)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) reinterpret_cast<int4 *>(spansrc)[i] = make_int4(0x7fffffff, -0x7fffffff, 0x7fffffff, -0x7fffffff);
 }
 
 // second half of the fused comparator: sum (peak: max) the per-tile, per-wave partials of a slot in a fixed order
@@ -1590,7 +1644,8 @@ __global__ void floating_select_kernel(const float *__restrict__ partial, const 
 // minimizer_engine.f90:936-942: per receiver sum of squares in fp32, receivers in order
 __global__ void global_kernel(float *misfit, const float *__restrict__ norm,
                               const int *__restrict__ rec_first /*[nrec_en+1]*/, int nrec_en, int nmis,
-                              int isrc0, int nsrc, float *__restrict__ global_out, const int *__restrict__ status)
+                              int isrc0, int nsrc, float *__restrict__ global_out, const int *__restrict__ status,
+                              const float *__restrict__ norm_src /* [source][slot] when the norm factors follow the pair's transform length */)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsrc) return;
@@ -1601,6 +1656,7 @@ __global__ void global_kernel(float *misfit, const float *__restrict__ norm,
         return;
     }
     const float *m = misfit + (size_t)(isrc0 + s) * nmis;
+    if (norm_src) norm = norm_src + (size_t)(isrc0 + s) * nmis;
     float mis = 0.f, nf = 0.f;
     for (int r = 0; r < nrec_en; r++) {
         float a = 0.f, b = 0.f;

@@ -38,6 +38,28 @@ def make_gfdb(nx=128, nz=6, ng=10, L=4096, dt=0.5, dx=4000.0, dz=2000.0, firstx=
     return dict(dt=dt, dx=dx, dz=dz, firstx=firstx, firstz=firstz, data=data, first=first, nsamp=nsamp)
 
 
+def pack_gfdb(gf):
+    """What a GFDB reader hands the engine for these traces: the reference stores every trace gap-compressed
+    (trace_pack, sparse_trace.f90:443-560), so a stored trace begins at its first non-zero sample and ends one sample
+    after its last non-zero one when a zero follows (an all-zero trace keeps ONE zero sample at its first position, :490-510).  Returns a new dict with `first`,
+    `nsamp` and left-aligned `data` of the packed traces; interior zero gaps stay as zeros of the dense row."""
+    data = np.ascontiguousarray(gf["data"], np.float32)
+    nx, nz, ng, L = data.shape
+    nzm = data != 0
+    anyv = nzm.any(-1)
+    lo = np.where(anyv, nzm.argmax(-1), 0)
+    hi = np.where(anyv, np.minimum(L - 1 - nzm[..., ::-1].argmax(-1) + 1, L - 1), 0)    # "add one of the zeros", :535,545
+    nsamp = (hi - lo + 1).astype(np.int32)
+    first = (np.asarray(gf["first"], np.int64) + lo).astype(np.int32)
+    idx = lo[..., None] + np.arange(L)[None, None, None, :]
+    out = np.take_along_axis(data, np.minimum(idx, L - 1), -1)
+    out[np.arange(L)[None, None, None, :] >= nsamp[..., None]] = 0.0
+    lmax = int(nsamp.max())
+    g = dict(gf)
+    g.update(data=np.ascontiguousarray(out[..., :lmax]), first=first, nsamp=nsamp)
+    return g
+
+
 def make_receivers(nrec=50, lat0=40.0, lon0=30.0, dmin=150e3, dspan=400e3, comps="ned"):
     """Ring of receivers around (lat0, lon0): azimuth 2 pi (i-1)/N + 0.1, distance dmin + dspan (i-1)/N."""
     i = np.arange(nrec)

@@ -48,3 +48,21 @@ def test_disabled_receiver_is_skipped():
     m1, n1, _ = e.get_misfits()
     assert len(m1) == len(m0) - 3
     assert np.array_equal(m1, np.delete(m0, [3, 4, 5]))
+
+
+def test_pack_gfdb_is_the_oracles_trace_pack():
+    """kiwi_amd.synthetic.pack_gfdb (what bench.py hands the product) == the spans and samples the oracle's trace_pack
+    restatement stores for the same dense array (first / last non-zero sample plus one zero, all-zero traces, interior gaps)."""
+    import numpy as np
+    from kiwi_amd import synthetic
+    from tests.common import Scenario
+    for variant in ("probe", "static"):
+        sc = Scenario(variant=variant, L=300)
+        sc.gf["data"][2, 1, 3, :] = 0.0
+        sc.gf["data"][3, 1, 4, :7] = 0.0
+        sc.gf["data"][4, 1, 4, -9:] = 0.0
+        sc.oracle()
+        f, n, d = sc.odb.dense_tables()
+        g = synthetic.pack_gfdb(sc.gf)
+        assert np.array_equal(f, g["first"]) and np.array_equal(n, g["nsamp"]) and np.array_equal(d, g["data"])
+        assert n.min() == 1 and n.max() == 300
