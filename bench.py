@@ -338,7 +338,8 @@ def main():
             copy_gbs = None
         out = {
             "metric": "trial-source misfit evals/s", "value": value, "unit": "evals/s",
-            "n_gpus": ngpus, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": ngpus, "rccl_world_size": dist.get_world_size() if dist is not None else None,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %s source, %.0f centroids x %d receivers x 3 comp x %d samples, "

@@ -54,6 +54,7 @@ program minimizer_hip
     character(len=8), allocatable :: components(:)
     logical, allocatable :: enabled(:)
     real(c_float) :: db_dt = 0.
+    character(len=16) :: db_format = ''
     real(c_double) :: ref_time = 0.d0
     real(c_float) :: effective_dt = 1.
     logical :: source_set = .false., evaluated = .false.
@@ -248,6 +249,12 @@ program minimizer_hip
         case ('output_distances');          call do_output_distances( a, ok_ )
         case ('output_source_model');       call do_output_source_model( a, ok_ )
         case ('get_cached_traces_memory');  call do_get_cached_traces_memory( ok_ )
+        case ('get_database_format')            ! which reader set_database took: "hdf5" (gfdb_io_hdf.f90 layout) or "kiwiflat"
+            if (len_trim(db_format) == 0) then
+                call fail( 'no database set' )
+            else
+                answer = trim(db_format); ok_ = .true.
+            end if
         case ('set_cached_traces_memory_limit'); ok_ = .true.      ! the database is resident on the device: nothing to limit
         case ('eval_sources');              call do_eval_sources( a, ok_ )
         case ('set_verbose', 'set_ignore_sigint'); ok_ = .true.
@@ -295,6 +302,7 @@ program minimizer_hip
         if (.not. need_ctx()) return
         ok_ = check( kiwi_hip_set_gfdb( ctx, nx, nz, ng, L, dt, dx, dz, firstx, firstz, G, first, nsamp ) )
         if (ok_) db_dt = dt
+        if (ok_) db_format = 'kiwiflat'
         evaluated = .false.
     end subroutine
 
@@ -342,6 +350,7 @@ program minimizer_hip
         if (.not. need_ctx()) return
         ok_ = check( kiwi_hip_set_gfdb( ctx, ix%nx, ix%nz, ix%ng, lmax, ix%dt, ix%dx, ix%dz, ix%firstx, ix%firstz, G, first, nsamp ) )
         if (ok_) db_dt = ix%dt
+        if (ok_) db_format = 'hdf5'
         evaluated = .false.
         return
 10      continue

@@ -136,6 +136,17 @@ int kiwi_gfdb_read_dense(const char *base, int L, float *G, int *first, int *nsa
                         free(packed); free(pofs); free(ofs); free(refs); H5Dclose(di); H5Fclose(f);
                         return fail(err, errlen, "gfdb: failed to read a trace from file: %s", fn);
                     }
+                    /* the strip table comes from the file: a truncated or corrupt chunk must end in the error above, not in
+                     * a copy outside the buffers -- 1 <= pofs <= npacked, pofs and ofs increasing, strips not overlapping */
+                    int okstrips = 1;
+                    for (int s = 0; s < n1 && okstrips; s++) {
+                        if (pofs[s] < 1 || pofs[s] > npacked) okstrips = 0;
+                        if (s > 0 && (pofs[s] <= pofs[s - 1] || ofs[s] < ofs[s - 1] + (pofs[s] - pofs[s - 1]))) okstrips = 0;
+                    }
+                    if (!okstrips) {
+                        free(packed); free(pofs); free(ofs); free(refs); H5Dclose(di); H5Fclose(f);
+                        return fail(err, errlen, "gfdb: failed to read a trace from file: %s", fn);
+                    }
                     /* trace_from_storable, sparse_trace.f90:849-877 */
                     const int gx = (ichunk - 1) * ix.nxc + ixc;
                     const size_t t = ((size_t)gx * ix.nz + iz) * ix.ng + ig;

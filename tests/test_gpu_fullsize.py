@@ -147,3 +147,96 @@ def test_bench_line_through_rccl_with_one_rank():
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+
+
+_TWO_RANK_WORKER = r"""
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.environ["KIWI_ROOT"])
+import torch
+import torch.distributed as dist
+rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+backend = os.environ["KIWI_TEST_BACKEND"]
+if backend == "nccl":                                   # one GPU per rank, RCCL
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+else:                                                   # one-GPU box: both ranks' engines on device 0, gloo carries the gather
+    local = 0
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+from kiwi_amd import synthetic
+from kiwi_amd.shard import sharded_misfits_for_sources
+from tests.common import Scenario
+from tests.test_gpu_parity import build
+out = {}
+for method, with_filter in (("l2norm", False), ("ampspec_l2norm", False), ("l2norm", True)):
+    sc = Scenario()
+    e = sc.oracle(); sc.make_references(e); sc.apply_setup(e, True)
+    p = sc.product(local); sc.apply_setup(p, False)
+    p.set_misfit_method(method)
+    if with_filter:
+        for ir in range(1, sc.nrec + 1):
+            p.set_misfit_filter(ir, [0.01, 0.03, 0.25, 0.4], [0., 1., 1., 0.])
+    trials = np.array([[0.3 * i, 0., 0., 9500. + 300 * i] + synthetic.mt_from_sdr(40. * i, 50. + 5 * i, -60. + 30 * i) + [1.0]
+                       for i in range(7)], np.float32)
+    trials[1, 10] = 150.0; trials[5, 10] = 170.0          # two transform lengths in the list, one in each shard
+    m, n, fails = sharded_misfits_for_sources(p, "moment_tensor", trials, dist, local)
+    out[method + ("+filter" if with_filter else "")] = (m, n)
+    if rank == 0:
+        m1, n1, f1 = p.make_misfits_for_sources("moment_tensor", trials)       # unsharded, this rank alone
+        assert fails == f1 == []
+        assert m.shape == m1.shape and m.tobytes() == m1.tobytes() and n.tobytes() == n1.tobytes(), (method, with_filter)
+        assert len({x.tobytes() for x in n1}) > (1 if method != "l2norm" or with_filter else 0)
+dist.barrier()
+if rank == 0:
+    print("TWO_RANK_OK world=%d" % dist.get_world_size())
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("backend", ["nccl", "gloo"])
+def test_two_ranks_sharded_equals_unsharded(tmp_path, backend):
+    """Trial sources sharded over TWO ranks (one process per rank, all-gather of the per-receiver misfits,
+    kiwi_amd/shard.py) == the same list evaluated by one rank, bit for bit -- time-domain L2, amplitude-spectrum L2 and
+    filtered L2 (whose transform lengths must not depend on which sources share a rank).  "nccl": one GPU per rank over
+    RCCL, needs two devices; "gloo": the same two processes with their engines on one GPU, runs on any GPU box."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (this box has %d)" % torch.cuda.device_count())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "two_rank_worker.py"
+    script.write_text(_TWO_RANK_WORKER)
+    env = dict(os.environ, KIWI_ROOT=root, HSA_ENABLE_IPC_MODE_LEGACY="0", KIWI_TEST_BACKEND=backend)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29543" if backend == "nccl" else "29544", "--max-restarts", "0", str(script)],
+                         capture_output=True, text=True,
+                         timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "TWO_RANK_OK world=2" in out.stdout
+
+
+def test_bench_gpus_flag_is_honoured():
+    """`python bench.py --gpus N` starts N ranks itself (the driver's command shape); with fewer devices than asked for it
+    fails loudly instead of silently measuring one GPU; a launcher/flag mismatch is an error too."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ndev = torch.cuda.device_count()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ndev + 1), "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode != 0 and "only %d GPU" % ndev in out.stderr and not out.stdout.strip()
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr
+    if ndev >= 2:
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "64"],
+                             capture_output=True, text=True, timeout=900, cwd=root)
+        assert out.returncode == 0, out.stderr[-3000:]
+        d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        assert d["n_gpus"] == 2 and d["rccl_world_size"] == 2 and d["cpu_baseline"] is None

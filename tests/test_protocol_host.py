@@ -8,14 +8,14 @@ import pytest
 from kiwi_amd import protocol, synthetic
 from kiwi_amd import lib as klib
 
-HAVE_FLANG = os.path.exists("/opt/rocm/bin/amdflang")
+from tests.common import HAVE_FLANG, HAVE_HDF5
 pytestmark = pytest.mark.skipif(not HAVE_FLANG, reason="amdflang not installed")
 
 
 @pytest.fixture(scope="module")
 def host():
     klib.build()
-    if os.path.exists("/opt/conda/include/hdf5.h"):
+    if HAVE_HDF5:
         from kiwi_amd import gfdb_hdf5
         gfdb_hdf5.build()
     return protocol.build_host()
@@ -267,11 +267,11 @@ def test_config1_mini_inp_command_sequence(host, tmp_path):
     from oracle import ko
     gf = synthetic.make_gfdb(nx=64, nz=7, ng=10, L=512, dx=25e3, dz=2000.0, firstx=300e3, firstz=4e3)
     base = str(tmp_path / "db")
-    if os.path.exists("/opt/conda/include/hdf5.h"):        # the reference's own database format (db.index + db.N.chunk)
+    if HAVE_HDF5:              # the reference's own database format (db.index + db.N.chunk)
         from kiwi_amd import gfdb_hdf5
         gfdb_hdf5.write(base, gf, nchunks=4)
         assert not os.path.exists(base + ".kiwiflat")
-    else:
+    else:                      # (tests/test_product_cpu.py fails on an image where this branch is taken unexpectedly)
         protocol.write_flat_gfdb(base, gf)
     table = os.path.join(os.path.dirname(__file__), "golden", "izmit-receivers.table")
     rec = [l.split() for l in open(table) if l.strip()]
@@ -281,7 +281,10 @@ def test_config1_mini_inp_command_sequence(host, tmp_path):
     p = protocol.MinimizerProcess(host)
     out = {}
     try:
+        with pytest.raises(protocol.SeismosizerReturnedError, match="no database set"):
+            p.do("get_database_format")
         p.do("set_database           ", base)
+        assert p.do("get_database_format") == ("hdf5" if HAVE_HDF5 else "kiwiflat")      # the reader that actually ran
         p.do("set_effective_dt        0.5")
         p.do("set_local_interpolation bilinear")
         p.do("set_receivers          ", table)
