@@ -88,6 +88,7 @@ struct kiwi_hip_ctx {
     bool have_db = false;
     DevBuf<float> G;
     DevBuf<int2> span;
+    DevBuf<unsigned char> endz;       // per GF row: the stored trace ends in an exact zero (its repeated end value is 0)
 
     // setup
     int bilinear = 0, xus = 1, zus = 1;
@@ -147,6 +148,7 @@ struct kiwi_hip_ctx {
     DevBuf<float> misfit_d, global_d;
     DevBuf<GeoRec> recs_d;
     DevBuf<int> tab_d;                // grouped kernel load descriptors, 128 ints per GeoRec
+    DevBuf<int> pairflag_d;           // cell mode: per (source of the chunk, receiver) "some centroid misses a trace"
     DevBuf<float> syn_d, proc_d;
     // floating norms
     bool floating = false;
@@ -159,6 +161,12 @@ struct kiwi_hip_ctx {
     int group_threads_env = 0;
     int group_threads = 128;          // workgroup size of the grouped kernel (tile = 4x); env KIWI_HIP_GROUP_THREADS
     int accum_mode = 0;               // 0 grouped (LDS-staged), 1 direct; env KIWI_HIP_ACCUM
+    // cell groups (accumulate_cell_kernel: raw node traces fetched once per run of centroids in the same GF cell):
+    // -1 decided per batch -- sources whose centroids are mostly different points --, 0 off, 1 on; env KIWI_HIP_CELL
+    int cell_mode = -1;
+    int cell_split = 0;               // 1: horizontal and vertical block in separate workgroups; env KIWI_HIP_CELL_SPLIT
+    int cell_spl = 2;                 // output samples per lane of the cell kernel (2: raw rows take 80 registers, 4: 160); env KIWI_HIP_CELL_SPL
+    double points_per_centroid = 0.0; // of the uploaded batch: distinct consecutive points / centroids
     int keep_which = 0;               // kiwi_hip_set_keep_synthetics
     int proc_chunk0 = 0, proc_chunkn = 0, proc_which_held = 0;   // what proc_d currently holds
     size_t chunk_bytes_limit = (size_t)16 << 30;      // workspace per launch; the device has 288 GB
@@ -251,7 +259,7 @@ void natural_spans(kiwi_hip_ctx *c, std::vector<int> &sb)
         EvalParams ep{ c->bilinear, c->xus, c->zus, nrec, s0 };
         dim3 grid((unsigned)((maxnc * nrec + 255) / 256), (unsigned)n);
         hipLaunchKernelGGL(geometry_kernel, grid, dim3(256), 0, c->stream, c->cent_d.p, c->centofs_d.p, ep, c->gm,
-                           c->span.p, c->recv_d.p, (GeoRec *)nullptr, (int *)nullptr, c->spanbuf_d.p, (int *)nullptr);
+                           c->span.p, c->recv_d.p, (GeoRec *)nullptr, (int *)nullptr, c->spanbuf_d.p, (int *)nullptr, (int *)nullptr, c->endz.p);
     }
     HIPCHECK(hipMemcpyAsync(sb.data(), c->spanbuf_d.p, sb.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));
@@ -795,7 +803,10 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
     float *proc = nullptr;
     if (proc_which) { c->proc_d.ensure((size_t)nsrc * c->syn_stride, &c->dev_bytes); proc = c->proc_d.p; }
 
-    EvalParams ep{ c->bilinear, c->xus, c->zus, nrec, isrc0 };
+    // cell groups pay where most centroids are points of their own (no blended tile to share between time steps)
+    // (with nearest-neighbour interpolation there is nothing to blend: same-point groups do)
+    const bool cell = c->accum_mode == 0 && (c->cell_mode == 1 || (c->cell_mode < 0 && c->bilinear && c->points_per_centroid > 0.5));
+    EvalParams ep{ c->bilinear, c->xus, c->zus, nrec, isrc0, cell ? 1 : 0 };
     int *spansrc = nullptr;
     if (c->any_untapered || c->want_spansrc || c->fft_needed) {     // per-source strip spans, initialised empty
         const size_t n = (size_t)nsrc * nrec;
@@ -807,8 +818,15 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
     record(c, 0, e0);
     if (maxnc > 0) {
         dim3 grid((unsigned)((maxnc * nrec + 255) / 256), (unsigned)nsrc);
+        if (cell) {
+            c->pairflag_d.ensure((size_t)nsrc * nrec, &c->dev_bytes);
+            HIPCHECK(hipMemsetAsync(c->pairflag_d.p, 0, (size_t)nsrc * nrec * sizeof(int), c->stream));
+        }
         hipLaunchKernelGGL(geometry_kernel, grid, dim3(256), 0, c->stream, c->cent_d.p, c->centofs_d.p, ep, c->gm,
-                           c->span.p, c->recv_d.p, c->recs_d.p, tab, (int *)nullptr, spansrc);
+                           c->span.p, c->recv_d.p, c->recs_d.p, tab, (int *)nullptr, spansrc, cell ? c->pairflag_d.p : (int *)nullptr, c->endz.p);
+        if (cell)
+            hipLaunchKernelGGL(cellgroup_kernel, grid, dim3(256), 0, c->stream, c->centofs_d.p, ep, c->gm, c->span.p, c->recv_d.p,
+                               c->recs_d.p, tab, c->pairflag_d.p, c->endz.p);
     }
     if (c->fft_needed) {
         // transform length of every (source, slot) pair from the source's own strip spans; the lengths travel to the host
@@ -822,7 +840,8 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
         HIPCHECK(hipEventRecord(c->size_event, c->stream));
     }
     record(c, 0, e1);
-    int fuse_T = 0, fuse_ntiles = 0;
+    int fuse_T = 0, fuse_ntiles = 0, fuse_nparts = 0;
+    bool fuse_all = false;
     {
         dim3 grid((unsigned)((c->max_wlen + kTile - 1) / kTile), (unsigned)nrec, (unsigned)nsrc);
         if (c->accum_mode == 1) {            // KIWI_HIP_ACCUM=direct: A/B reference kernel, no LDS staging
@@ -836,10 +855,14 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
             // workgroup size: env override, else by window length (halo overhead vs tile fit)
             const int T = c->group_threads_env ? c->group_threads : (c->max_wlen >= 2048 ? 256 : (c->max_wlen >= 384 ? 128 : 64));
             const int ntiles = (c->max_wlen + 4 * T - 1) / (4 * T);
+            // cell mode: accumulate_cell_kernel (256 threads, tile = spl x 256 samples) takes the pairs of cell_pair(), the
+            // grouped kernel behind it the others
+            const int spl = c->cell_spl, Tc = 256;
+            const int ntiles_c = (c->max_wlen + spl * Tc - 1) / (spl * Tc);
             // runs of geometry-identical single-group sources (chunk-local indices); singletons otherwise
             int *runs = nullptr;
             unsigned gx = (unsigned)nsrc;
-            if (c->share_runs) {
+            if (c->share_runs && !cell) {
                 std::vector<int> rf;
                 // keep enough workgroups in flight: no run longer than nsrc / 1024 rounded up, nor than max_run
                 const int cap = std::max(1, std::min(c->max_run, (nsrc * ntiles * nrec) / 8192));
@@ -863,25 +886,42 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
                 }
             }
             dim3 ggrid(gx, (unsigned)(ntiles * nrec));                   // source index fastest (L2 sharing)
+            dim3 cgrid((unsigned)nsrc, (unsigned)(ntiles_c * nrec));
             FuseParams fp{ nullptr, nullptr, nullptr, nullptr, 0, 1.f, 0, 0, 0 };
             if (fuse) {
-                const int nparts = ntiles * (T / 64);
+                // partial sums per (source, slot): [tile][wave] of the kernel that evaluated the pair.  In cell mode two
+                // kernels with different tilings share the buffer: it is cleared and misfit_finish_kernel sums all of it
+                const int nparts = cell ? std::max(ntiles * (T / 64), ntiles_c * (Tc / 64)) : ntiles * (T / 64);
                 c->fusepart_d.ensure((size_t)nsrc * c->nmis * nparts, &c->dev_bytes);
+                if (cell) HIPCHECK(hipMemsetAsync(c->fusepart_d.p, 0, (size_t)nsrc * c->nmis * nparts * sizeof(double), c->stream));
                 fp = FuseParams{ c->reft_d.p, c->tw_d.p, c->moment_d.p, c->fusepart_d.p, c->method, c->syn_factor, c->nmis, nparts, isrc0 };
+                fuse_nparts = nparts;
             }
-            fuse_T = T; fuse_ntiles = ntiles;
+            fuse_T = T; fuse_ntiles = ntiles; fuse_all = cell;
 #define KIWI_LAUNCH_G2(NGV, TV, FV, RV)                                                                     \
     hipLaunchKernelGGL((accumulate_grouped_kernel<NGV, TV, FV, RV>), ggrid, dim3(TV), 0, c->stream, c->G.p, c->span.p,   \
                        c->gm.pitch, c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p,          \
-                       c->syn_stride, ntiles, c->tab_d.p, runs, fp)
+                       c->syn_stride, ntiles, c->tab_d.p, runs, fp, cell ? c->pairflag_d.p : (const int *)nullptr)
 #define KIWI_LAUNCH_GROUPED(NGV, TV)                                                                        \
     do { if (fuse) { if (runs) KIWI_LAUNCH_G2(NGV, TV, true, true); else KIWI_LAUNCH_G2(NGV, TV, true, false); }   \
          else      { if (runs) KIWI_LAUNCH_G2(NGV, TV, false, true); else KIWI_LAUNCH_G2(NGV, TV, false, false); } } while (0)
+#define KIWI_LAUNCH_C3(NGV, SV, PV, FV)                                                                     \
+    hipLaunchKernelGGL((accumulate_cell_kernel<NGV, 256, SV, PV, FV>), cgrid, dim3(256), 0, c->stream, c->G.p, c->span.p,   \
+                       c->gm.pitch, c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p,          \
+                       c->syn_stride, ntiles_c, c->tab_d.p, fp, c->pairflag_d.p)
+#define KIWI_LAUNCH_C2(NGV, SV, FV) do { if (c->cell_split) { KIWI_LAUNCH_C3(NGV, SV, 1, FV); KIWI_LAUNCH_C3(NGV, SV, 2, FV); } \
+                                         else KIWI_LAUNCH_C3(NGV, SV, 0, FV); } while (0)
+#define KIWI_LAUNCH_CELL(NGV) do { if (spl == 2) { if (fuse) KIWI_LAUNCH_C2(NGV, 2, true); else KIWI_LAUNCH_C2(NGV, 2, false); } \
+                                   else          { if (fuse) KIWI_LAUNCH_C2(NGV, 4, true); else KIWI_LAUNCH_C2(NGV, 4, false); } } while (0)
+            if (cell) { if (c->gm.ng == 10) KIWI_LAUNCH_CELL(10); else KIWI_LAUNCH_CELL(8); }
             if (c->gm.ng == 10) {
                 if (T == 64) KIWI_LAUNCH_GROUPED(10, 64); else if (T == 256) KIWI_LAUNCH_GROUPED(10, 256); else KIWI_LAUNCH_GROUPED(10, 128);
             } else {
                 if (T == 64) KIWI_LAUNCH_GROUPED(8, 64); else if (T == 256) KIWI_LAUNCH_GROUPED(8, 256); else KIWI_LAUNCH_GROUPED(8, 128);
             }
+#undef KIWI_LAUNCH_CELL
+#undef KIWI_LAUNCH_C2
+#undef KIWI_LAUNCH_C3
 #undef KIWI_LAUNCH_GROUPED
 #undef KIWI_LAUNCH_G2
         }
@@ -905,7 +945,8 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
         if (fuse) {
             const int nth = nsrc * c->nmis;
             hipLaunchKernelGGL(misfit_finish_kernel, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, c->stream,
-                               c->fusepart_d.p, c->comps_d.p, c->nmis, fuse_ntiles * (fuse_T / 64), fuse_T / 64, 4 * fuse_T,
+                               c->fusepart_d.p, c->comps_d.p, c->nmis, fuse_all ? fuse_nparts : fuse_ntiles * (fuse_T / 64), fuse_T / 64,
+                               fuse_all ? 0 : 4 * fuse_T,
                                c->method, c->gm.dt, isrc0, nsrc, c->misfit_d.p);
         } else
         hipLaunchKernelGGL(misfit_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream,
@@ -1014,6 +1055,9 @@ int kiwi_hip_init(int device, kiwi_hip_ctx **out)
         }
         if (const char *m = std::getenv("KIWI_HIP_ACCUM")) c->accum_mode = (std::strcmp(m, "direct") == 0) ? 1 : 0;
         if (const char *m = std::getenv("KIWI_HIP_FUSE")) c->fuse_enabled = std::atoi(m);
+        if (const char *m = std::getenv("KIWI_HIP_CELL")) c->cell_mode = std::atoi(m) ? 1 : 0;
+        if (const char *m = std::getenv("KIWI_HIP_CELL_SPL")) c->cell_spl = std::atoi(m) == 4 ? 4 : 2;
+        if (const char *m = std::getenv("KIWI_HIP_CELL_SPLIT")) c->cell_split = std::atoi(m) ? 1 : 0;
         if (const char *m = std::getenv("KIWI_HIP_CHUNK_MB")) {      // workspace bound per launch (default 16 GiB); tests use it
             const long v = std::atol(m);
             if (v > 0) c->chunk_bytes_limit = (size_t)v << 20;
@@ -1078,6 +1122,8 @@ int kiwi_hip_set_gfdb(kiwi_hip_ctx *c, int nx, int nz, int ng, int L, float dt, 
     c->G.alloc(nrows * (size_t)pitch, &c->dev_bytes);
     c->span.alloc(nrows, &c->dev_bytes);
     std::vector<int2> sp(nrows);
+    std::vector<unsigned char> ez(nrows);
+    c->endz.alloc(nrows, &c->dev_bytes);
     const size_t slab = std::max<size_t>(1, ((size_t)64 << 20) / ((size_t)pitch * sizeof(float)));
     std::vector<float> stage(slab * (size_t)pitch);
     for (size_t r0 = 0; r0 < nrows; r0 += slab) {
@@ -1093,10 +1139,12 @@ int kiwi_hip_set_gfdb(kiwi_hip_ctx *c, int nx, int nz, int ng, int L, float dt, 
             const float tail = n > 0 ? src[n - 1] : 0.f;
             for (int k = kRowPad + n; k < pitch; k++) d[k] = tail;
             sp[row] = make_int2(first[row], first[row] + n - 1);       // n == 0 -> empty span = not stored
+            ez[row] = (tail == 0.f) ? 1 : 0;
         }
         HIPCHECK(hipMemcpy(c->G.p + r0 * (size_t)pitch, stage.data(), nr * (size_t)pitch * sizeof(float), hipMemcpyHostToDevice));
     }
     HIPCHECK(hipMemcpy(c->span.p, sp.data(), nrows * sizeof(int2), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(c->endz.p, ez.data(), nrows, hipMemcpyHostToDevice));
     c->gm = GfMeta{ nx, nz, ng, pitch, dt, dx, dz, firstx, firstz };
     c->have_db = true;
     c->prepared = false;            // dirtyfy_database, minimizer_engine.f90:1483
@@ -1409,6 +1457,19 @@ int kiwi_hip_set_sources(kiwi_hip_ctx *c, int nsrc, const int *cent_ofs, const f
             c->geo_hash[s] = h;
             c->single_group[s] = one ? 1 : 0;
         }
+        // how many of the centroids start a new point (sampled): decides between same-point and same-cell groups
+        long long npts = 0, ncen = 0;
+        const int stride = std::max(1, nsrc / 64);
+        for (int s = 0; s < nsrc; s += stride) {
+            const float *ce = cent + (size_t)cent_ofs[s] * 10;
+            const int nc = cent_ofs[s + 1] - cent_ofs[s];
+            for (int k = 0; k < nc; k++) {
+                const float *p = ce + (size_t)k * 10, *q = p - 10;
+                if (k == 0 || !(p[0] == q[0] && p[1] == q[1] && p[2] == q[2])) npts++;
+            }
+            ncen += nc;
+        }
+        c->points_per_centroid = ncen > 0 ? (double)npts / (double)ncen : 0.0;
     }
     c->cent_d.ensure(std::max<size_t>(ntot, 1) * 10, &c->dev_bytes);
     c->centofs_d.ensure((size_t)nsrc + 1, &c->dev_bytes);

@@ -136,6 +136,7 @@ struct EvalParams {
     int bilinear, xus, zus;
     int nrec;
     int isrc0;
+    int cellmode;      // groups = runs of centroids in the same 4-node GF cell (cellgroup_kernel marks them), not same-point runs
 };
 
 // Length of the centroid group that accumulate_grouped_kernel forms when a group STARTS at centroid c of a source: the
@@ -189,7 +190,7 @@ __device__ __forceinline__ bool starts_group(const float *__restrict__ cent, int
 // with the look-ups left every line open for microseconds: partial-line write-backs, 0.32 ms per 1.3 M records).
 template <int NG>
 __device__ __forceinline__ void write_tab(int *__restrict__ tb, const GeoRec &g, const int2 *__restrict__ span, int pitch, float sd,
-                                          bool full)
+                                          bool full, const unsigned char *__restrict__ endz)
 {
     // full: this centroid starts a group and the kernel reads the whole row; otherwise only its coefficients (they
     // share the row's last 128-byte line with the clamp floors of components 9 and 10, which are then not needed)
@@ -197,6 +198,12 @@ __device__ __forceinline__ void write_tab(int *__restrict__ tb, const GeoRec &g,
     int bases[NG][4], floors[NG][4], jend[12];
     int jmin_h = 0x7fffffff, jmin_d = 0x7fffffff;
     if (full) {
+    // Rows whose stored trace ends in an exact zero (the reference's trace_pack keeps one of the zeros that follow the last
+    // non-zero sample, sparse_trace.f90:535,545, so this is the normal case for traces that die out inside the database's
+    // time range): the repeated end value is 0 and the rule "factor * last after the span" (sparse_trace.f90:698-703) adds
+    // the same signed zeros as the interpolation formula does -- the kernel may then skip its tail variant for this group.
+    // endz[row]: the row's end value is zero (set by kiwi_hip_set_gfdb).
+    bool endzero = true;
 #pragma unroll
     for (int ig = 0; ig < NG; ig++) {
         int je = -0x7fffffff;
@@ -206,7 +213,7 @@ __device__ __forceinline__ void write_tab(int *__restrict__ tb, const GeoRec &g,
             const int2 sp = span[row];
             bases[ig][k] = row * pitch + kRowPad - sp.x;
             floors[ig][k] = row * pitch;
-            if (k < nn) je = max(je, sp.y);
+            if (k < nn) { je = max(je, sp.y); endzero = endzero && endz[row]; }
         }
         jend[ig] = je;
         const bool horiz = (ig <= 4) || (ig == 8);
@@ -214,8 +221,8 @@ __device__ __forceinline__ void write_tab(int *__restrict__ tb, const GeoRec &g,
     }
 #pragma unroll
     for (int ig = NG; ig < 10; ig++) jend[ig] = 0;
-    jend[10] = jmin_h;
-    jend[11] = jmin_d;
+    jend[10] = endzero ? 0x7fffffff : jmin_h;
+    jend[11] = endzero ? 0x7fffffff : jmin_d;
     }
     float cf[20];
     {
@@ -255,7 +262,9 @@ __device__ __forceinline__ void write_tab(int *__restrict__ tb, const GeoRec &g,
 __global__ __launch_bounds__(256) void geometry_kernel(
     const float *__restrict__ cent, const int *__restrict__ cent_ofs, EvalParams ep, GfMeta gm,
     const int2 *__restrict__ span, const RecvDev *__restrict__ recv, GeoRec *__restrict__ out,
-    int *__restrict__ tab, int *__restrict__ spanbuf, int *__restrict__ spansrc /* optional [source][receiver][4] */)
+    int *__restrict__ tab, int *__restrict__ spanbuf, int *__restrict__ spansrc /* optional [source][receiver][4] */,
+    int *__restrict__ pairflag /* optional [source][receiver]: some centroid of the pair misses a trace (cell mode) */,
+    const unsigned char *__restrict__ endz /* per GF row: its end value is zero (write_tab) */)
 {
     const int s = blockIdx.y;
     const int c0 = cent_ofs[ep.isrc0 + s], nc = cent_ofs[ep.isrc0 + s + 1] - c0;
@@ -390,7 +399,7 @@ __global__ __launch_bounds__(256) void geometry_kernel(
         const bool complete = (!rv.need_h || nlim_h == nH) && (!rv.has_d || nlim_d == nD);
         if (!complete) {
             if (nlim_h == 0 && nlim_d == 0) ok = false;                  // nothing of this centroid is added
-            else g.flags |= 8 | (nlim_h << 8) | (nlim_d << 12);
+            else { g.flags |= 8 | (nlim_h << 8) | (nlim_d << 12); if (pairflag) atomicOr(&pairflag[(size_t)s * ep.nrec + r], 1); }
         }
         if (!ok) g.row[0] = -1;
     }
@@ -399,7 +408,7 @@ __global__ __launch_bounds__(256) void geometry_kernel(
     // the spread of those shifts.  pad = len | (smax - ishift) << 8 | (ishift - smin) << 16
     {
         int len = 1, smin = g.ishift, smax = g.ishift;
-        if (g.row[0] >= 0) len = group_len(cent, c0, nc, c, gm.dt, smin, smax);
+        if (g.row[0] >= 0 && !ep.cellmode) len = group_len(cent, c0, nc, c, gm.dt, smin, smax);
         g.pad = len | ((smax - g.ishift) << 8) | ((g.ishift - smin) << 16);
     }
     // natural span of the synthetic strips (seismogram.f90:102-130 + sparse_trace.f90:648-668): union over
@@ -430,10 +439,72 @@ __global__ __launch_bounds__(256) void geometry_kernel(
     const size_t base = (size_t)(c0 - cent_ofs[ep.isrc0]) * ep.nrec + (size_t)r * nc + c;
     out[base] = g;
     if (tab && g.row[0] >= 0) {
-        const bool full = !(g.flags & 4) || starts_group(cent, c0, nc, c, gm.dt);
-        if (gm.ng == 10) write_tab<10>(tab + base * 128, g, span, gm.pitch, rv.sd, full);
-        else write_tab<8>(tab + base * 128, g, span, gm.pitch, rv.sd, full);
+        // cell mode: only the coefficient line here, cellgroup_kernel completes the rows of the group starts it finds
+        const bool full = !ep.cellmode && (!(g.flags & 4) || starts_group(cent, c0, nc, c, gm.dt));
+        if (gm.ng == 10) write_tab<10>(tab + base * 128, g, span, gm.pitch, rv.sd, full, endz);
+        else write_tab<8>(tab + base * 128, g, span, gm.pitch, rv.sd, full, endz);
     }
+}
+
+// Second geometry pass of the cell mode: consecutive centroids (table order) of one (source, receiver) whose four GF nodes
+// are the same -- neighbouring sub-faults of a rupture are hundreds of metres apart, the nodes kilometres -- form a
+// group: accumulate_cell_kernel fetches the raw node traces ONCE per group and blends them per centroid with that
+// centroid's weights.  Groups are cut greedily from the start of a same-cell run (length <= kMaxGroup, integer shifts
+// within the LDS halo).  Pairs accumulate_cell_kernel does not take (see cell_pair) get same-point groups.  Thread per record: a thread
+// that finds itself at a group start leaves the hint in its record and completes its descriptor row.
+__device__ __forceinline__ bool same_cell(const GeoRec *__restrict__ a, const int (&row)[4])
+{
+    const int4 r = *reinterpret_cast<const int4 *>(a->row);
+    return r.x == row[0] && r.y == row[1] && r.z == row[2] && r.w == row[3];
+}
+
+// is (source s, receiver r) evaluated by accumulate_cell_kernel?  Receivers with horizontal AND vertical components whose
+// centroids all find their traces; every other pair keeps same-point groups and goes through accumulate_grouped_kernel
+__device__ __forceinline__ bool cell_pair(const RecvDev &rv, const int *__restrict__ pairflag, int s, int nrec, int r)
+{
+    return rv.need_h && rv.has_d && !(pairflag[(size_t)s * nrec + r] & 1);
+}
+
+__global__ __launch_bounds__(256) void cellgroup_kernel(const int *__restrict__ cent_ofs, EvalParams ep, GfMeta gm,
+                                                        const int2 *__restrict__ span, const RecvDev *__restrict__ recv,
+                                                        GeoRec *__restrict__ recs, int *__restrict__ tab,
+                                                        const int *__restrict__ pairflag, const unsigned char *__restrict__ endz)
+{
+    const int s = blockIdx.y;
+    const int cb = cent_ofs[ep.isrc0], c0 = cent_ofs[ep.isrc0 + s], nc = cent_ofs[ep.isrc0 + s + 1] - c0;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nc * ep.nrec) return;
+    const int r = idx / nc, c = idx - r * nc;
+    const size_t base0 = (size_t)(c0 - cb) * ep.nrec + (size_t)r * nc;
+    GeoRec *__restrict__ rr = recs + base0;
+    const GeoRec me = rr[c];
+    if (me.row[0] < 0) return;
+    int len = 1, smin = me.ishift, smax = me.ishift;
+    {
+        // cell pairs: a group runs on while the four nodes stay the same; other pairs: while the POINT stays the same
+        // (flags bit 2 of the follower), which is what accumulate_grouped_kernel's shared blended tile needs
+        const bool cellp = cell_pair(recv[r], pairflag, s, ep.nrec, r);
+        int r0 = c;
+        while (r0 > 0 && same_cell(rr + r0 - 1, me.row) && (cellp || (rr[r0].flags & 4))) r0--;
+        int pos = r0;
+        for (;;) {
+            len = 1;
+            smin = smax = rr[pos].ishift;
+            for (int k = pos + 1; k < nc && len < kMaxGroup; k++) {
+                if (!same_cell(rr + k, me.row) || !(cellp || (rr[k].flags & 4))) break;
+                const int sh = rr[k].ishift;
+                const int nmin = min(smin, sh), nmax = max(smax, sh);
+                if (nmax - nmin > kHalo - 10) break;
+                smin = nmin; smax = nmax; len++;
+            }
+            if (pos == c) break;                  // this centroid starts a group
+            if (pos + len > c) return;            // inside a group: its coefficient line is all the kernel reads of its row
+            pos += len;
+        }
+    }
+    rr[c].pad = len | ((smax - me.ishift) << 8) | ((me.ishift - smin) << 16);
+    if (gm.ng == 10) write_tab<10>(tab + (base0 + c) * 128, me, span, gm.pitch, recv[r].sd, true, endz);
+    else write_tab<8>(tab + (base0 + c) * 128, me, span, gm.pitch, recv[r].sd, true, endz);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -825,7 +896,9 @@ typedef float f2v __attribute__((ext_vector_type(2)));
 // shift), the compiler fuses the reads of two q into one ds_read2st64_b32 whose result IS the aligned register pair a
 // packed multiply wants -- for every shift residue alike, so no v_pk_mov assemblies and no per-residue code variants.
 // LDS_TILE is a multiple of 64 dwords, which puts all components and q of a centroid within the instruction's offsets.
-struct TileRegs { f2v lo[2], hi[2]; };          // (q0, q1), (q2, q3): b[j-1] and b[j] of the lane's four outputs
+// NP register pairs per lane: 2 (four outputs per lane: q0,q1 | q2,q3) or 1 (two outputs per lane, accumulate_cell_kernel)
+template <int NP = 2> struct TileRegsN { f2v lo[NP], hi[NP]; };   // b[j-1] and b[j] of the lane's outputs
+typedef TileRegsN<2> TileRegs;
 
 // The lane's two LDS base addresses of a centroid: b[j-1] and b[j] of its output q = 0 in component 0.  The second is
 // the first plus one dword, but hidden from the compiler: it would otherwise pair the adjacent dwords (b[j-1], b[j]) of
@@ -843,22 +916,26 @@ __device__ __forceinline__ TileBase tile_base(const float *__restrict__ p)
     return b;
 }
 
-__device__ __forceinline__ TileRegs tile_load(const TileBase &b, int ofs)
+template <int NP = 2>
+__device__ __forceinline__ TileRegsN<NP> tile_load(const TileBase &b, int ofs)
 {
-    TileRegs t;
-    t.lo[0] = f2v{ b.lo[ofs], b.lo[ofs + 64] };   t.lo[1] = f2v{ b.lo[ofs + 128], b.lo[ofs + 192] };
-    t.hi[0] = f2v{ b.hi[ofs], b.hi[ofs + 64] };   t.hi[1] = f2v{ b.hi[ofs + 128], b.hi[ofs + 192] };
+    TileRegsN<NP> t;
+#pragma unroll
+    for (int h = 0; h < NP; h++) {
+        t.lo[h] = f2v{ b.lo[ofs + 128 * h], b.lo[ofs + 128 * h + 64] };
+        t.hi[h] = f2v{ b.hi[ofs + 128 * h], b.hi[ofs + 128 * h + 64] };
+    }
     return t;
 }
 
 // The lane's 4 output samples are held as two register pairs so that the multiplies and adds are
 // v_pk_mul_f32 / v_pk_add_f32 (two IEEE fp32 operations per lane and instruction, each rounded
 // separately exactly like the scalar form; no FMA).
-template <bool TAIL>
-__device__ __forceinline__ void tile_fma(f2v (&out)[2], const TileRegs &t, int jl, int jend, float factor, float wl, float wr)
+template <bool TAIL, int NP = 2>
+__device__ __forceinline__ void tile_fma(f2v (&out)[NP], const TileRegsN<NP> &t, int jl, int jend, float factor, float wl, float wr)
 {
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
+    for (int h = 0; h < NP; h++) {
         f2v c1 = { wl, wl }, c2 = { wr, wr };
         if (TAIL) {                               // sparse_trace.f90:698-703, jl = trace index of b[j-1] of the lane's output q = 0
             const bool t0 = (jl + 128 * h + 1) > jend, t1 = (jl + 128 * h + 64 + 1) > jend;
@@ -870,21 +947,21 @@ __device__ __forceinline__ void tile_fma(f2v (&out)[2], const TileRegs &t, int j
     }
 }
 
-template <bool TAIL>
-__device__ __forceinline__ void tile_add(f2v (&out)[2], const TileBase &b, int ofs, int jl, int jend,
+template <bool TAIL, int NP = 2>
+__device__ __forceinline__ void tile_add(f2v (&out)[NP], const TileBase &b, int ofs, int jl, int jend,
                                          float factor, float wfrac)
 {
-    const TileRegs t = tile_load(b, ofs);
+    const TileRegsN<NP> t = tile_load<NP>(b, ofs);
     float wr = wfrac;
     float wl = 1.f - wr;
     wr = wr * factor;
     wl = wl * factor;
-    tile_fma<TAIL>(out, t, jl, jend, factor, wl, wr);
+    tile_fma<TAIL, NP>(out, t, jl, jend, factor, wl, wr);
 }
 
 // all GF components of one centroid (reference order)
-template <int NG, int LDS_TILE, bool TAIL>
-__device__ __forceinline__ void centroid_apply(f2v (&ar1)[2], f2v (&ar2)[2], f2v (&dz)[2],
+template <int NG, int LDS_TILE, bool TAIL, int NP = 2>
+__device__ __forceinline__ void centroid_apply(f2v (&ar1)[NP], f2v (&ar2)[NP], f2v (&dz)[NP],
                                                const TileBase &chunk0, int jl, const int (&jend)[NG],
                                                bool need_h, bool has_d, int flags, float wfrac, float sd,
                                                float f0, float f1, float f2, float f3, float f4, float f5,
@@ -893,16 +970,18 @@ __device__ __forceinline__ void centroid_apply(f2v (&ar1)[2], f2v (&ar2)[2], f2v
     // components that are added, in application order (all of them unless a trace is missing: geometry_kernel)
     const int nlh = (flags & 8) ? (flags >> 8) & 15 : 15, nld = (flags & 8) ? (flags >> 12) & 15 : 15;
     constexpr int o9 = (NG == 10) ? 1 : 0;
-#define TADD(acc, ig, fac) tile_add<TAIL>(acc, chunk0, (ig) * LDS_TILE, jl, jend[ig], fac, wfrac)
+#define TADD(acc, ig, fac) tile_add<TAIL, NP>(acc, chunk0, (ig) * LDS_TILE, jl, jend[ig], fac, wfrac)
 #define TADDL(acc, pos, lim, ig, fac) do { if ((pos) < (lim)) TADD(acc, ig, fac); } while (0)
     if (need_h && nlh > 0) {
         if (flags & 2) {                         // seismogram.f90:160-203
-            f2v t1[2] = { { 0.f, 0.f }, { 0.f, 0.f } }, t2[2] = { { 0.f, 0.f }, { 0.f, 0.f } };
+            f2v t1[NP], t2[NP];
+#pragma unroll
+            for (int i = 0; i < NP; i++) { t1[i] = f2v{ 0.f, 0.f }; t2[i] = f2v{ 0.f, 0.f }; }
             TADD(t1, 0, f0); TADD(t1, 1, f1); TADD(t1, 2, f2);
             if constexpr (NG == 10) TADD(t1, 8, f5);
             TADD(t2, 3, f3); TADD(t2, 4, f4);
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
+            for (int i = 0; i < NP; i++) {
                 ar1[i] = ar1[i] + cl * t1[i] - sl * t2[i];
                 ar2[i] = ar2[i] + cl * t2[i] + sl * t1[i];
             }
@@ -924,8 +1003,8 @@ __device__ __forceinline__ void centroid_apply(f2v (&ar1)[2], f2v (&ar2)[2], f2v
 // of component i + kAhead are issued before the arithmetic of component i, so that a lone wave is not
 // stalled for a full LDS round trip per component (a wave can only issue every 4th cycle; with 3 waves per
 // SIMD exposed latency is what bounds this kernel).  Same operations in the same order as centroid_apply.
-template <int NG, int LDS_TILE, bool TAIL, bool SCOEF>
-__device__ __forceinline__ void centroid_apply_hd(f2v (&ar1)[2], f2v (&ar2)[2], f2v (&dz)[2],
+template <int NG, int LDS_TILE, bool TAIL, bool SCOEF, int NP = 2>
+__device__ __forceinline__ void centroid_apply_hd(f2v (&ar1)[NP], f2v (&ar2)[NP], f2v (&dz)[NP],
                                                   const TileBase &chunk0, int jl, const int (&jend)[NG],
                                                   int flags, const float *__restrict__ coef, int rec, float sd,
                                                   float cl, float sl)
@@ -946,8 +1025,9 @@ __device__ __forceinline__ void centroid_apply_hd(f2v (&ar1)[2], f2v (&ar2)[2], 
     const float fac10[10] = { f0, f1, f2, f5, f3, f4, f0 * sd, f1 * sd, f2 * sd, f5 * sd };
     const float fac8[8] = { f0, f1, f2, f3, f4, f0 * sd, f1 * sd, f2 * sd };
     const bool rot = (flags & 2) != 0;           // seismogram.f90:160-203 vs :205-231
-    f2v t1[2] = { { 0.f, 0.f }, { 0.f, 0.f } }, t2[2] = { { 0.f, 0.f }, { 0.f, 0.f } };
-    if (!rot) { t1[0] = ar1[0]; t1[1] = ar1[1]; t2[0] = ar2[0]; t2[1] = ar2[1]; }
+    f2v t1[NP], t2[NP];
+#pragma unroll
+    for (int k = 0; k < NP; k++) { t1[k] = rot ? f2v{ 0.f, 0.f } : ar1[k]; t2[k] = rot ? f2v{ 0.f, 0.f } : ar2[k]; }
     float cw[2 * NG];
     if constexpr (SCOEF) {                        // scalar loads, issued together with the first LDS reads
 #pragma unroll
@@ -957,28 +1037,29 @@ __device__ __forceinline__ void centroid_apply_hd(f2v (&ar1)[2], f2v (&ar2)[2], 
 #pragma unroll
         for (int i = 0; i < NG; i++) { const float f = (NG == 10) ? fac10[i] : fac8[i]; cw[2 * i] = wl0 * f; cw[2 * i + 1] = wr0 * f; }
     }
-    TileRegs tr[NG];
+    TileRegsN<NP> tr[NG];
 #pragma unroll
-    for (int i = 0; i < kAhead; i++) tr[i] = tile_load(chunk0, ((NG == 10) ? seq10[i] : seq8[i]) * LDS_TILE);
+    for (int i = 0; i < kAhead; i++) tr[i] = tile_load<NP>(chunk0, ((NG == 10) ? seq10[i] : seq8[i]) * LDS_TILE);
 #pragma unroll
     for (int i = 0; i < NG; i++) {
-        if (i + kAhead < NG) tr[i + kAhead] = tile_load(chunk0, ((NG == 10) ? seq10[i + kAhead] : seq8[i + kAhead]) * LDS_TILE);
+        if (i + kAhead < NG) tr[i + kAhead] = tile_load<NP>(chunk0, ((NG == 10) ? seq10[i + kAhead] : seq8[i + kAhead]) * LDS_TILE);
         __builtin_amdgcn_sched_barrier(0);
         const int ig = (NG == 10) ? seq10[i] : seq8[i];
         const float fac = (NG == 10) ? fac10[i] : fac8[i];
         const float wl = cw[2 * i], wr = cw[2 * i + 1];
-        if (i < nH1) tile_fma<TAIL>(t1, tr[i], jl, jend[ig], fac, wl, wr);
-        else if (i < nH1 + 2) tile_fma<TAIL>(t2, tr[i], jl, jend[ig], fac, wl, wr);
-        else tile_fma<TAIL>(dz, tr[i], jl, jend[ig], fac, wl, wr);
+        if (i < nH1) tile_fma<TAIL, NP>(t1, tr[i], jl, jend[ig], fac, wl, wr);
+        else if (i < nH1 + 2) tile_fma<TAIL, NP>(t2, tr[i], jl, jend[ig], fac, wl, wr);
+        else tile_fma<TAIL, NP>(dz, tr[i], jl, jend[ig], fac, wl, wr);
         if (i == nH1 + 1) {
             if (rot) {
 #pragma unroll
-                for (int k = 0; k < 2; k++) {
+                for (int k = 0; k < NP; k++) {
                     ar1[k] = ar1[k] + cl * t1[k] - sl * t2[k];
                     ar2[k] = ar2[k] + cl * t2[k] + sl * t1[k];
                 }
             } else {
-                ar1[0] = t1[0]; ar1[1] = t1[1]; ar2[0] = t2[0]; ar2[1] = t2[1];
+#pragma unroll
+                for (int k = 0; k < NP; k++) { ar1[k] = t1[k]; ar2[k] = t2[k]; }
             }
         }
     }
@@ -989,7 +1070,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
     const float *__restrict__ G, const int2 *__restrict__ span, int pitch,
     const GeoRec *__restrict__ recs, const int *__restrict__ cent_ofs, int isrc0, int nrec,
     const RecvDev *__restrict__ recv, float *__restrict__ syn, size_t syn_stride, int ntiles,
-    const int *__restrict__ tab, const int *__restrict__ run_first, FuseParams fp)
+    const int *__restrict__ tab, const int *__restrict__ run_first, FuseParams fp,
+    const int *__restrict__ pairflag /* cell mode: only the (source, receiver) pairs accumulate_cell_kernel leaves out */)
 {
     // run_first != nullptr: blockIdx.x indexes RUNS of consecutive trial sources [run_first[b], run_first[b+1]) that the
     // host found to have identical centroid geometry (same points and times: only the moment tensors differ, e.g. a
@@ -1013,6 +1095,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
     const RecvDev &rv = recv[r];
     if (!rv.enabled) return;
     if (tile * TILE >= rv.wlen) return;
+    if (pairflag && cell_pair(rv, pairflag, s, nrec, r)) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int t_tile0 = rv.wbeg + tile * TILE;
@@ -1233,6 +1316,332 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
     else if (!stored) {                                  // every centroid skipped: the run's synthetics are zero
         ar1[0] = ar1[1] = ar2[0] = ar2[1] = dz[0] = dz[1] = f2v{ 0.f, 0.f };
         for (int js = s; js < s_end; js++) store(js);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// accumulate, cell groups: the raw node traces stay in registers across the centroids of one GF cell
+//
+// Sources whose sub-faults are all different points (eikonal ruptures: one centroid per cell of the rupture grid) give
+// accumulate_grouped_kernel groups of ONE centroid: every centroid re-fetches its 4 x NG node rows although its
+// neighbours in the table sit in the same 4-node cell of the Green's function grid and need the very same rows -- only
+// the four blend weights change.  Here a group is a run of consecutive centroids in the same cell (cellgroup_kernel):
+// the workgroup loads the raw rows of the tile ONCE per group into registers (4 x NG dwordx4 per lane) and, per centroid,
+// blends them with that centroid's weights (gfdb.f90:944-949, same order) into the LDS tile the apply phase reads, exactly
+// as the grouped kernel does after its loads.  Per output sample the operations and their order are those of
+// accumulate_kernel, so the results are bit-identical.  The halo (positions beyond the tile that the shifts reach) is a
+// sixteenth of the tile: it is fetched per centroid by the halo lanes instead of occupying registers.
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));   // dword-aligned 8-byte load
+template <int SPL> struct RawVec;
+template <> struct RawVec<4> { typedef f4u type; };
+template <> struct RawVec<2> { typedef f2u type; };
+
+// raw rows of one cell over the tile's main chunk (SPL samples per lane at LDS position p): always the clamped form of the
+// address -- the loads run once per GROUP here, their address arithmetic does not matter -- and always all four nodes: a
+// centroid exactly on a node carries the weights (1, 0, 0, 0) and four times the same row, and 1 v + 0 v + 0 v + 0 v is v
+// bit for bit (also for -0), so no separate unblended form is needed (gfdb.f90:890-893 vs :944-949)
+// The components one workgroup of accumulate_cell_kernel works on, in APPLICATION order (seismogram.f90:171-250):
+// PART 0 = all of them; PART 1 = the horizontal block 1 2 3 [9] 4 5 (radial and transverse sums, rotated into the north /
+// east or away / right traces), PART 2 = the vertical block 6 7 8 [10].  Two workgroups per (source, tile, receiver) halve
+// the raw rows a lane keeps in registers (more waves per SIMD) at the price of doing the per-centroid bookkeeping twice.
+template <int NG, int PART> struct CellPart;
+template <> struct CellPart<10, 0> { static constexpr int n = 10; static constexpr int first = 0; __device__ static constexpr int ig(int i) { return i < 3 ? i : (i == 3 ? 8 : (i < 9 ? i - 1 : 9)); } };
+template <> struct CellPart<8, 0>  { static constexpr int n = 8; static constexpr int first = 0; __device__ static constexpr int ig(int i) { return i; } };
+template <> struct CellPart<10, 1> { static constexpr int n = 6; static constexpr int first = 0; __device__ static constexpr int ig(int i) { return i < 3 ? i : (i == 3 ? 8 : i - 1); } };
+template <> struct CellPart<10, 2> { static constexpr int n = 4; static constexpr int first = 6; __device__ static constexpr int ig(int i) { return i < 3 ? 5 + i : 9; } };
+template <> struct CellPart<8, 1>  { static constexpr int n = 5; static constexpr int first = 0; __device__ static constexpr int ig(int i) { return i; } };
+template <> struct CellPart<8, 2>  { static constexpr int n = 3; static constexpr int first = 5; __device__ static constexpr int ig(int i) { return 5 + i; } };
+
+template <int NG, int PART, int SPL> using RawArr = typename RawVec<SPL>::type[CellPart<NG, PART>::n][4];
+
+template <int NG, int PART, int SPL>
+__device__ __forceinline__ void raw_issue(RawArr<NG, PART, SPL> &v, int p, int jb,
+                                          const float *__restrict__ G, int pitch, int ta, int tb)
+{
+    typedef typename RawVec<SPL>::type RV;
+    typedef CellPart<NG, PART> P;
+    const int j = jb + p;
+#pragma unroll
+    for (int i = 0; i < P::n; i++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            // row start (wave-uniform: scalar base address) + this lane's clamped position inside the row (32-bit offset):
+            // one address register per load instead of a 64-bit pair, and nothing here overflows for tensors beyond 2^31 bytes
+            const int base = REC_I(ta, 4 * P::ig(i) + k), lo = REC_I(tb, 4 * P::ig(i) + k);
+            const float *rowp = G + (size_t)(unsigned)lo;
+            const int q = min(max(base - lo + j, 0), pitch - 4);
+            v[i][k] = *(const RV *)((const char *)rowp + (unsigned)(4 * q));
+        }
+    }
+}
+
+template <int NG, int PART, int SPL>
+__device__ __forceinline__ void raw_blend_store(const RawArr<NG, PART, SPL> &v, float *__restrict__ tile0,
+                                                int lds_tile, int p, float w0, float w1, float w2, float w3)
+{
+    typedef typename RawVec<SPL>::type RV;
+#pragma unroll
+    for (int i = 0; i < CellPart<NG, PART>::n; i++) {
+        RV b = w0 * v[i][0];                      // gfdb.f90:946-949, summed in this order
+        b = b + w1 * v[i][1];
+        b = b + w2 * v[i][2];
+        b = b + w3 * v[i][3];
+        if constexpr (SPL == 4) *(float4 *)(tile0 + i * lds_tile + p) = make_float4(b.x, b.y, b.z, b.w);
+        else                    *(float2 *)(tile0 + i * lds_tile + p) = make_float2(b.x, b.y);
+    }
+}
+
+// One centroid's components of PART from the LDS tiles (tile i = i-th component of the part in application order); the same
+// operations in the same order as centroid_apply_hd performs for these components.
+template <int NG, int PART, int LDS_TILE, bool TAIL, int NP>
+__device__ __forceinline__ void cell_apply(f2v (&ar1)[NP], f2v (&ar2)[NP], f2v (&dz)[NP], const TileBase &chunk0, int jl,
+                                           const int (&jend)[CellPart<NG, PART>::n], int flags, const float *__restrict__ coef, int rec,
+                                           float sd, float cl, float sl)
+{
+    typedef CellPart<NG, PART> P;
+    constexpr int nH1 = (NG == 10) ? 4 : 3;      // components summed into the radial trace
+    constexpr int nH = (NG == 10) ? 6 : 5;       // horizontal block
+    constexpr int g0 = P::first;                 // application-order index of the part's first component
+    float fac[P::n];
+#pragma unroll
+    for (int i = 0; i < P::n; i++) fac[i] = 0.f;
+    if constexpr (TAIL) {                         // the tail rule needs the plain factors (sparse_trace.f90:698-703)
+        const float f0 = REC_F(rec, 10), f1 = REC_F(rec, 11), f2 = REC_F(rec, 12), f3 = REC_F(rec, 13), f4 = REC_F(rec, 14), f5 = REC_F(rec, 15);
+        const float all10[10] = { f0, f1, f2, f5, f3, f4, f0 * sd, f1 * sd, f2 * sd, f5 * sd };
+        const float all8[8] = { f0, f1, f2, f3, f4, f0 * sd, f1 * sd, f2 * sd };
+#pragma unroll
+        for (int i = 0; i < P::n; i++) fac[i] = (NG == 10) ? all10[g0 + i] : all8[g0 + i];
+    }
+    float cw[2 * P::n];                           // scalar loads: (wl, wr) per component in application order (geometry_kernel)
+#pragma unroll
+    for (int i = 0; i < 2 * P::n; i++) cw[i] = coef[2 * g0 + i];
+    constexpr int kAhead = 2;
+    TileRegsN<NP> tr[P::n];
+#pragma unroll
+    for (int i = 0; i < kAhead && i < P::n; i++) tr[i] = tile_load<NP>(chunk0, i * LDS_TILE);
+    const bool rot = (flags & 2) != 0;           // seismogram.f90:160-203 vs :205-231
+    f2v t1[NP], t2[NP];
+    if constexpr (PART != 2) {
+#pragma unroll
+        for (int k = 0; k < NP; k++) { t1[k] = rot ? f2v{ 0.f, 0.f } : ar1[k]; t2[k] = rot ? f2v{ 0.f, 0.f } : ar2[k]; }
+    }
+#pragma unroll
+    for (int i = 0; i < P::n; i++) {
+        if (i + kAhead < P::n) tr[i + kAhead] = tile_load<NP>(chunk0, (i + kAhead) * LDS_TILE);
+        __builtin_amdgcn_sched_barrier(0);
+        const int a = g0 + i;                    // application-order index
+        if (a < nH1)     tile_fma<TAIL, NP>(t1, tr[i], jl, jend[i], fac[i], cw[2 * i], cw[2 * i + 1]);
+        else if (a < nH) tile_fma<TAIL, NP>(t2, tr[i], jl, jend[i], fac[i], cw[2 * i], cw[2 * i + 1]);
+        else             tile_fma<TAIL, NP>(dz, tr[i], jl, jend[i], fac[i], cw[2 * i], cw[2 * i + 1]);
+        if (a == nH - 1) {
+            if (rot) {
+#pragma unroll
+                for (int k = 0; k < NP; k++) {
+                    ar1[k] = ar1[k] + cl * t1[k] - sl * t2[k];
+                    ar2[k] = ar2[k] + cl * t2[k] + sl * t1[k];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NP; k++) { ar1[k] = t1[k]; ar2[k] = t2[k]; }
+            }
+        }
+    }
+}
+
+// waves per SIMD the register allocation aims at: the whole component set (PART 0) keeps 80 + 16 raw registers per lane and
+// runs best at two, a half set (PART 1 / 2) at three
+#ifndef KIWI_CELL_WAVES
+#define KIWI_CELL_WAVES(PART) ((PART) == 0 ? 2 : 3)
+#endif
+// SPL: output samples per lane (tile = SPL * T samples).  With four the raw rows of a group take 160 registers per lane and
+// leave room for one wave per SIMD only; with two they take 80 and the kernel keeps the grouped kernel's three waves.
+//
+// Takes the (source, receiver) pairs of cell_pair(): receivers with horizontal and vertical components, no centroid with a
+// missing trace; accumulate_grouped_kernel is launched behind it for the other pairs.
+//
+// Schedule.  Two LDS tile sets: while centroid k is applied from one, centroid k + 1 of the group is blended into the
+// other (ONE barrier per centroid, and the blend's arithmetic fills the issue slots the apply's LDS reads leave).  During
+// the last apply of a group the raw registers are free again, so the loads of the NEXT group's rows are issued there and
+// their L2 round trip is hidden behind that apply.
+template <int NG, int T, int SPL, int PART, bool FUSE>
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_CELL_WAVES(PART)))) void accumulate_cell_kernel(
+    const float *__restrict__ G, const int2 *__restrict__ span, int pitch,
+    const GeoRec *__restrict__ recs, const int *__restrict__ cent_ofs, int isrc0, int nrec,
+    const RecvDev *__restrict__ recv, float *__restrict__ syn, size_t syn_stride, int ntiles,
+    const int *__restrict__ tab, FuseParams fp, const int *__restrict__ pairflag)
+{
+    constexpr int NP = SPL / 2;
+    constexpr int TILE = SPL * T;
+    constexpr int LDS_TILE = TILE + kHalo;
+    static_assert(LDS_TILE % 64 == 0, "ds_read2st64 offsets");
+    typedef CellPart<NG, PART> P;
+    static_assert(16 * P::n <= T, "one halo chunk per lane");
+    __shared__ __attribute__((aligned(16))) float tiles[2][P::n][LDS_TILE];
+    const int s = (int)blockIdx.x;                        // source index fastest (see accumulate_grouped_kernel)
+    const int tile = blockIdx.y % ntiles, r = blockIdx.y / ntiles;
+    const RecvDev &rv = recv[r];
+    if (!rv.enabled) return;
+    if (tile * TILE >= rv.wlen) return;
+    if (!cell_pair(rv, pairflag, s, nrec, r)) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int t_tile0 = rv.wbeg + tile * TILE;
+    const int cb = cent_ofs[isrc0], c0 = cent_ofs[isrc0 + s], nc = cent_ofs[isrc0 + s + 1] - c0;
+    const GeoRec *__restrict__ rc = recs + ((size_t)(c0 - cb) * nrec + (size_t)r * nc);
+    const int *__restrict__ tc = tab + ((size_t)(c0 - cb) * nrec + (size_t)r * nc) * 128;
+    const float sd = rv.sd;
+    const int u0 = SPL * (tid & ~63) + lane;             // this lane's first tile sample (the others: + 64 q)
+    // halo: lane q < 16 n owns the 4-sample chunk (q & 15) of the part's component q >> 4 beyond the tile
+    const int hloc = min(tid >> 4, P::n - 1), hph = TILE + 4 * (tid & 15);
+    int hig = P::ig(0);
+#pragma unroll
+    for (int i = 1; i < P::n; i++) if (hloc == i) hig = P::ig(i);
+    const bool hslot = (tid >> 4) < P::n;
+
+    f2v ar1[NP], ar2[NP], dz[NP];
+#pragma unroll
+    for (int h = 0; h < NP; h++) { ar1[h] = f2v{ 0.f, 0.f }; ar2[h] = f2v{ 0.f, 0.f }; dz[h] = f2v{ 0.f, 0.f }; }
+    typename RawVec<SPL>::type raw[P::n][4];             // raw rows of the current group over the tile's main chunk
+    HaloRegs hraw;                                       // ... and over the halo chunk of this lane
+
+    // issue the loads of the group with head fields (pad, ishift) and descriptors ta_ / tb_
+#define CELL_LOAD(head_pad, head_ishift, ta_, tb_) do { \
+        const int smax_ = (head_ishift) + (((head_pad) >> 8) & 0xff), smin_ = (head_ishift) - (((head_pad) >> 16) & 0xff); \
+        const int jb_ = t_tile0 - smax_ - 1, npos_ = TILE + (smax_ - smin_) + 8; \
+        raw_issue<NG, PART, SPL>(raw, SPL * tid, jb_, G, pitch, ta_, tb_); \
+        hraw = halo_issue<true, false>(hslot && hph < npos_, hig, hph, jb_, G, pitch, ta_, tb_); \
+    } while (0)
+    // blend the registers with the weights in lanes 4..7 of record `rec_` into tile set `buf_`
+#define CELL_BLEND(rec_, buf_, npos_) do { \
+        GeoRec gw_; \
+        gw_.w[0] = REC_F(rec_, 4); gw_.w[1] = REC_F(rec_, 5); gw_.w[2] = REC_F(rec_, 6); gw_.w[3] = REC_F(rec_, 7); \
+        float *tile0_ = &tiles[buf_][0][0]; \
+        raw_blend_store<NG, PART, SPL>(raw, tile0_, LDS_TILE, SPL * tid, gw_.w[0], gw_.w[1], gw_.w[2], gw_.w[3]); \
+        halo_finish<true>(hslot && hph < (npos_), hraw, tile0_, LDS_TILE, hloc, hph, gw_); \
+    } while (0)
+
+    int c = 0;
+    int cur = rec_load(rc, 0, nc, lane);                 // record c, lane-distributed; nx1: record c + 1
+    int nx1 = rec_load(rc, 1, nc, lane);
+    int ta = tc[lane], tb = tc[64 + lane];               // load descriptors of record c
+    bool preloaded = false;                              // the loads of the group starting at c were issued during the previous apply
+    while (c < nc) {
+        const int row0 = REC_I(cur, 0), pad0 = REC_I(cur, 19), ishift0 = REC_I(cur, 8);
+        if (row0 < 0) {                                  // nothing of this centroid is added
+            c++;
+            cur = nx1;
+            nx1 = rec_load(rc, c + 1, nc, lane);
+            if (c < nc) { ta = tc[(size_t)c * 128 + lane]; tb = tc[(size_t)c * 128 + 64 + lane]; }
+            preloaded = false;
+            continue;
+        }
+        const int cend = c + (pad0 & 0xff);
+        const int smax = ishift0 + ((pad0 >> 8) & 0xff), smin = ishift0 - ((pad0 >> 16) & 0xff);
+        const int jb = t_tile0 - smax - 1;               // LDS position p holds blended trace sample jb + p
+        const int npos = TILE + (smax - smin) + 8;
+        int jend[P::n];
+#pragma unroll
+        for (int i = 0; i < P::n; i++) jend[i] = REC_I(ta, 40 + P::ig(i));
+        const int jend_min = PART == 0 ? min(REC_I(ta, 50), REC_I(ta, 51)) : REC_I(ta, PART == 1 ? 50 : 51);
+        if (!preloaded) CELL_LOAD(pad0, ishift0, ta, tb);
+        // descriptors of the NEXT group
+        int ta_n = 0, tb_n = 0;
+        if (cend < nc) { ta_n = tc[(size_t)cend * 128 + lane]; tb_n = tc[(size_t)cend * 128 + 64 + lane]; }
+        const size_t crow = ((size_t)(c0 - cb) * nrec + (size_t)r * nc + c) * 128 + 64 + 40;
+        const unsigned clo = __builtin_amdgcn_readfirstlane((unsigned)crow), chi = __builtin_amdgcn_readfirstlane((unsigned)(crow >> 32));
+        const float *__restrict__ coef_grp = (const float *)(tab + (((size_t)chi << 32) | clo));
+        // ---- first centroid of the group: its tile goes into set 0 (every set is free after the barrier that ended the last group)
+        CELL_BLEND(cur, 0, npos);
+        __syncthreads();
+        int bsel = 0;
+        preloaded = false;
+        for (int cc = c; cc < cend; cc++) {
+            const int nx2 = rec_load(rc, cc + 2, nc, lane);      // two records ahead: the next one is needed for its weights now
+            const int flags = REC_I(cur, 18);
+            // ---- centroid cc + 1 of the group into the other tile set (a centroid at the point of its predecessor keeps the tile)
+            const bool blend_next = (cc + 1 < cend) && !(REC_I(nx1, 18) & 4);
+            if (blend_next) CELL_BLEND(nx1, bsel ^ 1, npos);
+            // ---- last centroid of the group: the raw registers are free, the next group's rows can be on their way
+            if (cc + 1 == cend && cend < nc && REC_I(nx1, 0) >= 0) {
+                CELL_LOAD(REC_I(nx1, 19), REC_I(nx1, 8), ta_n, tb_n);
+                preloaded = true;
+            }
+            // ---- apply centroid cc from tile set bsel (as accumulate_grouped_kernel)
+            const int ishift = REC_I(cur, 8);
+            const float cl = REC_F(cur, 16), sl = REC_F(cur, 17);
+            const float *__restrict__ coef = coef_grp + (size_t)(cc - c) * 128;
+            const int e = smax - ishift;
+            const TileBase chunk0 = tile_base(&tiles[bsel][0][e + u0]);
+            const int jl = jb + e + u0;
+            const bool tail = (jb + e + TILE) > jend_min;
+            if (!tail) cell_apply<NG, PART, LDS_TILE, false, NP>(ar1, ar2, dz, chunk0, jl, jend, flags, coef, cur, sd, cl, sl);
+            else       cell_apply<NG, PART, LDS_TILE, true, NP>(ar1, ar2, dz, chunk0, jl, jend, flags, coef, cur, sd, cl, sl);
+            __syncthreads();                             // set bsel may be overwritten, set bsel ^ 1 is complete
+            if (blend_next) bsel ^= 1;
+            cur = nx1; nx1 = nx2;
+        }
+        ta = ta_n; tb = tb_n;
+        c = cend;
+    }
+#undef CELL_LOAD
+#undef CELL_BLEND
+    // ---- rotation to N/E, signs, store or fused comparator (seismogram.f90:256-283), as accumulate_grouped_kernel
+    {
+        const int tl = tile * TILE + u0;
+        if (!FUSE && tl >= rv.wlen) return;
+        float *__restrict__ so = syn + (size_t)s * syn_stride + tl;
+        float a1[SPL], a2[SPL], ad[SPL];
+#pragma unroll
+        for (int h = 0; h < NP; h++) {
+            a1[2 * h] = ar1[h].x; a1[2 * h + 1] = ar1[h].y; a2[2 * h] = ar2[h].x; a2[2 * h + 1] = ar2[h].y;
+            ad[2 * h] = dz[h].x; ad[2 * h + 1] = dz[h].y;
+        }
+        float mom = 0.f;
+        if constexpr (FUSE) mom = fp.moment[fp.isrc0 + s];
+        const bool unit = (fp.syn_factor == 1.f);
+        for (int k = 0; k < rv.ncomp; k++) {
+            if (PART != 0 && (rv.comp[k] == 3) != (PART == 2)) continue;      // the vertical trace belongs to the PART 2 workgroup
+            const float sg = rv.sign[k];
+            float o[SPL];
+#pragma unroll
+            for (int i = 0; i < SPL; i++) {
+                switch (rv.comp[k]) {
+                case 1: o[i] = a1[i] * sg; break;
+                case 2: o[i] = a2[i] * sg; break;
+                case 3: o[i] = ad[i]; break;
+                case 4: o[i] = (rv.cl0 * a1[i] - rv.sl0 * a2[i]) * sg; break;
+                default: o[i] = (rv.cl0 * a2[i] + rv.sl0 * a1[i]) * sg; break;
+                }
+            }
+            if constexpr (!FUSE) {
+#pragma unroll
+                for (int i = 0; i < SPL; i++)
+                    if (tl + 64 * i < rv.wlen) so[rv.synofs[k] + 64 * i] = o[i];
+                continue;
+            }
+            double acc = 0.0;
+            const float *__restrict__ rt = fp.reft + rv.refofs[k] + tl, *__restrict__ tp = fp.tw + rv.refofs[k] + tl;
+#pragma unroll
+            for (int i = 0; i < SPL; i++) {
+                if (tl + 64 * i >= rv.wlen) break;
+                const float v = o[i] * mom;
+                const float vt = v * tp[64 * i];
+                const float a = rt[64 * i];
+                switch (fp.method) {
+                case 1: { const float d = unit ? (a - vt) : (1.f * a - fp.syn_factor * vt); acc += (double)d * (double)d; break; }
+                case 2: { const float d = unit ? fabsf(a - vt) : fabsf(1.f * a - fp.syn_factor * vt); acc += (double)d; break; }
+                case 5: acc += unit ? (double)(a * vt) : (double)(a * 1.f * vt * fp.syn_factor); break;
+                default: { const double x = (double)(1.f * a), y = (double)(fp.syn_factor * vt); acc = fmax(acc, sqrt(x * x + y * y)); break; }
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double other = __shfl_down(acc, off, 64);
+                acc = (fp.method == 6) ? fmax(acc, other) : acc + other;
+            }
+            if (lane == 0)
+                fp.partial[((size_t)s * fp.nmis + rv.slot0 + k) * fp.nparts + tile * (T / 64) + (tid >> 6)] = acc;
+        }
     }
 }
 
@@ -1547,7 +1956,8 @@ __global__ void misfit_finish_kernel(const double *__restrict__ partial, const C
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nsrc * nmis) return;
     const int s = idx / nmis, m = idx - s * nmis;
-    const int np = ((comps[m].wlen + tile_len - 1) / tile_len) * waves_per_tile;      // tiles this slot's window spans
+    // tiles this slot's window spans; tile_len == 0: every entry (the buffer was cleared; two kernels with different tilings)
+    const int np = tile_len > 0 ? ((comps[m].wlen + tile_len - 1) / tile_len) * waves_per_tile : nparts;
     const double *p = partial + (size_t)idx * nparts;
     double tot = 0.0;
     for (int q = 0; q < np; q++) tot = (method == 6) ? fmax(tot, p[q]) : tot + p[q];
