@@ -6,11 +6,13 @@ north_star target is quoted on -- `bilateral` extended rupture discretised into 
 50 receivers x 3 components (n,e,d), 4096-sample Green's functions (ng = 10, bilinear
 interpolation = 4 neighbour traces), time-domain L2 misfit over a 4096-sample tapered window.
 `--workload cfg2|cfg4|cfg5` run the other BASELINE.json configurations (moment-tensor grid;
-mt_eikonal 468 centroids x 200 receivers; spectral comparator with frequency filter) the same way.
+mt_eikonal 468 centroids x 200 receivers; spectral comparator with frequency filter) the same way;
+`cfg3-100pt` is the same source type with 100 sub-fault POINTS (200 centroids), `cfg3-scatter` the
+cfg3 source over a shuffled location grid (no Green's function rows shared between neighbouring trials).
 One "step" = one pass of the hot path (geometry -> accumulate -> misfit) over a batch of
 --batch trial sources per GPU, everything already resident in HBM.  N > 1: every rank evaluates
 its own contiguous shard of the trial list (weak scaling) and the per-source global misfits are
-all-gathered over RCCL.
+all-gathered over RCCL; `python bench.py --gpus N` starts the N ranks itself.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` and `cpu_baseline`.
 """
@@ -27,6 +29,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+# Peak FP32 (vector) 157.3 TFLOP/s counts fused multiply-adds; the reference rounds every multiply and every add on its
+# own (the library is built with -ffp-contract=off and parity is bit-level), so a lane does one flop per packed slot:
+VALU_PEAK_TFLOPS = 157.3 / 2.0
 NORM_ID = {"l2norm": 1, "l1norm": 2, "ampspec_l2norm": 3, "ampspec_l1norm": 4}
 
 
@@ -84,9 +89,12 @@ def setup_product(device, wl, L):
     sample = trials[:: max(1, len(trials) // 16)]
     if wl["crust"] is not None:
         st = 4 if wl["sourcetype"] == "eikonal" else 5
-        nc = [len(discretize_eikonal(st, t, 0.5, wl["crust"], *wl["constraints"])[0]) for t in sample]
+        tabs = [discretize_eikonal(st, t, 0.5, wl["crust"], *wl["constraints"])[0] for t in sample]
     else:
-        nc = [len(discretize(wl["sourcetype"], t, 0.5)[0]) for t in sample]
+        tabs = [discretize(wl["sourcetype"], t, 0.5)[0] for t in sample]
+    nc = [len(t) for t in tabs]
+    # sub-fault POINTS (runs of centroids at one position: the time steps of a sub-fault share their blended traces)
+    wl["npoints"] = float(np.mean([1 + np.count_nonzero(np.any(t[1:, :3] != t[:-1, :3], axis=1)) for t in tabs]))
     return p, gf, (lat, lon, depth, comps), refs, tapers, float(np.mean(nc))
 
 
@@ -144,7 +152,7 @@ def oracle_engine(wl, gf, recv, refs, tapers, cores, fresh=False):
     return e, db, evaluate
 
 
-def cpu_baseline(wl, gf, recv, refs, tapers, gpu_global, budget_s=20.0):
+def cpu_baseline(wl, gf, recv, refs, tapers, gpu_global, gpu_misfits, gpu_norms, budget_s=20.0):
     """The oracle (C restatement, OpenMP over receivers like minimizer_engine.f90:893-903) timed on
     this box's host cores for a bounded number of the SAME trial sources."""
     # the reference parallelises make_seismogram over receivers (minimizer_engine.f90:893-903): no more threads than
@@ -154,7 +162,7 @@ def cpu_baseline(wl, gf, recv, refs, tapers, gpu_global, budget_s=20.0):
     e, db, evaluate = oracle_engine(wl, gf, recv, refs, tapers, cores)
 
     def one(t):
-        return evaluate(t)[2]
+        return evaluate(t)
 
     one(trials[0])                                    # warm-up (allocations)
     t0 = time.perf_counter()
@@ -162,9 +170,16 @@ def cpu_baseline(wl, gf, recv, refs, tapers, gpu_global, budget_s=20.0):
     t1 = time.perf_counter() - t0
     n = int(max(2, min(len(trials), budget_s / max(t1, 1e-3))))
     t0 = time.perf_counter()
-    gl = np.array([one(trials[i]) for i in range(n)])
+    res = [one(trials[i]) for i in range(n)]
     dtm = time.perf_counter() - t0
+    gl = np.array([r[2] for r in res])
     err = float(np.max(np.abs(gpu_global[:n] - gl) / np.abs(gl)))
+    # every per-receiver-component misfit of the sample, not only the global one: difference relative to the slot's
+    # norm factor (a misfit can be arbitrarily close to zero), and the norm factors themselves
+    om = np.array([r[0] for r in res], np.float64)
+    on = np.array([r[1] for r in res], np.float64)
+    slot_err = float(np.max(np.abs(gpu_misfits[:n] - om) / on))
+    norm_err = float(np.max(np.abs(gpu_norms[:n] - on) / on))
     # the same on ONE core (SURVEY 8d asks for both), two sources
     e.set_nthreads(1)
     t0 = time.perf_counter()
@@ -180,7 +195,8 @@ def cpu_baseline(wl, gf, recv, refs, tapers, gpu_global, budget_s=20.0):
             "value_1core": v1,
             "reference_in_dev_container": "the reference itself (amdflang -O2, 135 centroids, 8 vCPU Xeon 2.1 GHz): 0.76 evals/s "
                                           "on 8 threads, 0.11 on one (BASELINE.md section 2); this port there: 6.2 on 8 threads",
-            "max_rel_misfit_diff_vs_gpu": err}
+            "max_rel_misfit_diff_vs_gpu": err,
+            "max_slot_misfit_diff_vs_gpu_rel_to_norm": slot_err, "max_rel_norm_factor_diff_vs_gpu": norm_err}
 
 
 def measured_copy_bandwidth(torch, device):
@@ -230,10 +246,10 @@ def main():
                     help="ranks = GPUs of this node (default: WORLD_SIZE when started by a launcher, else 1)")
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5", "cfg3-100pt", "cfg3-scatter"],
                     help="BASELINE.json configs[1..4]; cfg3 (default) is the one the metric is quoted on")
     ap.add_argument("--batch", type=int, default=0,
-                    help="trial sources per GPU per step (default: 12960 cfg2, 256 cfg3/cfg5, 128 cfg4)")
+                    help="trial sources per GPU per step (default: 12960 cfg2, 1024 cfg3 / cfg3-scatter, 512 cfg3-100pt / cfg5, 128 cfg4)")
     ap.add_argument("--samples", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -268,7 +284,7 @@ def main():
     from kiwi_amd.shard import shard_range, gather_misfits
     from kiwi_amd import synthetic
     if args.batch <= 0:
-        args.batch = {"cfg2": 12960, "cfg3": 256, "cfg4": 128, "cfg5": 256}[args.workload]
+        args.batch = {"cfg2": 12960, "cfg3": 1024, "cfg3-scatter": 1024, "cfg3-100pt": 512, "cfg4": 128, "cfg5": 512}[args.workload]
     lo, hi = shard_range(args.batch * ngpus, ngpus, rank)
     wl = synthetic.workload(args.workload, hi - lo, lo)
     p, gf, recv, refs, tapers, ncent = setup_product(local_rank, wl, args.samples)
@@ -314,62 +330,78 @@ def main():
         total_evals = args.batch * ngpus * args.steps
         value = total_evals / elapsed
         n_ip, ng, L, W = 4, gf["data"].shape[2], args.samples, args.samples
-        b_eval = int(ncent * nrec * ng * n_ip * L * 4 + nrec * 3 * W * 4 * 2)
+        npts = wl["npoints"]
         acc_s = float(ms[1]) * 1e-3
-        bytes_launched = b_eval * args.batch * args.steps           # rank 0's launches
-        achieved = bytes_launched / acc_s / 1e9 if acc_s > 0 else 0.0
-        # fabric (L2 <-> Infinity Cache / HBM) bytes per launch from the committed PMC passes of this same
-        # command (profiles/*_summary.json: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE); PMC
-        # counters cannot be collected from inside this process, so this is null when no profile matches
-        traffic = None
+        launches_acc = max(int(launches[1]), 1)
+        # ---- what the accumulate kernel has to execute per trial source: separately rounded fp32
+        # multiplies and adds in the reference's order -- apply: 4 per GF component, centroid and output sample + 8 for the
+        # per-centroid rotation (seismogram.f90:171-250, sparse_trace.f90:684-703); blend: 7 per component and sample,
+        # once per sub-fault POINT and receiver (gfdb.f90:944-949; the time steps of a point share the blended trace)
+        flops_eval = ncent * nrec * W * (4 * ng + 8) + npts * nrec * W * ng * 7
+        achieved_tflops = flops_eval * args.batch * args.steps / acc_s / 1e12 if acc_s > 0 else 0.0
+        # ---- the SURVEY 8d byte model (no reuse at all: every centroid re-reads its n_g x n_ip rows over the window)
+        b_eval = int(ncent * nrec * ng * n_ip * L * 4 + nrec * 3 * W * 4 * 2)
+        no_reuse_gbs = b_eval * args.batch * args.steps / acc_s / 1e9 if acc_s > 0 else 0.0
+        # ---- measured counters of this same command from the committed rocprofv3 passes (profiles/r*_summary.json):
+        # PMC counters cannot be collected from inside this process, so these are null when no profile matches
+        prof = {}
         try:
             import glob
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json"))):
-                prof = json.load(open(f))
-                tb = prof.get("traffic_bytes_per_launch")
-                if tb and tb.get("batch") and os.environ.get("KIWI_HIP_ACCUM") != "direct" and \
-                        tb.get("workload", "cfg3") == args.workload:
-                    traffic = tb["total"] * args.batch / tb["batch"]
+                w = json.load(open(f)).get("workloads", {}).get(args.workload)
+                if w and w.get("batch") and os.environ.get("KIWI_HIP_ACCUM") != "direct":
+                    prof = dict(w, file=os.path.basename(f))
         except Exception:
-            traffic = None
+            prof = {}
+        scale = args.batch / prof["batch"] if prof else 0.0
+        traffic = prof["hbm_bytes_per_launch"] * scale if prof.get("hbm_bytes_per_launch") else None
+        avg_ms = float(ms[1]) / launches_acc
         try:
             copy_gbs = measured_copy_bandwidth(torch, torch.device("cuda", local_rank))
         except Exception:
             copy_gbs = None
+        kernel = "accumulate_kernel (KIWI_HIP_ACCUM=direct)" if os.environ.get("KIWI_HIP_ACCUM") == "direct" else \
+            ("accumulate_cell_kernel<10,256,2,0> (+ accumulate_grouped_kernel for the pairs it leaves)" if npts > 0.5 * ncent
+             else "accumulate_grouped_kernel<10,256>")
         out = {
             "metric": "trial-source misfit evals/s", "value": value, "unit": "evals/s",
             "n_gpus": ngpus, "rccl_world_size": dist.get_world_size() if dist is not None else None,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %s source, %.0f centroids x %d receivers x 3 comp x %d samples, "
+            "config": {"workload": "%s: %s source, %.0f centroids (%.0f sub-fault points) x %d receivers x 3 comp x %d samples, "
                                    "ng=10, bilinear GF interpolation, %s%s, tapered %d-sample window"
-                                   % (wl["name"], wl["sourcetype"], ncent, nrec, L, wl["method"],
+                                   % (wl["name"], wl["sourcetype"], ncent, npts, nrec, L, wl["method"],
                                       " + frequency filter" if wl["filter"] is not None else "", W),
                        "trial_sources_per_gpu_per_step": args.batch, "misfits_per_source": nmis,
                        "parallelism": "trial-source shard x%d, all-gather of global misfits" % ngpus},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "peak_measured_copy": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs if copy_gbs else None,
-                         "kernel": "accumulate_grouped_kernel<10,256>" if os.environ.get("KIWI_HIP_ACCUM") != "direct" else "accumulate_kernel<10>", "launches": int(launches[1]),
-                         "avg_launch_ms": float(ms[1]) / max(int(launches[1]), 1),
-                         "algorithmic_bytes_per_eval": b_eval,
-                         # the issue-side view: separately rounded fp32 multiplies and adds the kernel has to execute per
-                         # launch (apply: 4 per component and sample and centroid + 8 for the rotation; blend: 7 per
-                         # component and sample and sub-fault) against the packed-fp32 issue rate measured by
-                         # profiles/microbench/pk_rate.hip (256 CUs x 4 SIMDs x 16 lanes x 2 per lane x ~2.3 GHz, no FMA)
-                         "valu": {"achieved_tflops": (ncent * nrec * L * (ng * 4 + 8) + ncent / 5.0 * nrec * L * 1.0625 * ng * 7)
-                                  * args.batch * args.steps / acc_s / 1e12 if acc_s > 0 else 0.0,
-                                  "peak_tflops": 74.0, "unit": "Tflop/s fp32 mul/add, unfused"},
-                         "note": "achieved = no-reuse algorithmic bytes (SURVEY 8d) / kernel time; it exceeds the HBM peak because the "
-                                 "Green's function tensor is cache resident and every blended tile is reused by the time steps of a "
-                                 "sub-fault: `traffic` is what actually crossed the fabric per launch.  The kernel runs against L2->CU "
-                                 "bandwidth and VALU issue (DESIGN.md section 3, profiles/README.md)",
+            # The dominant kernel runs against the vector ALU's issue rate, not against HBM: the Green's function tensor
+            # (130-160 MB) is resident in L2 / Infinity Cache and HBM is nearly idle, by design (see `hbm` below).  `achieved`
+            # = required flops / measured kernel time, `peak` = the unfused fp32 vector rate, so frac <= 1 by construction.
+            "roofline": {"bound": "valu_issue", "achieved": achieved_tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved_tflops / VALU_PEAK_TFLOPS,
+                         "traffic": traffic,
+                         "kernel": kernel, "launches": int(launches[1]), "avg_launch_ms": avg_ms,
+                         "flops_per_eval": flops_eval,
+                         "issue_slots": {"valu_busy_frac": prof.get("valu_issue_frac"), "lds_busy_frac": prof.get("lds_busy_frac"),
+                                         "valu_insts_per_launch": prof["valu_insts_per_launch"] * scale if prof.get("valu_insts_per_launch") else None,
+                                         "source": prof.get("file")},
+                         "hbm": {"actual_gbs": traffic / (avg_ms * 1e-3) / 1e9 if traffic else None, "peak_gbs": HBM_PEAK_GBS,
+                                 "frac": traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None,
+                                 "peak_measured_copy_gbs": copy_gbs,
+                                 "l2_request_gbs": prof["l2_request_bytes_per_launch"] * scale / (avg_ms * 1e-3) / 1e9
+                                 if prof.get("l2_request_bytes_per_launch") else None,
+                                 "algorithmic_no_reuse_gbs": no_reuse_gbs, "algorithmic_bytes_per_eval": b_eval,
+                                 "reuse_factor": b_eval * args.batch / traffic if traffic else None,
+                                 "note": "algorithmic_no_reuse_gbs is the SURVEY 8d byte model (every centroid re-reads its 40 rows) "
+                                         "over the kernel time; it exceeds the HBM peak by reuse_factor because the rows are served "
+                                         "from cache and every blended tile is shared by the time steps of a sub-fault"},
                          "other_kernels_ms_per_step": {"geometry": float(ms[0]) / args.steps,
                                                        "misfit": float(ms[2]) / args.steps}},
         }
         if ngpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(wl, gf, recv, refs, tapers, np.asarray(allg))
+            gm, gn, gg = p.get_misfits()
+            out["cpu_baseline"] = cpu_baseline(wl, gf, recv, refs, tapers, np.asarray(allg), gm, gn)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -1118,6 +1118,11 @@ int kiwi_hip_set_gfdb(kiwi_hip_ctx *c, int nx, int nz, int ng, int L, float dt, 
     // >= pad + n + 5 for load5's clamp; the extra halo of repeated end values lets the grouped kernel's last
     // tile (which overhangs the window by up to kHalo samples) take its clamp-free path
     const int pitch = (kRowPad + lmax + kHalo + 32 + 3) / 4 * 4;
+    // The LDS-staged kernels address a group's rows relative to the first row of its cell with 32-bit offsets (write_tab):
+    // the tensor itself may have any size, one cell (two neighbouring distances, all depths between, all components) must
+    // stay below 2^31 floats.  set_interp checks the same with the undersampling factors.
+    if (((size_t)nz + 2) * (size_t)ng * (size_t)pitch >= ((size_t)1 << 31))
+        throw std::runtime_error("database rows too long: one distance step of the grid exceeds 2^31 samples");
     // host staging in slabs of rows: [kRowPad zeros | samples | repeated end value]
     c->G.alloc(nrows * (size_t)pitch, &c->dev_bytes);
     c->span.alloc(nrows, &c->dev_bytes);
@@ -1156,6 +1161,8 @@ int kiwi_hip_set_interp(kiwi_hip_ctx *c, int bilinear, int xus, int zus)
 {
     if (!c) return fail(nullptr, "null context");
     if (xus < 1 || zus < 1) return fail(c, "undersampling must be >= 1");
+    if (c->have_db && ((size_t)xus * c->gm.nz + zus + 1) * (size_t)c->gm.ng * (size_t)c->gm.pitch >= ((size_t)1 << 31))
+        return fail(c, "undersampling too coarse for this database: one interpolation cell exceeds 2^31 samples");
     c->bilinear = bilinear ? 1 : 0; c->xus = xus; c->zus = zus;
     // set_local_interpolation / set_spacial_undersampling dirty the seismograms (minimizer_engine.f90:1483-1493):
     // natural-span windows, transform lengths and any kept synthetics are stale

@@ -177,8 +177,9 @@ __device__ __forceinline__ bool starts_group(const float *__restrict__ cent, int
 
 // Load descriptors for accumulate_grouped_kernel, 128 ints per record, laid out so that one coalesced load per wave
 // brings them in lane-distributed: for component ig and node k
-//   tab[4*ig + k]      = row*pitch + kRowPad - first   (float index of trace sample 0, minus... + j)
-//   tab[64 + 4*ig + k] = row*pitch                     (clamp floor; ceiling = floor + pitch - 4)
+//   tab[4*ig + k]      = (row - row0)*pitch + kRowPad - first   (float index of trace sample 0 relative to the group base
+//                                                        G + row0*pitch, row0 = first row of the cell's first node)
+//   tab[64 + 4*ig + k] = (row - row0)*pitch             (clamp floor; ceiling = floor + pitch - 4)
 //   tab[40 + ig]       = last stored sample of the blended trace (max over the nodes)
 //   tab[50], tab[51]   = minimum of those over the horizontal (1-5, 9) / vertical (6-8, 10) components
 //   tab[64 + 40 + 2*i], [.. + 1] = wl, wr: per-component interpolation coefficients of THIS centroid
@@ -211,8 +212,10 @@ __device__ __forceinline__ void write_tab(int *__restrict__ tb, const GeoRec &g,
         for (int k = 0; k < 4; k++) {
             const int row = g.row[k < nn ? k : 0] + ig;
             const int2 sp = span[row];
-            bases[ig][k] = row * pitch + kRowPad - sp.x;
-            floors[ig][k] = row * pitch;
+            // offsets are relative to the first row of the cell's first node (g.row[0]): the kernels add them to a 64-bit
+            // base, so a tensor of any size works as long as one cell spans less than 2^31 floats (checked by the host)
+            bases[ig][k] = (row - g.row[0]) * pitch + kRowPad - sp.x;
+            floors[ig][k] = (row - g.row[0]) * pitch;
             if (k < nn) { je = max(je, sp.y); endzero = endzero && endz[row]; }
         }
         jend[ig] = je;
@@ -1190,15 +1193,17 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
         const int jend_min = min(need_h ? jend_h : 0x7fffffff, has_d ? jend_d : 0x7fffffff);
         {
             float *tile0 = &tiles[0][0];
+            // descriptors are relative to the first row of the group's cell (64-bit base, see write_tab)
+            const float *__restrict__ Gg = G + (size_t)g0.row[0] * (size_t)pitch;
             // all 40 rows of the group cover [jb, jb + LDS_TILE) inside their padded storage?  (lane l < 40 holds
             // row l's descriptors; workgroup-uniform because every wave holds the same table)
             const bool lane_ok = lane >= 4 * NG || (ta + jb >= tb && ta + jb + LDS_TILE <= tb + pitch);
             const bool fast = __builtin_amdgcn_ballot_w64(lane_ok) == ~0ull;
 #define BUILD_B(IGS, P) do { \
-                if (fast) { if (direct) build_batch<false, true>(tile0, LDS_TILE, IGS, P, jb, G, pitch, ta, tb, g0); \
-                            else        build_batch<true, true>(tile0, LDS_TILE, IGS, P, jb, G, pitch, ta, tb, g0); } \
-                else      { if (direct) build_batch<false, false>(tile0, LDS_TILE, IGS, P, jb, G, pitch, ta, tb, g0); \
-                            else        build_batch<true, false>(tile0, LDS_TILE, IGS, P, jb, G, pitch, ta, tb, g0); } \
+                if (fast) { if (direct) build_batch<false, true>(tile0, LDS_TILE, IGS, P, jb, Gg, pitch, ta, tb, g0); \
+                            else        build_batch<true, true>(tile0, LDS_TILE, IGS, P, jb, Gg, pitch, ta, tb, g0); } \
+                else      { if (direct) build_batch<false, false>(tile0, LDS_TILE, IGS, P, jb, Gg, pitch, ta, tb, g0); \
+                            else        build_batch<true, false>(tile0, LDS_TILE, IGS, P, jb, Gg, pitch, ta, tb, g0); } \
             } while (0)
             constexpr int H1 = NG / 2;
             int igA[H1], igB[NG - H1];
@@ -1227,10 +1232,10 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
                 hact[it] = slot < ncmp && hph[it] < npos;
             }
 #define HALO_ISSUE() do { _Pragma("unroll") for (int it = 0; it < kHaloIter; it++) { \
-                if (fast) { if (direct) hr[it] = halo_issue<false, true>(hact[it], hig[it], hph[it], jb, G, pitch, ta, tb); \
-                            else        hr[it] = halo_issue<true, true>(hact[it], hig[it], hph[it], jb, G, pitch, ta, tb); } \
-                else      { if (direct) hr[it] = halo_issue<false, false>(hact[it], hig[it], hph[it], jb, G, pitch, ta, tb); \
-                            else        hr[it] = halo_issue<true, false>(hact[it], hig[it], hph[it], jb, G, pitch, ta, tb); } } } while (0)
+                if (fast) { if (direct) hr[it] = halo_issue<false, true>(hact[it], hig[it], hph[it], jb, Gg, pitch, ta, tb); \
+                            else        hr[it] = halo_issue<true, true>(hact[it], hig[it], hph[it], jb, Gg, pitch, ta, tb); } \
+                else      { if (direct) hr[it] = halo_issue<false, false>(hact[it], hig[it], hph[it], jb, Gg, pitch, ta, tb); \
+                            else        hr[it] = halo_issue<true, false>(hact[it], hig[it], hph[it], jb, Gg, pitch, ta, tb); } } } while (0)
 #define HALO_FINISH() do { _Pragma("unroll") for (int it = 0; it < kHaloIter; it++) { \
                 if (direct) halo_finish<false>(hact[it], hr[it], tile0, LDS_TILE, hig[it], hph[it], g0); \
                 else        halo_finish<true>(hact[it], hr[it], tile0, LDS_TILE, hig[it], hph[it], g0); } } while (0)
@@ -1239,14 +1244,14 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
                 constexpr int NP = NG / 2;
 #define STREAM(BL, FA) do { \
                     f4u va[2][BL ? 4 : 1], vb[2][BL ? 4 : 1]; \
-                    pair_issue<BL, FA>(va, 0, 4 * tid, jb, G, pitch, ta, tb); \
-                    pair_issue<BL, FA>(vb, 2, 4 * tid, jb, G, pitch, ta, tb); \
+                    pair_issue<BL, FA>(va, 0, 4 * tid, jb, Gg, pitch, ta, tb); \
+                    pair_issue<BL, FA>(vb, 2, 4 * tid, jb, Gg, pitch, ta, tb); \
                     _Pragma("unroll") for (int i = 0; i < NP; i++) { \
                         __builtin_amdgcn_sched_barrier(0); \
                         if ((i & 1) == 0) { pair_finish<BL>(va, tile0, LDS_TILE, 2 * i, 4 * tid, g0); \
-                                            if (i + 2 < NP) pair_issue<BL, FA>(va, 2 * (i + 2), 4 * tid, jb, G, pitch, ta, tb); } \
+                                            if (i + 2 < NP) pair_issue<BL, FA>(va, 2 * (i + 2), 4 * tid, jb, Gg, pitch, ta, tb); } \
                         else              { pair_finish<BL>(vb, tile0, LDS_TILE, 2 * i, 4 * tid, g0); \
-                                            if (i + 2 < NP) pair_issue<BL, FA>(vb, 2 * (i + 2), 4 * tid, jb, G, pitch, ta, tb); } \
+                                            if (i + 2 < NP) pair_issue<BL, FA>(vb, 2 * (i + 2), 4 * tid, jb, Gg, pitch, ta, tb); } \
                         if (i == NP - 3) HALO_ISSUE(); \
                     } } while (0)
                 if (fast) { if (direct) STREAM(false, true); else STREAM(true, true); }
@@ -1505,11 +1510,12 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_CELL_WAV
     HaloRegs hraw;                                       // ... and over the halo chunk of this lane
 
     // issue the loads of the group with head fields (pad, ishift) and descriptors ta_ / tb_
-#define CELL_LOAD(head_pad, head_ishift, ta_, tb_) do { \
+#define CELL_LOAD(head_row0, head_pad, head_ishift, ta_, tb_) do { \
         const int smax_ = (head_ishift) + (((head_pad) >> 8) & 0xff), smin_ = (head_ishift) - (((head_pad) >> 16) & 0xff); \
         const int jb_ = t_tile0 - smax_ - 1, npos_ = TILE + (smax_ - smin_) + 8; \
-        raw_issue<NG, PART, SPL>(raw, SPL * tid, jb_, G, pitch, ta_, tb_); \
-        hraw = halo_issue<true, false>(hslot && hph < npos_, hig, hph, jb_, G, pitch, ta_, tb_); \
+        const float *__restrict__ Gg_ = G + (size_t)(head_row0) * (size_t)pitch;     /* descriptors are relative to it (write_tab) */ \
+        raw_issue<NG, PART, SPL>(raw, SPL * tid, jb_, Gg_, pitch, ta_, tb_); \
+        hraw = halo_issue<true, false>(hslot && hph < npos_, hig, hph, jb_, Gg_, pitch, ta_, tb_); \
     } while (0)
     // blend the registers with the weights in lanes 4..7 of record `rec_` into tile set `buf_`
 #define CELL_BLEND(rec_, buf_, npos_) do { \
@@ -1543,7 +1549,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_CELL_WAV
 #pragma unroll
         for (int i = 0; i < P::n; i++) jend[i] = REC_I(ta, 40 + P::ig(i));
         const int jend_min = PART == 0 ? min(REC_I(ta, 50), REC_I(ta, 51)) : REC_I(ta, PART == 1 ? 50 : 51);
-        if (!preloaded) CELL_LOAD(pad0, ishift0, ta, tb);
+        if (!preloaded) CELL_LOAD(row0, pad0, ishift0, ta, tb);
         // descriptors of the NEXT group
         int ta_n = 0, tb_n = 0;
         if (cend < nc) { ta_n = tc[(size_t)cend * 128 + lane]; tb_n = tc[(size_t)cend * 128 + 64 + lane]; }
@@ -1563,7 +1569,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_CELL_WAV
             if (blend_next) CELL_BLEND(nx1, bsel ^ 1, npos);
             // ---- last centroid of the group: the raw registers are free, the next group's rows can be on their way
             if (cc + 1 == cend && cend < nc && REC_I(nx1, 0) >= 0) {
-                CELL_LOAD(REC_I(nx1, 19), REC_I(nx1, 8), ta_n, tb_n);
+                CELL_LOAD(REC_I(nx1, 0), REC_I(nx1, 19), REC_I(nx1, 8), ta_n, tb_n);
                 preloaded = true;
             }
             // ---- apply centroid cc from tile set bsel (as accumulate_grouped_kernel)

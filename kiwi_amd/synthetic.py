@@ -173,6 +173,29 @@ def workload(name, nsrc=None, trial0=0):
         tr[:, 5] += 0.1 * trial0
         return dict(name="cfg3-bilat", sourcetype="bilateral", true=np.array(base, np.float32), trials=tr, nrec=50,
                     nx=128, method="l2norm", filter=None, crust=None, constraints=None)
+    if name == "cfg3-100pt":
+        # the north star's "100 sub-faults" taken literally: 25 x 4 sub-fault points of an 18 km x 4.5 km rupture, two
+        # source-time-function steps each (200 centroids)
+        base = [0., 0., 0., 10000., 1e20, 91., 87., 164., 0., 12000., 6000., 4500., 3000., 0.5]
+        n = 256 if nsrc is None else nsrc
+        tr = bilat_strike_sweep(n, step=0.1, base=base)
+        tr[:, 5] += 0.1 * trial0
+        return dict(name="cfg3-100pt", sourcetype="bilateral", true=np.array(base, np.float32), trials=tr, nrec=50,
+                    nx=128, method="l2norm", filter=None, crust=None, constraints=None)
+    if name == "cfg3-scatter":
+        # the cfg3 source on a LOCATION grid (4 km steps over +-32 km north and east, 8 depths, strike sweep on top), in
+        # shuffled order: co-resident workgroups of neighbouring trial sources do not read the same Green's function rows
+        base = [0., 0., 0., 10000., 1e20, 91., 87., 164., 0., 4800., 2000., 2000., 3000., 2.]
+        n = 256 if nsrc is None else nsrc
+        total = 1 << 15
+        idx = np.random.default_rng(20261002).permutation(total)[(trial0 + np.arange(n)) % total]
+        tr = np.tile(np.array(base, np.float32), (n, 1))
+        tr[:, 1] = 4000.0 * (idx % 16 - 8)
+        tr[:, 2] = 4000.0 * ((idx // 16) % 16 - 8)
+        tr[:, 3] = 8000.0 + 500.0 * ((idx // 256) % 8)
+        tr[:, 5] = 91.0 + 0.1 * (idx // 2048)
+        return dict(name="cfg3-scatter", sourcetype="bilateral", true=np.array(base, np.float32), trials=tr, nrec=50,
+                    nx=128, method="l2norm", filter=None, crust=None, constraints=None)
     if name == "cfg4":
         grid = mt_eikonal_location_grid()
         n = 32 if nsrc is None else nsrc

@@ -1,18 +1,32 @@
-import sys, time, numpy as np
-sys.path.insert(0, '.')
-import bench
-from kiwi_amd import synthetic
-wl = synthetic.workload('cfg3', 256, 0)
+"""Host-inclusive rate of the boundary (DESIGN.md "PCIe / host-inclusive rate"): per batch `set_source_params` (host
+discretiser + H2D of the centroid tables), `eval`, `get_misfits` (D2H of all misfits), against the resident-input figure
+bench.py reports.  Usage: python profiles/e2e_host_inclusive.py [cfg3|cfg4|cfg3-100pt ...] [batch]
+For the eikonal workloads the host discretiser is a fast-marching solve per trial source (SURVEY 8f-4 asks what share of a
+step it is before an on-GPU discretiser is considered)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench                                   # noqa: E402
+from kiwi_amd import synthetic                 # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else {"cfg4": 128}.get(name, 256)
+wl = synthetic.workload(name, batch, 0)
 p, gf, recv, refs, tapers, ncent = bench.setup_product(0, wl, 4096)
-tr = wl['trials']
+tr = wl["trials"]
+reps = 3 if name == "cfg4" else 10
 for rep in range(3):
     t0 = time.perf_counter()
-    for _ in range(10):
-        p.set_source_params('bilateral', tr)      # host discretisation + upload of centroid tables
-        p.eval(); m, n, g = p.get_misfits()       # kernels + download of all misfits
-    dt = (time.perf_counter() - t0) / 10
+    for _ in range(reps):
+        p.set_source_params(wl["sourcetype"], tr)     # host discretisation + upload of centroid tables
+        p.eval()
+        m, n, g = p.get_misfits()                     # kernels + download of all misfits
+    dt = (time.perf_counter() - t0) / reps
     t0 = time.perf_counter()
-    for _ in range(10):
-        p.set_source_params('bilateral', tr)
-    ds = (time.perf_counter() - t0) / 10
-    print("end-to-end per 256-source batch: %.2f ms (%.0f evals/s); of which set_source_params (host discretiser + H2D) %.2f ms" % (dt * 1e3, 256 / dt, ds * 1e3))
+    for _ in range(reps):
+        p.set_source_params(wl["sourcetype"], tr)
+    ds = (time.perf_counter() - t0) / reps
+    print("%s: end-to-end per %d-source batch: %.2f ms (%.0f evals/s); of which set_source_params (host discretiser, "
+          "%d threads at most + H2D) %.2f ms = %.1f %%" % (name, batch, dt * 1e3, batch / dt, os.cpu_count() or 1, ds * 1e3, 100 * ds / dt))

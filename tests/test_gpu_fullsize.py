@@ -147,6 +147,61 @@ def test_bench_line_through_rccl_with_one_rank():
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+    assert 0.0 < d["roofline"]["frac"] <= 1.0 and d["roofline"]["bound"] == "valu_issue"
+
+
+def test_database_beyond_two_to_the_31_samples(monkeypatch):
+    """A Green's function tensor of 9.3 GB (2.3e9 floats: ordinary for real Kiwi databases on a 288 GB device): the
+    LDS-staged kernels address a group's rows with 32-bit offsets relative to a 64-bit per-group base, so sources whose
+    nodes sit beyond 2^31 floats must give the same synthetics as the direct kernel (which indexes with size_t), bit for
+    bit.  Only the traces around the nodes in use are stored; the host array is untouched zero pages elsewhere."""
+    from kiwi_amd import Engine
+    nx, nz, ng, L = 1100, 50, 10, 4096
+    dt, dx, dz, firstx, firstz = 0.5, 1000.0, 500.0, 100e3, 2e3
+    data = np.zeros((nx, nz, ng, L), np.float32)
+    first = np.zeros((nx, nz, ng), np.int32)
+    nsamp = np.zeros((nx, nz, ng), np.int32)
+    rng = np.random.default_rng(31)
+    ix0, iz0 = 1080, 14                                   # rows from ((1080 * 50 + 14) * 10) * 4224 = 2.28e9 floats on
+    sl = (slice(ix0, ix0 + 12), slice(iz0, iz0 + 6))
+    i = np.arange(L)
+    for a in range(ix0, ix0 + 12):
+        for b in range(iz0, iz0 + 6):
+            for g in range(ng):
+                data[a, b, g] = (1e-20 * np.sin(0.02 * i * (1 + 0.05 * g) + 0.3 * g + 0.1 * b) *
+                                 np.exp(-((i - 700 - 30 * g) / 350.0) ** 2) * (1 + 0.01 * (a - ix0))).astype(np.float32)
+    first[sl] = 300
+    nsamp[sl] = L
+    x = firstx + (ix0 + 5.3) * dx
+    lat, lon, depth, comps, dist = synthetic.make_receivers(6, dmin=x, dspan=3000.0)
+    trials = synthetic.bilat_strike_sweep(3, step=5.0)
+    trials[:, 3] = firstz + (iz0 + 2.4) * dz
+    res = {}
+    for mode in ("grouped", "cell", "direct"):
+        monkeypatch.delenv("KIWI_HIP_ACCUM", raising=False)
+        monkeypatch.delenv("KIWI_HIP_CELL", raising=False)
+        if mode == "direct":
+            monkeypatch.setenv("KIWI_HIP_ACCUM", "direct")
+        if mode == "cell":
+            monkeypatch.setenv("KIWI_HIP_CELL", "1")
+        p = Engine(0)
+        p.set_database(dt, dx, dz, firstx, firstz, data, first, nsamp)
+        assert p.device_bytes() > 9.0e9
+        p.set_receivers(lat, lon, depth, comps)
+        p.set_source_location(40.0, 30.0, 0.0)
+        p.set_effective_dt(0.5)
+        p.set_local_interpolation("bilinear")
+        p.set_source_params("bilateral", trials)
+        p.set_keep_synthetics(1)
+        p.eval()
+        rows = p.get_geometry(0, 1)["row"]
+        assert rows.min() >= 0 and int(rows.min()) * 4224 > 2 ** 31
+        res[mode] = [p.get_synthetics(s, ir, k, 1)[1] for s in range(3) for ir in range(1, 7) for k in (1, 2, 3)]
+        p.close()
+    assert any(np.any(a != 0) for a in res["direct"])
+    for mode in ("grouped", "cell"):
+        for a, b in zip(res[mode], res["direct"]):
+            assert a.tobytes() == b.tobytes(), mode
 
 
 _TWO_RANK_WORKER = r"""

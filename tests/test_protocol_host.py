@@ -186,6 +186,26 @@ def test_protocol_host_matches_python_host_and_oracle(host, tmp_path):
         assert len(c) > 20 and ri == np.float32(1.2)
         e.set_centroids(c, mo, ri)
         assert abs(gl - e.get_misfits()[2]) <= 2e-5 * gl
+        # a sweep with trial sources the discretiser rejects: listed in the answer (seismosizer.py:703-720: failings),
+        # their rows zeros, the others evaluated; a single rejected source is an error as in the reference
+        bad = ep.copy()
+        bad[3] = 500.0                                          # above the 6.5 km constraint: "Empty rupture area"
+        ep2 = ep.copy()
+        ep2[5] += 7.0
+        pf = tmp_path / "esweep.txt"
+        with open(pf, "w") as f:
+            for t in (ep, bad, ep2, bad):
+                f.write(" ".join("%.9g" % v for v in t) + "\n")
+        assert p.eval_sources("eikonal", str(pf), str(tmp_path / "eout.txt")) == (4, [1, 3])
+        eo = np.loadtxt(tmp_path / "eout.txt")
+        assert eo.shape[0] == 4 and np.all(eo[[1, 3]] == 0) and abs(eo[0, 0] - gl) <= 1e-6 * gl and eo[2, 0] > 0 and eo[2, 0] != eo[0, 0]
+        with pytest.raises(protocol.SeismosizerReturnedError, match="Empty rupture area"):
+            p.do("set_source_params", "eikonal", *["%.9g" % v for v in bad])
+        with open(pf, "w") as f:
+            f.write(" ".join("%.9g" % v for v in bad) + "\n" + " ".join("%.9g" % v for v in bad) + "\n")
+        assert p.eval_sources("eikonal", str(pf), str(tmp_path / "eout.txt")) == (2, [0, 1])
+        p.do("set_source_params", "eikonal", *["%.9g" % v for v in ep])
+        assert float(p.do("get_global_misfit")) == gl
         # floating norms over the wire (minimizer.f90:388-445)
         p.do("set_source_params", "bilateral", *["%.9g" % v for v in trials[1]])
         plain = float(p.do("get_global_misfit"))
