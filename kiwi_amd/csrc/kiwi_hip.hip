@@ -135,6 +135,13 @@ struct kiwi_hip_ctx {
     DevBuf<int> status_d;
     // runs of consecutive sources with identical centroid geometry (points and times), single group each: the
     // grouped kernel builds their blended tiles once (env KIWI_HIP_RUNS=0 switches the sharing off)
+    // sources whose whole centroid table (points, times AND moment tensors) equals an earlier one's: only moment and/or
+    // rise time differ, which act after the synthesis -- evaluated by re-scaling the earlier source's synthetics
+    // (minimizer_engine.f90:516-521, source_bilat.f90:206, source_mt_eikonal.f90:234-239).  same_as[s] = that source, or s
+    std::vector<int> same_as;
+    bool any_same = false;
+    DevBuf<int> synrow_d;
+    int dedupe_enabled = 1;           // env KIWI_HIP_DEDUPE=0 switches it off
     std::vector<unsigned long long> geo_hash;
     std::vector<char> single_group;
     DevBuf<int> runfirst_d;
@@ -259,7 +266,7 @@ void natural_spans(kiwi_hip_ctx *c, std::vector<int> &sb)
         EvalParams ep{ c->bilinear, c->xus, c->zus, nrec, s0 };
         dim3 grid((unsigned)((maxnc * nrec + 255) / 256), (unsigned)n);
         hipLaunchKernelGGL(geometry_kernel, grid, dim3(256), 0, c->stream, c->cent_d.p, c->centofs_d.p, ep, c->gm,
-                           c->span.p, c->recv_d.p, (GeoRec *)nullptr, (int *)nullptr, c->spanbuf_d.p, (int *)nullptr, (int *)nullptr, c->endz.p);
+                           c->span.p, c->recv_d.p, (GeoRec *)nullptr, (int *)nullptr, c->spanbuf_d.p, (int *)nullptr, (int *)nullptr, c->endz.p, (const int *)nullptr);
     }
     HIPCHECK(hipMemcpyAsync(sb.data(), c->spanbuf_d.p, sb.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));
@@ -798,7 +805,26 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
         // geometry_kernel did not write shows as a wild address instead of passing by accident
         if (std::getenv("KIWI_HIP_POISON")) HIPCHECK(hipMemsetAsync(tab, 0x7f, (size_t)(cend - cbeg) * nrec * 128 * sizeof(int), c->stream));
     }
-    const bool fuse = c->fuse_now;
+    // ---- sources of this chunk that can take an earlier source's synthetics (same centroid table, same chunk): not
+    // synthesised, compared from that source's row with their own moment and rise time.  Plain time-domain comparator only.
+    const int *synrow = nullptr;
+    if (c->dedupe_enabled && c->any_same && !c->fft_needed && !c->floating && !c->any_untapered && !c->want_spansrc && !c->synth_only &&
+        proc_which == 0) {
+        std::vector<int> sr((size_t)nsrc);
+        bool any = false;
+        for (int s = 0; s < nsrc; s++) {
+            const int f = c->same_as[(size_t)isrc0 + s];
+            sr[s] = (f >= isrc0 && f != isrc0 + s) ? f - isrc0 : s;
+            any = any || sr[s] != s;
+        }
+        if (any) {
+            c->synrow_d.ensure((size_t)nsrc, &c->dev_bytes);
+            HIPCHECK(hipMemcpyAsync(c->synrow_d.p, sr.data(), (size_t)nsrc * sizeof(int), hipMemcpyHostToDevice, c->stream));
+            HIPCHECK(hipStreamSynchronize(c->stream));
+            synrow = c->synrow_d.p;
+        }
+    }
+    const bool fuse = c->fuse_now && !synrow;      // shared synthetics have to exist in memory
     if (!fuse) c->syn_d.ensure((size_t)nsrc * c->syn_stride, &c->dev_bytes);
     float *proc = nullptr;
     if (proc_which) { c->proc_d.ensure((size_t)nsrc * c->syn_stride, &c->dev_bytes); proc = c->proc_d.p; }
@@ -823,10 +849,10 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
             HIPCHECK(hipMemsetAsync(c->pairflag_d.p, 0, (size_t)nsrc * nrec * sizeof(int), c->stream));
         }
         hipLaunchKernelGGL(geometry_kernel, grid, dim3(256), 0, c->stream, c->cent_d.p, c->centofs_d.p, ep, c->gm,
-                           c->span.p, c->recv_d.p, c->recs_d.p, tab, (int *)nullptr, spansrc, cell ? c->pairflag_d.p : (int *)nullptr, c->endz.p);
+                           c->span.p, c->recv_d.p, c->recs_d.p, tab, (int *)nullptr, spansrc, cell ? c->pairflag_d.p : (int *)nullptr, c->endz.p, synrow);
         if (cell)
             hipLaunchKernelGGL(cellgroup_kernel, grid, dim3(256), 0, c->stream, c->centofs_d.p, ep, c->gm, c->span.p, c->recv_d.p,
-                               c->recs_d.p, tab, c->pairflag_d.p, c->endz.p);
+                               c->recs_d.p, tab, c->pairflag_d.p, c->endz.p, synrow);
     }
     if (c->fft_needed) {
         // transform length of every (source, slot) pair from the source's own strip spans; the lengths travel to the host
@@ -847,10 +873,10 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
         if (c->accum_mode == 1) {            // KIWI_HIP_ACCUM=direct: A/B reference kernel, no LDS staging
             if (c->gm.ng == 10)
                 hipLaunchKernelGGL(accumulate_kernel<10>, grid, dim3(256), 0, c->stream, c->G.p, c->span.p, c->gm.pitch,
-                                   c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p, c->syn_stride);
+                                   c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p, c->syn_stride, synrow);
             else
                 hipLaunchKernelGGL(accumulate_kernel<8>, grid, dim3(256), 0, c->stream, c->G.p, c->span.p, c->gm.pitch,
-                                   c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p, c->syn_stride);
+                                   c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p, c->syn_stride, synrow);
         } else {
             // workgroup size: env override, else by window length (halo overhead vs tile fit)
             const int T = c->group_threads_env ? c->group_threads : (c->max_wlen >= 2048 ? 256 : (c->max_wlen >= 384 ? 128 : 64));
@@ -862,7 +888,7 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
             // runs of geometry-identical single-group sources (chunk-local indices); singletons otherwise
             int *runs = nullptr;
             unsigned gx = (unsigned)nsrc;
-            if (c->share_runs && !cell) {
+            if (c->share_runs && !cell && !synrow) {
                 std::vector<int> rf;
                 // keep enough workgroups in flight: no run longer than nsrc / 1024 rounded up, nor than max_run
                 const int cap = std::max(1, std::min(c->max_run, (nsrc * ntiles * nrec) / 8192));
@@ -901,14 +927,14 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
 #define KIWI_LAUNCH_G2(NGV, TV, FV, RV)                                                                     \
     hipLaunchKernelGGL((accumulate_grouped_kernel<NGV, TV, FV, RV>), ggrid, dim3(TV), 0, c->stream, c->G.p, c->span.p,   \
                        c->gm.pitch, c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p,          \
-                       c->syn_stride, ntiles, c->tab_d.p, runs, fp, cell ? c->pairflag_d.p : (const int *)nullptr)
+                       c->syn_stride, ntiles, c->tab_d.p, runs, fp, cell ? c->pairflag_d.p : (const int *)nullptr, synrow)
 #define KIWI_LAUNCH_GROUPED(NGV, TV)                                                                        \
     do { if (fuse) { if (runs) KIWI_LAUNCH_G2(NGV, TV, true, true); else KIWI_LAUNCH_G2(NGV, TV, true, false); }   \
          else      { if (runs) KIWI_LAUNCH_G2(NGV, TV, false, true); else KIWI_LAUNCH_G2(NGV, TV, false, false); } } while (0)
 #define KIWI_LAUNCH_C3(NGV, SV, PV, FV)                                                                     \
     hipLaunchKernelGGL((accumulate_cell_kernel<NGV, 256, SV, PV, FV>), cgrid, dim3(256), 0, c->stream, c->G.p, c->span.p,   \
                        c->gm.pitch, c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p,          \
-                       c->syn_stride, ntiles_c, c->tab_d.p, fp, c->pairflag_d.p)
+                       c->syn_stride, ntiles_c, c->tab_d.p, fp, c->pairflag_d.p, synrow)
 #define KIWI_LAUNCH_C2(NGV, SV, FV) do { if (c->cell_split) { KIWI_LAUNCH_C3(NGV, SV, 1, FV); KIWI_LAUNCH_C3(NGV, SV, 2, FV); } \
                                          else KIWI_LAUNCH_C3(NGV, SV, 0, FV); } while (0)
 #define KIWI_LAUNCH_CELL(NGV) do { if (spl == 2) { if (fuse) KIWI_LAUNCH_C2(NGV, 2, true); else KIWI_LAUNCH_C2(NGV, 2, false); } \
@@ -952,7 +978,7 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
         hipLaunchKernelGGL(misfit_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream,
                            c->syn_d.p, c->syn_stride, c->comps_d.p, c->reft_d.p, c->tw_d.p, c->moment_d.p,
                            c->risetime_d.p, mp, c->misfit_d.p, proc, c->fft_d.p, c->vt_d.p,
-                           spansrc, nrec, fold_halfwidth(c->max_risetime, c->gm.dt), c->pairs_d.p);
+                           spansrc, nrec, fold_halfwidth(c->max_risetime, c->gm.dt), c->pairs_d.p, synrow);
         if (c->floating) {
             hipLaunchKernelGGL(floating_norm_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream,
                                c->vt_d.p, c->syn_stride, c->comps_d.p, c->refx_d.p, c->tw_d.p, fl_method, c->gm.dt,
@@ -1014,7 +1040,7 @@ int eval_impl(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
         int n = 0;
         while (s + n < isrc0 + nsrc) {
             const size_t nc = (size_t)(c->cent_ofs[s + n + 1] - c->cent_ofs[s + n]);
-            const size_t syn_bytes = c->fuse_now ? (size_t)c->nmis * 64 * sizeof(double)
+            const size_t syn_bytes = (c->fuse_now && !(c->dedupe_enabled && c->any_same)) ? (size_t)c->nmis * 64 * sizeof(double)
                                                              : c->syn_stride * sizeof(float) * ((proc_which ? 2 : 1) + (c->floating ? 1 : 0));
             const size_t add = nc * nrec * (sizeof(GeoRec) + (c->accum_mode == 0 ? 512 : 0)) + syn_bytes;
             if (n > 0 && (bytes + add > c->chunk_bytes_limit || n >= 65535)) break;
@@ -1056,6 +1082,7 @@ int kiwi_hip_init(int device, kiwi_hip_ctx **out)
         if (const char *m = std::getenv("KIWI_HIP_ACCUM")) c->accum_mode = (std::strcmp(m, "direct") == 0) ? 1 : 0;
         if (const char *m = std::getenv("KIWI_HIP_FUSE")) c->fuse_enabled = std::atoi(m);
         if (const char *m = std::getenv("KIWI_HIP_CELL")) c->cell_mode = std::atoi(m) ? 1 : 0;
+        if (const char *m = std::getenv("KIWI_HIP_DEDUPE")) c->dedupe_enabled = std::atoi(m) ? 1 : 0;
         if (const char *m = std::getenv("KIWI_HIP_CELL_SPL")) c->cell_spl = std::atoi(m) == 4 ? 4 : 2;
         if (const char *m = std::getenv("KIWI_HIP_CELL_SPLIT")) c->cell_split = std::atoi(m) ? 1 : 0;
         if (const char *m = std::getenv("KIWI_HIP_CHUNK_MB")) {      // workspace bound per launch (default 16 GiB); tests use it
@@ -1464,6 +1491,34 @@ int kiwi_hip_set_sources(kiwi_hip_ctx *c, int nsrc, const int *cent_ofs, const f
             c->geo_hash[s] = h;
             c->single_group[s] = one ? 1 : 0;
         }
+        // identical tables (hash over all ten columns, confirmed by comparison)
+        c->same_as.assign((size_t)nsrc, 0);
+        c->any_same = false;
+        {
+            std::vector<unsigned long long> th((size_t)nsrc);
+#pragma omp parallel for schedule(static) num_threads(std::max(1, std::min(8, nsrc / 512)))
+            for (int s = 0; s < nsrc; s++) {
+                const unsigned int *w = reinterpret_cast<const unsigned int *>(cent + (size_t)cent_ofs[s] * 10);
+                const size_t n = (size_t)(cent_ofs[s + 1] - cent_ofs[s]) * 10;
+                unsigned long long h = 1469598103934665603ull ^ (unsigned long long)n;
+                for (size_t q = 0; q < n; q++) { h ^= w[q]; h *= 1099511628211ull; }
+                th[s] = h;
+            }
+            std::map<unsigned long long, int> first_of;
+            for (int s = 0; s < nsrc; s++) {
+                c->same_as[s] = s;
+                const int nc = cent_ofs[s + 1] - cent_ofs[s];
+                if (nc == 0) continue;
+                auto it = first_of.find(th[s]);
+                if (it == first_of.end()) { first_of[th[s]] = s; continue; }
+                const int f = it->second;
+                if (cent_ofs[f + 1] - cent_ofs[f] == nc &&
+                    std::memcmp(cent + (size_t)cent_ofs[f] * 10, cent + (size_t)cent_ofs[s] * 10, (size_t)nc * 10 * sizeof(float)) == 0) {
+                    c->same_as[s] = f;
+                    c->any_same = true;
+                }
+            }
+        }
         // how many of the centroids start a new point (sampled): decides between same-point and same-cell groups
         long long npts = 0, ncen = 0;
         const int stride = std::max(1, nsrc / 64);
@@ -1519,7 +1574,10 @@ int kiwi_hip_set_sources_params(kiwi_hip_ctx *c, int sourcetype, int nsrc, const
     // a few threads only: the discretisers take microseconds per source, and idle OpenMP workers spin for their
     // block time after the loop, competing with the HIP runtime's own threads for the caller's next calls
     // (the eikonal discretisers run a fast-marching solve per source: milliseconds, one thread per source pays)
-    const int nthreads = std::max(1, eikonal ? std::min({ omp_get_max_threads(), nsrc, 64 })
+    // (measured on the GPU box, cfg4: a 25 m fine grid of 1200 x 360 points per source, 160 ms per solve: with 64 threads
+    // the discretiser took 390 ms per 128 sources against 290 ms for their evaluation on the device -- every hardware
+    // thread gets a source)
+    const int nthreads = std::max(1, eikonal ? std::min({ omp_get_max_threads(), nsrc, 512 })
                                              : std::min({ omp_get_max_threads(), (nsrc + 31) / 32, 16 }));
     (void)nthreads;
 #pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)

@@ -86,11 +86,11 @@ inline std::vector<V3> clip(const std::vector<V3> &poly, const HalfSpace &h)
 
 // index heap keyed by an external array, with back pointers (heap.f90); indices 1-based as there
 struct IndexHeap {
-    std::vector<int> h;      // h[1..n]
+    std::vector<int> &h;     // h[1..n]; storage lent by the caller (reused from solve to solve)
     int n = 0;
     const float *keys;
     int *bp;
-    IndexHeap(int cap, const float *k, int *b) : h((size_t)cap + 2), keys(k), bp(b) {}
+    IndexHeap(int cap, const float *k, int *b, std::vector<int> &store) : h(store), keys(k), bp(b) { h.resize((size_t)cap + 2); }
     float key(int pos) const { return keys[h[pos] - 1]; }
     void swp(int u, int v) { std::swap(h[u], h[v]); std::swap(bp[h[u] - 1], bp[h[v] - 1]); }
     void up(int v)                                   // upheap :205-229
@@ -133,8 +133,11 @@ inline void fast_marching(const std::vector<float> &speed, int nx, int ny, const
     constexpr int FARAWAY = -1, ALIVE = 0;
     const float inf = std::numeric_limits<float>::max() * 0.1f;
     const float dx = delta[0], dy = delta[1];
+    // The work arrays of a solve (a few MB on the 25 m grid of a 30 km rupture) are kept per thread: a fresh allocation per
+    // trial source means a million page faults per batch, which serialise in the kernel when every core discretises at once.
+    static thread_local std::vector<int> bp, heap_store;
     times.assign((size_t)nx * ny, inf);
-    std::vector<int> bp((size_t)nx * ny, FARAWAY);
+    bp.assign((size_t)nx * ny, FARAWAY);
     auto id = [nx](int x, int y) { return (y - 1) * nx + x; };
     int ix = (int)((start[0] - origin[0]) / dx) + 1, iy = (int)((start[1] - origin[1]) / dy) + 1;
     ix = std::min(std::max(ix, 1), nx);
@@ -143,7 +146,7 @@ inline void fast_marching(const std::vector<float> &speed, int nx, int ny, const
     if (nx == 1 && ny == 1) return;
     bp[id(ix, iy) - 1] = ALIVE;
     int nalive = 1;
-    IndexHeap heap(nx * ny, times.data(), bp.data());
+    IndexHeap heap(nx * ny, times.data(), bp.data(), heap_store);
     auto T = [&](int x, int y) -> float & { return times[id(x, y) - 1]; };
     auto S = [&](int x, int y) { return speed[id(x, y) - 1]; };
     if (1 < ix) T(ix - 1, iy) = dx / S(ix - 1, iy);
@@ -260,8 +263,10 @@ inline std::string discretize_eikonal(int type, const float *P, float doi, const
             return "position of nucleation point is outside of rupture region";
     }
     const int fx = nf[0], fy = nf[1];
-    std::vector<float> speed((size_t)fx * fy), ftimes;
-    std::vector<V3> fpt((size_t)fx * fy);
+    static thread_local std::vector<float> speed, ftimes;       // per-thread work arrays, see fast_marching
+    static thread_local std::vector<V3> fpt;
+    speed.assign((size_t)fx * fy, 0.f);
+    fpt.resize((size_t)fx * fy);
     float minspeed = std::numeric_limits<float>::max();
     for (int iy = 1; iy <= fy; iy++)
         for (int ix = 1; ix <= fx; ix++) {

@@ -267,9 +267,11 @@ __global__ __launch_bounds__(256) void geometry_kernel(
     const int2 *__restrict__ span, const RecvDev *__restrict__ recv, GeoRec *__restrict__ out,
     int *__restrict__ tab, int *__restrict__ spanbuf, int *__restrict__ spansrc /* optional [source][receiver][4] */,
     int *__restrict__ pairflag /* optional [source][receiver]: some centroid of the pair misses a trace (cell mode) */,
-    const unsigned char *__restrict__ endz /* per GF row: its end value is zero (write_tab) */)
+    const unsigned char *__restrict__ endz /* per GF row: its end value is zero (write_tab) */,
+    const int *__restrict__ synrow /* optional [source]: source whose synthetics this one shares; != own index: nothing to do */)
 {
     const int s = blockIdx.y;
+    if (synrow && synrow[s] != s) return;
     const int c0 = cent_ofs[ep.isrc0 + s], nc = cent_ofs[ep.isrc0 + s + 1] - c0;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= nc * ep.nrec) return;
@@ -471,9 +473,11 @@ __device__ __forceinline__ bool cell_pair(const RecvDev &rv, const int *__restri
 __global__ __launch_bounds__(256) void cellgroup_kernel(const int *__restrict__ cent_ofs, EvalParams ep, GfMeta gm,
                                                         const int2 *__restrict__ span, const RecvDev *__restrict__ recv,
                                                         GeoRec *__restrict__ recs, int *__restrict__ tab,
-                                                        const int *__restrict__ pairflag, const unsigned char *__restrict__ endz)
+                                                        const int *__restrict__ pairflag, const unsigned char *__restrict__ endz,
+                                                        const int *__restrict__ synrow)
 {
     const int s = blockIdx.y;
+    if (synrow && synrow[s] != s) return;
     const int cb = cent_ofs[ep.isrc0], c0 = cent_ofs[ep.isrc0 + s], nc = cent_ofs[ep.isrc0 + s + 1] - c0;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= nc * ep.nrec) return;
@@ -673,9 +677,10 @@ template <int NG>
 __global__ __launch_bounds__(256) void accumulate_kernel(
     const float *__restrict__ G, const int2 *__restrict__ span, int pitch,
     const GeoRec *__restrict__ recs, const int *__restrict__ cent_ofs, int isrc0, int nrec,
-    const RecvDev *__restrict__ recv, float *__restrict__ syn, size_t syn_stride)
+    const RecvDev *__restrict__ recv, float *__restrict__ syn, size_t syn_stride, const int *__restrict__ synrow)
 {
     const int tile = blockIdx.x, r = blockIdx.y, s = blockIdx.z;
+    if (synrow && synrow[s] != s) return;
     const RecvDev &rv = recv[r];
     if (!rv.enabled) return;
     if (tile * kTile >= rv.wlen) return;
@@ -1074,7 +1079,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
     const GeoRec *__restrict__ recs, const int *__restrict__ cent_ofs, int isrc0, int nrec,
     const RecvDev *__restrict__ recv, float *__restrict__ syn, size_t syn_stride, int ntiles,
     const int *__restrict__ tab, const int *__restrict__ run_first, FuseParams fp,
-    const int *__restrict__ pairflag /* cell mode: only the (source, receiver) pairs accumulate_cell_kernel leaves out */)
+    const int *__restrict__ pairflag /* cell mode: only the (source, receiver) pairs accumulate_cell_kernel leaves out */,
+    const int *__restrict__ synrow /* optional: sources that share another source's synthetics are not synthesised */)
 {
     // run_first != nullptr: blockIdx.x indexes RUNS of consecutive trial sources [run_first[b], run_first[b+1]) that the
     // host found to have identical centroid geometry (same points and times: only the moment tensors differ, e.g. a
@@ -1099,6 +1105,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
     if (!rv.enabled) return;
     if (tile * TILE >= rv.wlen) return;
     if (pairflag && cell_pair(rv, pairflag, s, nrec, r)) return;
+    if (synrow && synrow[s] != s) return;            // (never together with RUNS: the host does not form runs then)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int t_tile0 = rv.wbeg + tile * TILE;
@@ -1473,7 +1480,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_CELL_WAV
     const float *__restrict__ G, const int2 *__restrict__ span, int pitch,
     const GeoRec *__restrict__ recs, const int *__restrict__ cent_ofs, int isrc0, int nrec,
     const RecvDev *__restrict__ recv, float *__restrict__ syn, size_t syn_stride, int ntiles,
-    const int *__restrict__ tab, FuseParams fp, const int *__restrict__ pairflag)
+    const int *__restrict__ tab, FuseParams fp, const int *__restrict__ pairflag, const int *__restrict__ synrow)
 {
     constexpr int NP = SPL / 2;
     constexpr int TILE = SPL * T;
@@ -1488,6 +1495,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_CELL_WAV
     if (!rv.enabled) return;
     if (tile * TILE >= rv.wlen) return;
     if (!cell_pair(rv, pairflag, s, nrec, r)) return;
+    if (synrow && synrow[s] != s) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int t_tile0 = rv.wbeg + tile * TILE;
@@ -1676,7 +1684,10 @@ __global__ __launch_bounds__(256) void misfit_kernel(
     float *__restrict__ misfit_out, float *__restrict__ proc /* optional [src][stride] processed synthetics */,
     float *__restrict__ fftbuf, float *__restrict__ vt_out /* optional [src][stride] tapered synthetics */,
     const int *__restrict__ spansrc /* per-source strip spans, un-tapered receivers only */, int nrec, int fold_grow,
-    const FftPair *__restrict__ pairs /* [source][slot], fft_mode only */)
+    const FftPair *__restrict__ pairs /* [source][slot], fft_mode only */,
+    const int *__restrict__ synrow /* optional [source]: read the synthetics of that source -- sources whose centroid tables are
+                                      identical differ only in moment / rise time, which are applied here (the reference
+                                      re-scales without re-synthesising then, minimizer_engine.f90:516-521) */)
 {
     const int m = blockIdx.x, s = blockIdx.y;
     const CompDev cd = comps[m];
@@ -1691,7 +1702,7 @@ __global__ __launch_bounds__(256) void misfit_kernel(
     }
     const float mom = moment[mp.isrc0 + s];
     const float rise = risetime[mp.isrc0 + s];
-    const float *__restrict__ sy = syn + (size_t)s * syn_stride + cd.synofs + cd.halo;   // sy[i] = sample w0 + i
+    const float *__restrict__ sy = syn + (size_t)(synrow ? synrow[s] : s) * syn_stride + cd.synofs + cd.halo;   // sy[i] = sample w0 + i
     const float *__restrict__ rt = reft + cd.refofs;
     const float *__restrict__ tp = tw + cd.refofs;
 

@@ -162,20 +162,20 @@ def test_database_beyond_two_to_the_31_samples(monkeypatch):
     first = np.zeros((nx, nz, ng), np.int32)
     nsamp = np.zeros((nx, nz, ng), np.int32)
     rng = np.random.default_rng(31)
-    ix0, iz0 = 1080, 14                                   # rows from ((1080 * 50 + 14) * 10) * 4224 = 2.28e9 floats on
-    sl = (slice(ix0, ix0 + 12), slice(iz0, iz0 + 6))
+    ix0, iz0 = 1070, 8                                    # rows from ((1070 * 50 + 8) * 10) * 4224 = 2.26e9 floats on
+    sl = (slice(ix0, ix0 + 24), slice(iz0, iz0 + 16))
     i = np.arange(L)
-    for a in range(ix0, ix0 + 12):
-        for b in range(iz0, iz0 + 6):
+    for a in range(ix0, ix0 + 24):
+        for b in range(iz0, iz0 + 16):
             for g in range(ng):
                 data[a, b, g] = (1e-20 * np.sin(0.02 * i * (1 + 0.05 * g) + 0.3 * g + 0.1 * b) *
                                  np.exp(-((i - 700 - 30 * g) / 350.0) ** 2) * (1 + 0.01 * (a - ix0))).astype(np.float32)
     first[sl] = 300
     nsamp[sl] = L
-    x = firstx + (ix0 + 5.3) * dx
+    x = firstx + (ix0 + 10.3) * dx
     lat, lon, depth, comps, dist = synthetic.make_receivers(6, dmin=x, dspan=3000.0)
     trials = synthetic.bilat_strike_sweep(3, step=5.0)
-    trials[:, 3] = firstz + (iz0 + 2.4) * dz
+    trials[:, 3] = firstz + (iz0 + 7.4) * dz
     res = {}
     for mode in ("grouped", "cell", "direct"):
         monkeypatch.delenv("KIWI_HIP_ACCUM", raising=False)

@@ -522,6 +522,62 @@ def test_eikonal_sources_with_risetime_fold(stype):
     assert failings == [0, 1] and np.all(mis == 0) and np.all(nor == 0)
 
 
+@pytest.mark.parametrize("stype", ["bilateral", "mt_eikonal"])
+def test_moment_and_risetime_sweeps_rescale_instead_of_resynthesising(monkeypatch, stype):
+    """minimizer_engine.f90:516-521 (source_bilat.f90:206, source_mt_eikonal.f90:234-239): when only the moment (or, for the
+    eikonal types, the rise time) changes the reference re-scales the seismograms without synthesising them again.  Here
+    trial sources of one batch whose centroid tables are identical are synthesised once; their misfits are bit-identical to
+    evaluating every source on its own (KIWI_HIP_DEDUPE=0) and match the oracle, and the accumulate kernel ran for the
+    distinct tables only (its time shows it)."""
+    import os
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "eikonal_vectors.npz"))
+    sc = Scenario(nz=6)
+    e, p = build(sc)
+    if stype == "bilateral":
+        base = synthetic.bilat_strike_sweep(3, step=4.0)
+        trials = np.repeat(base, 4, axis=0)
+        trials[:, 4] *= np.tile([1.0, 0.5, 2.0, 1.7], 3)               # moment
+        sid = 1
+    else:
+        t0 = np.array([0.2, 300., -200., 10500., 1.0, 85., 70., 100., -50., 2900., 200., 200., 0.8] +
+                      synthetic.mt_from_sdr(40., 60., -70., 7e17) + [0.0], np.float32)
+        t1 = t0.copy(); t1[5] += 8.0
+        trials = np.repeat(np.stack([t0, t1]), 4, axis=0)
+        trials[:, 19] = np.tile([0.0, 1.5, 0.8, 1.5], 2)                # rise time
+        trials[:, 4] = np.tile([1.0, 1.0, 0.6, 2.0], 2)                 # moment factor
+        sid = 5
+        cp = np.array([[0, 0, 6500.0], [0, 0, 15500.0]], np.float32)
+        cn = np.array([[0, 0, -1.0], [0, 0, 1.0]], np.float32)
+        for q in (p,):
+            q.set_source_crust(G["rupture_profile"], G["origin_profile"])
+            q.set_source_constraints(cp, cn)
+    trials = trials[np.array([0, 1, 4, 2, 5, 3] + list(range(6, len(trials))))]      # identical tables need not be neighbours
+    p.set_source_params(stype, trials)
+    p.eval()
+    a = [x.copy() for x in p.get_misfits()]
+    ms_shared, _ = p.kernel_ms()
+    monkeypatch.setenv("KIWI_HIP_DEDUPE", "0")
+    q = sc.product()
+    sc.apply_setup(q, False)
+    if sid == 5:
+        q.set_source_crust(G["rupture_profile"], G["origin_profile"])
+        q.set_source_constraints(cp, cn)
+    q.set_source_params(stype, trials)
+    q.eval()
+    b = q.get_misfits()
+    for x, y in zip(a, b):
+        assert x.tobytes() == y.tobytes()
+    assert len({x.tobytes() for x in a[0]}) == len(trials)             # every trial has its own misfits
+    if sid == 1:
+        m, n, g = oracle_misfits(e, 1, trials)
+        assert misfit_close(a[0], m) and misfit_close(a[2], g)
+    p.eval(0, 2)                                                        # a chunk that holds the first of a family only
+    p.eval(2, len(trials) - 2)                                          # ... the rest refers back across the chunk border: synthesised
+    c = p.get_misfits()
+    for x, y in zip(a, c):
+        assert x.tobytes() == y.tobytes()
+
+
 def _knock_out(sc, holes):
     """Mark single traces (ix, iz, ig; 0-based) of the scenario's database as not stored (nsamp = 0: the chunk index holds no
     reference for them, gfdb.f90:1003)."""
