@@ -140,7 +140,7 @@ struct kiwi_hip_ctx {
     // (minimizer_engine.f90:516-521, source_bilat.f90:206, source_mt_eikonal.f90:234-239).  same_as[s] = that source, or s
     std::vector<int> same_as;
     bool any_same = false;
-    DevBuf<int> synrow_d;
+    DevBuf<int> synrow_d, famofs_d, famlist_d;
     int dedupe_enabled = 1;           // env KIWI_HIP_DEDUPE=0 switches it off
     std::vector<unsigned long long> geo_hash;
     std::vector<char> single_group;
@@ -807,8 +807,12 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
     }
     // ---- sources of this chunk that can take an earlier source's synthetics (same centroid table, same chunk): not
     // synthesised, compared from that source's row with their own moment and rise time.  Plain time-domain comparator only.
-    const int *synrow = nullptr;
-    if (c->dedupe_enabled && c->any_same && !c->fft_needed && !c->floating && !c->any_untapered && !c->want_spansrc && !c->synth_only &&
+    // (Their geometry records are still made: a run of geometry-identical sources takes its group structure from its first
+    // member, whichever that is; the geometry kernel is a few per cent of a step.)
+    const int *synrow = nullptr, *famofs = nullptr, *famlist = nullptr;
+    // (point sources -- a couple of centroids each -- cost less to synthesise than to look up: left alone unless forced, = 2)
+    const bool heavy = c->dedupe_enabled == 2 || (size_t)(cend - cbeg) >= (size_t)8 * (size_t)nsrc;
+    if (c->dedupe_enabled && heavy && c->any_same && !c->fft_needed && !c->floating && !c->any_untapered && !c->want_spansrc && !c->synth_only &&
         proc_which == 0) {
         std::vector<int> sr((size_t)nsrc);
         bool any = false;
@@ -820,11 +824,26 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
         if (any) {
             c->synrow_d.ensure((size_t)nsrc, &c->dev_bytes);
             HIPCHECK(hipMemcpyAsync(c->synrow_d.p, sr.data(), (size_t)nsrc * sizeof(int), hipMemcpyHostToDevice, c->stream));
-            HIPCHECK(hipStreamSynchronize(c->stream));
             synrow = c->synrow_d.p;
+            if (c->fuse_now) {
+                // fused comparator: the workgroup that synthesised a source compares its followers too (their moments differ)
+                std::vector<int> ofs((size_t)nsrc + 1, 0), lst;
+                for (int s = 0; s < nsrc; s++) if (sr[s] != s) ofs[(size_t)sr[s] + 1]++;
+                for (int s = 0; s < nsrc; s++) ofs[(size_t)s + 1] += ofs[s];
+                lst.resize((size_t)ofs[nsrc]);
+                std::vector<int> fill(ofs.begin(), ofs.end() - 1);
+                for (int s = 0; s < nsrc; s++) if (sr[s] != s) lst[(size_t)fill[sr[s]]++] = s;
+                c->famofs_d.ensure(ofs.size(), &c->dev_bytes);
+                c->famlist_d.ensure(std::max<size_t>(lst.size(), 1), &c->dev_bytes);
+                HIPCHECK(hipMemcpyAsync(c->famofs_d.p, ofs.data(), ofs.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+                HIPCHECK(hipMemcpyAsync(c->famlist_d.p, lst.data(), lst.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+                HIPCHECK(hipStreamSynchronize(c->stream));            // ofs / lst go out of scope
+                famofs = c->famofs_d.p; famlist = c->famlist_d.p;
+            }
+            HIPCHECK(hipStreamSynchronize(c->stream));
         }
     }
-    const bool fuse = c->fuse_now && !synrow;      // shared synthetics have to exist in memory
+    const bool fuse = c->fuse_now;
     if (!fuse) c->syn_d.ensure((size_t)nsrc * c->syn_stride, &c->dev_bytes);
     float *proc = nullptr;
     if (proc_which) { c->proc_d.ensure((size_t)nsrc * c->syn_stride, &c->dev_bytes); proc = c->proc_d.p; }
@@ -849,10 +868,10 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
             HIPCHECK(hipMemsetAsync(c->pairflag_d.p, 0, (size_t)nsrc * nrec * sizeof(int), c->stream));
         }
         hipLaunchKernelGGL(geometry_kernel, grid, dim3(256), 0, c->stream, c->cent_d.p, c->centofs_d.p, ep, c->gm,
-                           c->span.p, c->recv_d.p, c->recs_d.p, tab, (int *)nullptr, spansrc, cell ? c->pairflag_d.p : (int *)nullptr, c->endz.p, synrow);
+                           c->span.p, c->recv_d.p, c->recs_d.p, tab, (int *)nullptr, spansrc, cell ? c->pairflag_d.p : (int *)nullptr, c->endz.p, (const int *)nullptr);
         if (cell)
             hipLaunchKernelGGL(cellgroup_kernel, grid, dim3(256), 0, c->stream, c->centofs_d.p, ep, c->gm, c->span.p, c->recv_d.p,
-                               c->recs_d.p, tab, c->pairflag_d.p, c->endz.p, synrow);
+                               c->recs_d.p, tab, c->pairflag_d.p, c->endz.p, (const int *)nullptr);
     }
     if (c->fft_needed) {
         // transform length of every (source, slot) pair from the source's own strip spans; the lengths travel to the host
@@ -888,7 +907,7 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
             // runs of geometry-identical single-group sources (chunk-local indices); singletons otherwise
             int *runs = nullptr;
             unsigned gx = (unsigned)nsrc;
-            if (c->share_runs && !cell && !synrow) {
+            if (c->share_runs && !cell && (!synrow || fuse)) {     // (runs + shared synthetics: only with the fused comparator)
                 std::vector<int> rf;
                 // keep enough workgroups in flight: no run longer than nsrc / 1024 rounded up, nor than max_run
                 const int cap = std::max(1, std::min(c->max_run, (nsrc * ntiles * nrec) / 8192));
@@ -927,14 +946,14 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
 #define KIWI_LAUNCH_G2(NGV, TV, FV, RV)                                                                     \
     hipLaunchKernelGGL((accumulate_grouped_kernel<NGV, TV, FV, RV>), ggrid, dim3(TV), 0, c->stream, c->G.p, c->span.p,   \
                        c->gm.pitch, c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p,          \
-                       c->syn_stride, ntiles, c->tab_d.p, runs, fp, cell ? c->pairflag_d.p : (const int *)nullptr, synrow)
+                       c->syn_stride, ntiles, c->tab_d.p, runs, fp, cell ? c->pairflag_d.p : (const int *)nullptr, synrow, famofs, famlist)
 #define KIWI_LAUNCH_GROUPED(NGV, TV)                                                                        \
     do { if (fuse) { if (runs) KIWI_LAUNCH_G2(NGV, TV, true, true); else KIWI_LAUNCH_G2(NGV, TV, true, false); }   \
          else      { if (runs) KIWI_LAUNCH_G2(NGV, TV, false, true); else KIWI_LAUNCH_G2(NGV, TV, false, false); } } while (0)
 #define KIWI_LAUNCH_C3(NGV, SV, PV, FV)                                                                     \
     hipLaunchKernelGGL((accumulate_cell_kernel<NGV, 256, SV, PV, FV>), cgrid, dim3(256), 0, c->stream, c->G.p, c->span.p,   \
                        c->gm.pitch, c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p,          \
-                       c->syn_stride, ntiles_c, c->tab_d.p, fp, c->pairflag_d.p, synrow)
+                       c->syn_stride, ntiles_c, c->tab_d.p, fp, c->pairflag_d.p, synrow, famofs, famlist)
 #define KIWI_LAUNCH_C2(NGV, SV, FV) do { if (c->cell_split) { KIWI_LAUNCH_C3(NGV, SV, 1, FV); KIWI_LAUNCH_C3(NGV, SV, 2, FV); } \
                                          else KIWI_LAUNCH_C3(NGV, SV, 0, FV); } while (0)
 #define KIWI_LAUNCH_CELL(NGV) do { if (spl == 2) { if (fuse) KIWI_LAUNCH_C2(NGV, 2, true); else KIWI_LAUNCH_C2(NGV, 2, false); } \
@@ -1040,7 +1059,7 @@ int eval_impl(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
         int n = 0;
         while (s + n < isrc0 + nsrc) {
             const size_t nc = (size_t)(c->cent_ofs[s + n + 1] - c->cent_ofs[s + n]);
-            const size_t syn_bytes = (c->fuse_now && !(c->dedupe_enabled && c->any_same)) ? (size_t)c->nmis * 64 * sizeof(double)
+            const size_t syn_bytes = c->fuse_now ? (size_t)c->nmis * 64 * sizeof(double)
                                                              : c->syn_stride * sizeof(float) * ((proc_which ? 2 : 1) + (c->floating ? 1 : 0));
             const size_t add = nc * nrec * (sizeof(GeoRec) + (c->accum_mode == 0 ? 512 : 0)) + syn_bytes;
             if (n > 0 && (bytes + add > c->chunk_bytes_limit || n >= 65535)) break;
@@ -1082,7 +1101,7 @@ int kiwi_hip_init(int device, kiwi_hip_ctx **out)
         if (const char *m = std::getenv("KIWI_HIP_ACCUM")) c->accum_mode = (std::strcmp(m, "direct") == 0) ? 1 : 0;
         if (const char *m = std::getenv("KIWI_HIP_FUSE")) c->fuse_enabled = std::atoi(m);
         if (const char *m = std::getenv("KIWI_HIP_CELL")) c->cell_mode = std::atoi(m) ? 1 : 0;
-        if (const char *m = std::getenv("KIWI_HIP_DEDUPE")) c->dedupe_enabled = std::atoi(m) ? 1 : 0;
+        if (const char *m = std::getenv("KIWI_HIP_DEDUPE")) c->dedupe_enabled = std::atoi(m);      // 0 off, 1 default, 2 also for point sources
         if (const char *m = std::getenv("KIWI_HIP_CELL_SPL")) c->cell_spl = std::atoi(m) == 4 ? 4 : 2;
         if (const char *m = std::getenv("KIWI_HIP_CELL_SPLIT")) c->cell_split = std::atoi(m) ? 1 : 0;
         if (const char *m = std::getenv("KIWI_HIP_CHUNK_MB")) {      // workspace bound per launch (default 16 GiB); tests use it

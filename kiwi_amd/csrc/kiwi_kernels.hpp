@@ -1080,7 +1080,9 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
     const RecvDev *__restrict__ recv, float *__restrict__ syn, size_t syn_stride, int ntiles,
     const int *__restrict__ tab, const int *__restrict__ run_first, FuseParams fp,
     const int *__restrict__ pairflag /* cell mode: only the (source, receiver) pairs accumulate_cell_kernel leaves out */,
-    const int *__restrict__ synrow /* optional: sources that share another source's synthetics are not synthesised */)
+    const int *__restrict__ synrow /* optional: sources that share another source's synthetics are not synthesised */,
+    const int *__restrict__ fam_ofs, const int *__restrict__ fam_list /* FUSE with synrow: the sources that share source s's
+                                          synthetics, fam_list[fam_ofs[s] .. fam_ofs[s + 1]): compared here with their moments */)
 {
     // run_first != nullptr: blockIdx.x indexes RUNS of consecutive trial sources [run_first[b], run_first[b+1]) that the
     // host found to have identical centroid geometry (same points and times: only the moment tensors differ, e.g. a
@@ -1105,7 +1107,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
     if (!rv.enabled) return;
     if (tile * TILE >= rv.wlen) return;
     if (pairflag && cell_pair(rv, pairflag, s, nrec, r)) return;
-    if (synrow && synrow[s] != s) return;            // (never together with RUNS: the host does not form runs then)
+    if (synrow && !multi && synrow[s] != s) return;  // (in a run the sources that share synthetics are left out one by one)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int t_tile0 = rv.wbeg + tile * TILE;
@@ -1169,6 +1171,14 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
             }
             if (lane == 0)
                 fp.partial[((size_t)js * fp.nmis + rv.slot0 + k) * fp.nparts + tile * (T / 64) + (tid >> 6)] = acc;
+        }
+    };
+    // a source and, with the fused comparator, the sources that share its synthetics (other moments; minimizer_engine.f90:516-521)
+    auto store_family = [&](int js) {
+        store(js);
+        if constexpr (FUSE) {
+            if (fam_ofs)
+                for (int q = fam_ofs[js]; q < fam_ofs[js + 1]; q++) store(fam_list[q]);
         }
     };
     bool stored = false;
@@ -1289,6 +1299,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
         if (multi) {
             if (js + 1 < s_end) cur_next_src = rec_load(recs + ((size_t)(cent_ofs[isrc0 + js + 1] - cb) * nrec + (size_t)r * nc), c, nc, lane);
             ar1[0] = ar1[1] = ar2[0] = ar2[1] = dz[0] = dz[1] = f2v{ 0.f, 0.f };
+            if (synrow && synrow[js] != js) { cur = cur_next_src; continue; }      // evaluated with the source it shares synthetics with
         }
         // coefficient rows of the group's centroids: wave-uniform by construction; readfirstlane tells the compiler so
         // (-> scalar address arithmetic and scalar loads of the coefficients)
@@ -1318,16 +1329,17 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
 #undef APPLY
             cur = nxt;
         }
-        if (multi) { store(js); cur = cur_next_src; }
+        if (multi) { store_family(js); cur = cur_next_src; }
         }
         stored = multi;
         __syncthreads();                                 // tiles are rebuilt by the next group
         c = cend;
     }
-    if (!multi) store(s);
+    if (!multi) store_family(s);
     else if (!stored) {                                  // every centroid skipped: the run's synthetics are zero
         ar1[0] = ar1[1] = ar2[0] = ar2[1] = dz[0] = dz[1] = f2v{ 0.f, 0.f };
-        for (int js = s; js < s_end; js++) store(js);
+        for (int js = s; js < s_end; js++)
+            if (!(synrow && synrow[js] != js)) store_family(js);
     }
 }
 
@@ -1480,7 +1492,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_CELL_WAV
     const float *__restrict__ G, const int2 *__restrict__ span, int pitch,
     const GeoRec *__restrict__ recs, const int *__restrict__ cent_ofs, int isrc0, int nrec,
     const RecvDev *__restrict__ recv, float *__restrict__ syn, size_t syn_stride, int ntiles,
-    const int *__restrict__ tab, FuseParams fp, const int *__restrict__ pairflag, const int *__restrict__ synrow)
+    const int *__restrict__ tab, FuseParams fp, const int *__restrict__ pairflag, const int *__restrict__ synrow,
+    const int *__restrict__ fam_ofs, const int *__restrict__ fam_list)
 {
     constexpr int NP = SPL / 2;
     constexpr int TILE = SPL * T;
@@ -1599,11 +1612,14 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_CELL_WAV
     }
 #undef CELL_LOAD
 #undef CELL_BLEND
-    // ---- rotation to N/E, signs, store or fused comparator (seismogram.f90:256-283), as accumulate_grouped_kernel
-    {
+    // ---- rotation to N/E, signs, store or fused comparator (seismogram.f90:256-283), as accumulate_grouped_kernel; with the
+    // fused comparator also for the sources that share these synthetics (fam_list), each with its own moment
+    const int nfam = (FUSE && fam_ofs) ? fam_ofs[s + 1] - fam_ofs[s] : 0;
+    for (int qf = -1; qf < nfam; qf++) {
+        const int js = qf < 0 ? s : fam_list[fam_ofs[s] + qf];
         const int tl = tile * TILE + u0;
         if (!FUSE && tl >= rv.wlen) return;
-        float *__restrict__ so = syn + (size_t)s * syn_stride + tl;
+        float *__restrict__ so = syn + (size_t)js * syn_stride + tl;
         float a1[SPL], a2[SPL], ad[SPL];
 #pragma unroll
         for (int h = 0; h < NP; h++) {
@@ -1611,7 +1627,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_CELL_WAV
             ad[2 * h] = dz[h].x; ad[2 * h + 1] = dz[h].y;
         }
         float mom = 0.f;
-        if constexpr (FUSE) mom = fp.moment[fp.isrc0 + s];
+        if constexpr (FUSE) mom = fp.moment[fp.isrc0 + js];
         const bool unit = (fp.syn_factor == 1.f);
         for (int k = 0; k < rv.ncomp; k++) {
             if (PART != 0 && (rv.comp[k] == 3) != (PART == 2)) continue;      // the vertical trace belongs to the PART 2 workgroup
@@ -1654,7 +1670,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_CELL_WAV
                 acc = (fp.method == 6) ? fmax(acc, other) : acc + other;
             }
             if (lane == 0)
-                fp.partial[((size_t)s * fp.nmis + rv.slot0 + k) * fp.nparts + tile * (T / 64) + (tid >> 6)] = acc;
+                fp.partial[((size_t)js * fp.nmis + rv.slot0 + k) * fp.nparts + tile * (T / 64) + (tid >> 6)] = acc;
         }
     }
 }

@@ -522,7 +522,7 @@ def test_eikonal_sources_with_risetime_fold(stype):
     assert failings == [0, 1] and np.all(mis == 0) and np.all(nor == 0)
 
 
-@pytest.mark.parametrize("stype", ["bilateral", "mt_eikonal"])
+@pytest.mark.parametrize("stype", ["bilateral", "mt_eikonal", "moment_tensor"])
 def test_moment_and_risetime_sweeps_rescale_instead_of_resynthesising(monkeypatch, stype):
     """minimizer_engine.f90:516-521 (source_bilat.f90:206, source_mt_eikonal.f90:234-239): when only the moment (or, for the
     eikonal types, the rise time) changes the reference re-scales the seismograms without synthesising them again.  Here
@@ -538,6 +538,12 @@ def test_moment_and_risetime_sweeps_rescale_instead_of_resynthesising(monkeypatc
         trials = np.repeat(base, 4, axis=0)
         trials[:, 4] *= np.tile([1.0, 0.5, 2.0, 1.7], 3)               # moment
         sid = 1
+    elif stype == "moment_tensor":
+        # point sources at one location (runs of geometry-identical sources share blended tiles) with exact repeats, as the
+        # degenerate strike / dip / rake combinations of a double-couple grid produce them
+        mts = [synthetic.mt_from_sdr(30. * i, 60., -90. + 20 * i) for i in range(5)]
+        trials = np.array([[0., 0., 0., 10000.] + mts[k] + [1.0] for k in (0, 1, 0, 2, 1, 3, 3, 4, 0, 2, 4, 1)], np.float32)
+        sid = 6
     else:
         t0 = np.array([0.2, 300., -200., 10500., 1.0, 85., 70., 100., -50., 2900., 200., 200., 0.8] +
                       synthetic.mt_from_sdr(40., 60., -70., 7e17) + [0.0], np.float32)
@@ -552,6 +558,13 @@ def test_moment_and_risetime_sweeps_rescale_instead_of_resynthesising(monkeypatc
             q.set_source_crust(G["rupture_profile"], G["origin_profile"])
             q.set_source_constraints(cp, cn)
     trials = trials[np.array([0, 1, 4, 2, 5, 3] + list(range(6, len(trials))))]      # identical tables need not be neighbours
+    monkeypatch.setenv("KIWI_HIP_DEDUPE", "2")             # also for point sources (by default only sources of >= 8 centroids)
+    p.close()
+    p = sc.product()
+    sc.apply_setup(p, False)
+    if sid == 5:
+        p.set_source_crust(G["rupture_profile"], G["origin_profile"])
+        p.set_source_constraints(cp, cn)
     p.set_source_params(stype, trials)
     p.eval()
     a = [x.copy() for x in p.get_misfits()]
@@ -567,9 +580,12 @@ def test_moment_and_risetime_sweeps_rescale_instead_of_resynthesising(monkeypatc
     b = q.get_misfits()
     for x, y in zip(a, b):
         assert x.tobytes() == y.tobytes()
-    assert len({x.tobytes() for x in a[0]}) == len(trials)             # every trial has its own misfits
-    if sid == 1:
-        m, n, g = oracle_misfits(e, 1, trials)
+    if sid != 6:
+        assert len({x.tobytes() for x in a[0]}) == len(trials)         # every trial has its own misfits
+    else:
+        assert len({x.tobytes() for x in a[0]}) == 5
+    if sid in (1, 6):
+        m, n, g = oracle_misfits(e, sid, trials)
         assert misfit_close(a[0], m) and misfit_close(a[2], g)
     p.eval(0, 2)                                                        # a chunk that holds the first of a family only
     p.eval(2, len(trials) - 2)                                          # ... the rest refers back across the chunk border: synthesised
