@@ -572,6 +572,21 @@ __global__ __launch_bounds__(256) void shake_kernel(const float *__restrict__ pr
 
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned 16-byte load
 
+// Raw buffer loads for the rows of one group: the descriptor holds the group base (64 bit), the row's start comes as the
+// instruction's SCALAR offset and the lane's position as its 32-bit vector offset -- no per-load vector address arithmetic
+// (a global_load needs a 64-bit VGPR address per load: one v_lshl_add_u64 each, 40 per group).
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v2i_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t gf_rsrc(const float *base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, -1, 0x00020000);      // raw buffer, 32-bit data, no range limit below 4 GB
+}
+__device__ __forceinline__ f4u buf_load4(__amdgpu_buffer_rsrc_t r, int voff_floats, int soff_floats)
+{
+    const v4i_t v = __builtin_amdgcn_raw_buffer_load_b128(r, 4 * voff_floats, 4 * soff_floats, 0);
+    return f4u{ __int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w) };
+}
+
 // five consecutive samples l-1 .. l+3 of one GF row (l relative to the row's first sample).
 // The row is stored as [kRowPad zeros | n samples | end value repeated up to pitch], so clamping
 // the start position implements "zero before the span, last value repeated after it"
@@ -787,8 +802,7 @@ __device__ __forceinline__ void build_batch(float *__restrict__ tile0, int lds_t
         for (int k = 0; k < (BLEND ? 4 : 1); k++) {
             const int base = REC_I(ta, 4 * igs[q] + k);
             if constexpr (FAST) {
-                const float *rowp = G + (size_t)(unsigned)(base + jb);
-                v[q][k] = *(const f4u *)((const char *)rowp + (unsigned)(4 * p));      // saddr + 32-bit voffset
+                v[q][k] = buf_load4(gf_rsrc(G), p, base + jb);       // scalar row offset + the lane's position
             } else {
                 const int lo = REC_I(tb, 4 * igs[q] + k);
                 const int idx = min(max(base + j, lo), lo + pitch - 4);
@@ -825,8 +839,7 @@ __device__ __forceinline__ void pair_issue(f4u (&v)[2][BLEND ? 4 : 1], int ig0, 
         for (int k = 0; k < (BLEND ? 4 : 1); k++) {
             const int base = REC_I(ta, 4 * (ig0 + q) + k);
             if constexpr (FAST) {
-                const float *rowp = G + (size_t)(unsigned)(base + jb);
-                v[q][k] = *(const f4u *)((const char *)rowp + (unsigned)(4 * p));
+                v[q][k] = buf_load4(gf_rsrc(G), p, base + jb);
             } else {
                 const int lo = REC_I(tb, 4 * (ig0 + q) + k);
                 const int idx = min(max(base + j, lo), lo + pitch - 4);
