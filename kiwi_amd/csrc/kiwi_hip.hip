@@ -1593,15 +1593,35 @@ int kiwi_hip_set_sources_params(kiwi_hip_ctx *c, int sourcetype, int nsrc, const
     // a few threads only: the discretisers take microseconds per source, and idle OpenMP workers spin for their
     // block time after the loop, competing with the HIP runtime's own threads for the caller's next calls
     // (the eikonal discretisers run a fast-marching solve per source: milliseconds, one thread per source pays)
-    // (measured on the GPU box, cfg4: a 25 m fine grid of 1200 x 360 points per source, 160 ms per solve: with 64 threads
-    // the discretiser took 390 ms per 128 sources against 290 ms for their evaluation on the device -- every hardware
-    // thread gets a source)
-    const int nthreads = std::max(1, eikonal ? std::min({ omp_get_max_threads(), nsrc, 512 })
+    // (measured on the GPU box, cfg4: a 25 m fine grid of 1200 x 360 points per source, 0.1-0.16 s per solve: the
+    // discretiser takes 350-420 ms per 128 sources against 290 ms for their evaluation on the device)
+    int ecap = 512;
+    if (const char *m = std::getenv("KIWI_HIP_DISC_THREADS")) ecap = std::max(1, std::atoi(m));
+    const int nthreads = std::max(1, eikonal ? std::min({ omp_get_max_threads(), nsrc, ecap })
                                              : std::min({ omp_get_max_threads(), (nsrc + 31) / 32, 16 }));
     (void)nthreads;
+    // Eikonal types: trial sources that differ from an earlier one of the batch only in moment (factor) and rise time have
+    // the same rupture -- psm%moment and psm%risetime do not enter psm_to_tdsm (source_eikonal.f90:228-229,
+    // source_mt_eikonal.f90:243-244) -- so the fast-marching solve is done once per distinct rupture and the table copied.
+    std::vector<int> solve_of((size_t)nsrc);
+    for (int s = 0; s < nsrc; s++) solve_of[s] = s;
+    if (eikonal) {
+        const int imom = 4, irise = sourcetype == 5 ? 19 : 14;
+        std::map<std::vector<unsigned int>, int> seen;
+        std::vector<unsigned int> key((size_t)np);
+        for (int s = 0; s < nsrc; s++) {
+            std::memcpy(key.data(), params + (size_t)s * np, (size_t)np * sizeof(float));
+            key[imom] = 0; key[irise] = 0;
+            auto it = seen.find(key);
+            if (it == seen.end()) seen.emplace(key, s); else solve_of[s] = it->second;
+        }
+    }
+    // (eikonal: the batch's solves together are bound by something shared -- 128 of them take 350-420 ms on the 64-core box
+    // whether 16, 32 or 96 threads work on them; grabs of four keep the thread count at a quarter of the batch)
 #pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
     for (int s = 0; s < nsrc; s++) {
         std::string err;
+        if (solve_of[s] != s) continue;
         if (eikonal) err = discretize_eikonal(sourcetype, params + (size_t)s * np, c->effective_dt, c->rupture_profile, c->constraints, ds[s]);
         else if (!discretize(sourcetype, params + (size_t)s * np, c->effective_dt, ds[s])) err = why;
         if (!err.empty()) {
@@ -1611,6 +1631,14 @@ int kiwi_hip_set_sources_params(kiwi_hip_ctx *c, int sourcetype, int nsrc, const
             { nbad++; if (bad < 0 || s < bad) { bad = s; why = err; } }
         }
     }
+    for (int s = 0; s < nsrc; s++)
+        if (solve_of[s] != s) {                  // same rupture as an earlier source: its table, own moment and rise time
+            const int f = solve_of[s];
+            status[s] = status[f];
+            ds[s].centroids = ds[f].centroids;
+            if (status[f] == 0) { ds[s].moment = params[(size_t)s * np + 4]; ds[s].risetime = params[(size_t)s * np + (sourcetype == 5 ? 19 : 14)]; }
+            else { ds[s].moment = 0.f; ds[s].risetime = 0.f; nbad++; }
+        }
     // wrong type / parameter count is the caller's error for the whole batch; a source the discretiser rejects
     // ("Empty rupture area", ...) is recorded and skipped like seismosizer.py:703-720 does (failings)
     if (bad >= 0 && !eikonal) throw std::runtime_error(why + " (source " + std::to_string(bad + 1) + ")");
