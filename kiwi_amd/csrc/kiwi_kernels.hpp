@@ -1397,7 +1397,8 @@ __device__ __forceinline__ void raw_issue(RawArr<NG, PART, SPL> &v, int p, int j
 {
     typedef typename RawVec<SPL>::type RV;
     typedef CellPart<NG, PART> P;
-    const int j = jb + p;
+    __builtin_assume(pitch >= 8);
+    const int p4 = 4 * p, hi4 = 4 * (pitch - 4);
 #pragma unroll
     for (int i = 0; i < P::n; i++) {
 #pragma unroll
@@ -1405,9 +1406,19 @@ __device__ __forceinline__ void raw_issue(RawArr<NG, PART, SPL> &v, int p, int j
             // row start (wave-uniform: scalar base address) + this lane's clamped position inside the row (32-bit offset):
             // one address register per load instead of a 64-bit pair, and nothing here overflows for tensors beyond 2^31 bytes
             const int base = REC_I(ta, 4 * P::ig(i) + k), lo = REC_I(tb, 4 * P::ig(i) + k);
-            const float *rowp = G + (size_t)(unsigned)lo;
-            const int q = min(max(base - lo + j, 0), pitch - 4);
-            v[i][k] = *(const RV *)((const char *)rowp + (unsigned)(4 * q));
+            // lane position inside the row, clamped (one v_add + one v_med3 per load); the row start is the load's scalar offset
+            // byte offset of LDS position 0 inside the row: scalar arithmetic (kept there by hand -- left to itself the
+            // compiler re-associates it into the lanes), then one add and one v_med3 per load for the lane's clamped position
+            int u4, q4;
+            asm("s_sub_i32 %0, %1, %2\n\ts_add_i32 %0, %0, %3\n\ts_lshl_b32 %0, %0, 2" : "=&s"(u4) : "s"(base), "s"(lo), "s"(jb) : "scc");
+            asm("v_add_u32 %0, %1, %2\n\tv_med3_i32 %0, %0, 0, %3" : "=&v"(q4) : "s"(u4), "v"(p4), "s"(hi4));
+            if constexpr (SPL == 4) {
+                const v4i_t w = __builtin_amdgcn_raw_buffer_load_b128(gf_rsrc(G), q4, 4 * lo, 0);
+                v[i][k] = RV{ __int_as_float(w.x), __int_as_float(w.y), __int_as_float(w.z), __int_as_float(w.w) };
+            } else {
+                const v2i_t w = __builtin_amdgcn_raw_buffer_load_b64(gf_rsrc(G), q4, 4 * lo, 0);
+                v[i][k] = RV{ __int_as_float(w.x), __int_as_float(w.y) };
+            }
         }
     }
 }
@@ -1530,12 +1541,14 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_CELL_WAV
     const int *__restrict__ tc = tab + ((size_t)(c0 - cb) * nrec + (size_t)r * nc) * 128;
     const float sd = rv.sd;
     const int u0 = SPL * (tid & ~63) + lane;             // this lane's first tile sample (the others: + 64 q)
-    // halo: lane q < 16 n owns the 4-sample chunk (q & 15) of the part's component q >> 4 beyond the tile
-    const int hloc = min(tid >> 4, P::n - 1), hph = TILE + 4 * (tid & 15);
+    // halo: lane q < 16 n owns the 4-sample chunk q / n of the part's component q % n beyond the tile.  Chunk-major: a
+    // group needs the first few chunks only (its shift range plus 8 samples), so the active lanes are the first ones and
+    // the waves behind them skip the halo's blend
+    const int hloc = tid % P::n, hph = TILE + 4 * (tid / P::n);
     int hig = P::ig(0);
 #pragma unroll
     for (int i = 1; i < P::n; i++) if (hloc == i) hig = P::ig(i);
-    const bool hslot = (tid >> 4) < P::n;
+    const bool hslot = tid < 16 * P::n;
 
     f2v ar1[NP], ar2[NP], dz[NP];
 #pragma unroll
