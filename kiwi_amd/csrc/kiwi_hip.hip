@@ -558,6 +558,7 @@ __global__ void ref_filt_kernel(const float *__restrict__ fftbuf, const FftPair 
 template <class T> void pin_ensure(T *&p, size_t &have, size_t want)
 {
     if (want <= have) return;
+    (void)hipDeviceSynchronize();                        // a copy from / to the old block may still be in flight (rare: growth only)
     if (p) (void)hipHostFree(p);
     p = nullptr; have = 0;
     HIPCHECK(hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault));

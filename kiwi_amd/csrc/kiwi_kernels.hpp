@@ -1197,7 +1197,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
     bool stored = false;
     int c = 0;
     int cur = rec_load(rc, 0, nc, lane);                 // record c, lane-distributed
-    int ta = tc[lane], tb = tc[64 + lane];               // load descriptors of record c
+    int ta = 0, tb = 0;                                  // load descriptors of record c (a rejected trial source has no centroids, no rows)
+    if (nc > 0) { ta = tc[lane]; tb = tc[64 + lane]; }
     while (c < nc) {
         GeoRec g0;
         rec_head(cur, 0, g0);
@@ -1366,17 +1367,17 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
 // the workgroup loads the raw rows of the tile ONCE per group into registers (4 x NG dwordx4 per lane) and, per centroid,
 // blends them with that centroid's weights (gfdb.f90:944-949, same order) into the LDS tile the apply phase reads, exactly
 // as the grouped kernel does after its loads.  Per output sample the operations and their order are those of
-// accumulate_kernel, so the results are bit-identical.  The halo (positions beyond the tile that the shifts reach) is a
-// sixteenth of the tile: it is fetched per centroid by the halo lanes instead of occupying registers.
+// accumulate_kernel, so the results are bit-identical.  The halo (positions beyond the tile that the shifts reach) is held
+// the same way: one 4-sample chunk of one component per halo lane, 16 more registers.
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));   // dword-aligned 8-byte load
 template <int SPL> struct RawVec;
 template <> struct RawVec<4> { typedef f4u type; };
 template <> struct RawVec<2> { typedef f2u type; };
 
 // raw rows of one cell over the tile's main chunk (SPL samples per lane at LDS position p): always the clamped form of the
-// address -- the loads run once per GROUP here, their address arithmetic does not matter -- and always all four nodes: a
-// centroid exactly on a node carries the weights (1, 0, 0, 0) and four times the same row, and 1 v + 0 v + 0 v + 0 v is v
-// bit for bit (also for -0), so no separate unblended form is needed (gfdb.f90:890-893 vs :944-949)
+// address (no separate clamp-free variant: the loads run once per GROUP) and always all four nodes: a centroid exactly on
+// a node carries the weights (1, 0, 0, 0) and four times the same row, and 1 v + 0 v + 0 v + 0 v is v bit for bit (also
+// for -0), so no separate unblended form is needed (gfdb.f90:890-893 vs :944-949)
 // The components one workgroup of accumulate_cell_kernel works on, in APPLICATION order (seismogram.f90:171-250):
 // PART 0 = all of them; PART 1 = the horizontal block 1 2 3 [9] 4 5 (radial and transverse sums, rotated into the north /
 // east or away / right traces), PART 2 = the vertical block 6 7 8 [10].  Two workgroups per (source, tile, receiver) halve
@@ -1576,7 +1577,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_CELL_WAV
     int c = 0;
     int cur = rec_load(rc, 0, nc, lane);                 // record c, lane-distributed; nx1: record c + 1
     int nx1 = rec_load(rc, 1, nc, lane);
-    int ta = tc[lane], tb = tc[64 + lane];               // load descriptors of record c
+    int ta = 0, tb = 0;                                  // load descriptors of record c (none for a source without centroids)
+    if (nc > 0) { ta = tc[lane]; tb = tc[64 + lane]; }
     bool preloaded = false;                              // the loads of the group starting at c were issued during the previous apply
     while (c < nc) {
         const int row0 = REC_I(cur, 0), pad0 = REC_I(cur, 19), ishift0 = REC_I(cur, 8);

@@ -57,6 +57,29 @@ def test_cfg3_bilateral_100_centroids_50_receivers():
     assert np.array_equal(m, m2) and np.array_equal(g, g2)
 
 
+@pytest.mark.parametrize("name,ncent_want", [("cfg3-100pt", 200), ("cfg3-scatter", 100)])
+def test_cfg3_variants_at_full_size(name, ncent_want):
+    """The literal "100 sub-faults" source (100 sub-fault points x 2 time steps) and the cfg3 source over a shuffled
+    location grid (no Green's function rows shared between neighbouring trials), full size, oracle spot checks."""
+    wl, p, gf, recv, refs, tapers, ncent = setup(name, 20)
+    assert ncent == ncent_want and wl["nrec"] == 50
+    if name == "cfg3-100pt":
+        assert wl["npoints"] == 100
+    tr = wl["trials"].copy()
+    tr[0] = wl["true"]
+    p.set_source_params("bilateral", tr)
+    p.eval()
+    m, n, g = p.get_misfits()
+    assert m.shape == (20, 150) and np.all(m[0] == 0.0) and g[0] == 0.0
+    if name == "cfg3-scatter":                              # the trials really are scattered: 4 km steps north / east
+        assert len(np.unique(tr[1:, 1])) > 5 and len(np.unique(tr[1:, 2])) > 5 and np.all(g[1:] > 0.1)
+    e, db, evaluate = bench.oracle_engine(wl, gf, recv, refs, tapers, CORES)
+    for i in (1, 7, 19):
+        om, on, og = evaluate(tr[i])
+        assert rel(m[i], om) <= 1e-6 and abs(g[i] - og) <= 1e-6 * og and np.array_equal(n[i], on)
+    e.close(); db.close()
+
+
 def test_cfg2_moment_tensor_grid():
     wl, p, gf, recv, refs, tapers, ncent = setup("cfg2", 512)
     tr = wl["trials"].copy()
