@@ -383,6 +383,7 @@ void prepare(kiwi_hip_ctx *c)
             cd.fl_lo = 0; cd.fl_ns = 1; cd.refxofs = 0;
             cd.untapered = untapered ? 1 : 0;
             cd.vertical = std::abs(r.comp[k]) == 3 ? 1 : 0;
+            { const int a = std::abs(r.comp[k]); cd.spankind = a == 3 ? 3 : (a == 1 ? 0 : (a == 2 ? 1 : 2)); }   // receiver.f90:35-48: 1 away 2 right 3 down 4 north 5 east
             d.synofs[k] = (int)synofs;
             d.refofs[k] = cd.refofs;
             synofs += ((size_t)d.wlen + 3) / 4 * 4;
@@ -856,8 +857,8 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
     int *spansrc = nullptr;
     if (c->any_untapered || c->want_spansrc || c->fft_needed) {     // per-source strip spans, initialised empty
         const size_t n = (size_t)nsrc * nrec;
-        c->spansrc_d.ensure(n * 4, &c->dev_bytes);
-        hipLaunchKernelGGL(span_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->spansrc_d.p, n);
+        c->spansrc_d.ensure(n * kSpanInts, &c->dev_bytes);
+        hipLaunchKernelGGL(span_init_kernel, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, c->stream, c->spansrc_d.p, 2 * n);
         spansrc = c->spansrc_d.p;
     }
     hipEvent_t e0, e1, e2, e3;

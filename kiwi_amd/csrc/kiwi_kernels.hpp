@@ -94,7 +94,10 @@ struct CompDev {
     // reference over [w0 - fl_hi, w0 + wlen - 1 - fl_lo] lives
     int fl_lo, fl_ns, refxofs;
     // un-tapered comparator (comparator.f90:798-800): norms run over the union of the two data spans
-    int untapered, rf0, rf1, vertical;      // reference data span [rf0, rf1]; which strip span applies to the synthetic
+    int untapered, rf0, rf1, vertical;      // reference data span [rf0, rf1]; which strip span applies to the synthetic:
+    // vertical: 0 away / right ... see spankind; kept for the shake diagnostics
+    int spankind;    // 0: the radial strip (components a / c), 1: the transverse strip (r / l), 2: both made equal (n / e,
+                     // seismogram.f90:268-283), 3: the vertical strip -- see strip_span()
 };
 
 // Spectral / filtered comparator, one record per (trial source of the chunk, misfit slot) -- or per reference variant
@@ -119,6 +122,21 @@ struct ShakeRec {
     int untapered;   // no taper: the norm runs over the union of the synthetic strips' data spans (comparator.f90:733-736)
     int rec;
 };
+
+// Data spans of one (source, receiver)'s synthetic strips, 8 ints: [lo, hi] of the radial sum displacement_ar(1), of the
+// transverse sum displacement_ar(2), of the vertical strip, 2 unused; lo > hi = empty.  The two horizontal sums are
+// separate strips in the reference: a centroid that leaves at a missing trace in the plain (non-rotating) branch may have
+// extended one and not the other (seismogram.f90:205-231), the rotating branch makes them equal before it adds
+// (strip_extend_to_same_span_4, :196-197), and so does the rotation to north / east at the end (:268-283), AFTER the away /
+// right components have taken theirs (:256-267).
+constexpr int kSpanInts = 8;
+__device__ __forceinline__ void strip_span(const int *__restrict__ sp, int kind, int &lo, int &hi)
+{
+    if (kind == 3) { lo = sp[4]; hi = sp[5]; return; }
+    if (kind == 0) { lo = sp[0]; hi = sp[1]; return; }
+    if (kind == 1) { lo = sp[2]; hi = sp[3]; return; }
+    lo = min(sp[0], sp[2]); hi = max(sp[1], sp[3]);          // (an empty span is (+inf, -inf): the union is the other one)
+}
 
 // ------------------------------------------------------------------------------------------------
 // geometry
@@ -265,7 +283,7 @@ __device__ __forceinline__ void write_tab(int *__restrict__ tb, const GeoRec &g,
 __global__ __launch_bounds__(256) void geometry_kernel(
     const float *__restrict__ cent, const int *__restrict__ cent_ofs, EvalParams ep, GfMeta gm,
     const int2 *__restrict__ span, const RecvDev *__restrict__ recv, GeoRec *__restrict__ out,
-    int *__restrict__ tab, int *__restrict__ spanbuf, int *__restrict__ spansrc /* optional [source][receiver][4] */,
+    int *__restrict__ tab, int *__restrict__ spanbuf, int *__restrict__ spansrc /* optional [source][receiver][kSpanInts] */,
     int *__restrict__ pairflag /* optional [source][receiver]: some centroid of the pair misses a trace (cell mode) */,
     const unsigned char *__restrict__ endz /* per GF row: its end value is zero (write_tab) */,
     const int *__restrict__ synrow /* optional [source]: source whose synthetics this one shares; != own index: nothing to do */)
@@ -421,23 +439,30 @@ __global__ __launch_bounds__(256) void geometry_kernel(
     // separately; only needed to size the comparator's FFT (comparator.f90:464-486)
     if ((spanbuf || spansrc) && g.row[0] >= 0) {
         const int nn = (g.flags & 1) ? 1 : 4;
-        int lo_h = 0x7fffffff, hi_h = -0x7fffffff, lo_d = 0x7fffffff, hi_d = -0x7fffffff;
+        int lo_1 = 0x7fffffff, hi_1 = -0x7fffffff, lo_2 = 0x7fffffff, hi_2 = -0x7fffffff, lo_d = 0x7fffffff, hi_d = -0x7fffffff;
+        const int nH1 = gm.ng == 10 ? 4 : 3;          // components of the radial sum
         for (int i = 0; i < nlim_h + nlim_d; i++) {   // the components that are added (all of the needed ones, normally)
             const bool horiz = i < nlim_h;
             const int q = horiz ? i : i - nlim_h;
             const int ig = horiz ? (gm.ng == 10 ? (q < 3 ? q : (q == 3 ? 8 : q - 1)) : q) : (q < 3 ? 5 + q : 9);
             int lo = 0x7fffffff, hi = -0x7fffffff;
             for (int k = 0; k < nn; k++) { const int2 sp = span[g.row[k] + ig]; lo = min(lo, sp.x); hi = max(hi, sp.y); }
-            if (horiz) { lo_h = min(lo_h, lo); hi_h = max(hi_h, hi); } else { lo_d = min(lo_d, lo); hi_d = max(hi_d, hi); }
+            if (!horiz) { lo_d = min(lo_d, lo); hi_d = max(hi_d, hi); }
+            else if (q < nH1) { lo_1 = min(lo_1, lo); hi_1 = max(hi_1, hi); }
+            else { lo_2 = min(lo_2, lo); hi_2 = max(hi_2, hi); }
         }
-        if (spanbuf) {
-            if (nlim_h) { atomicMin(&spanbuf[4 * r + 0], lo_h + g.ishift); atomicMax(&spanbuf[4 * r + 1], hi_h + g.ishift + 1); }
+        if ((g.flags & 2) && nlim_h) {                // rotating branch: both sums get the union before the rotated add
+            lo_1 = lo_2 = min(lo_1, lo_2); hi_1 = hi_2 = max(hi_1, hi_2);
+        }
+        if (spanbuf) {                                // per receiver over all sources: [horizontal lo, hi, vertical lo, hi]
+            if (nlim_h) { atomicMin(&spanbuf[4 * r + 0], min(lo_1, lo_2) + g.ishift); atomicMax(&spanbuf[4 * r + 1], max(hi_1, hi_2) + g.ishift + 1); }
             if (nlim_d) { atomicMin(&spanbuf[4 * r + 2], lo_d + g.ishift); atomicMax(&spanbuf[4 * r + 3], hi_d + g.ishift + 1); }
         }
-        if (spansrc) {                               // the same per trial source: data spans of ITS synthetic strips
-            int *sp = spansrc + ((size_t)s * ep.nrec + r) * 4;
-            if (nlim_h) { atomicMin(&sp[0], lo_h + g.ishift); atomicMax(&sp[1], hi_h + g.ishift + 1); }
-            if (nlim_d) { atomicMin(&sp[2], lo_d + g.ishift); atomicMax(&sp[3], hi_d + g.ishift + 1); }
+        if (spansrc) {                               // the same per trial source and strip: data spans of ITS synthetic strips
+            int *sp = spansrc + ((size_t)s * ep.nrec + r) * kSpanInts;
+            if (hi_1 >= lo_1) { atomicMin(&sp[0], lo_1 + g.ishift); atomicMax(&sp[1], hi_1 + g.ishift + 1); }
+            if (hi_2 >= lo_2) { atomicMin(&sp[2], lo_2 + g.ishift); atomicMax(&sp[3], hi_2 + g.ishift + 1); }
+            if (nlim_d) { atomicMin(&sp[4], lo_d + g.ishift); atomicMax(&sp[5], hi_d + g.ishift + 1); }
         }
     }
     if (!out) return;
@@ -530,8 +555,9 @@ __global__ __launch_bounds__(256) void shake_kernel(const float *__restrict__ pr
     if (sr.untapered) {
         int lo = 0x7fffffff, hi = -0x7fffffff;
         for (int k = 0; k < sr.np; k++) {
-            const int *sp = spansrc + (size_t)sr.rec * 4 + (comps[sr.slot[k]].vertical ? 2 : 0);
-            if (sp[1] >= sp[0]) { lo = min(lo, sp[0] - fold_grow); hi = max(hi, sp[1] + (fold_grow ? fold_grow + 1 : 0)); }
+            int s0, s1;
+            strip_span(spansrc + (size_t)sr.rec * kSpanInts, comps[sr.slot[k]].spankind, s0, s1);
+            if (s1 >= s0) { lo = min(lo, s0 - fold_grow); hi = max(hi, s1 + (fold_grow ? fold_grow + 1 : 0)); }
         }
         i_lo = max(lo - c0.w0, 0); i_hi = min(hi - c0.w0, c0.wlen - 1);
         if (hi < lo) { if (threadIdx.x == 0) out[blockIdx.x] = 0.f; return; }
@@ -1739,9 +1765,10 @@ __global__ __launch_bounds__(256) void misfit_kernel(
     // span and the data span of this source's synthetic strip (probes_norm_timedomain, comparator.f90:798-800)
     int i_lo = 0, i_hi = cd.wlen - 1;
     if (cd.untapered) {
-        const int *sp = spansrc + ((size_t)s * nrec + cd.rec) * 4 + (cd.vertical ? 2 : 0);
+        int s0, s1;
+        strip_span(spansrc + ((size_t)(synrow ? synrow[s] : s) * nrec + cd.rec) * kSpanInts, cd.spankind, s0, s1);
         int lo = cd.rf0, hi = cd.rf1;
-        if (sp[1] >= sp[0]) { lo = min(lo, sp[0] - fold_grow); hi = max(hi, sp[1] + (fold_grow ? fold_grow + 1 : 0)); }
+        if (s1 >= s0) { lo = min(lo, s0 - fold_grow); hi = max(hi, s1 + (fold_grow ? fold_grow + 1 : 0)); }
         i_lo = max(lo - cd.w0, 0); i_hi = min(hi - cd.w0, cd.wlen - 1);
     }
     const float mom = moment[mp.isrc0 + s];
@@ -1989,9 +2016,9 @@ __global__ void fft_size_kernel(const int *__restrict__ spansrc, const CompDev *
     if (idx >= nsrc * nmis) return;
     const int s = idx / nmis, m = idx - s * nmis;
     const CompDev cd = comps[m];
-    const int *sp = spansrc + ((size_t)s * nrec + cd.rec) * 4 + (cd.vertical ? 2 : 0);
-    int s0 = sp[0], s1 = sp[1];
-    if (s1 < s0) { s0 = cd.rf0; s1 = cd.rf0; }                       // no centroid reached this receiver
+    int s0, s1;
+    strip_span(spansrc + ((size_t)s * nrec + cd.rec) * kSpanInts, cd.spankind, s0, s1);
+    if (s1 < s0) { s0 = cd.rf0; s1 = cd.rf0; }                       // no centroid reached this strip
     if (fold_grow > 0) { s0 -= fold_grow; s1 += fold_grow + 1; }
     const int len_ref = cd.rf1 - cd.rf0 + 1, len_syn = s1 - s0 + 1;
     const int len_u = max(cd.rf1, s1) - min(cd.rf0, s0) + 1;
@@ -2005,7 +2032,7 @@ __global__ void fft_size_kernel(const int *__restrict__ spansrc, const CompDev *
 // empty spans for the per-source reduction of geometry_kernel
 __global__ void span_init_kernel(int *__restrict__ spansrc, size_t n4)
 {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;          // n4 = number of int4s = pairs of (lo, hi) pairs
     if (i < n4) reinterpret_cast<int4 *>(spansrc)[i] = make_int4(0x7fffffff, -0x7fffffff, 0x7fffffff, -0x7fffffff);
 }
 
@@ -2046,8 +2073,9 @@ __global__ __launch_bounds__(256) void floating_norm_kernel(
     const CompDev cd = comps[m];
     int s_lo = 0x7fffffff, s_hi = -0x7fffffff;          // data span of this source's synthetic strip (un-tapered only)
     if (cd.untapered) {
-        const int *sp = spansrc + ((size_t)s * nrec + cd.rec) * 4 + (cd.vertical ? 2 : 0);
-        if (sp[1] >= sp[0]) { s_lo = sp[0] - fold_grow; s_hi = sp[1] + (fold_grow ? fold_grow + 1 : 0); }
+        int s0, s1;
+        strip_span(spansrc + ((size_t)s * nrec + cd.rec) * kSpanInts, cd.spankind, s0, s1);
+        if (s1 >= s0) { s_lo = s0 - fold_grow; s_hi = s1 + (fold_grow ? fold_grow + 1 : 0); }
     }
     const float *__restrict__ sy = vt + (size_t)s * syn_stride + cd.synofs + cd.halo;
     const float *__restrict__ rx = refx + cd.refxofs;

@@ -667,6 +667,43 @@ def test_cycle_at_the_first_missing_trace(monkeypatch, bilinear, accum):
     assert 0 < nempty < 10
 
 
+@pytest.mark.parametrize("method", ["ampspec_l2norm", "l2norm_untapered"])
+def test_radial_and_transverse_strips_keep_their_own_spans(method):
+    """The two horizontal sums are separate strips (seismogram.f90:205-231): a point source at the origin (no rotation) whose
+    transverse traces are missing extends the radial strip only, so the right / left component's probe stays empty while the
+    away and the north / east components (made equal before the final rotation, :268-283) carry data.  Matters wherever the
+    comparator follows the strips' data spans: transform lengths of the spectral norms, un-tapered norms (found by the
+    randomised sweep with missing traces)."""
+    comps = ["ar", "nl", "ne", "lc", "rd", "n"]
+    sc = Scenario(nrec=6, comps_list=comps, L=96, nx=10, nz=5)
+    e = sc.oracle()
+    sc.make_references(e)
+    if method == "l2norm_untapered":
+        sc.tapers = {}
+    _knock_out(sc, [(ix, iz, 3) for ix in range(10) for iz in range(5)])      # every first transverse trace: 4 and 5 never added
+    mt = np.array([[0., 0., 0., 10000.] + synthetic.mt_from_sdr(30. * i, 60., -90. + 20 * i) + [1.0] for i in range(3)], np.float32)
+    sc.oracle()                              # (the product takes its tables from the scenario's packed database: rebuild it)
+    p = sc.product()
+    sc.apply_setup(p, False)
+    mid = 3 if method == "ampspec_l2norm" else 1
+    p.set_misfit_method(method.split("_untapered")[0])
+    p.set_source_params("moment_tensor", mt)
+    p.eval()
+    pm, pn, pg = p.get_misfits()
+    for i in range(3):                       # fresh engine per source: the reference's spans remember earlier sources
+        ef = sc.oracle()
+        sc.apply_setup(ef, True)
+        ef.set_misfit_method(mid)
+        ef.set_source_params(6, mt[i])
+        om, on, og = ef.get_misfits()
+        tol = SPEC_RTOL if mid == 3 else MISFIT_RTOL
+        assert np.allclose(pn[i], on, rtol=tol, atol=0), (i, pn[i], on)
+        assert np.allclose(pm[i], om, rtol=tol, atol=tol * np.abs(on).max()), (i, np.max(np.abs(pm[i] - om) / on))
+        ef.close()
+    # the transverse probes see no synthetic at all: their misfit is the norm of the reference
+    assert np.allclose(pm[:, 1], pn[:, 1], rtol=SPEC_RTOL) and not np.allclose(pm[:, 0], pn[:, 0], rtol=1e-3)
+
+
 def test_grouped_and_direct_accumulate_are_bit_identical(monkeypatch):
     """The LDS-staged kernel only moves where the blended traces are read from: its synthetics equal the direct kernel's
     bit for bit (also with traces missing from the database and the static variant's repeated end values)."""
