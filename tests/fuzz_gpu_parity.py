@@ -143,6 +143,14 @@ def one_case(rng, verbose):
             ms.append(a); ns.append(b); gs.append(cglob)
         m, nn, g = np.array(ms), np.array(ns), np.array(gs, np.float32)
     else:
+        # a fifth of the multi-source cases: some trials repeated with another moment (bilateral / circular / point_lp:
+        # parameter 5) -- identical centroid tables, synthesised once and re-scaled (KIWI_HIP_DEDUPE=2 includes point sources)
+        if n > 1 and stype in (1, 2, 3) and rng.random() < 0.2:
+            k = int(rng.integers(1, n))
+            extra = tr[rng.integers(0, n, k)].copy()
+            extra[:, 4] *= rng.choice([0.5, 2.0, 3.7], k).astype(np.float32)
+            tr = np.concatenate([tr, extra])[rng.permutation(n + k)]
+            n = len(tr)
         m, nn, g = oracle_misfits(e, stype, tr)
     p.set_source_params(name, tr)
     p.eval()
