@@ -157,7 +157,9 @@ def cpu_baseline(wl, gf, recv, refs, tapers, gpu_global, gpu_misfits, gpu_norms,
     this box's host cores for a bounded number of the SAME trial sources."""
     # the reference parallelises make_seismogram over receivers (minimizer_engine.f90:893-903): no more threads than
     # receivers can do work
-    cores = min(os.cpu_count() or 1, wl["nrec"])
+    from kiwi_amd import lib as _lib
+    avail = int(_lib.load().kiwi_hip_effective_cpus())      # hardware threads cut to the container's CPU quota
+    cores = min(avail, wl["nrec"])
     trials = wl["trials"]
     e, db, evaluate = oracle_engine(wl, gf, recv, refs, tapers, cores)
 
@@ -191,8 +193,8 @@ def cpu_baseline(wl, gf, recv, refs, tapers, gpu_global, gpu_misfits, gpu_norms,
     e.close()
     db.close()
     return {"value": n / dtm, "unit": "evals/s", "cores": cores, "kind": "port",
-            "sample": "%d of the timed trial sources, oracle/libko.so, OpenMP over the %d receivers (host has %d hardware threads)"
-                      % (n, wl["nrec"], os.cpu_count() or 1),
+            "sample": "%d of the timed trial sources, oracle/libko.so, OpenMP over the %d receivers (host: %d hardware threads, "
+                      "CPU quota of this container %d)" % (n, wl["nrec"], os.cpu_count() or 1, avail),
             "value_1core": v1,
             "reference_in_dev_container": "the reference itself (amdflang -O2, 135 centroids, 8 vCPU Xeon 2.1 GHz): 0.76 evals/s "
                                           "on 8 threads, 0.11 on one (BASELINE.md section 2); this port there: 6.2 on 8 threads",
@@ -245,7 +247,7 @@ def launch_ranks(n):
         port = so.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(os.cpu_count() or n, 64) // n)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(port), "--max-restarts", "0",
            os.path.abspath(__file__)] + sys.argv[1:]

@@ -22,6 +22,7 @@
 #include <vector>
 #include <stdexcept>
 #include <omp.h>
+#include <future>
 #include <limits>
 
 using namespace kiwi;
@@ -1580,27 +1581,65 @@ int kiwi_hip_set_sources(kiwi_hip_ctx *c, int nsrc, const int *cent_ofs, const f
     GUARD_END(c)
 }
 
-int kiwi_hip_set_sources_params(kiwi_hip_ctx *c, int sourcetype, int nsrc, const float *params)
+// CPUs this process may actually keep busy: the hardware threads it is allowed on, cut to the cgroup's CPU quota (a
+// container sees every hardware thread of the machine but is throttled at its quota -- on the GPU boxes 16 CPUs of 256:
+// more discretiser threads than that do not finish sooner, they are stopped for the rest of each scheduling period)
+static int effective_cpus()
 {
-    GUARD_BEGIN
+    static const int n = [] {
+        int hw = std::max(1, omp_get_num_procs());
+        double quota = 0.0;
+        if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {                       // cgroup v2: "<quota|max> <period>"
+            char q[64]; long long per = 0;
+            if (std::fscanf(f, "%63s %lld", q, &per) == 2 && std::strcmp(q, "max") != 0 && per > 0) quota = std::atof(q) / (double)per;
+            std::fclose(f);
+        } else {
+            long long q = -1, per = 0;
+            if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (std::fscanf(g, "%lld", &q) != 1) q = -1; std::fclose(g); }
+            if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(g, "%lld", &per) != 1) per = 0; std::fclose(g); }
+            if (q > 0 && per > 0) quota = (double)q / (double)per;
+        }
+        if (quota > 0.0) hw = std::min(hw, std::max(1, (int)std::floor(quota + 0.5)));
+        return hw;
+    }();
+    return n;
+}
+
+int kiwi_hip_effective_cpus(void) { return effective_cpus(); }
+
+// One batch of trial sources after the host discretiser, before anything touches the device
+struct HostBatch {
+    int nsrc = 0, nbad = 0, bad = -1;
+    std::string why;
+    std::vector<int> ofs, status;
+    std::vector<float> cent, mom, rise;
+};
+
+// psm_set + psm_to_tdsm of every source of the batch (minimizer_engine.f90:500-523), host only: reads the context's
+// discretiser settings (effective dt, crust profile, constraints), writes nothing of it -- so the next piece of a trial list
+// can be discretised while the device evaluates the present one (kiwi_hip_misfits_for_params).  `spare` = CPUs left to
+// the caller's other threads.
+static void discretise_batch(const kiwi_hip_ctx *c, int sourcetype, int nsrc, const float *params, int spare, HostBatch &hb)
+{
     const int np = nparams_any(sourcetype);
     if (np < 0) throw std::runtime_error("source type not supported by the host discretiser");
     if (nsrc < 1) throw std::runtime_error("need at least one source");
     const bool eikonal = source_nparams_eikonal(sourcetype) > 0;
     if (eikonal && !c->have_crust) throw std::runtime_error("eikonal sources need the crust profiles (kiwi_hip_set_source_crust)");
     std::vector<DiscreteSource> ds((size_t)nsrc);
-    std::vector<int> status((size_t)nsrc, 0);
-    int bad = -1, nbad = 0;
-    std::string why = "source discretisation failed";
+    hb.nsrc = nsrc;
+    hb.status.assign((size_t)nsrc, 0);
+    hb.nbad = 0; hb.bad = -1;
+    hb.why = "source discretisation failed";
     // a few threads only: the discretisers take microseconds per source, and idle OpenMP workers spin for their
-    // block time after the loop, competing with the HIP runtime's own threads for the caller's next calls
-    // (the eikonal discretisers run a fast-marching solve per source: milliseconds, one thread per source pays)
-    // (measured on the GPU box, cfg4: a 25 m fine grid of 1200 x 360 points per source, 0.1-0.16 s per solve: the
-    // discretiser takes 350-420 ms per 128 sources against 290 ms for their evaluation on the device)
-    int ecap = 512;
+    // block time after the loop, competing with the HIP runtime's own threads for the caller's next calls.
+    // The eikonal discretisers run a fast-marching solve per source (cfg4: a 25 m fine grid of 1200 x 360 points, 43 ms per
+    // solve on a core of the GPU box): one thread per source pays, up to the CPUs this process really has -- measured
+    // there, 128 solves: 5.5 s on one thread, 0.70 s on 8, 0.37 s on 16 = the container's CPU quota, 0.43-0.54 s on 32-128.
+    int ecap = std::max(1, effective_cpus() - std::max(0, spare));
     if (const char *m = std::getenv("KIWI_HIP_DISC_THREADS")) ecap = std::max(1, std::atoi(m));
     const int nthreads = std::max(1, eikonal ? std::min({ omp_get_max_threads(), nsrc, ecap })
-                                             : std::min({ omp_get_max_threads(), (nsrc + 31) / 32, 16 }));
+                                             : std::min({ omp_get_max_threads(), (nsrc + 31) / 32, 16, ecap }));
     (void)nthreads;
     // Eikonal types: trial sources that differ from an earlier one of the batch only in moment (factor) and rise time have
     // the same rupture -- psm%moment and psm%risetime do not enter psm_to_tdsm (source_eikonal.f90:228-229,
@@ -1618,19 +1657,31 @@ int kiwi_hip_set_sources_params(kiwi_hip_ctx *c, int sourcetype, int nsrc, const
             if (it == seen.end()) seen.emplace(key, s); else solve_of[s] = it->second;
         }
     }
-    // (eikonal: the batch's solves together are bound by something shared -- 128 of them take 350-420 ms on the 64-core box
-    // whether 16, 32 or 96 threads work on them; grabs of four keep the thread count at a quarter of the batch)
-#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
-    for (int s = 0; s < nsrc; s++) {
-        std::string err;
-        if (solve_of[s] != s) continue;
-        if (eikonal) err = discretize_eikonal(sourcetype, params + (size_t)s * np, c->effective_dt, c->rupture_profile, c->constraints, ds[s]);
-        else if (!discretize(sourcetype, params + (size_t)s * np, c->effective_dt, ds[s])) err = why;
-        if (!err.empty()) {
-            status[s] = !eikonal ? 3 : (err[0] == 'E' ? 5 : 6);
-            ds[s].centroids.clear(); ds[s].moment = 0.f; ds[s].risetime = 0.f;
+    const float edt = c->effective_dt;
+    int nbad = 0, bad = -1;
+    std::string why = hb.why;
+    std::vector<int> &status = hb.status;
+    if (eikonal) {
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+        for (int s = 0; s < nsrc; s++) {
+            if (solve_of[s] != s) continue;
+            const std::string err = discretize_eikonal(sourcetype, params + (size_t)s * np, edt, c->rupture_profile, c->constraints, ds[s]);
+            if (!err.empty()) {
+                status[s] = err[0] == 'E' ? 5 : 6;
+                ds[s].centroids.clear(); ds[s].moment = 0.f; ds[s].risetime = 0.f;
 #pragma omp critical
-            { nbad++; if (bad < 0 || s < bad) { bad = s; why = err; } }
+                { nbad++; if (bad < 0 || s < bad) { bad = s; why = err; } }
+            }
+        }
+    } else {
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
+        for (int s = 0; s < nsrc; s++) {
+            if (!discretize(sourcetype, params + (size_t)s * np, edt, ds[s])) {
+                status[s] = 3;
+                ds[s].centroids.clear(); ds[s].moment = 0.f; ds[s].risetime = 0.f;
+#pragma omp critical
+                { nbad++; if (bad < 0 || s < bad) bad = s; }
+            }
         }
     }
     for (int s = 0; s < nsrc; s++)
@@ -1641,25 +1692,40 @@ int kiwi_hip_set_sources_params(kiwi_hip_ctx *c, int sourcetype, int nsrc, const
             if (status[f] == 0) { ds[s].moment = params[(size_t)s * np + 4]; ds[s].risetime = params[(size_t)s * np + (sourcetype == 5 ? 19 : 14)]; }
             else { ds[s].moment = 0.f; ds[s].risetime = 0.f; nbad++; }
         }
+    hb.nbad = nbad; hb.bad = bad; hb.why = why;
     // wrong type / parameter count is the caller's error for the whole batch; a source the discretiser rejects
     // ("Empty rupture area", ...) is recorded and skipped like seismosizer.py:703-720 does (failings)
     if (bad >= 0 && !eikonal) throw std::runtime_error(why + " (source " + std::to_string(bad + 1) + ")");
-    std::vector<int> ofs((size_t)nsrc + 1, 0);
-    for (int s = 0; s < nsrc; s++) ofs[s + 1] = ofs[s] + (int)ds[s].centroids.size();
-    std::vector<float> cent((size_t)ofs[nsrc] * 10), mom((size_t)nsrc), rise((size_t)nsrc);
+    hb.ofs.assign((size_t)nsrc + 1, 0);
+    for (int s = 0; s < nsrc; s++) hb.ofs[s + 1] = hb.ofs[s] + (int)ds[s].centroids.size();
+    hb.cent.resize((size_t)hb.ofs[nsrc] * 10); hb.mom.resize((size_t)nsrc); hb.rise.resize((size_t)nsrc);
     for (int s = 0; s < nsrc; s++) {
-        std::memcpy(cent.data() + (size_t)ofs[s] * 10, ds[s].centroids.data(), ds[s].centroids.size() * sizeof(Centroid));
-        mom[s] = ds[s].moment; rise[s] = ds[s].risetime;
+        std::memcpy(hb.cent.data() + (size_t)hb.ofs[s] * 10, ds[s].centroids.data(), ds[s].centroids.size() * sizeof(Centroid));
+        hb.mom[s] = ds[s].moment; hb.rise[s] = ds[s].risetime;
     }
-    if (int rc = kiwi_hip_set_sources(c, nsrc, ofs.data(), cent.data(), mom.data(), rise.data())) return rc;
-    if (nbad > 0) {
-        c->src_status = status;
+}
+
+// the discretised batch becomes the context's uploaded sources; throws when no source of it could be discretised
+static void upload_batch(kiwi_hip_ctx *c, const HostBatch &hb)
+{
+    const int nsrc = hb.nsrc;
+    if (kiwi_hip_set_sources(c, nsrc, hb.ofs.data(), hb.cent.data(), hb.mom.data(), hb.rise.data())) throw std::runtime_error(c->err);
+    if (hb.nbad > 0) {
+        c->src_status = hb.status;
         c->any_failed = true;
         c->status_d.ensure((size_t)nsrc, &c->dev_bytes);
-        HIPCHECK(hipMemcpy(c->status_d.p, status.data(), (size_t)nsrc * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(c->status_d.p, hb.status.data(), (size_t)nsrc * sizeof(int), hipMemcpyHostToDevice));
         // no source of the batch could be discretised (a batch of one: the reference's `set_source_params: nok >`)
-        if (nbad == nsrc) throw std::runtime_error(why + " (source " + std::to_string(bad + 1) + ")");
+        if (hb.nbad == nsrc) throw std::runtime_error(hb.why + " (source " + std::to_string(hb.bad + 1) + ")");
     }
+}
+
+int kiwi_hip_set_sources_params(kiwi_hip_ctx *c, int sourcetype, int nsrc, const float *params)
+{
+    GUARD_BEGIN
+    HostBatch hb;
+    discretise_batch(c, sourcetype, nsrc, params, 0, hb);
+    upload_batch(c, hb);
     return 0;
     GUARD_END(c)
 }
@@ -1850,6 +1916,51 @@ int kiwi_hip_get_misfits(kiwi_hip_ctx *c, int isrc0, int nsrc, float *misfit, fl
         }
     if (global)
         HIPCHECK(hipMemcpy(global, c->global_d.p + isrc0, (size_t)nsrc * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+    GUARD_END(c)
+}
+
+// make_misfits_for_sources for a whole trial list in one call (seismosizer.py:682-722), host and device overlapped: the
+// list is cut into pieces; while the device evaluates piece k, a second host thread discretises piece k + 1.  Per piece
+// the calls are exactly kiwi_hip_set_sources_params + kiwi_hip_eval + kiwi_hip_get_misfits + kiwi_hip_get_source_status,
+// so results do not depend on `piece` (a source's evaluation does not depend on its batch: tests).
+int kiwi_hip_misfits_for_params(kiwi_hip_ctx *c, int sourcetype, int nsrc, const float *params, int piece,
+                                float *misfit, float *norm, float *global, int *status)
+{
+    GUARD_BEGIN
+    const int np = nparams_any(sourcetype);
+    if (np < 0) throw std::runtime_error("source type not supported by the host discretiser");
+    if (nsrc < 1) throw std::runtime_error("need at least one source");
+    HIPCHECK(hipSetDevice(c->device));
+    prepare(c);
+    if (c->synth_only) throw std::runtime_error("misfits need a reference seismogram and a misfit taper for every enabled receiver component "
+                                                "(the device comparator evaluates norms over the taper span, comparator.f90:782-792)");
+    const size_t nmis = (size_t)c->nmis;
+    if (piece <= 0) piece = source_nparams_eikonal(sourcetype) > 0 ? 128 : 1024;
+    const int npieces = (nsrc + piece - 1) / piece;
+    auto work = [c, sourcetype, np, params, piece, nsrc, npieces](int k) {
+        HostBatch hb;
+        const int s0 = k * piece;
+        discretise_batch(c, sourcetype, std::min(piece, nsrc - s0), params + (size_t)s0 * np, npieces > 1 ? 1 : 0, hb);
+        return hb;
+    };
+    std::future<HostBatch> next = std::async(std::launch::async, work, 0);
+    for (int k = 0; k < npieces; k++) {
+        const HostBatch hb = next.get();
+        if (k + 1 < npieces) next = std::async(std::launch::async, work, k + 1);
+        const int s0 = k * piece, n = hb.nsrc;
+        if (status) std::memcpy(status + s0, hb.status.data(), (size_t)n * sizeof(int));
+        if (hb.nbad == n) {                       // nothing of this piece to evaluate: every trial of it is a failing
+            if (misfit) std::memset(misfit + (size_t)s0 * nmis, 0, (size_t)n * nmis * sizeof(float));
+            if (norm) std::memset(norm + (size_t)s0 * nmis, 0, (size_t)n * nmis * sizeof(float));
+            if (global) std::memset(global + s0, 0, (size_t)n * sizeof(float));
+            continue;
+        }
+        upload_batch(c, hb);
+        eval_impl(c, 0, n, c->keep_which);
+        if (kiwi_hip_get_misfits(c, 0, n, misfit ? misfit + (size_t)s0 * nmis : nullptr, norm ? norm + (size_t)s0 * nmis : nullptr,
+                                 global ? global + s0 : nullptr)) throw std::runtime_error(c->err);
+    }
     return 0;
     GUARD_END(c)
 }

@@ -84,45 +84,52 @@ inline std::vector<V3> clip(const std::vector<V3> &poly, const HalfSpace &h)
     return out;
 }
 
-// index heap keyed by an external array, with back pointers (heap.f90); indices 1-based as there
+// index heap keyed by an external array, with back pointers (heap.f90); indices 1-based as there.  The key of an entry
+// is kept next to its index (one load per comparison instead of two dependent ones); the comparisons, swaps and with
+// them the order among equal keys are those of heap.f90.
+struct HeapEntry { float key; int idx; };
+struct FmmNode { float t; int bp; };
 struct IndexHeap {
-    std::vector<int> &h;     // h[1..n]; storage lent by the caller (reused from solve to solve)
+    std::vector<HeapEntry> &h;     // h[1..n]; storage lent by the caller (reused from solve to solve)
     int n = 0;
-    const float *keys;
-    int *bp;
-    IndexHeap(int cap, const float *k, int *b, std::vector<int> &store) : h(store), keys(k), bp(b) { h.resize((size_t)cap + 2); }
-    float key(int pos) const { return keys[h[pos] - 1]; }
-    void swp(int u, int v) { std::swap(h[u], h[v]); std::swap(bp[h[u] - 1], bp[h[v] - 1]); }
+    FmmNode *nodes;
+    IndexHeap(int cap, FmmNode *nd, std::vector<HeapEntry> &store) : h(store), nodes(nd) { h.resize((size_t)cap + 2); }
+    void place(int pos, HeapEntry e) { h[pos] = e; nodes[e.idx - 1].bp = pos; }
     void up(int v)                                   // upheap :205-229
     {
+        const HeapEntry e = h[v];
         while (v > 1) {
             const int u = (v - 2) / 2 + 1;
-            if (key(u) <= key(v)) return;
-            swp(u, v);
+            if (h[u].key <= e.key) break;
+            place(v, h[u]);
             v = u;
         }
+        place(v, e);
     }
     void down(int v)                                 // downheap :172-203
     {
+        const HeapEntry e = h[v];
         int w = 2 * (v - 1) + 2;
         while (w <= n) {
-            if (w + 1 <= n && key(w + 1) < key(w)) w++;
-            if (key(v) <= key(w)) return;
-            swp(v, w);
+            if (w + 1 <= n && h[w + 1].key < h[w].key) w++;
+            if (e.key <= h[w].key) break;
+            place(v, h[w]);
             v = w;
             w = 2 * (v - 1) + 2;
         }
+        place(v, e);
     }
-    void push(int idx) { n++; h[n] = idx; bp[idx - 1] = n; up(n); }          // pushheap :76-101
+    void push(int idx) { n++; h[n] = HeapEntry{ nodes[idx - 1].t, idx }; nodes[idx - 1].bp = n; up(n); }   // pushheap :76-101
+    void rekey(int pos, float key) { h[pos].key = key; }
     int pop()                                                                // popheap :103-131
     {
         if (n == 0) return 0;
-        swp(1, n);
-        bp[h[n] - 1] = 0;
-        const int idx = h[n];
+        const HeapEntry top = h[1];
+        h[1] = h[n];
+        nodes[top.idx - 1].bp = 0;
         n--;
-        down(1);
-        return idx;
+        if (n >= 1) down(1);
+        return top.idx;
     }
 };
 
@@ -135,19 +142,20 @@ inline void fast_marching(const std::vector<float> &speed, int nx, int ny, const
     const float dx = delta[0], dy = delta[1];
     // The work arrays of a solve (a few MB on the 25 m grid of a 30 km rupture) are kept per thread: a fresh allocation per
     // trial source means a million page faults per batch, which serialise in the kernel when every core discretises at once.
-    static thread_local std::vector<int> bp, heap_store;
-    times.assign((size_t)nx * ny, inf);
-    bp.assign((size_t)nx * ny, FARAWAY);
+    static thread_local std::vector<FmmNode> nodes;
+    static thread_local std::vector<HeapEntry> heap_store;
+    nodes.assign((size_t)nx * ny, FmmNode{ inf, FARAWAY });
     auto id = [nx](int x, int y) { return (y - 1) * nx + x; };
     int ix = (int)((start[0] - origin[0]) / dx) + 1, iy = (int)((start[1] - origin[1]) / dy) + 1;
     ix = std::min(std::max(ix, 1), nx);
     iy = std::min(std::max(iy, 1), ny);
-    times[id(ix, iy) - 1] = 0.f;
-    if (nx == 1 && ny == 1) return;
-    bp[id(ix, iy) - 1] = ALIVE;
+    auto finish = [&] { times.resize((size_t)nx * ny); for (size_t k = 0; k < times.size(); k++) times[k] = nodes[k].t; };
+    nodes[id(ix, iy) - 1].t = 0.f;
+    if (nx == 1 && ny == 1) { finish(); return; }
+    nodes[id(ix, iy) - 1].bp = ALIVE;
     int nalive = 1;
-    IndexHeap heap(nx * ny, times.data(), bp.data(), heap_store);
-    auto T = [&](int x, int y) -> float & { return times[id(x, y) - 1]; };
+    IndexHeap heap(nx * ny, nodes.data(), heap_store);
+    auto T = [&](int x, int y) -> float & { return nodes[id(x, y) - 1].t; };
     auto S = [&](int x, int y) { return speed[id(x, y) - 1]; };
     if (1 < ix) T(ix - 1, iy) = dx / S(ix - 1, iy);
     if (ix < nx) T(ix + 1, iy) = dx / S(ix + 1, iy);
@@ -157,28 +165,30 @@ inline void fast_marching(const std::vector<float> &speed, int nx, int ny, const
     if (ix < nx) heap.push(id(ix + 1, iy));
     if (1 < iy) heap.push(id(ix, iy - 1));
     if (iy < ny) heap.push(id(ix, iy + 1));
+    const float dx2 = dx * dx, dy2 = dy * dy, dxy2 = dx2 * dy2, dsum = dx2 + dy2;
     auto update = [&](int x, int y) {                // update_neighbor :121-186
         const int i = id(x, y);
-        if (bp[i - 1] == ALIVE) return;
-        if (bp[i - 1] == FARAWAY) heap.push(i);
+        FmmNode &nd = nodes[i - 1];
+        if (nd.bp == ALIVE) return;
+        if (nd.bp == FARAWAY) heap.push(i);
         float a = inf, b = inf, c = inf, d = inf;
-        const float told = T(x, y), sp = S(x, y);
-        if (1 < x) a = T(x - 1, y);
-        if (x < nx) b = T(x + 1, y);
-        if (1 < y) c = T(x, y - 1);
-        if (y < ny) d = T(x, y + 1);
+        const float told = nd.t, sp = speed[i - 1];
+        if (1 < x) a = nodes[i - 2].t;
+        if (x < nx) b = nodes[i].t;
+        if (1 < y) c = nodes[i - 1 - nx].t;
+        if (y < ny) d = nodes[i - 1 + nx].t;
         float t = 0.f;
         const float aa = std::min(a, b), cc = std::min(c, d);
         if (std::max(aa, cc) != inf) {
             const float q = (aa - cc) * sp;
-            const float s = (dx * dx) * (dy * dy) * ((dx * dx) + (dy * dy) - q * q);
-            if (s >= 0.f) t = std::max(t, ((aa * (dy * dy) + cc * (dx * dx)) * sp + std::sqrt(s)) / (sp * ((dx * dx) + (dy * dy))));
+            const float s = dxy2 * (dsum - q * q);
+            if (s >= 0.f) t = std::max(t, ((aa * dy2 + cc * dx2) * sp + std::sqrt(s)) / (sp * dsum));
         }
-        if (std::min(c, d) == inf) {
+        if (cc == inf) {
             if (a < inf) t = std::max(t, a + dx / sp);
             if (b < inf) t = std::max(t, b + dx / sp);
         }
-        if (std::min(a, b) == inf) {
+        if (aa == inf) {
             if (c < inf) t = std::max(t, c + dy / sp);
             if (d < inf) t = std::max(t, d + dy / sp);
         }
@@ -190,10 +200,10 @@ inline void fast_marching(const std::vector<float> &speed, int nx, int ny, const
             if (d < inf) t = std::min(t, d + dy / sp);
         }
         if (t != 0.f && told != t) {                 // updateheap, heap.f90:133-156
-            const float old = times[i - 1];
-            times[i - 1] = t;
-            if (t < old) heap.up(bp[i - 1]);
-            if (t > old) heap.down(bp[i - 1]);
+            nd.t = t;
+            heap.rekey(nd.bp, t);
+            if (t < told) heap.up(nd.bp);
+            if (t > told) heap.down(nd.bp);
         }
     };
     while (nalive <= nx * ny) {
@@ -201,13 +211,14 @@ inline void fast_marching(const std::vector<float> &speed, int nx, int ny, const
         if (imin == 0) break;
         ix = (imin - 1) % nx + 1;
         iy = (imin - 1) / nx + 1;
-        bp[imin - 1] = ALIVE;
+        nodes[imin - 1].bp = ALIVE;
         nalive++;
         if (1 < ix) update(ix - 1, iy);
         if (ix < nx) update(ix + 1, iy);
         if (1 < iy) update(ix, iy - 1);
         if (iy < ny) update(ix, iy + 1);
     }
+    finish();
 }
 
 } // namespace eik
@@ -296,17 +307,23 @@ inline std::string discretize_eikonal(int type, const float *P, float doi, const
     const size_t nc = (size_t)nxc * nyc;
     std::vector<float> cnt(nc, 0.f), ct(nc, -1.f), cs(nc, 0.f), cdur(nc, 0.f), cw(nc, 0.f);
     std::vector<V3> cp(nc, V3{ 0.f, 0.f, 0.f });
-    auto cell = [&](size_t k) -> long {
+    // floor() of a value inside the int range, as an integer (std::floor is a library call without SSE4.1)
+    auto ifloor = [](float v) { int i = (int)v; return i - ((float)i > v ? 1 : 0); };
+    auto cell = [&](size_t k) -> int {
         const V3 rc = ned_to_rc(fpt[k]);
-        const int ixc = (int)std::floor((rc[0] - lo[0]) / cd[0]) + 1, iyc = (int)std::floor((rc[1] - lo[1]) / cd[1]) + 1;
+        const int ixc = ifloor((rc[0] - lo[0]) / cd[0]) + 1, iyc = ifloor((rc[1] - lo[1]) / cd[1]) + 1;
         if (ixc < 1 || iyc < 1 || ixc > nxc || iyc > nyc) return -1;          // "orphaned point"
-        return (long)(iyc - 1) * nxc + ixc - 1;
+        return (iyc - 1) * nxc + ixc - 1;
     };
+    static thread_local std::vector<int> cellof;      // coarse cell of every fine point (-1: none), for the second pass
+    cellof.resize(speed.size());
     int npf = 0;
     for (size_t k = 0; k < speed.size(); k++) {
+        cellof[k] = -1;
         if (ftimes[k] < 0.f) continue;
-        const long ic = cell(k);
+        const int ic = cell(k);
         if (ic < 0) continue;
+        cellof[k] = ic;
         cnt[ic] = cnt[ic] + 1.f;
         if (ct[ic] == -1.f) ct[ic] = 0.f;
         ct[ic] = ct[ic] + ftimes[k];
@@ -321,8 +338,7 @@ inline std::string discretize_eikonal(int type, const float *P, float doi, const
     }
     for (size_t ic = 0; ic < nc; ic++) cw[ic] = cnt[ic] / (float)npf;
     for (size_t k = 0; k < speed.size(); k++) {
-        if (ftimes[k] < 0.f) continue;
-        const long ic = cell(k);
+        const int ic = cellof[k];
         if (ic < 0) continue;
         cdur[ic] = cdur[ic] + std::fabs(ftimes[k] - ct[ic]);
     }

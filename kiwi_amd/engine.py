@@ -368,24 +368,48 @@ class Engine:
         return b.value
 
     # ------------------------------------------------------------------ seismosizer.py counterparts
-    def make_misfits_for_sources(self, sourcetype=None, params=None):
+    def misfits_for_params(self, sourcetype, params, piece=0):
+        """A whole trial list in one call (kiwi_hip_misfits_for_params): the list is evaluated in pieces of `piece` sources
+        (0: 128 for the eikonal types, 1024 otherwise), the host discretiser of piece k + 1 running while the device
+        evaluates piece k.  Returns (misfit[N,nmis], norm[N,nmis], global[N], status[N]); piece size does not change a bit."""
+        p = np.ascontiguousarray(np.atleast_2d(params), np.float32)
+        st = SOURCE_TYPES.get(sourcetype, sourcetype)
+        if p.shape[1] != self.L.kiwi_hip_source_nparams(st):
+            raise KiwiHipError("set_source_params: wrong number of source parameters")
+        if piece <= 0:
+            piece = 128 if st in (4, 5) else 1024
+        N, nm = p.shape[0], self.nmisfits()
+        m = np.zeros((N, nm), np.float32)
+        n = np.zeros((N, nm), np.float32)
+        g = np.zeros(N, np.float32)
+        status = np.zeros(N, np.int32)
+        self._ck(self.L.kiwi_hip_misfits_for_params(self.h, st, N, _fp(p), piece, _fp(m), _fp(n), _fp(g), _ip(status)),
+                 "get_misfits")
+        for s0 in range(((N - 1) // piece) * piece, -1, -piece):      # the context holds the last piece it evaluated
+            if np.any(status[s0:s0 + piece] == 0):
+                self.nsrc = min(piece, N - s0)
+                break
+        return m, n, g, status
+
+    def make_misfits_for_sources(self, sourcetype=None, params=None, piece=0):
         """seismosizer.py:682-722: returns (misfits_by_src[N_s,N_r,N_k], norms_by_src[...], failings) -- float64 arrays,
         receivers in file order, components in string order, disabled receivers as zeros; `failings` lists the indices of
-        the trial sources the engine rejected (`SeismosizersReturnedErrors` there, :716-717), whose rows stay zero."""
+        the trial sources the engine rejected (`SeismosizersReturnedErrors` there, :716-717), whose rows stay zero.
+        With `params` the trial list goes through misfits_for_params (discretiser and device overlapped, pieces of
+        `piece` sources); without, the sources uploaded before are evaluated."""
         if params is not None:
-            try:
-                self.set_source_params(sourcetype, params)
-            except KiwiHipError:
-                # "no source of the batch could be discretised": every trial is a failing, not an error of the sweep
-                if self.nsrc != len(np.atleast_2d(params)) or not np.all(self.get_source_status() != 0):
-                    raise
-        failings = [int(i) for i in np.nonzero(self.get_source_status())[0]]
-        self.eval()
-        m, n, _ = self.get_misfits()
+            m, n, _, status = self.misfits_for_params(sourcetype, params, piece)
+            nsrc = len(m)
+        else:
+            status = self.get_source_status()
+            self.eval()
+            m, n, _ = self.get_misfits()
+            nsrc = self.nsrc
+        failings = [int(i) for i in np.nonzero(status)[0]]
         nrec = len(self.components)
         nk = max([len(c) for c in self.components] + [1])
-        mis = np.zeros((self.nsrc, nrec, nk))
-        nor = np.zeros((self.nsrc, nrec, nk))
+        mis = np.zeros((nsrc, nrec, nk))
+        nor = np.zeros((nsrc, nrec, nk))
         j = 0
         for ir, comps in enumerate(self.components):
             if not self.enabled[ir]:

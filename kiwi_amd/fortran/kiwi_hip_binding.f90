@@ -234,6 +234,21 @@ module kiwi_hip_binding
             character(kind=c_char), intent(out) :: buf(*)
         end function
 
+        integer(c_int) function kiwi_hip_misfits_for_params( ctx, sourcetype, nsrc, params, piece, misfit, norm, global, &
+                status ) bind(C, name='kiwi_hip_misfits_for_params')
+            import :: c_int, c_ptr, c_float
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: sourcetype, nsrc, piece   ! piece <= 0: library default
+            real(c_float), intent(in) :: params(*)             ! (nparams, nsrc)
+            real(c_float), intent(out) :: misfit(*), norm(*)   ! (nmis, nsrc)
+            real(c_float), intent(out) :: global(*)            ! (nsrc)
+            integer(c_int), intent(out) :: status(*)           ! (nsrc)
+        end function
+
+        integer(c_int) function kiwi_hip_effective_cpus() bind(C, name='kiwi_hip_effective_cpus')
+            import :: c_int
+        end function
+
         integer(c_int) function kiwi_hip_eval( ctx, isrc0, nsrc ) bind(C, name='kiwi_hip_eval')
             import :: c_int, c_ptr
             type(c_ptr), value :: ctx

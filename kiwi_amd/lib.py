@@ -2,6 +2,7 @@
 GPU, at init time) is missing the caller gets an exception."""
 import ctypes as C
 import os
+import sys
 import re
 import subprocess
 
@@ -47,6 +48,16 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise KiwiHipError("%s not built -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "or `make -C kiwi_amd/csrc`" % LIB_PATH)
+    # One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64 (same soname as /opt/rocm's, which this library is
+    # linked against); whichever copy initialises the GPU first owns it, the other then reports "no ROCm-capable device"
+    # (measured on the GPU box: this library + kiwi_hip_init, then `import torch` -> torch.cuda sees no GPU; torch's copy
+    # initialised by another module, then kiwi_hip_init -> no device).  Loaded AFTER torch this library binds to torch's
+    # copy and both work, so torch goes first wherever it is installed.
+    if "torch" not in sys.modules and os.environ.get("KIWI_HIP_WITHOUT_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     sig = {
@@ -82,6 +93,8 @@ def load():
         "kiwi_hip_set_sources_params": [vp, C.c_int, C.c_int, c_float_p],
         "kiwi_hip_get_source_status": [vp, C.c_int, C.c_int, c_int_p],
         "kiwi_hip_source_status_message": [C.c_int, C.c_char_p, C.c_int],
+        "kiwi_hip_misfits_for_params": [vp, C.c_int, C.c_int, c_float_p, C.c_int, c_float_p, c_float_p, c_float_p, c_int_p],
+        "kiwi_hip_effective_cpus": [],
         "kiwi_hip_eval": [vp, C.c_int, C.c_int],
         "kiwi_hip_sync": [vp],
         "kiwi_hip_set_keep_synthetics": [vp, C.c_int],

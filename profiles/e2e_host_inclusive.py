@@ -2,7 +2,8 @@
 discretiser + H2D of the centroid tables), `eval`, `get_misfits` (D2H of all misfits), against the resident-input figure
 bench.py reports.  Usage: python profiles/e2e_host_inclusive.py [cfg3|cfg4|cfg3-100pt ...] [batch]
 For the eikonal workloads the host discretiser is a fast-marching solve per trial source (SURVEY 8f-4 asks what share of a
-step it is before an on-GPU discretiser is considered)."""
+step it is before an on-GPU discretiser is considered).  Third line: the same trial sources as a list of `nb` batches
+through ONE call of kiwi_hip_misfits_for_params (host discretiser of piece k + 1 while the device evaluates piece k)."""
 import os
 import sys
 import time
@@ -29,4 +30,24 @@ for rep in range(3):
         p.set_source_params(wl["sourcetype"], tr)
     ds = (time.perf_counter() - t0) / reps
     print("%s: end-to-end per %d-source batch: %.2f ms (%.0f evals/s); of which set_source_params (host discretiser, "
-          "%d threads at most + H2D) %.2f ms = %.1f %%" % (name, batch, dt * 1e3, batch / dt, os.cpu_count() or 1, ds * 1e3, 100 * ds / dt))
+          "%d threads at most + H2D) %.2f ms = %.1f %%" % (name, batch, dt * 1e3, batch / dt, p.L.kiwi_hip_effective_cpus(), ds * 1e3,
+                                                         100 * ds / dt))
+# a trial list of nb batches: one after the other, and through the overlapped call
+import numpy as np                             # noqa: E402
+nb = 4
+big = synthetic.workload(name, batch * nb, 0)["trials"]
+for rep in range(2):
+    t0 = time.perf_counter()
+    seq = []
+    for k in range(nb):
+        p.set_source_params(wl["sourcetype"], big[k * batch:(k + 1) * batch])
+        p.eval()
+        seq.append(p.get_misfits())
+    dseq = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    m, n, g, st = p.misfits_for_params(wl["sourcetype"], big, batch)
+    dpipe = time.perf_counter() - t0
+    same = np.array_equal(m, np.concatenate([x[0] for x in seq])) and np.array_equal(g, np.concatenate([x[2] for x in seq]))
+    print("%s: %d trial sources in pieces of %d: one after the other %.1f ms (%.0f evals/s); one overlapped call %.1f ms "
+          "(%.0f evals/s); identical results: %s" % (name, len(big), batch, dseq * 1e3, len(big) / dseq, dpipe * 1e3,
+                                                     len(big) / dpipe, same))

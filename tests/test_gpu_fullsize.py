@@ -9,10 +9,11 @@ import numpy as np
 import pytest
 
 import bench
+from kiwi_amd import lib as _lib
 from kiwi_amd import synthetic
 
 pytestmark = pytest.mark.gpu
-CORES = os.cpu_count() or 1
+CORES = int(_lib.load().kiwi_hip_effective_cpus())      # hardware threads cut to the container's CPU quota
 
 
 def rel(a, b):

@@ -520,6 +520,55 @@ def test_eikonal_sources_with_risetime_fold(stype):
     # the same through the sweep API when every trial fails: all failings, no exception
     mis, nor, failings = p.make_misfits_for_sources(stype, np.concatenate([bad, bad], 0))
     assert failings == [0, 1] and np.all(mis == 0) and np.all(nor == 0)
+    # one call for the whole trial list, discretiser and device overlapped (kiwi_hip_misfits_for_params): whatever the piece
+    # size -- pieces that hold failings, a piece of nothing but failings (sources 7 and 8 at piece = 2 ... ) -- the results are
+    # those of the calls above, bit for bit
+    big = np.concatenate([grid, bad, bad, trials[:1]], 0)
+    want_status = [0, 0, 5, 0, 5, 0, 6, 5, 5, 0]
+    for piece in (1, 2, 3, 4, 7, 10, 0):
+        fm, fn, fg, fs = p.misfits_for_params(stype, big, piece)
+        assert list(fs) == want_status, piece
+        ok = [0, 1, 3, 5, 9]
+        assert np.array_equal(fm[ok], pm[[0, 1, 2, 3, 0]]) and np.array_equal(fn[ok], pn[[0, 1, 2, 3, 0]]), piece
+        assert np.array_equal(fg[ok], pg[[0, 1, 2, 3, 0]]), piece
+        nok = [i for i in range(10) if i not in ok]
+        assert np.all(fm[nok] == 0) and np.all(fn[nok] == 0) and np.all(fg[nok] == 0), piece
+    mis2, nor2, failings2 = p.make_misfits_for_sources(stype, big, piece=3)
+    mis3, nor3, failings3 = p.make_misfits_for_sources(stype, big)
+    assert failings2 == [2, 4, 6, 7, 8] == failings3
+    assert np.array_equal(mis2, mis3) and np.array_equal(nor2, nor3)
+    assert np.all(mis2[failings2] == 0) and np.all(mis2[[0, 1, 3, 5, 9]][:, 0] != 0)
+
+
+@pytest.mark.parametrize("method,filt", [("l2norm", False), ("ampspec_l1norm", True), ("l1norm", True)])
+def test_one_call_for_a_trial_list_equals_the_piecewise_calls(method, filt):
+    """kiwi_hip_misfits_for_params (make_misfits_for_sources in one call, seismosizer.py:682-722; the host discretiser of
+    the next piece runs while the device evaluates the present one) returns what set_source_params + get_misfits return
+    for the whole list, bit for bit and for every piece size -- time-domain, spectral and filtered comparators (the
+    spectral norm factors are per source: they must not depend on the piece a source falls in either)."""
+    sc = Scenario(nz=6)
+    e, p = build(sc)
+    p.set_misfit_method(method)
+    if filt:
+        for ir in range(1, sc.nrec + 1):
+            p.set_misfit_filter(ir, [0.01, 0.03, 0.2, 0.4], [0., 1., 1., 0.])
+    trials = synthetic.bilat_strike_sweep(23, step=3.0)
+    trials[:, 3] += 150.0 * np.arange(23)
+    trials[::5, 13] = 6.0                                   # some long rise times: other data spans, other transform lengths
+    p.set_source_params("bilateral", trials)
+    p.eval()
+    m0, n0, g0 = p.get_misfits()
+    assert np.all(m0 != 0)
+    for piece in (1, 4, 8, 23, 64, 0):
+        m, n, g, st = p.misfits_for_params("bilateral", trials, piece)
+        assert not st.any()
+        assert np.array_equal(m, m0) and np.array_equal(n, n0) and np.array_equal(g, g0), piece
+        pe = piece or 1024
+        assert p.nsrc == 23 - (22 // pe) * pe
+        gm = p.get_misfits()[0]                             # the context holds the last piece
+        assert np.array_equal(gm, m0[23 - p.nsrc:])
+    with pytest.raises(KiwiHipError, match="wrong number"):
+        p.misfits_for_params("moment_tensor", trials, 4)
 
 
 @pytest.mark.parametrize("stype", ["bilateral", "mt_eikonal", "moment_tensor"])
