@@ -156,11 +156,12 @@ int kiwi_hip_source_status_message(int code, char *buf, int buflen);
 
 /* make_misfits_for_sources for a whole trial list in ONE call (python/tunguska/seismosizer.py:682-722), host and device
  * overlapped: the list is cut into pieces of `piece` sources (<= 0: 128 for the eikonal types, 1024 otherwise); while the
- * device evaluates piece k a second host thread discretises piece k + 1.  Per piece this IS kiwi_hip_set_sources_params +
+ * device evaluates one piece a second host thread discretises the next.  Per piece this IS kiwi_hip_set_sources_params +
  * kiwi_hip_eval + kiwi_hip_get_misfits + kiwi_hip_get_source_status, so misfit[nsrc][nmis], norm[nsrc][nmis], global[nsrc]
  * and status[nsrc] (any may be NULL) are bit for bit what those calls return for any piece size; a piece none of whose
- * sources could be discretised is all failings (zeros), not an error.  Afterwards the context holds the last evaluated
- * piece.  For the eikonal source types the host discretiser (a fast-marching solve per trial source, eikonal.f90:29-199)
+ * sources could be discretised is all failings (zeros), not an error.  Pieces are taken from the end of the list, so the
+ * context is left with its HEAD (sources 0 .. piece - 1, evaluated), as after kiwi_hip_set_sources_params + kiwi_hip_eval
+ * of those.  For the eikonal source types the host discretiser (a fast-marching solve per trial source, eikonal.f90:29-199)
  * costs as much as the device evaluation; overlapped, a sweep runs at the slower of the two instead of their sum. */
 int kiwi_hip_misfits_for_params(kiwi_hip_ctx *ctx, int sourcetype, int nsrc, const float *params, int piece,
                                 float *misfit, float *norm, float *global, int *status);

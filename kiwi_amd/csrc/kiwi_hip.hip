@@ -1921,7 +1921,7 @@ int kiwi_hip_get_misfits(kiwi_hip_ctx *c, int isrc0, int nsrc, float *misfit, fl
 }
 
 // make_misfits_for_sources for a whole trial list in one call (seismosizer.py:682-722), host and device overlapped: the
-// list is cut into pieces; while the device evaluates piece k, a second host thread discretises piece k + 1.  Per piece
+// list is cut into pieces; while the device evaluates one piece, a second host thread discretises the next.  Per piece
 // the calls are exactly kiwi_hip_set_sources_params + kiwi_hip_eval + kiwi_hip_get_misfits + kiwi_hip_get_source_status,
 // so results do not depend on `piece` (a source's evaluation does not depend on its batch: tests).
 int kiwi_hip_misfits_for_params(kiwi_hip_ctx *c, int sourcetype, int nsrc, const float *params, int piece,
@@ -1944,10 +1944,11 @@ int kiwi_hip_misfits_for_params(kiwi_hip_ctx *c, int sourcetype, int nsrc, const
         discretise_batch(c, sourcetype, std::min(piece, nsrc - s0), params + (size_t)s0 * np, npieces > 1 ? 1 : 0, hb);
         return hb;
     };
-    std::future<HostBatch> next = std::async(std::launch::async, work, 0);
-    for (int k = 0; k < npieces; k++) {
+    // last piece first: the context is left with the HEAD of the list (sources 0 .. piece - 1), its source 0 the list's
+    std::future<HostBatch> next = std::async(std::launch::async, work, npieces - 1);
+    for (int k = npieces - 1; k >= 0; k--) {
         const HostBatch hb = next.get();
-        if (k + 1 < npieces) next = std::async(std::launch::async, work, k + 1);
+        if (k > 0) next = std::async(std::launch::async, work, k - 1);
         const int s0 = k * piece, n = hb.nsrc;
         if (status) std::memcpy(status + s0, hb.status.data(), (size_t)n * sizeof(int));
         if (hb.nbad == n) {                       // nothing of this piece to evaluate: every trial of it is a failing

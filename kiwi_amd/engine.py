@@ -370,8 +370,8 @@ class Engine:
     # ------------------------------------------------------------------ seismosizer.py counterparts
     def misfits_for_params(self, sourcetype, params, piece=0):
         """A whole trial list in one call (kiwi_hip_misfits_for_params): the list is evaluated in pieces of `piece` sources
-        (0: 128 for the eikonal types, 1024 otherwise), the host discretiser of piece k + 1 running while the device
-        evaluates piece k.  Returns (misfit[N,nmis], norm[N,nmis], global[N], status[N]); piece size does not change a bit."""
+        (0: 128 for the eikonal types, 1024 otherwise), the host discretiser of one piece running while the device
+        evaluates another; afterwards the engine holds the head of the list (sources 0 .. piece - 1).  Returns (misfit[N,nmis], norm[N,nmis], global[N], status[N]); piece size does not change a bit."""
         p = np.ascontiguousarray(np.atleast_2d(params), np.float32)
         st = SOURCE_TYPES.get(sourcetype, sourcetype)
         if p.shape[1] != self.L.kiwi_hip_source_nparams(st):
@@ -385,7 +385,7 @@ class Engine:
         status = np.zeros(N, np.int32)
         self._ck(self.L.kiwi_hip_misfits_for_params(self.h, st, N, _fp(p), piece, _fp(m), _fp(n), _fp(g), _ip(status)),
                  "get_misfits")
-        for s0 in range(((N - 1) // piece) * piece, -1, -piece):      # the context holds the last piece it evaluated
+        for s0 in range(0, N, piece):      # pieces are evaluated from the end of the list: the context holds its head
             if np.any(status[s0:s0 + piece] == 0):
                 self.nsrc = min(piece, N - s0)
                 break

@@ -1304,24 +1304,19 @@ program minimizer_hip
         close( unit )
         if (.not. need_ctx()) return
       ! trial sources the discretiser rejects do not fail the sweep (seismosizer.py:703-720): they are listed in the
-      ! answer and their rows are zeros.  The call itself reports an error when NO source could be discretised.
+      ! answer and their rows are zeros.  One call for the whole list: the library cuts it into pieces and discretises one
+      ! piece on the host while the device evaluates another (kiwi_hip_misfits_for_params); it leaves the engine with the
+      ! head of the list, so source 1 of the file is the current source afterwards.  A list of ONE source that cannot be
+      ! discretised is the reference's `set_source_params: nok >`.
         allocate( status(nsrc) )
-        rc = kiwi_hip_set_sources_params( ctx, int(st,c_int), int(nsrc,c_int), p )
-        if (rc /= 0) then
-            if (kiwi_hip_get_source_status( ctx, 0_c_int, int(nsrc,c_int), status ) /= 0) then
-                ok_ = check( rc ); return
-            end if
-            if (any(status == 0) .or. nsrc == 1) then
-                ok_ = check( rc ); return
-            end if
-        else
-            if (.not. check( kiwi_hip_get_source_status( ctx, 0_c_int, int(nsrc,c_int), status ) )) return
-        end if
-        source_set = .true.
-        if (.not. check( kiwi_hip_eval( ctx, 0_c_int, int(nsrc,c_int) ) )) return
         if (.not. check( kiwi_hip_nmisfits( ctx, nmis ) )) return
         allocate( m(nmis*nsrc), n(nmis*nsrc), g(nsrc) )
-        if (.not. check( kiwi_hip_get_misfits( ctx, 0_c_int, int(nsrc,c_int), m, n, g ) )) return
+        if (.not. check( kiwi_hip_misfits_for_params( ctx, int(st,c_int), int(nsrc,c_int), p, 0_c_int, m, n, g, status ) )) return
+        if (nsrc == 1 .and. status(1) /= 0) then
+            rc = kiwi_hip_set_sources_params( ctx, int(st,c_int), 1_c_int, p )      ! for its message
+            ok_ = check( rc ); return
+        end if
+        source_set = .true.
         open( newunit=unit, file=trim(ofile), status='unknown', iostat=ios )
         if (ios /= 0) then
             call fail( 'failed to open file for output: '//trim(ofile) ); return

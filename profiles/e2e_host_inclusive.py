@@ -3,7 +3,7 @@ discretiser + H2D of the centroid tables), `eval`, `get_misfits` (D2H of all mis
 bench.py reports.  Usage: python profiles/e2e_host_inclusive.py [cfg3|cfg4|cfg3-100pt ...] [batch]
 For the eikonal workloads the host discretiser is a fast-marching solve per trial source (SURVEY 8f-4 asks what share of a
 step it is before an on-GPU discretiser is considered).  Third line: the same trial sources as a list of `nb` batches
-through ONE call of kiwi_hip_misfits_for_params (host discretiser of piece k + 1 while the device evaluates piece k)."""
+through ONE call of kiwi_hip_misfits_for_params (host discretiser of one piece while the device evaluates another)."""
 import os
 import sys
 import time
