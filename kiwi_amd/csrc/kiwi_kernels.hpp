@@ -291,8 +291,12 @@ __global__ __launch_bounds__(256) void geometry_kernel(
     const int s = blockIdx.y;
     if (synrow && synrow[s] != s) return;
     const int c0 = cent_ofs[ep.isrc0 + s], nc = cent_ofs[ep.isrc0 + s + 1] - c0;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= nc * ep.nrec) return;
+    int idx = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x * 256 >= nc * ep.nrec) return;                    // (whole workgroup)
+    // lanes past the end of the source's records stay in the wave -- the span reduction below is a wave operation --
+    // as copies of its last record that neither store nor count
+    const bool live = idx < nc * ep.nrec;
+    if (!live) { if (!spanbuf && !spansrc) return; idx = nc * ep.nrec - 1; }
     const int r = idx / nc, c = idx - r * nc;
     const RecvDev &rv = recv[r];
     const float *ce = cent + (size_t)(c0 + c) * 10;
@@ -437,34 +441,61 @@ __global__ __launch_bounds__(256) void geometry_kernel(
     // natural span of the synthetic strips (seismogram.f90:102-130 + sparse_trace.f90:648-668): union over
     // centroids of [first + shift, last + shift + 1], horizontals (all share one span, :196-197) and vertical
     // separately; only needed to size the comparator's FFT (comparator.f90:464-486)
-    if ((spanbuf || spansrc) && g.row[0] >= 0) {
-        const int nn = (g.flags & 1) ? 1 : 4;
+    if (spanbuf || spansrc) {
         int lo_1 = 0x7fffffff, hi_1 = -0x7fffffff, lo_2 = 0x7fffffff, hi_2 = -0x7fffffff, lo_d = 0x7fffffff, hi_d = -0x7fffffff;
-        const int nH1 = gm.ng == 10 ? 4 : 3;          // components of the radial sum
-        for (int i = 0; i < nlim_h + nlim_d; i++) {   // the components that are added (all of the needed ones, normally)
-            const bool horiz = i < nlim_h;
-            const int q = horiz ? i : i - nlim_h;
-            const int ig = horiz ? (gm.ng == 10 ? (q < 3 ? q : (q == 3 ? 8 : q - 1)) : q) : (q < 3 ? 5 + q : 9);
-            int lo = 0x7fffffff, hi = -0x7fffffff;
-            for (int k = 0; k < nn; k++) { const int2 sp = span[g.row[k] + ig]; lo = min(lo, sp.x); hi = max(hi, sp.y); }
-            if (!horiz) { lo_d = min(lo_d, lo); hi_d = max(hi_d, hi); }
-            else if (q < nH1) { lo_1 = min(lo_1, lo); hi_1 = max(hi_1, hi); }
-            else { lo_2 = min(lo_2, lo); hi_2 = max(hi_2, hi); }
+        if (live && g.row[0] >= 0) {
+            const int nn = (g.flags & 1) ? 1 : 4;
+            const int nH1 = gm.ng == 10 ? 4 : 3;          // components of the radial sum
+            for (int i = 0; i < nlim_h + nlim_d; i++) {   // the components that are added (all of the needed ones, normally)
+                const bool horiz = i < nlim_h;
+                const int q = horiz ? i : i - nlim_h;
+                const int ig = horiz ? (gm.ng == 10 ? (q < 3 ? q : (q == 3 ? 8 : q - 1)) : q) : (q < 3 ? 5 + q : 9);
+                int lo = 0x7fffffff, hi = -0x7fffffff;
+                for (int k = 0; k < nn; k++) { const int2 sp = span[g.row[k] + ig]; lo = min(lo, sp.x); hi = max(hi, sp.y); }
+                if (!horiz) { lo_d = min(lo_d, lo); hi_d = max(hi_d, hi); }
+                else if (q < nH1) { lo_1 = min(lo_1, lo); hi_1 = max(hi_1, hi); }
+                else { lo_2 = min(lo_2, lo); hi_2 = max(hi_2, hi); }
+            }
+            if ((g.flags & 2) && nlim_h) {                // rotating branch: both sums get the union before the rotated add
+                lo_1 = lo_2 = min(lo_1, lo_2); hi_1 = hi_2 = max(hi_1, hi_2);
+            }
+            // strip spans of this centroid's contribution: [first + shift, last + shift + 1]; empty stays (+inf, -inf)
+            if (hi_1 >= lo_1) { lo_1 += g.ishift; hi_1 += g.ishift + 1; }
+            if (hi_2 >= lo_2) { lo_2 += g.ishift; hi_2 += g.ishift + 1; }
+            if (nlim_d && hi_d >= lo_d) { lo_d += g.ishift; hi_d += g.ishift + 1; } else { lo_d = 0x7fffffff; hi_d = -0x7fffffff; }
         }
-        if ((g.flags & 2) && nlim_h) {                // rotating branch: both sums get the union before the rotated add
-            lo_1 = lo_2 = min(lo_1, lo_2); hi_1 = hi_2 = max(hi_1, hi_2);
+        // Union over the centroids of one (source, receiver): the lanes of a wave that belong to the same receiver are
+        // consecutive (idx = r * nc + c), so a segmented suffix reduction leaves the union of each run in its first lane
+        // and only that lane goes to memory -- a 64th of the atomics (135 centroids updating the same six words made this
+        // kernel 4 x slower per record at cfg5 than at cfg3).
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int kr = __shfl_down(r, off, 64);
+            const int a1 = __shfl_down(lo_1, off, 64), b1 = __shfl_down(hi_1, off, 64);
+            const int a2 = __shfl_down(lo_2, off, 64), b2 = __shfl_down(hi_2, off, 64);
+            const int ad = __shfl_down(lo_d, off, 64), bd = __shfl_down(hi_d, off, 64);
+            if (lane + off < 64 && kr == r) {
+                lo_1 = min(lo_1, a1); hi_1 = max(hi_1, b1);
+                lo_2 = min(lo_2, a2); hi_2 = max(hi_2, b2);
+                lo_d = min(lo_d, ad); hi_d = max(hi_d, bd);
+            }
         }
-        if (spanbuf) {                                // per receiver over all sources: [horizontal lo, hi, vertical lo, hi]
-            if (nlim_h) { atomicMin(&spanbuf[4 * r + 0], min(lo_1, lo_2) + g.ishift); atomicMax(&spanbuf[4 * r + 1], max(hi_1, hi_2) + g.ishift + 1); }
-            if (nlim_d) { atomicMin(&spanbuf[4 * r + 2], lo_d + g.ishift); atomicMax(&spanbuf[4 * r + 3], hi_d + g.ishift + 1); }
-        }
-        if (spansrc) {                               // the same per trial source and strip: data spans of ITS synthetic strips
-            int *sp = spansrc + ((size_t)s * ep.nrec + r) * kSpanInts;
-            if (hi_1 >= lo_1) { atomicMin(&sp[0], lo_1 + g.ishift); atomicMax(&sp[1], hi_1 + g.ishift + 1); }
-            if (hi_2 >= lo_2) { atomicMin(&sp[2], lo_2 + g.ishift); atomicMax(&sp[3], hi_2 + g.ishift + 1); }
-            if (nlim_d) { atomicMin(&sp[4], lo_d + g.ishift); atomicMax(&sp[5], hi_d + g.ishift + 1); }
+        const int rprev = __shfl_up(r, 1, 64);
+        if (lane == 0 || rprev != r) {
+            if (spanbuf) {                                // per receiver over all sources: [horizontal lo, hi, vertical lo, hi]
+                if (max(hi_1, hi_2) >= min(lo_1, lo_2)) { atomicMin(&spanbuf[4 * r + 0], min(lo_1, lo_2)); atomicMax(&spanbuf[4 * r + 1], max(hi_1, hi_2)); }
+                if (hi_d >= lo_d) { atomicMin(&spanbuf[4 * r + 2], lo_d); atomicMax(&spanbuf[4 * r + 3], hi_d); }
+            }
+            if (spansrc) {                               // the same per trial source and strip: data spans of ITS synthetic strips
+                int *sp = spansrc + ((size_t)s * ep.nrec + r) * kSpanInts;
+                if (hi_1 >= lo_1) { atomicMin(&sp[0], lo_1); atomicMax(&sp[1], hi_1); }
+                if (hi_2 >= lo_2) { atomicMin(&sp[2], lo_2); atomicMax(&sp[3], hi_2); }
+                if (hi_d >= lo_d) { atomicMin(&sp[4], lo_d); atomicMax(&sp[5], hi_d); }
+            }
         }
     }
+    if (!live) return;
     if (!out) return;
     const size_t base = (size_t)(c0 - cent_ofs[ep.isrc0]) * ep.nrec + (size_t)r * nc + c;
     out[base] = g;
