@@ -169,6 +169,13 @@ def one_case(rng, verbose):
         tol = 1e-6 if mid not in (5,) else 2e-6
         bad = np.abs(pm - m) > tol * scale
         ok = np.array_equal(pn[0], nn[0]) and not bad.any()
+    # the whole list through the overlapped one-call in random pieces: the same bits as the calls above
+    if ok and n > 1 and rng.random() < 0.5:
+        piece = int(rng.integers(1, n + 1))
+        qm, qn, qg, qs = p.misfits_for_params(name, tr, piece)
+        if not (np.array_equal(qm, pm) and np.array_equal(qn, pn) and np.array_equal(qg, pg) and not qs.any()):
+            ok = False
+            print("BAD misfits_for_params in pieces of %d differs from set_source_params + get_misfits" % piece)
     if not ok and os.environ.get("KIWI_HIP_DEBUG"):
         import ctypes as C
         from oracle import ko as _ko
