@@ -35,6 +35,38 @@ def test_init_fails_loudly_without_gpu():
         keng.Engine(0)
 
 
+def test_effective_cpus_follows_the_cgroup_quota():
+    """The discretiser's team size: allowed hardware threads cut to the container's CPU quota (cgroup v2 cpu.max or v1
+    cfs quota) -- a container sees every hardware thread of its host but is throttled at the quota."""
+    n = klib.load().kiwi_hip_effective_cpus()
+    allowed = len(os.sched_getaffinity(0))
+    assert 1 <= n <= allowed
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except OSError:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                quota = q / per
+        except OSError:
+            pass
+    if quota is not None:
+        assert n == max(1, min(allowed, int(quota + 0.5)))
+    else:
+        assert n == allowed
+
+
+def test_loader_puts_torch_first():
+    """One HIP runtime per process: the library is loaded after torch (whose libamdhip64 it then binds to); see lib.load."""
+    import sys
+    klib.load()
+    assert "torch" in sys.modules
+
+
 def test_source_nparams():
     L = klib.load()
     assert L.kiwi_hip_source_nparams(1) == 14
