@@ -201,6 +201,9 @@ struct kiwi_hip_ctx {
     std::vector<FftBucket> buckets;                              // of the chunk being evaluated
     hipEvent_t size_event = nullptr;
     std::map<std::tuple<int, int, int>, hipfftHandle> plans;     // (ntrans, batch, type) -> plan
+    DevBuf<float2> fused_tab[kFusedFftMaxLog2 + 1];              // twiddle tables of spec_fft_norm_kernel, by log2(ntrans)
+    bool fused_fft = true;                                       // KIWI_HIP_FUSED_FFT=0: amplitude spectra through hipFFT
+    bool fused_fft_attr = false;
 
     std::vector<EventPair> events;
     std::vector<hipEvent_t> event_pool;
@@ -535,6 +538,50 @@ void fft_buckets(kiwi_hip_ctx *c, bool forward)
 
 int next_pow2(int n) { int m = 1; while (m < n) m *= 2; return m; }      // comparator.f90:1111-1118 (integer form)
 
+// spec_fft_norm_kernel takes these lengths (LDS holds ntrans / 2 complex points)
+bool fused_fft_takes(const kiwi_hip_ctx *c, int ntrans)
+{
+    return c->fused_fft && ntrans >= (1 << kFusedFftMinLog2) && ntrans <= (1 << kFusedFftMaxLog2) && (ntrans & (ntrans - 1)) == 0;
+}
+
+// twiddle table of one length (layout: fused_fft_table_size / spec_fft_norm_kernel), made in double precision
+void fused_fft_table(kiwi_hip_ctx *c, int ntrans)
+{
+    int lg = 0;
+    while ((1 << lg) < ntrans) lg++;
+    if (c->fused_tab[lg].p) return;
+    const int M = ntrans / 2;
+    std::vector<float2> t;
+    t.reserve(fused_fft_table_size(ntrans));
+    const double twopi = 6.283185307179586476925286766559;
+    for (int len = M; len >= 4; len >>= 2) {
+        const int q = len >> 2;
+        for (int r = 1; r <= 3; r++)
+            for (int pos = 0; pos < q; pos++) {
+                const double a = -twopi * (double)r * (double)pos / (double)len;
+                t.push_back(make_float2((float)std::cos(a), (float)std::sin(a)));
+            }
+    }
+    for (int k = 0; k <= M; k++) {
+        const double a = -twopi * (double)k / (double)ntrans;
+        t.push_back(make_float2((float)std::cos(a), (float)std::sin(a)));
+    }
+    c->fused_tab[lg].alloc(t.size(), &c->dev_bytes);
+    HIPCHECK(hipMemcpy(c->fused_tab[lg].p, t.data(), t.size() * sizeof(float2), hipMemcpyHostToDevice));
+}
+
+FusedFftTables fused_fft_tables(kiwi_hip_ctx *c)
+{
+    FusedFftTables ft;
+    for (int i = 0; i <= kFusedFftMaxLog2; i++) ft.tab[i] = c->fused_tab[i].p;
+    if (!c->fused_fft_attr) {          // more than 64 KB of dynamic LDS per workgroup has to be asked for
+        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&spec_fft_norm_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 << kFusedFftMaxLog2));
+        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&spec_fft_norm_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 << kFusedFftMaxLog2));
+        c->fused_fft_attr = true;
+    }
+    return ft;
+}
+
 __global__ void ref_amp_kernel(const float2 *__restrict__ spec, const FftPair *__restrict__ pairs,
                                const float *__restrict__ filtw, float *__restrict__ refamp)
 {
@@ -675,8 +722,21 @@ void make_variants(kiwi_hip_ctx *c, const std::vector<std::pair<int, int>> &want
             i = j;
         }
     };
-    for_each_length(true);
-    hipLaunchKernelGGL(ref_amp_kernel, dim3((unsigned)prs.size()), dim3(256), 0, c->stream, c->spec_d.p, prs_d.p, c->filtw_d.p, c->refamp_d.p);
+    bool fused = spectral;
+    int longest = 0;
+    for (auto &pr : prs) { fused = fused && fused_fft_takes(c, pr.ntrans); longest = std::max(longest, pr.ntrans); }
+    if (fused) {
+        // amplitude spectra of the references by the transform the trial sources go through (spec_fft_norm_kernel): a trial
+        // source that reproduces the reference trace bit for bit then has the misfit 0 exactly
+        for (auto &pr : prs) fused_fft_table(c, pr.ntrans);
+        const FusedFftTables ft = fused_fft_tables(c);
+        SpecParams sp{ c->method, dt, c->syn_factor, c->nmis, 0, c->any_filter ? 1 : 0 };
+        hipLaunchKernelGGL(spec_fft_norm_kernel<1>, dim3((unsigned)prs.size()), dim3(256), (size_t)longest * 4, c->stream, c->fft_d.p, prs_d.p, ft,
+                           (const float *)nullptr, c->filtw_d.p, sp, (float *)nullptr, c->refamp_d.p);
+    } else {
+        for_each_length(true);
+        hipLaunchKernelGGL(ref_amp_kernel, dim3((unsigned)prs.size()), dim3(256), 0, c->stream, c->spec_d.p, prs_d.p, c->filtw_d.p, c->refamp_d.p);
+    }
     if (c->any_filter && !spectral) {
         hipLaunchKernelGGL(spec_filter_kernel, dim3((unsigned)prs.size()), dim3(256), 0, c->stream, c->spec_d.p, prs_d.p, c->comps_d.p, c->filtw_d.p);
         for_each_length(false);
@@ -1012,11 +1072,20 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
         }
         if (c->fft_needed) {
             SpecParams sp{ c->method, c->gm.dt, c->syn_factor, c->nmis, isrc0, c->any_filter ? 1 : 0 };
-            fft_buckets(c, true);
-            if (spectral) {
+            bool fused = spectral;
+            int longest = 0;
+            for (auto &b : c->buckets) { fused = fused && fused_fft_takes(c, b.ntrans); longest = std::max(longest, b.ntrans); }
+            if (fused) {
+                // transform, amplitude, filter and norm of every (slot, source) row in one pass through LDS
+                for (auto &b : c->buckets) fused_fft_table(c, b.ntrans);
+                hipLaunchKernelGGL(spec_fft_norm_kernel<0>, dim3((unsigned)nsrc, (unsigned)c->nmis), dim3(256), (size_t)longest * 4, c->stream,
+                                   c->fft_d.p, c->pairs_d.p, fused_fft_tables(c), c->refamp_d.p, c->filtw_d.p, sp, c->misfit_d.p, (float *)nullptr);
+            } else if (spectral) {
+                fft_buckets(c, true);
                 hipLaunchKernelGGL(spec_norm_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream,
                                    c->spec_d.p, c->pairs_d.p, c->refamp_d.p, c->filtw_d.p, sp, c->misfit_d.p);
             } else {
+                fft_buckets(c, true);
                 hipLaunchKernelGGL(spec_filter_kernel, dim3((unsigned)(c->nmis * nsrc)), dim3(256), 0, c->stream,
                                    c->spec_d.p, c->pairs_d.p, c->comps_d.p, c->filtw_d.p);
                 fft_buckets(c, false);
@@ -1105,6 +1174,7 @@ int kiwi_hip_init(int device, kiwi_hip_ctx **out)
         if (const char *m = std::getenv("KIWI_HIP_FUSE")) c->fuse_enabled = std::atoi(m);
         if (const char *m = std::getenv("KIWI_HIP_CELL")) c->cell_mode = std::atoi(m) ? 1 : 0;
         if (const char *m = std::getenv("KIWI_HIP_DEDUPE")) c->dedupe_enabled = std::atoi(m);      // 0 off, 1 default, 2 also for point sources
+        if (const char *m = std::getenv("KIWI_HIP_FUSED_FFT")) c->fused_fft = std::atoi(m) != 0;   // 0: amplitude spectra through hipFFT
         if (const char *m = std::getenv("KIWI_HIP_CELL_SPL")) c->cell_spl = std::atoi(m) == 4 ? 4 : 2;
         if (const char *m = std::getenv("KIWI_HIP_CELL_SPLIT")) c->cell_split = std::atoi(m) ? 1 : 0;
         if (const char *m = std::getenv("KIWI_HIP_CHUNK_MB")) {      // workspace bound per launch (default 16 GiB); tests use it
@@ -2074,6 +2144,8 @@ int kiwi_hip_get_amp_spectrum(kiwi_hip_ctx *c, int isrc, int irec, int icomp, in
     c->method = KIWI_AMPSPEC_L2NORM;
     if (!filtered) c->recv[irec - 1].filter = Plf();              // plain: as if this receiver had no filter
     c->prepared = false;
+    const bool fused0 = c->fused_fft;
+    c->fused_fft = false;                                         // the spectrum itself is wanted: library transform into spec_d
     std::string err;
     try {
         prepare(c);
@@ -2112,6 +2184,7 @@ int kiwi_hip_get_amp_spectrum(kiwi_hip_ctx *c, int isrc, int irec, int icomp, in
     } catch (const std::exception &e) { err = e.what(); }
     c->method = method0;
     c->recv[irec - 1].filter = filter0;
+    c->fused_fft = fused0;
     c->prepared = false;
     if (!err.empty()) throw std::runtime_error(err);
     return 0;

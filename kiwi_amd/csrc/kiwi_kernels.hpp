@@ -1965,6 +1965,184 @@ __global__ __launch_bounds__(256) void spec_norm_kernel(
     }
 }
 
+// ---- amplitude-spectrum norms without the library transform ---------------------------------------------------------
+// ampspec_l2norm / ampspec_l1norm need |X[k]| of the tapered, zero-padded trace only to compare it with the reference's
+// (comparator.f90:861-886,1186-1231): the spectrum itself is never used again.  hipFFT's r2c is two kernels (a complex
+// transform of half the length and a post-processing pass) that write and re-read the whole spectrum, and spec_norm_kernel
+// reads it once more -- four passes over 2.5 GB at cfg5.  Here one workgroup per (slot, source) pair transforms its row in
+// LDS and reduces it to the one number that leaves the chip:
+//   z[n] = x[2n] + i x[2n+1], n < M = ntrans / 2;  Z = DFT_M(z) by decimation in frequency, radix 4 (one radix-2 stage
+//   at the end when log2 M is odd), in place -- stage `len` turns each block of len points into four blocks of len / 4
+//   whose transforms are the outputs 4k', 4k'+1, 4k'+2, 4k'+3, so frequency k ends at position
+//   sum_j digit_j(k) * len_j / 4 (digit-reversed; the norm needs every bin once, in no particular order);
+//   X[k] = E[k] + exp(-2 pi i k / ntrans) O[k],  E = (Z[k] + conj Z[M-k]) / 2,  O = (Z[k] - conj Z[M-k]) / (2i),  k = 0 .. M.
+// Twiddle factors come from a table per length made on the host in double precision: per stage three runs of len / 4
+// factors w^pos, w^2pos, w^3pos (read with unit stride), then exp(-2 pi i k / ntrans) for k = 0 .. M.
+constexpr int kFusedFftMinLog2 = 6, kFusedFftMaxLog2 = 15;       // 64 .. 32768 samples (M * 8 B of LDS: up to 128 KB)
+struct FusedFftTables { const float2 *tab[kFusedFftMaxLog2 + 1]; };
+
+__host__ __device__ inline size_t fused_fft_table_size(int ntrans)
+{
+    const int M = ntrans / 2;
+    size_t n = 0;
+    for (int len = M; len >= 4; len >>= 2) n += 3 * (size_t)(len >> 2);
+    return n + (size_t)M + 1;
+}
+
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+// one radix-4 decimation-in-frequency butterfly: a, b, c, d a quarter block apart, w1..w3 = w^pos, w^2pos, w^3pos
+__device__ __forceinline__ void fused_fft_r4(float2 &a, float2 &b, float2 &c, float2 &d, float2 w1, float2 w2, float2 w3)
+{
+    const float2 t0 = make_float2(a.x + c.x, a.y + c.y), t1 = make_float2(a.x - c.x, a.y - c.y);
+    const float2 t2 = make_float2(b.x + d.x, b.y + d.y), t3 = make_float2(b.y - d.y, d.x - b.x);     // -i (b - d)
+    a = make_float2(t0.x + t2.x, t0.y + t2.y);
+    b = cmulf(make_float2(t1.x + t3.x, t1.y + t3.y), w1);
+    c = cmulf(make_float2(t0.x - t2.x, t0.y - t2.y), w2);
+    d = cmulf(make_float2(t1.x - t3.x, t1.y - t3.y), w3);
+}
+
+// position of frequency k (0 <= k < M) after the in-place stages: the base-4 digits of k in reverse order (bit reversal
+// with the two bits of every digit swapped back), the odd top bit of k -- the radix-2 stage -- at the bottom
+__device__ __forceinline__ int fused_fft_pos(int k, int lgM)
+{
+    const int nd = lgM & ~1;                                             // bits taken by the radix-4 digits
+    unsigned r = __brev((unsigned)k << (32 - nd));                       // low nd bits of k, reversed
+    r = ((r & 0xaaaaaaaau) >> 1) | ((r & 0x55555555u) << 1);
+    return (lgM & 1) ? (int)((r << 1) | ((unsigned)k >> nd)) : (int)r;
+}
+
+// LDS index of point p: the five bits that select the bank pair are mixed with higher bits, so that every access pattern of
+// the kernel -- consecutive points, the stages' strides of len / 4, the digit-reversed reads at the end (64 lanes on ONE
+// bank pair without it) -- spreads over all banks (at most 3 lanes per bank pair, 2 is the floor for 8-byte accesses;
+// found by search over xor masks; a bijection of [0, M) for M >= 32)
+__device__ __forceinline__ int fused_fft_lds(int p) { return p ^ (((p >> 2) ^ (p >> 5) ^ (p >> 10)) & 31); }
+
+// |x + i y| without overflow or underflow of the squares (the scale is a power of two: exact)
+__device__ __forceinline__ float amp2f(float x, float y)
+{
+    const float m = fmaxf(fabsf(x), fabsf(y));
+    if (!(m > 0.f) || m > 3.0e38f) return m != m ? m : fabsf(x) + fabsf(y);     // 0, inf, nan
+    const int e = __builtin_amdgcn_frexp_expf(m);
+    const float sx = ldexpf(x, -e), sy = ldexpf(y, -e);
+    return ldexpf(sqrtf(sx * sx + sy * sy), e);
+}
+
+// mode 0: misfit of pair (source s = blockIdx.x, slot m = blockIdx.y) of `pairs[s * nmis + m]` into misfit_out
+// mode 1: rows of reference variants, pairs[blockIdx.x]: amp_out[specofs + k] = |X[k]| * filtw[specofs + k]
+template <int MODE>
+__global__ __launch_bounds__(256) void spec_fft_norm_kernel(
+    const float *__restrict__ fftbuf, const FftPair *__restrict__ pairs, FusedFftTables tabs,
+    const float *__restrict__ refamp, const float *__restrict__ filtw, SpecParams sp, float *__restrict__ misfit_out,
+    float *__restrict__ amp_out)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 zf[];
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    // (mode 0: source index fastest -- the workgroups in flight share the reference and filter rows of a few slots)
+    const int m = MODE == 0 ? (int)blockIdx.y : 0, s = MODE == 0 ? (int)blockIdx.x : 0;
+    const FftPair pr = MODE == 0 ? pairs[(size_t)s * sp.nmis + m] : pairs[blockIdx.x];
+    const int N = pr.ntrans, M = N >> 1;
+    const float2 *__restrict__ tw = tabs.tab[31 - __clz(N)];
+    const float2 *__restrict__ row = reinterpret_cast<const float2 *>(fftbuf + pr.fft_ofs);
+#pragma unroll 8
+    for (int n = tid; n < M; n += 256) zf[fused_fft_lds(n)] = row[n];
+    __syncthreads();
+    int len = M;
+    // two radix-4 stages at a time while the block length allows: the 16 points base + a len/4 + b len/16 stay in registers
+    // between the stage over a and the stage over b (same operations as two single stages, half the LDS round trips)
+    for (; len >= 16; len >>= 4) {
+        const int q1 = len >> 2, q2 = len >> 4;
+        const float2 *__restrict__ tw2 = tw + 3 * q1;
+        for (int j = tid; j < (M >> 4); j += 256) {
+            const int pos = j & (q2 - 1), base = ((j - pos) << 4) + pos;
+            float2 v[4][4];
+            float2 w1[4][3], w2[3];
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+#pragma unroll
+                for (int r = 0; r < 3; r++) w1[b][r] = tw[r * q1 + pos + b * q2];
+#pragma unroll
+            for (int r = 0; r < 3; r++) w2[r] = tw2[r * q2 + pos];
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) v[a][b] = zf[fused_fft_lds(base + a * q1 + b * q2)];
+#pragma unroll
+            for (int b = 0; b < 4; b++) fused_fft_r4(v[0][b], v[1][b], v[2][b], v[3][b], w1[b][0], w1[b][1], w1[b][2]);
+#pragma unroll
+            for (int a = 0; a < 4; a++) fused_fft_r4(v[a][0], v[a][1], v[a][2], v[a][3], w2[0], w2[1], w2[2]);
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) zf[fused_fft_lds(base + a * q1 + b * q2)] = v[a][b];
+        }
+        tw += 3 * q1 + 3 * q2;
+        __syncthreads();
+    }
+    if (len >= 4) {
+        const int q = len >> 2;
+#pragma unroll 4
+        for (int j = tid; j < (M >> 2); j += 256) {
+            const int pos = j & (q - 1), base = ((j - pos) << 2) + pos;
+            const int ia = fused_fft_lds(base), ib = fused_fft_lds(base + q), ic = fused_fft_lds(base + 2 * q), id = fused_fft_lds(base + 3 * q);
+            float2 a = zf[ia], b = zf[ib], c = zf[ic], d = zf[id];
+            fused_fft_r4(a, b, c, d, tw[pos], tw[q + pos], tw[2 * q + pos]);
+            zf[ia] = a; zf[ib] = b; zf[ic] = c; zf[id] = d;
+        }
+        tw += 3 * q;
+        len >>= 2;
+        __syncthreads();
+    }
+    if (len == 2) {
+        for (int j = tid; j < (M >> 1); j += 256) {
+            const int ia = fused_fft_lds(2 * j), ib = fused_fft_lds(2 * j + 1);
+            const float2 a = zf[ia], b = zf[ib];
+            zf[ia] = make_float2(a.x + b.x, a.y + b.y);
+            zf[ib] = make_float2(a.x - b.x, a.y - b.y);
+        }
+        __syncthreads();
+    }
+    const float *__restrict__ ra = MODE == 0 ? refamp + pr.specofs : nullptr;
+    const float *__restrict__ fw = filtw + pr.specofs;
+    const bool unit = (sp.syn_factor == 1.f);
+    const int lgM = 31 - __clz(M);
+    double acc = 0.0;
+    auto bin = [&](int k, float re, float im) {
+        float b = amp2f(re, im);                                         // amp_spectrum = abs(spectrum), comparator.f90:1213
+        if (MODE == 1) { amp_out[pr.specofs + k] = b * fw[k]; return; }
+        if (sp.has_filter) b = b * fw[k];                                // make_spectrum_filtered, :1226-1228
+        const float a = ra[k];                                           // reference, already filtered
+        if (sp.method == 3) {                                            // l2norm_func on amplitude spectra
+            const float d = unit ? (a - b) : (1.f * a - sp.syn_factor * b);
+            acc += (double)d * (double)d;
+        } else {
+            const float d = unit ? fabsf(a - b) : fabsf(1.f * a - sp.syn_factor * b);
+            acc += (double)d;
+        }
+    };
+    // bins k and M - k come from the same two points: X[k] = E + w O, X[M-k] = conj(E - w O), w = exp(-2 pi i k / ntrans)
+    // (k = 0 gives bins 0 and M, k = M / 2 one bin)
+#pragma unroll 2
+    for (int k = tid; k <= (M >> 1); k += 256) {
+        const float2 zk = zf[fused_fft_lds(fused_fft_pos(k, lgM))];
+        float2 zm = zf[fused_fft_lds(fused_fft_pos((M - k) & (M - 1), lgM))];
+        zm.y = -zm.y;                                                    // conj Z[M - k]
+        const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y + zm.y));
+        const float2 o = make_float2(0.5f * (zk.y - zm.y), -0.5f * (zk.x - zm.x));
+        const float2 wo = cmulf(tw[k], o);
+        bin(k, e.x + wo.x, e.y + wo.y);
+        if (2 * k != M) bin(M - k, e.x - wo.x, e.y - wo.y);
+    }
+    if (MODE == 1) return;
+    const double tot = block_sum(acc, red);
+    if (tid == 0) {
+        const float df = 1.f / ((float)N * sp.dt);                       // comparator.f90:1215
+        misfit_out[(size_t)(sp.isrc0 + s) * sp.nmis + m] =
+            (sp.method == 3) ? (float)sqrt((double)df * tot) : (float)((double)df * tot);
+    }
+}
+
 // spectrum_filtered = spectrum * filter(j df) (comparator.f90:1224-1225), in place, before the c2r; block per entry of
 // `pairs` (trial-source pairs of a chunk, or reference variants)
 __global__ __launch_bounds__(256) void spec_filter_kernel(float2 *__restrict__ spec, const FftPair *__restrict__ pairs,
