@@ -577,6 +577,7 @@ FusedFftTables fused_fft_tables(kiwi_hip_ctx *c)
     if (!c->fused_fft_attr) {          // more than 64 KB of dynamic LDS per workgroup has to be asked for
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&spec_fft_norm_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 << kFusedFftMaxLog2));
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&spec_fft_norm_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 << kFusedFftMaxLog2));
+        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&spec_fft_norm_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 << kFusedFftMaxLog2));
         c->fused_fft_attr = true;
     }
     return ft;
@@ -732,7 +733,7 @@ void make_variants(kiwi_hip_ctx *c, const std::vector<std::pair<int, int>> &want
         const FusedFftTables ft = fused_fft_tables(c);
         SpecParams sp{ c->method, dt, c->syn_factor, c->nmis, 0, c->any_filter ? 1 : 0 };
         hipLaunchKernelGGL(spec_fft_norm_kernel<1>, dim3((unsigned)prs.size()), dim3(256), (size_t)longest * 4, c->stream, c->fft_d.p, prs_d.p, ft,
-                           (const float *)nullptr, c->filtw_d.p, sp, (float *)nullptr, c->refamp_d.p);
+                           (const float *)nullptr, c->filtw_d.p, sp, (float *)nullptr, c->refamp_d.p, SynRows{});
     } else {
         for_each_length(true);
         hipLaunchKernelGGL(ref_amp_kernel, dim3((unsigned)prs.size()), dim3(256), 0, c->stream, c->spec_d.p, prs_d.p, c->filtw_d.p, c->refamp_d.p);
@@ -1056,7 +1057,14 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
                                c->fusepart_d.p, c->comps_d.p, c->nmis, fuse_all ? fuse_nparts : fuse_ntiles * (fuse_T / 64), fuse_T / 64,
                                fuse_all ? 0 : 4 * fuse_T,
                                c->method, c->gm.dt, isrc0, nsrc, c->misfit_d.p);
-        } else
+        }
+        // amplitude-spectrum norms whose transforms fit spec_fft_norm_kernel: that kernel takes the plain synthetics itself
+        // (fold, moment, taper while the row goes into LDS) unless the processed synthetics are to be kept
+        bool spec_fused = spectral && c->fft_needed;
+        int spec_longest = 0;
+        if (spec_fused) for (auto &b : c->buckets) { spec_fused = spec_fused && fused_fft_takes(c, b.ntrans); spec_longest = std::max(spec_longest, b.ntrans); }
+        const bool spec_direct = spec_fused && !proc && !fuse;
+        if (!fuse && !spec_direct)
         hipLaunchKernelGGL(misfit_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream,
                            c->syn_d.p, c->syn_stride, c->comps_d.p, c->reft_d.p, c->tw_d.p, c->moment_d.p,
                            c->risetime_d.p, mp, c->misfit_d.p, proc, c->fft_d.p, c->vt_d.p,
@@ -1072,14 +1080,16 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
         }
         if (c->fft_needed) {
             SpecParams sp{ c->method, c->gm.dt, c->syn_factor, c->nmis, isrc0, c->any_filter ? 1 : 0 };
-            bool fused = spectral;
-            int longest = 0;
-            for (auto &b : c->buckets) { fused = fused && fused_fft_takes(c, b.ntrans); longest = std::max(longest, b.ntrans); }
-            if (fused) {
+            if (spec_fused) {
                 // transform, amplitude, filter and norm of every (slot, source) row in one pass through LDS
                 for (auto &b : c->buckets) fused_fft_table(c, b.ntrans);
-                hipLaunchKernelGGL(spec_fft_norm_kernel<0>, dim3((unsigned)nsrc, (unsigned)c->nmis), dim3(256), (size_t)longest * 4, c->stream,
-                                   c->fft_d.p, c->pairs_d.p, fused_fft_tables(c), c->refamp_d.p, c->filtw_d.p, sp, c->misfit_d.p, (float *)nullptr);
+                const SynRows sr{ c->syn_d.p, c->syn_stride, c->comps_d.p, c->tw_d.p, c->moment_d.p, c->risetime_d.p, synrow };
+                if (spec_direct)
+                    hipLaunchKernelGGL(spec_fft_norm_kernel<2>, dim3((unsigned)nsrc, (unsigned)c->nmis), dim3(256), (size_t)spec_longest * 4, c->stream,
+                                       (const float *)nullptr, c->pairs_d.p, fused_fft_tables(c), c->refamp_d.p, c->filtw_d.p, sp, c->misfit_d.p, (float *)nullptr, sr);
+                else
+                    hipLaunchKernelGGL(spec_fft_norm_kernel<0>, dim3((unsigned)nsrc, (unsigned)c->nmis), dim3(256), (size_t)spec_longest * 4, c->stream,
+                                       c->fft_d.p, c->pairs_d.p, fused_fft_tables(c), c->refamp_d.p, c->filtw_d.p, sp, c->misfit_d.p, (float *)nullptr, sr);
             } else if (spectral) {
                 fft_buckets(c, true);
                 hipLaunchKernelGGL(spec_norm_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream,

@@ -1778,6 +1778,51 @@ struct MisfitParams {
     int skip_norm;       // floating norms: only produce the tapered synthetics (vt_out), norms follow in floating_norm_kernel
 };
 
+// rise-time fold of a source (receiver.f90:868-886): weights, integer shifts and fractions of the 1 + 2 nint(rise / 2 dt) taps
+__device__ __forceinline__ int fold_setup(float rise, float dt, float *fw, int *fs, float *fr)
+{
+    int n = 0;
+    if (rise > 0.f) {
+        const float rr0 = -rise / 2.f, rr1 = +rise / 2.f;
+        n = 1 + 2 * (int)roundf(0.5f * rise / dt);
+        if (n > kMaxFold) n = kMaxFold;       // guarded on the host (set_sources)
+        float sum = 0.f;
+        for (int is = 1; is <= n; is++) {
+            const float ts = ((float)(is - 1) - 0.5f * (float)(n - 1)) * dt;
+            const float lo = fmaxf(rr0, ts - dt / 2.f), hi = fminf(rr1, ts + dt / 2.f);
+            fw[is - 1] = fmaxf(0.f, hi - lo);
+            const float sh = ts / dt;
+            const float fl = floorf(sh);
+            fs[is - 1] = (int)fl;
+            fr[is - 1] = sh - (float)(int)fl;
+            sum = sum + fw[is - 1];
+        }
+        for (int i = 0; i < n; i++) fw[i] = fw[i] / sum;
+    }
+    return n;
+}
+
+// window sample i of a synthetic, folded (strip_fold, sparse_trace.f90:379-402) and scaled by the moment
+// (probe_set_array(..., factor_=moment), comparator.f90:264); sy[i] = plain synthetic at window sample i
+__device__ __forceinline__ float folded_scaled_sample(const float *__restrict__ sy, int i, int nf, const float *fw, const int *fs,
+                                                      const float *fr, float mom)
+{
+    float v;
+    if (nf > 0) {
+        v = 0.f;
+        for (int k = 0; k < nf; k++) {
+            float wr = fr[k];
+            float wl = 1.f - wr;
+            wr = wr * fw[k]; wl = wl * fw[k];
+            v = v + wl * sy[i - fs[k]];
+            v = v + wr * sy[i - fs[k] - 1];
+        }
+    } else {
+        v = sy[i];
+    }
+    return v * mom;
+}
+
 __global__ __launch_bounds__(256) void misfit_kernel(
     const float *__restrict__ syn, size_t syn_stride, const CompDev *__restrict__ comps,
     const float *__restrict__ reft, const float *__restrict__ tw,
@@ -1813,28 +1858,7 @@ __global__ __launch_bounds__(256) void misfit_kernel(
     __shared__ float fr[kMaxFold];
     __shared__ int nfold;
     __shared__ double red[256];
-    if (threadIdx.x == 0) {                       // receiver.f90:868-886
-        int n = 0;
-        if (rise > 0.f) {
-            const float dt = mp.dt;
-            const float rr0 = -rise / 2.f, rr1 = +rise / 2.f;
-            n = 1 + 2 * (int)roundf(0.5f * rise / dt);
-            if (n > kMaxFold) n = kMaxFold;       // guarded on the host (set_sources)
-            float sum = 0.f;
-            for (int is = 1; is <= n; is++) {
-                const float ts = ((float)(is - 1) - 0.5f * (float)(n - 1)) * dt;
-                const float lo = fmaxf(rr0, ts - dt / 2.f), hi = fminf(rr1, ts + dt / 2.f);
-                fw[is - 1] = fmaxf(0.f, hi - lo);
-                const float sh = ts / dt;
-                const float fl = floorf(sh);
-                fs[is - 1] = (int)fl;
-                fr[is - 1] = sh - (float)(int)fl;
-                sum = sum + fw[is - 1];
-            }
-            for (int i = 0; i < n; i++) fw[i] = fw[i] / sum;
-        }
-        nfold = n;
-    }
+    if (threadIdx.x == 0) nfold = fold_setup(rise, mp.dt, fw, fs, fr);
     __syncthreads();
     const int nf = nfold;
     const bool unit = (mp.syn_factor == 1.f);
@@ -1851,20 +1875,7 @@ __global__ __launch_bounds__(256) void misfit_kernel(
         for (int i = cd.wlen + threadIdx.x; i < pr.ntrans; i += 256) frow[i] = 0.f;      // zero padding
     }
     for (int i = threadIdx.x; i < cd.wlen; i += 256) {
-        float v;
-        if (nf > 0) {                             // strip_fold, sparse_trace.f90:379-402
-            v = 0.f;
-            for (int k = 0; k < nf; k++) {
-                float wr = fr[k];
-                float wl = 1.f - wr;
-                wr = wr * fw[k]; wl = wl * fw[k];
-                v = v + wl * sy[i - fs[k]];
-                v = v + wr * sy[i - fs[k] - 1];
-            }
-        } else {
-            v = sy[i];
-        }
-        v = v * mom;                              // probe_set_array(..., factor_=moment), comparator.f90:264
+        const float v = folded_scaled_sample(sy, i, nf, fw, fs, fr, mom);
         const float vt = v * tp[i];               // make_array_tapered, comparator.f90:1173-1184
         if (proc) proc[(size_t)s * syn_stride + cd.synofs + cd.halo + i] = mp.write_tapered == 2 ? vt : v;
         if (frow) { frow[i] = vt; continue; }
@@ -2028,25 +2039,59 @@ __device__ __forceinline__ float amp2f(float x, float y)
     return ldexpf(sqrtf(sx * sx + sy * sy), e);
 }
 
-// mode 0: misfit of pair (source s = blockIdx.x, slot m = blockIdx.y) of `pairs[s * nmis + m]` into misfit_out
+// where the rows come from when the kernel takes the plain synthetics itself (mode 2): what misfit_kernel is given
+struct SynRows {
+    const float *syn; size_t syn_stride;
+    const CompDev *comps;
+    const float *taper;                    // taper weights per window sample, [refofs + i]
+    const float *moment, *risetime;        // per uploaded source
+    const int *synrow;                     // optional: the source whose synthetics this one shares
+};
+
+// mode 0: misfit of pair (source s = blockIdx.x, slot m = blockIdx.y) of `pairs[s * nmis + m]` into misfit_out; the row is
+//         the tapered, zero-padded synthetic misfit_kernel left in fftbuf
+// mode 2: the same from the PLAIN synthetics: rise-time fold, moment and taper (what misfit_kernel does per sample) are
+//         applied while the row is brought into LDS, the zero padding is never stored anywhere
 // mode 1: rows of reference variants, pairs[blockIdx.x]: amp_out[specofs + k] = |X[k]| * filtw[specofs + k]
 template <int MODE>
 __global__ __launch_bounds__(256) void spec_fft_norm_kernel(
     const float *__restrict__ fftbuf, const FftPair *__restrict__ pairs, FusedFftTables tabs,
     const float *__restrict__ refamp, const float *__restrict__ filtw, SpecParams sp, float *__restrict__ misfit_out,
-    float *__restrict__ amp_out)
+    float *__restrict__ amp_out, SynRows sr)
 {
     extern __shared__ __attribute__((aligned(16))) float2 zf[];
     __shared__ double red[256];
     const int tid = threadIdx.x;
-    // (mode 0: source index fastest -- the workgroups in flight share the reference and filter rows of a few slots)
-    const int m = MODE == 0 ? (int)blockIdx.y : 0, s = MODE == 0 ? (int)blockIdx.x : 0;
-    const FftPair pr = MODE == 0 ? pairs[(size_t)s * sp.nmis + m] : pairs[blockIdx.x];
+    // (modes 0, 2: source index fastest -- the workgroups in flight share the reference and filter rows of a few slots)
+    const int m = MODE != 1 ? (int)blockIdx.y : 0, s = MODE != 1 ? (int)blockIdx.x : 0;
+    const FftPair pr = MODE != 1 ? pairs[(size_t)s * sp.nmis + m] : pairs[blockIdx.x];
     const int N = pr.ntrans, M = N >> 1;
     const float2 *__restrict__ tw = tabs.tab[31 - __clz(N)];
-    const float2 *__restrict__ row = reinterpret_cast<const float2 *>(fftbuf + pr.fft_ofs);
+    if constexpr (MODE == 2) {
+        __shared__ float fw[kMaxFold];
+        __shared__ int fs[kMaxFold];
+        __shared__ float fr[kMaxFold];
+        __shared__ int nfold;
+        const CompDev cd = sr.comps[m];
+        const float mom = sr.moment[sp.isrc0 + s];
+        if (tid == 0) nfold = fold_setup(sr.risetime[sp.isrc0 + s], sp.dt, fw, fs, fr);
+        __syncthreads();
+        const int nf = nfold;
+        const float *__restrict__ sy = sr.syn + (size_t)(sr.synrow ? sr.synrow[s] : s) * sr.syn_stride + cd.synofs + cd.halo;
+        const float *__restrict__ tp = sr.taper + cd.refofs;
+#pragma unroll 4
+        for (int n = tid; n < M; n += 256) {
+            const int i = 2 * n;
+            float2 x = make_float2(0.f, 0.f);
+            if (i < cd.wlen) x.x = folded_scaled_sample(sy, i, nf, fw, fs, fr, mom) * tp[i];           // make_array_tapered, comparator.f90:1173-1184
+            if (i + 1 < cd.wlen) x.y = folded_scaled_sample(sy, i + 1, nf, fw, fs, fr, mom) * tp[i + 1];
+            zf[fused_fft_lds(n)] = x;
+        }
+    } else {
+        const float2 *__restrict__ row = reinterpret_cast<const float2 *>(fftbuf + pr.fft_ofs);
 #pragma unroll 8
-    for (int n = tid; n < M; n += 256) zf[fused_fft_lds(n)] = row[n];
+        for (int n = tid; n < M; n += 256) zf[fused_fft_lds(n)] = row[n];
+    }
     __syncthreads();
     int len = M;
     // two radix-4 stages at a time while the block length allows: the 16 points base + a len/4 + b len/16 stay in registers
@@ -2103,7 +2148,7 @@ __global__ __launch_bounds__(256) void spec_fft_norm_kernel(
         }
         __syncthreads();
     }
-    const float *__restrict__ ra = MODE == 0 ? refamp + pr.specofs : nullptr;
+    const float *__restrict__ ra = MODE != 1 ? refamp + pr.specofs : nullptr;
     const float *__restrict__ fw = filtw + pr.specofs;
     const bool unit = (sp.syn_factor == 1.f);
     const int lgM = 31 - __clz(M);

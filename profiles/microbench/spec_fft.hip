@@ -51,11 +51,11 @@ int main(int argc, char **argv)
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&spec_fft_norm_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     SpecParams sp{ 3, 0.5f, 1.f, rows, 0, 1 };
     // check: amplitudes of row 1 against a double-precision DFT
-    hipLaunchKernelGGL(spec_fft_norm_kernel<1>, dim3(2), dim3(256), (size_t)N * 4, 0, buf, prd, ft, (const float *)nullptr, filtw, sp, (float *)nullptr, amp);
+    hipLaunchKernelGGL(spec_fft_norm_kernel<1>, dim3(2), dim3(256), (size_t)N * 4, 0, buf, prd, ft, (const float *)nullptr, filtw, sp, (float *)nullptr, amp, SynRows{});
     CK(hipDeviceSynchronize());
     std::vector<float> got(nb);
     CK(hipMemcpy(got.data(), amp, nb * 4, hipMemcpyDeviceToHost));        // (both blocks write the same array: row 1 last or first; rows 0 and 1 differ)
-    hipLaunchKernelGGL(spec_fft_norm_kernel<1>, dim3(1), dim3(256), (size_t)N * 4, 0, buf, prd, ft, (const float *)nullptr, filtw, sp, (float *)nullptr, amp);
+    hipLaunchKernelGGL(spec_fft_norm_kernel<1>, dim3(1), dim3(256), (size_t)N * 4, 0, buf, prd, ft, (const float *)nullptr, filtw, sp, (float *)nullptr, amp, SynRows{});
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(got.data(), amp, nb * 4, hipMemcpyDeviceToHost));
     double worst = 0, amax = 0, l2 = 0;
@@ -73,7 +73,7 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int rep = 0; rep < 3; rep++) {
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(spec_fft_norm_kernel<0>, dim3(1, rows), dim3(256), (size_t)N * 4, 0, buf, prd, ft, refamp, filtw, sp, mis, (float *)nullptr);
+        hipLaunchKernelGGL(spec_fft_norm_kernel<0>, dim3(1, rows), dim3(256), (size_t)N * 4, 0, buf, prd, ft, refamp, filtw, sp, mis, (float *)nullptr, SynRows{});
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("N %d rows %d: %.3f ms  (%.2f TB/s of input)\n", N, rows, ms, (double)rows * N * 4 / ms / 1e9);

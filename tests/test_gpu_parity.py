@@ -385,6 +385,63 @@ def test_time_domain_norms_with_frequency_filter(method):
     assert np.max(np.abs(so[a - lo_o:b - lo_o] - sp[a - lo_p:b - lo_p])) <= 2e-5 * np.max(np.abs(so))
 
 
+@pytest.mark.parametrize("method,with_filter", [("ampspec_l2norm", True), ("ampspec_l1norm", False)])
+def test_amplitude_spectrum_norms_in_one_kernel(method, with_filter, monkeypatch):
+    """ampspec_* norms: spec_fft_norm_kernel transforms every (slot, source) row in LDS and reduces it to the misfit.  Its two
+    row sources -- the plain synthetics (fold, moment and taper applied on the way in; the default) and the tapered rows
+    misfit_kernel writes when the processed synthetics are kept -- give the same bits; the library path
+    (KIWI_HIP_FUSED_FFT=0: hipFFT r2c + spec_norm_kernel) agrees to transform round-off, and all agree with the oracle.
+    Sources with a rise time (the fold runs inside the load), two transform lengths in the batch."""
+    sc = Scenario()
+    mid = {"ampspec_l2norm": 3, "ampspec_l1norm": 4}[method]
+    trials = np.array([[0.3 * i, 0., 0., 9500. + 300 * i] + synthetic.mt_from_sdr(40. * i, 50. + 5 * i, -60. + 30 * i) + [1.0 + 0.7 * i]
+                       for i in range(6)], np.float32)
+    trials[4, 10] = 170.0                                   # a long source time function: the next transform length
+    res = {}
+    for mode in ("fused", "library"):
+        monkeypatch.setenv("KIWI_HIP_FUSED_FFT", "1" if mode == "fused" else "0")
+        e, p = build(sc)
+        e.set_misfit_method(mid)
+        p.set_misfit_method(method)
+        if with_filter:
+            fx, fy = [0.01, 0.03, 0.25, 0.4], [0., 1., 1., 0.]
+            for ir in range(1, sc.nrec + 1):
+                if ir != 2:
+                    e.set_filter(ir, fx, fy)
+                    p.set_misfit_filter(ir, fx, fy)
+        p.set_source_params("moment_tensor", trials)
+        p.eval()
+        direct = [x.copy() for x in p.get_misfits()]
+        p.set_keep_synthetics(2)                            # processed synthetics kept: misfit_kernel writes the rows
+        p.eval()
+        kept = p.get_misfits()
+        p.set_keep_synthetics(0)
+        for a, b in zip(direct, kept):
+            assert a.tobytes() == b.tobytes(), mode
+        res[mode] = direct
+        if mode == "fused":
+            for i, t in enumerate(trials):                  # every source against a fresh oracle engine
+                fe = sc.oracle(); sc.apply_setup(fe, True); fe.set_misfit_method(mid)
+                if with_filter:
+                    for ir in range(1, sc.nrec + 1):
+                        if ir != 2:
+                            fe.set_filter(ir, fx, fy)
+                om, on, og = oracle_misfits(fe, 6, t[None, :])
+                assert np.allclose(direct[1][i], on[0], rtol=SPEC_RTOL, atol=0), i
+                assert np.allclose(direct[0][i], om[0], rtol=SPEC_RTOL, atol=SPEC_RTOL * np.abs(on[0]).max()), i
+                fe.close()
+            # the source the references were made from (by the oracle: equal to the device's synthetics to an ulp or two)
+            p.set_source_params(sc.true_type, sc.true_params[None, :])
+            p.eval()
+            tm, tn, _ = p.get_misfits()
+            assert np.all(tm <= 1e-5 * tn)
+        p.close(); e.close()
+    fm, fn, fg = res["fused"]
+    lm, ln, lg = res["library"]
+    assert len({x.tobytes() for x in fn}) > 1                # two transform lengths
+    assert np.allclose(fn, ln, rtol=2e-6, atol=0) and np.allclose(fm, lm, rtol=0, atol=4e-6 * np.abs(fn).max())
+
+
 @pytest.mark.parametrize("method,with_filter", [("ampspec_l2norm", False), ("ampspec_l1norm", True), ("l2norm", True)])
 def test_spectral_results_do_not_depend_on_the_batch(method, with_filter, monkeypatch):
     """The transform length of a probe pair follows the trial source's OWN strips (what a fresh reference engine gives it,
