@@ -25,6 +25,13 @@ here = os.path.dirname(os.path.abspath(__file__))
 out = {"tag": tag, "command": "rocprofv3 <pass> -- python3 bench.py --workload <w> --steps 6 --warmup 2 --no-cpu-baseline",
        "note": "per step = sum over the accumulate kernels of one bench step of the per-dispatch medians; FETCH_SIZE / WRITE_SIZE "
                "are in KiB as rocprofv3 reports them", "workloads": {}}
+# a re-collection of some workloads keeps the entries of the others
+_prev = os.path.join(here, tag + "_summary.json")
+if os.path.exists(_prev):
+    try:
+        out["workloads"].update(json.load(open(_prev)).get("workloads", {}))
+    except ValueError:
+        pass
 
 
 def counters(d):
