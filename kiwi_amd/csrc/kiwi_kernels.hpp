@@ -2036,7 +2036,7 @@ __device__ __forceinline__ float amp2f(float x, float y)
     if (!(m > 0.f) || m > 3.0e38f) return m != m ? m : fabsf(x) + fabsf(y);     // 0, inf, nan
     const int e = __builtin_amdgcn_frexp_expf(m);
     const float sx = ldexpf(x, -e), sy = ldexpf(y, -e);
-    return ldexpf(sqrtf(sx * sx + sy * sy), e);
+    return ldexpf(__builtin_amdgcn_sqrtf(sx * sx + sy * sy), e);          // argument in [1/4, 2): the hardware root (1 ulp) needs no fix-ups
 }
 
 // where the rows come from when the kernel takes the plain synthetics itself (mode 2): what misfit_kernel is given
@@ -2099,8 +2099,13 @@ __global__ __launch_bounds__(256) void spec_fft_norm_kernel(
     for (; len >= 16; len >>= 4) {
         const int q1 = len >> 2, q2 = len >> 4;
         const float2 *__restrict__ tw2 = tw + 3 * q1;
+        // the swizzle is linear over xor and base, a q1, b q2 occupy different bits: index = lds(base) ^ lds(a q1) ^ lds(b q2),
+        // the last two the same for every lane
+        int sa[4], sb[4];
+#pragma unroll
+        for (int a = 0; a < 4; a++) { sa[a] = fused_fft_lds(a * q1); sb[a] = fused_fft_lds(a * q2); }
         for (int j = tid; j < (M >> 4); j += 256) {
-            const int pos = j & (q2 - 1), base = ((j - pos) << 4) + pos;
+            const int pos = j & (q2 - 1), base = fused_fft_lds(((j - pos) << 4) + pos);
             float2 v[4][4];
             float2 w1[4][3], w2[3];
 #pragma unroll
@@ -2112,7 +2117,7 @@ __global__ __launch_bounds__(256) void spec_fft_norm_kernel(
 #pragma unroll
             for (int a = 0; a < 4; a++)
 #pragma unroll
-                for (int b = 0; b < 4; b++) v[a][b] = zf[fused_fft_lds(base + a * q1 + b * q2)];
+                for (int b = 0; b < 4; b++) v[a][b] = zf[base ^ sa[a] ^ sb[b]];
 #pragma unroll
             for (int b = 0; b < 4; b++) fused_fft_r4(v[0][b], v[1][b], v[2][b], v[3][b], w1[b][0], w1[b][1], w1[b][2]);
 #pragma unroll
@@ -2120,7 +2125,7 @@ __global__ __launch_bounds__(256) void spec_fft_norm_kernel(
 #pragma unroll
             for (int a = 0; a < 4; a++)
 #pragma unroll
-                for (int b = 0; b < 4; b++) zf[fused_fft_lds(base + a * q1 + b * q2)] = v[a][b];
+                for (int b = 0; b < 4; b++) zf[base ^ sa[a] ^ sb[b]] = v[a][b];
         }
         tw += 3 * q1 + 3 * q2;
         __syncthreads();

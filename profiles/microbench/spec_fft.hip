@@ -2,7 +2,7 @@
 // against a double-precision DFT, and the time for `rows` rows of one length (all rows share one reference / filter row).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -I../../kiwi_amd/csrc -I../../include \
 //         -o spec_fft spec_fft.hip && ./spec_fft 8192 65535
-// MI355X (r02): max |amp - dft| / peak = 4e-8 .. 1.1e-7 for 64 .. 32768 samples; 65535 rows of 8192 samples: 1.6 ms
+// MI355X (r02): max |amp - dft| / peak = 4e-8 .. 1.1e-7 for 64 .. 32768 samples; 65535 rows of 8192 samples: 1.4 ms
 // (hipFFT r2c + spec_norm_kernel on the same rows: 3.3 ms); 80 % of the vector issue slots busy, LDS pipe 17 %.
 #include <hip/hip_runtime.h>
 #include <cstdio>
