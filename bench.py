@@ -8,7 +8,8 @@ interpolation = 4 neighbour traces), time-domain L2 misfit over a 4096-sample ta
 `--workload cfg2|cfg4|cfg5` run the other BASELINE.json configurations (moment-tensor grid;
 mt_eikonal 468 centroids x 200 receivers; spectral comparator with frequency filter) the same way;
 `cfg3-100pt` is the same source type with 100 sub-fault POINTS (200 centroids), `cfg3-scatter` the
-cfg3 source over a shuffled location grid (no Green's function rows shared between neighbouring trials).
+cfg3 source over a shuffled location grid (no Green's function rows shared between neighbouring trials), `cfg5-td` the cfg5
+trial set under a time-domain norm on frequency-filtered traces.
 One "step" = one pass of the hot path (geometry -> accumulate -> misfit) over a batch of
 --batch trial sources per GPU, everything already resident in HBM.  N > 1: every rank evaluates
 its own contiguous shard of the trial list (weak scaling) and the per-source global misfits are
@@ -260,10 +261,10 @@ def main():
                     help="ranks = GPUs of this node (default: WORLD_SIZE when started by a launcher, else 1)")
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5", "cfg3-100pt", "cfg3-scatter"],
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5", "cfg5-td", "cfg3-100pt", "cfg3-scatter"],
                     help="BASELINE.json configs[1..4]; cfg3 (default) is the one the metric is quoted on")
     ap.add_argument("--batch", type=int, default=0,
-                    help="trial sources per GPU per step (default: 12960 cfg2, 1024 cfg3 / cfg3-scatter, 512 cfg3-100pt / cfg5, 128 cfg4)")
+                    help="trial sources per GPU per step (default: 12960 cfg2, 1024 cfg3 / cfg3-scatter, 512 cfg3-100pt / cfg5 / cfg5-td, 128 cfg4)")
     ap.add_argument("--samples", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -298,7 +299,7 @@ def main():
     from kiwi_amd.shard import shard_range, gather_misfits
     from kiwi_amd import synthetic
     if args.batch <= 0:
-        args.batch = {"cfg2": 12960, "cfg3": 1024, "cfg3-scatter": 1024, "cfg3-100pt": 512, "cfg4": 128, "cfg5": 512}[args.workload]
+        args.batch = {"cfg2": 12960, "cfg3": 1024, "cfg3-scatter": 1024, "cfg3-100pt": 512, "cfg4": 128, "cfg5": 512, "cfg5-td": 512}[args.workload]
     lo, hi = shard_range(args.batch * ngpus, ngpus, rank)
     wl = synthetic.workload(args.workload, hi - lo, lo)
     p, gf, recv, refs, tapers, ncent = setup_product(local_rank, wl, args.samples)

@@ -578,6 +578,8 @@ FusedFftTables fused_fft_tables(kiwi_hip_ctx *c)
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&spec_fft_norm_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 << kFusedFftMaxLog2));
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&spec_fft_norm_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 << kFusedFftMaxLog2));
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&spec_fft_norm_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 << kFusedFftMaxLog2));
+        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&spec_fft_filter_norm_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 << kFusedFftMaxLog2));
+        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&spec_fft_filter_norm_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 << kFusedFftMaxLog2));
         c->fused_fft_attr = true;
     }
     return ft;
@@ -739,10 +741,22 @@ void make_variants(kiwi_hip_ctx *c, const std::vector<std::pair<int, int>> &want
         hipLaunchKernelGGL(ref_amp_kernel, dim3((unsigned)prs.size()), dim3(256), 0, c->stream, c->spec_d.p, prs_d.p, c->filtw_d.p, c->refamp_d.p);
     }
     if (c->any_filter && !spectral) {
-        hipLaunchKernelGGL(spec_filter_kernel, dim3((unsigned)prs.size()), dim3(256), 0, c->stream, c->spec_d.p, prs_d.p, c->comps_d.p, c->filtw_d.p);
-        for_each_length(false);
-        hipLaunchKernelGGL(ref_filt_kernel, dim3((unsigned)prs.size()), dim3(256), 0, c->stream, c->fft_d.p, prs_d.p, c->comps_d.p,
-                           c->zmask_d.p, c->reffilt_d.p);
+        bool ffused = true;
+        for (auto &pr : prs) ffused = ffused && fused_fft_takes(c, pr.ntrans);
+        if (ffused) {
+            // filtered references by the transform pair the trial sources go through (spec_fft_filter_norm_kernel); the rows in
+            // fft_d are untouched by the library transform above (out of place)
+            for (auto &pr : prs) fused_fft_table(c, pr.ntrans);
+            SpecParams sp{ c->method, dt, c->syn_factor, c->nmis, 0, 1 };
+            hipLaunchKernelGGL(spec_fft_filter_norm_kernel<1>, dim3((unsigned)prs.size()), dim3(256), (size_t)longest * 4, c->stream, c->fft_d.p, prs_d.p,
+                               fused_fft_tables(c), c->comps_d.p, c->filtw_d.p, (const float *)nullptr, c->zmask_d.p, sp, (float *)nullptr,
+                               c->reffilt_d.p, SynRows{});
+        } else {
+            hipLaunchKernelGGL(spec_filter_kernel, dim3((unsigned)prs.size()), dim3(256), 0, c->stream, c->spec_d.p, prs_d.p, c->comps_d.p, c->filtw_d.p);
+            for_each_length(false);
+            hipLaunchKernelGGL(ref_filt_kernel, dim3((unsigned)prs.size()), dim3(256), 0, c->stream, c->fft_d.p, prs_d.p, c->comps_d.p,
+                               c->zmask_d.p, c->reffilt_d.p);
+        }
     }
     HIPCHECK(hipGetLastError());
     // results of the fresh variants down to the host mirrors (the device arrays were re-allocated if they grew: the
@@ -1064,6 +1078,11 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
         int spec_longest = 0;
         if (spec_fused) for (auto &b : c->buckets) { spec_fused = spec_fused && fused_fft_takes(c, b.ntrans); spec_longest = std::max(spec_longest, b.ntrans); }
         const bool spec_direct = spec_fused && !proc && !fuse;
+        // time-domain norms on filtered traces: the same in-LDS transform, forward and back (spec_fft_filter_norm_kernel)
+        bool filt_fused = !spectral && c->fft_needed && !proc && !fuse;
+        int filt_longest = 0;
+        if (filt_fused) for (auto &b : c->buckets) { filt_fused = filt_fused && fused_fft_takes(c, b.ntrans); filt_longest = std::max(filt_longest, b.ntrans); }
+        if (filt_fused) mp.fft_mode |= 4;
         if (!fuse && !spec_direct)
         hipLaunchKernelGGL(misfit_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream,
                            c->syn_d.p, c->syn_stride, c->comps_d.p, c->reft_d.p, c->tw_d.p, c->moment_d.p,
@@ -1094,6 +1113,12 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
                 fft_buckets(c, true);
                 hipLaunchKernelGGL(spec_norm_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream,
                                    c->spec_d.p, c->pairs_d.p, c->refamp_d.p, c->filtw_d.p, sp, c->misfit_d.p);
+            } else if (filt_fused) {
+                for (auto &b : c->buckets) fused_fft_table(c, b.ntrans);
+                const SynRows sr{ c->syn_d.p, c->syn_stride, c->comps_d.p, c->tw_d.p, c->moment_d.p, c->risetime_d.p, synrow };
+                hipLaunchKernelGGL(spec_fft_filter_norm_kernel<0>, dim3((unsigned)nsrc, (unsigned)c->nmis), dim3(256), (size_t)filt_longest * 4, c->stream,
+                                   (const float *)nullptr, c->pairs_d.p, fused_fft_tables(c), c->comps_d.p, c->filtw_d.p, c->reffilt_d.p, c->zmask_d.p, sp,
+                                   c->misfit_d.p, (float *)nullptr, sr);
             } else {
                 fft_buckets(c, true);
                 hipLaunchKernelGGL(spec_filter_kernel, dim3((unsigned)(c->nmis * nsrc)), dim3(256), 0, c->stream,

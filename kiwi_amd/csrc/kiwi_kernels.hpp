@@ -1773,7 +1773,8 @@ struct MisfitParams {
     int nmis;
     int isrc0;
     int write_tapered;   // keep scaled+folded (+tapered) synthetics for get_synthetics
-    int fft_mode;        // 1: write the tapered synthetic zero-padded to ntrans into fftbuf, no norm
+    int fft_mode;        // bit0: write the tapered synthetic zero-padded to ntrans into fftbuf, no norm; bit1: every slot (spectral norms);
+                         // bit2: the rows are not needed (spec_fft_filter_norm_kernel reads the synthetics)
     int chunk_nsrc;      // sources in this launch (row stride of the FFT groups)
     int skip_norm;       // floating norms: only produce the tapered synthetics (vt_out), norms follow in floating_norm_kernel
 };
@@ -1869,6 +1870,7 @@ __global__ __launch_bounds__(256) void misfit_kernel(
     // without a frequency filter under a time-domain method is compared right here (probes_norm_timedomain takes the
     // plain tapered arrays then, comparator.f90:806-813)
     const bool to_fft = mp.fft_mode && (cd.has_filter || (mp.fft_mode & 2));
+    if (to_fft && (mp.fft_mode & 4) && !proc) return;      // the transform kernel takes the plain synthetics itself (workgroup-uniform)
     if (to_fft) {
         const FftPair pr = pairs[(size_t)s * mp.nmis + m];
         frow = fftbuf + pr.fft_ofs;
@@ -2039,60 +2041,10 @@ __device__ __forceinline__ float amp2f(float x, float y)
     return ldexpf(__builtin_amdgcn_sqrtf(sx * sx + sy * sy), e);          // argument in [1/4, 2): the hardware root (1 ulp) needs no fix-ups
 }
 
-// where the rows come from when the kernel takes the plain synthetics itself (mode 2): what misfit_kernel is given
-struct SynRows {
-    const float *syn; size_t syn_stride;
-    const CompDev *comps;
-    const float *taper;                    // taper weights per window sample, [refofs + i]
-    const float *moment, *risetime;        // per uploaded source
-    const int *synrow;                     // optional: the source whose synthetics this one shares
-};
-
-// mode 0: misfit of pair (source s = blockIdx.x, slot m = blockIdx.y) of `pairs[s * nmis + m]` into misfit_out; the row is
-//         the tapered, zero-padded synthetic misfit_kernel left in fftbuf
-// mode 2: the same from the PLAIN synthetics: rise-time fold, moment and taper (what misfit_kernel does per sample) are
-//         applied while the row is brought into LDS, the zero padding is never stored anywhere
-// mode 1: rows of reference variants, pairs[blockIdx.x]: amp_out[specofs + k] = |X[k]| * filtw[specofs + k]
-template <int MODE>
-__global__ __launch_bounds__(256) void spec_fft_norm_kernel(
-    const float *__restrict__ fftbuf, const FftPair *__restrict__ pairs, FusedFftTables tabs,
-    const float *__restrict__ refamp, const float *__restrict__ filtw, SpecParams sp, float *__restrict__ misfit_out,
-    float *__restrict__ amp_out, SynRows sr)
+// In-place forward transform of the M points in `zf` (decimation in frequency; frequency k ends at fused_fft_pos(k)); `tw`:
+// the stage tables of this length; returns the table that follows them (exp(-2 pi i k / ntrans)).  Ends with a barrier.
+__device__ __forceinline__ const float2 *fused_fft_forward(float2 *zf, const float2 *__restrict__ tw, int M, int tid)
 {
-    extern __shared__ __attribute__((aligned(16))) float2 zf[];
-    __shared__ double red[256];
-    const int tid = threadIdx.x;
-    // (modes 0, 2: source index fastest -- the workgroups in flight share the reference and filter rows of a few slots)
-    const int m = MODE != 1 ? (int)blockIdx.y : 0, s = MODE != 1 ? (int)blockIdx.x : 0;
-    const FftPair pr = MODE != 1 ? pairs[(size_t)s * sp.nmis + m] : pairs[blockIdx.x];
-    const int N = pr.ntrans, M = N >> 1;
-    const float2 *__restrict__ tw = tabs.tab[31 - __clz(N)];
-    if constexpr (MODE == 2) {
-        __shared__ float fw[kMaxFold];
-        __shared__ int fs[kMaxFold];
-        __shared__ float fr[kMaxFold];
-        __shared__ int nfold;
-        const CompDev cd = sr.comps[m];
-        const float mom = sr.moment[sp.isrc0 + s];
-        if (tid == 0) nfold = fold_setup(sr.risetime[sp.isrc0 + s], sp.dt, fw, fs, fr);
-        __syncthreads();
-        const int nf = nfold;
-        const float *__restrict__ sy = sr.syn + (size_t)(sr.synrow ? sr.synrow[s] : s) * sr.syn_stride + cd.synofs + cd.halo;
-        const float *__restrict__ tp = sr.taper + cd.refofs;
-#pragma unroll 4
-        for (int n = tid; n < M; n += 256) {
-            const int i = 2 * n;
-            float2 x = make_float2(0.f, 0.f);
-            if (i < cd.wlen) x.x = folded_scaled_sample(sy, i, nf, fw, fs, fr, mom) * tp[i];           // make_array_tapered, comparator.f90:1173-1184
-            if (i + 1 < cd.wlen) x.y = folded_scaled_sample(sy, i + 1, nf, fw, fs, fr, mom) * tp[i + 1];
-            zf[fused_fft_lds(n)] = x;
-        }
-    } else {
-        const float2 *__restrict__ row = reinterpret_cast<const float2 *>(fftbuf + pr.fft_ofs);
-#pragma unroll 8
-        for (int n = tid; n < M; n += 256) zf[fused_fft_lds(n)] = row[n];
-    }
-    __syncthreads();
     int len = M;
     // two radix-4 stages at a time while the block length allows: the 16 points base + a len/4 + b len/16 stay in registers
     // between the stage over a and the stage over b (same operations as two single stages, half the LDS round trips)
@@ -2153,6 +2105,144 @@ __global__ __launch_bounds__(256) void spec_fft_norm_kernel(
         }
         __syncthreads();
     }
+    return tw;
+}
+
+// transposed butterfly for the way back: twiddles (conjugated) first, then the 4-point inverse transform across the quarters
+__device__ __forceinline__ void fused_fft_r4_inv(float2 &a, float2 &b, float2 &c, float2 &d, float2 w1, float2 w2, float2 w3)
+{
+    w1.y = -w1.y; w2.y = -w2.y; w3.y = -w3.y;
+    b = cmulf(b, w1); c = cmulf(c, w2); d = cmulf(d, w3);
+    const float2 t0 = make_float2(a.x + c.x, a.y + c.y), t1 = make_float2(a.x - c.x, a.y - c.y);
+    const float2 t2 = make_float2(b.x + d.x, b.y + d.y), t3 = make_float2(d.y - b.y, b.x - d.x);     // +i (b - d)
+    a = make_float2(t0.x + t2.x, t0.y + t2.y);
+    b = make_float2(t1.x + t3.x, t1.y + t3.y);
+    c = make_float2(t0.x - t2.x, t0.y - t2.y);
+    d = make_float2(t1.x - t3.x, t1.y - t3.y);
+}
+
+// In-place inverse (unnormalised: M times the inverse transform) of M points that sit where fused_fft_forward leaves them
+// (frequency k at fused_fft_pos(k)); the result is in natural order.  The forward stages transposed, last stage first:
+// the DFT matrix is symmetric, so (stages)^T applied to the digit-reversed arrangement is the transform itself;
+// conjugated twiddles and +i make it the inverse.  `tab`: start of the length's stage tables (stage `len` at tab + M - len).
+__device__ __forceinline__ void fused_fft_inverse(float2 *zf, const float2 *__restrict__ tab, int M, int tid)
+{
+    int rem = M;
+    while (rem >= 16) rem >>= 4;                       // what the forward pass had left after its double stages: 1, 2, 4 or 8
+    int len = 1;
+    if (rem == 2 || rem == 8) {                        // the radix-2 stage
+        for (int j = tid; j < (M >> 1); j += 256) {
+            const int ia = fused_fft_lds(2 * j), ib = fused_fft_lds(2 * j + 1);
+            const float2 a = zf[ia], b = zf[ib];
+            zf[ia] = make_float2(a.x + b.x, a.y + b.y);
+            zf[ib] = make_float2(a.x - b.x, a.y - b.y);
+        }
+        len = 2;
+        __syncthreads();
+    }
+    if (rem >= 4) {                                    // the single radix-4 stage (block length 4 or 8)
+        len <<= 2;
+        const int q = len >> 2;
+        const float2 *__restrict__ tw = tab + (M - len);
+#pragma unroll 4
+        for (int j = tid; j < (M >> 2); j += 256) {
+            const int pos = j & (q - 1), base = ((j - pos) << 2) + pos;
+            const int ia = fused_fft_lds(base), ib = fused_fft_lds(base + q), ic = fused_fft_lds(base + 2 * q), id = fused_fft_lds(base + 3 * q);
+            float2 a = zf[ia], b = zf[ib], c = zf[ic], d = zf[id];
+            fused_fft_r4_inv(a, b, c, d, tw[pos], tw[q + pos], tw[2 * q + pos]);
+            zf[ia] = a; zf[ib] = b; zf[ic] = c; zf[id] = d;
+        }
+        __syncthreads();
+    }
+    while (len < M) {                                  // double stages, small block length first: stage len / 4 (over b), then len (over a)
+        len <<= 4;
+        const int q1 = len >> 2, q2 = len >> 4;
+        const float2 *__restrict__ tw = tab + (M - len), *__restrict__ tw2 = tw + 3 * q1;
+        int sa[4], sb[4];
+#pragma unroll
+        for (int a = 0; a < 4; a++) { sa[a] = fused_fft_lds(a * q1); sb[a] = fused_fft_lds(a * q2); }
+        for (int j = tid; j < (M >> 4); j += 256) {
+            const int pos = j & (q2 - 1), base = fused_fft_lds(((j - pos) << 4) + pos);
+            float2 v[4][4];
+            float2 w1[4][3], w2[3];
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+#pragma unroll
+                for (int r = 0; r < 3; r++) w1[b][r] = tw[r * q1 + pos + b * q2];
+#pragma unroll
+            for (int r = 0; r < 3; r++) w2[r] = tw2[r * q2 + pos];
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) v[a][b] = zf[base ^ sa[a] ^ sb[b]];
+#pragma unroll
+            for (int a = 0; a < 4; a++) fused_fft_r4_inv(v[a][0], v[a][1], v[a][2], v[a][3], w2[0], w2[1], w2[2]);
+#pragma unroll
+            for (int b = 0; b < 4; b++) fused_fft_r4_inv(v[0][b], v[1][b], v[2][b], v[3][b], w1[b][0], w1[b][1], w1[b][2]);
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) zf[base ^ sa[a] ^ sb[b]] = v[a][b];
+        }
+        __syncthreads();
+    }
+}
+
+// where the rows come from when the kernel takes the plain synthetics itself (mode 2): what misfit_kernel is given
+struct SynRows {
+    const float *syn; size_t syn_stride;
+    const CompDev *comps;
+    const float *taper;                    // taper weights per window sample, [refofs + i]
+    const float *moment, *risetime;        // per uploaded source
+    const int *synrow;                     // optional: the source whose synthetics this one shares
+};
+
+// mode 0: misfit of pair (source s = blockIdx.x, slot m = blockIdx.y) of `pairs[s * nmis + m]` into misfit_out; the row is
+//         the tapered, zero-padded synthetic misfit_kernel left in fftbuf
+// mode 2: the same from the PLAIN synthetics: rise-time fold, moment and taper (what misfit_kernel does per sample) are
+//         applied while the row is brought into LDS, the zero padding is never stored anywhere
+// mode 1: rows of reference variants, pairs[blockIdx.x]: amp_out[specofs + k] = |X[k]| * filtw[specofs + k]
+template <int MODE>
+__global__ __launch_bounds__(256) void spec_fft_norm_kernel(
+    const float *__restrict__ fftbuf, const FftPair *__restrict__ pairs, FusedFftTables tabs,
+    const float *__restrict__ refamp, const float *__restrict__ filtw, SpecParams sp, float *__restrict__ misfit_out,
+    float *__restrict__ amp_out, SynRows sr)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 zf[];
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    // (modes 0, 2: source index fastest -- the workgroups in flight share the reference and filter rows of a few slots)
+    const int m = MODE != 1 ? (int)blockIdx.y : 0, s = MODE != 1 ? (int)blockIdx.x : 0;
+    const FftPair pr = MODE != 1 ? pairs[(size_t)s * sp.nmis + m] : pairs[blockIdx.x];
+    const int N = pr.ntrans, M = N >> 1;
+    const float2 *__restrict__ tw = tabs.tab[31 - __clz(N)];
+    if constexpr (MODE == 2) {
+        __shared__ float fw[kMaxFold];
+        __shared__ int fs[kMaxFold];
+        __shared__ float fr[kMaxFold];
+        __shared__ int nfold;
+        const CompDev cd = sr.comps[m];
+        const float mom = sr.moment[sp.isrc0 + s];
+        if (tid == 0) nfold = fold_setup(sr.risetime[sp.isrc0 + s], sp.dt, fw, fs, fr);
+        __syncthreads();
+        const int nf = nfold;
+        const float *__restrict__ sy = sr.syn + (size_t)(sr.synrow ? sr.synrow[s] : s) * sr.syn_stride + cd.synofs + cd.halo;
+        const float *__restrict__ tp = sr.taper + cd.refofs;
+#pragma unroll 4
+        for (int n = tid; n < M; n += 256) {
+            const int i = 2 * n;
+            float2 x = make_float2(0.f, 0.f);
+            if (i < cd.wlen) x.x = folded_scaled_sample(sy, i, nf, fw, fs, fr, mom) * tp[i];           // make_array_tapered, comparator.f90:1173-1184
+            if (i + 1 < cd.wlen) x.y = folded_scaled_sample(sy, i + 1, nf, fw, fs, fr, mom) * tp[i + 1];
+            zf[fused_fft_lds(n)] = x;
+        }
+    } else {
+        const float2 *__restrict__ row = reinterpret_cast<const float2 *>(fftbuf + pr.fft_ofs);
+#pragma unroll 8
+        for (int n = tid; n < M; n += 256) zf[fused_fft_lds(n)] = row[n];
+    }
+    __syncthreads();
+    tw = fused_fft_forward(zf, tw, M, tid);
     const float *__restrict__ ra = MODE != 1 ? refamp + pr.specofs : nullptr;
     const float *__restrict__ fw = filtw + pr.specofs;
     const bool unit = (sp.syn_factor == 1.f);
@@ -2190,6 +2280,128 @@ __global__ __launch_bounds__(256) void spec_fft_norm_kernel(
         const float df = 1.f / ((float)N * sp.dt);                       // comparator.f90:1215
         misfit_out[(size_t)(sp.isrc0 + s) * sp.nmis + m] =
             (sp.method == 3) ? (float)sqrt((double)df * tot) : (float)((double)df * tot);
+    }
+}
+
+// ---- time-domain norms on frequency-filtered traces without the library transforms --------------------------------
+// comparator.f90:810-813,1224-1263: spectrum * filter(j df), back to the time domain, / ntrans, zero where the taper is zero,
+// then the time-domain norm against the reference processed the same way.  With hipFFT that is r2c (two kernels),
+// spec_filter_kernel, c2r (two kernels) and filtered_norm_kernel -- six passes over the padded rows; here the row goes
+// forward and back inside LDS:
+//   forward as in spec_fft_norm_kernel; per point pair (Z[k], Z[M-k]): X[k] = E + w O and conj X[M-k] = E - w O are
+//   multiplied by their filter weights and packed again for the way back, Z''[k] = A + i B, Z''[M-k] = conj A + i conj B with
+//   A = Y[k] + conj Y[M-k], B = (Y[k] - conj Y[M-k]) conj w  (twice the spectra of the even / odd samples: the factor makes
+//   the unnormalised inverse ntrans times the filtered trace, what c2r delivers);
+//   inverse of M points (fused_fft_inverse) -> y[2n] + i y[2n+1] in natural order.
+// mode 0: trial source rows from the plain synthetics (fold, moment, taper on the way in) -> misfit of the pair
+// mode 1: reference variants, rows (tapered reference, zero padded) from fftbuf -> ref_filt[filtofs + i]
+template <int MODE>
+__global__ __launch_bounds__(256) void spec_fft_filter_norm_kernel(
+    const float *__restrict__ fftbuf, const FftPair *__restrict__ pairs, FusedFftTables tabs, const CompDev *__restrict__ comps,
+    const float *__restrict__ filtw, const float *__restrict__ ref_filt, const float *__restrict__ zmask, SpecParams sp,
+    float *__restrict__ misfit_out, float *__restrict__ filt_out, SynRows sr)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 zf[];
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    const int m = MODE == 0 ? (int)blockIdx.y : 0, s = MODE == 0 ? (int)blockIdx.x : 0;
+    const FftPair pr = MODE == 0 ? pairs[(size_t)s * sp.nmis + m] : pairs[blockIdx.x];
+    const CompDev cd = comps[MODE == 0 ? m : pr.slot];
+    if (!cd.has_filter) return;                           // compared by misfit_kernel on the plain tapered arrays
+    const int N = pr.ntrans, M = N >> 1;
+    const float2 *__restrict__ tab = tabs.tab[31 - __clz(N)];
+    if constexpr (MODE == 0) {
+        __shared__ float fw[kMaxFold];
+        __shared__ int fs[kMaxFold];
+        __shared__ float fr[kMaxFold];
+        __shared__ int nfold;
+        const float mom = sr.moment[sp.isrc0 + s];
+        if (tid == 0) nfold = fold_setup(sr.risetime[sp.isrc0 + s], sp.dt, fw, fs, fr);
+        __syncthreads();
+        const int nf = nfold;
+        const float *__restrict__ sy = sr.syn + (size_t)(sr.synrow ? sr.synrow[s] : s) * sr.syn_stride + cd.synofs + cd.halo;
+        const float *__restrict__ tp = sr.taper + cd.refofs;
+#pragma unroll 4
+        for (int n = tid; n < M; n += 256) {
+            const int i = 2 * n;
+            float2 x = make_float2(0.f, 0.f);
+            if (i < cd.wlen) x.x = folded_scaled_sample(sy, i, nf, fw, fs, fr, mom) * tp[i];
+            if (i + 1 < cd.wlen) x.y = folded_scaled_sample(sy, i + 1, nf, fw, fs, fr, mom) * tp[i + 1];
+            zf[fused_fft_lds(n)] = x;
+        }
+    } else {
+        const float2 *__restrict__ row = reinterpret_cast<const float2 *>(fftbuf + pr.fft_ofs);
+#pragma unroll 8
+        for (int n = tid; n < M; n += 256) zf[fused_fft_lds(n)] = row[n];
+    }
+    __syncthreads();
+    const float2 *__restrict__ tw = fused_fft_forward(zf, tab, M, tid);
+    const float *__restrict__ fwt = filtw + pr.specofs;
+    const int lgM = 31 - __clz(M);
+#pragma unroll 2
+    for (int k = tid; k <= (M >> 1); k += 256) {
+        const int pk = fused_fft_lds(fused_fft_pos(k, lgM)), pm = fused_fft_lds(fused_fft_pos((M - k) & (M - 1), lgM));
+        const float2 zk = zf[pk];
+        float2 zm = zf[pm];
+        zm.y = -zm.y;                                                    // conj Z[M - k]
+        const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y + zm.y));
+        const float2 o = make_float2(0.5f * (zk.y - zm.y), -0.5f * (zk.x - zm.x));
+        const float2 w = tw[k];
+        const float2 wo = cmulf(w, o);
+        const float fk = fwt[k], fm = fwt[M - k];
+        const float2 yk = make_float2((e.x + wo.x) * fk, (e.y + wo.y) * fk);          // spectrum * filter, comparator.f90:1224-1225
+        const float2 ym = make_float2((e.x - wo.x) * fm, (e.y - wo.y) * fm);          // conj of bin M - k, filtered
+        const float2 A = make_float2(yk.x + ym.x, yk.y + ym.y);
+        const float2 B = cmulf(make_float2(yk.x - ym.x, yk.y - ym.y), make_float2(w.x, -w.y));
+        zf[pk] = make_float2(A.x - B.y, A.y + B.x);                                   // A + i B
+        if (pm != pk) zf[pm] = make_float2(A.x + B.y, B.x - A.y);                     // conj A + i conj B
+    }
+    __syncthreads();
+    fused_fft_inverse(zf, tab, M, tid);
+    const float *__restrict__ zm_ = zmask + cd.refofs;
+    if constexpr (MODE == 1) {
+        for (int i = tid; i < cd.wlen; i += 256) {
+            const float2 z = zf[fused_fft_lds(i >> 1)];
+            const float v = ((i & 1) ? z.y : z.x) / (float)N;
+            filt_out[pr.filtofs + i] = v * zm_[i];
+        }
+        return;
+    }
+    const float *__restrict__ rf = ref_filt + pr.filtofs;
+    const bool unit = (sp.syn_factor == 1.f);
+    double acc = 0.0, peak = 0.0;
+    for (int i = tid; i < cd.wlen; i += 256) {
+        const float2 z = zf[fused_fft_lds(i >> 1)];
+        float v = ((i & 1) ? z.y : z.x) / (float)N;                      // normalize result, comparator.f90:1251
+        v = v * zm_[i];                                                  // :1254-1258
+        const float a = rf[i];
+        switch (sp.method) {
+        case 1: { const float d = unit ? (a - v) : (1.f * a - sp.syn_factor * v); acc += (double)d * (double)d; break; }
+        case 2: { const float d = unit ? fabsf(a - v) : fabsf(1.f * a - sp.syn_factor * v); acc += (double)d; break; }
+        case 5: acc += unit ? (double)(a * v) : (double)(a * 1.f * v * sp.syn_factor); break;
+        default: { const double x = (double)(1.f * a), y = (double)(sp.syn_factor * v); peak = fmax(peak, sqrt(x * x + y * y)); break; }
+        }
+    }
+    double tot;
+    if (sp.method == 6) {
+        red[tid] = peak;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (tid < st) red[tid] = fmax(red[tid], red[tid + st]);
+            __syncthreads();
+        }
+        tot = red[0];
+    } else {
+        tot = block_sum(acc, red);
+    }
+    if (tid == 0) {
+        float res;
+        switch (sp.method) {
+        case 1: res = (float)sqrt((double)sp.dt * tot); break;
+        case 2: res = (float)((double)sp.dt * tot); break;
+        default: res = (float)tot; break;
+        }
+        misfit_out[(size_t)(sp.isrc0 + s) * sp.nmis + m] = res;
     }
 }
 

@@ -208,4 +208,10 @@ def workload(name, nsrc=None, trial0=0):
         tr = bilat_sweep_5d(n + trial0)[trial0:]
         return dict(name="cfg5-spectral", sourcetype="bilateral", true=np.array(TRUE_BILAT, np.float32), trials=tr,
                     nrec=50, nx=128, method="ampspec_l2norm", filter=SPECTRAL_FILTER, crust=None, constraints=None)
+    if name == "cfg5-td":
+        # the cfg5 trial set under a TIME-domain norm on frequency-filtered traces (the comparator transforms forward, filters,
+        # transforms back: comparator.f90:810-813,1233-1263) -- the other way the reference uses its misfit filter
+        w = workload("cfg5", nsrc, trial0)
+        w.update(name="cfg5-td-filtered", method="l2norm")
+        return w
     raise ValueError("unknown workload " + name)

@@ -385,15 +385,21 @@ def test_time_domain_norms_with_frequency_filter(method):
     assert np.max(np.abs(so[a - lo_o:b - lo_o] - sp[a - lo_p:b - lo_p])) <= 2e-5 * np.max(np.abs(so))
 
 
-@pytest.mark.parametrize("method,with_filter", [("ampspec_l2norm", True), ("ampspec_l1norm", False)])
+@pytest.mark.parametrize("method,with_filter", [("ampspec_l2norm", True), ("ampspec_l1norm", False), ("l2norm", True), ("l1norm", True),
+                                                ("scalar_product", True), ("peak", True)])
 def test_amplitude_spectrum_norms_in_one_kernel(method, with_filter, monkeypatch):
     """ampspec_* norms: spec_fft_norm_kernel transforms every (slot, source) row in LDS and reduces it to the misfit.  Its two
     row sources -- the plain synthetics (fold, moment and taper applied on the way in; the default) and the tapered rows
     misfit_kernel writes when the processed synthetics are kept -- give the same bits; the library path
     (KIWI_HIP_FUSED_FFT=0: hipFFT r2c + spec_norm_kernel) agrees to transform round-off, and all agree with the oracle.
-    Sources with a rise time (the fold runs inside the load), two transform lengths in the batch."""
+    Sources with a rise time (the fold runs inside the load), two transform lengths in the batch.
+    The time-domain norms on frequency-filtered traces go through the same transform forward AND back
+    (spec_fft_filter_norm_kernel; with kept synthetics the library pair r2c / c2r runs): same checks to round-off."""
     sc = Scenario()
-    mid = {"ampspec_l2norm": 3, "ampspec_l1norm": 4}[method]
+    mid = {"ampspec_l2norm": 3, "ampspec_l1norm": 4, "l2norm": 1, "l1norm": 2, "scalar_product": 5, "peak": 6}[method]
+    spectral = mid in (3, 4)
+    # an l1 / peak value of a filtered trace carries the transforms' round-off linearly: looser than the l2 figures
+    tol = SPEC_RTOL if (spectral or mid in (1, 5)) else 1e-3
     trials = np.array([[0.3 * i, 0., 0., 9500. + 300 * i] + synthetic.mt_from_sdr(40. * i, 50. + 5 * i, -60. + 30 * i) + [1.0 + 0.7 * i]
                        for i in range(6)], np.float32)
     trials[4, 10] = 170.0                                   # a long source time function: the next transform length
@@ -417,7 +423,10 @@ def test_amplitude_spectrum_norms_in_one_kernel(method, with_filter, monkeypatch
         kept = p.get_misfits()
         p.set_keep_synthetics(0)
         for a, b in zip(direct, kept):
-            assert a.tobytes() == b.tobytes(), mode
+            if spectral or mode == "library":
+                assert a.tobytes() == b.tobytes(), mode
+            else:                                           # kept synthetics: the library transforms run instead
+                assert np.allclose(a, b, rtol=0, atol=tol * np.abs(direct[1]).max()), mode
         res[mode] = direct
         if mode == "fused":
             for i, t in enumerate(trials):                  # every source against a fresh oracle engine
@@ -427,19 +436,21 @@ def test_amplitude_spectrum_norms_in_one_kernel(method, with_filter, monkeypatch
                         if ir != 2:
                             fe.set_filter(ir, fx, fy)
                 om, on, og = oracle_misfits(fe, 6, t[None, :])
-                assert np.allclose(direct[1][i], on[0], rtol=SPEC_RTOL, atol=0), i
-                assert np.allclose(direct[0][i], om[0], rtol=SPEC_RTOL, atol=SPEC_RTOL * np.abs(on[0]).max()), i
+                assert np.allclose(direct[1][i], on[0], rtol=tol, atol=0), i
+                assert np.allclose(direct[0][i], om[0], rtol=tol, atol=tol * np.abs(on[0]).max()), i
                 fe.close()
             # the source the references were made from (by the oracle: equal to the device's synthetics to an ulp or two)
             p.set_source_params(sc.true_type, sc.true_params[None, :])
             p.eval()
             tm, tn, _ = p.get_misfits()
-            assert np.all(tm <= 1e-5 * tn)
+            if mid not in (5, 6):                           # (scalar product and peak are not difference measures)
+                assert np.all(tm <= max(1e-5, tol) * tn)
         p.close(); e.close()
     fm, fn, fg = res["fused"]
     lm, ln, lg = res["library"]
-    assert len({x.tobytes() for x in fn}) > 1                # two transform lengths
-    assert np.allclose(fn, ln, rtol=2e-6, atol=0) and np.allclose(fm, lm, rtol=0, atol=4e-6 * np.abs(fn).max())
+    if spectral:
+        assert len({x.tobytes() for x in fn}) > 1            # two transform lengths
+    assert np.allclose(fn, ln, rtol=max(2e-6, tol / 10), atol=0) and np.allclose(fm, lm, rtol=0, atol=max(4e-6, tol / 5) * np.abs(fn).max())
 
 
 @pytest.mark.parametrize("method,with_filter", [("ampspec_l2norm", False), ("ampspec_l1norm", True), ("l2norm", True)])
