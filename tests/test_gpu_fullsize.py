@@ -124,8 +124,11 @@ def test_cfg4_mt_eikonal_468_centroids_200_receivers():
     e.close(); db.close()
 
 
-def test_cfg5_spectral_comparator_with_filter():
-    wl, p, gf, recv, refs, tapers, ncent = setup("cfg5", 16)
+@pytest.mark.parametrize("name", ["cfg5", "cfg5-td"])
+def test_cfg5_spectral_comparator_with_filter(name):
+    """cfg5: amplitude-spectrum L2 with frequency filter; cfg5-td: the same trials under the time-domain L2 on filtered traces
+    (transform forward, filter, transform back: comparator.f90:810-813,1224-1263) -- same tolerances."""
+    wl, p, gf, recv, refs, tapers, ncent = setup(name, 16)
     tr = wl["trials"].copy()
     tr[0] = wl["true"]
     p.set_source_params("bilateral", tr)
