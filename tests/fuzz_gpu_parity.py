@@ -163,7 +163,10 @@ def one_case(rng, verbose):
         # linearly over the window: relative to the norm factor that grows with the crest factor (seen: 5.2e-4 at L = 2300)
         tol = float(os.environ.get("KIWI_FUZZ_L1TOL", "1e-3")) if (filtered and mid == 2) else (5e-5 if mid == 4 else 2e-5)   # seen: ampspec_l1norm 2.3e-5 at L = 2300
         bad = np.abs(pm - m) > tol * scale
-        ok = bool(np.all(np.abs(pn[0] - nn[0]) <= tol * nn[0])) and not bad.any()
+        # norm factor of a FILTERED reference: where the filter rejects almost all of a trace, the transforms' round-off (relative
+        # to the unfiltered trace) is what is left of the small remainder (seen: 2.5e-5 of a slot's norm factor, in-LDS transform)
+        ntol = max(tol, 5e-5) if filtered else tol
+        ok = bool(np.all(np.abs(pn[0] - nn[0]) <= ntol * nn[0])) and not bad.any()
     else:
         scale = np.maximum(np.abs(m), 1e-6 * np.maximum(nn, 1e-30))
         tol = 1e-6 if mid not in (5,) else 2e-6
@@ -188,7 +191,7 @@ def one_case(rng, verbose):
                 L_.ko_engine_probe_spans(e.h, ir + 1, k + 1, 1, b)
                 print("oracle rec %d comp %d: ref span %s data %s | syn span %s data %s -> ntrans %d" %
                       (ir + 1, k + 1, list(a[:2]), list(a[2:]), list(b[:2]), list(b[2:]), a[1] - a[0] + 1))
-        print("gpu", pm[0], "oracle", m[0], "norm gpu", pn[0], "oracle", nn[0])
+        print("gpu", pm[0], "oracle", m[0], "norm gpu", pn[0], "oracle", nn[0], "rel norm diff", np.abs(pn[0] - nn[0]) / nn[0])
     if verbose or not ok:
         print("%s ng=%d L=%d nrec=%d comps=%s bil=%d %s edt=%.1f %s x%d method=%s%s factor=%.1f -> worst %.2e (median misfit / norm %.3f)"
               % ("ok " if ok else "BAD", ng, L, nrec, comps, bil, variant, edt, name, n, method, "+filter" if filtered else "", f,
