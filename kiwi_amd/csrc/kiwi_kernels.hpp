@@ -1143,6 +1143,31 @@ __device__ __forceinline__ void centroid_apply_hd(f2v (&ar1)[NP], f2v (&ar2)[NP]
     }
 }
 
+// Sum (or maximum of non-negative values) over the 64 lanes of a wave in fp64, through DPP moves instead of LDS permutes:
+// inclusive scan inside each row of 16 lanes (row_shr 1, 2, 4, 8; lanes shifted in from outside the row read 0), then the
+// row totals travel up (row_bcast 15 into rows 1 and 3, row_bcast 31 into rows 2 and 3).  The result is valid in lane 63;
+// the order of the additions is fixed.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_reduce_f64(double v, bool is_max)
+{
+#define KIWI_STEP(CTRL, MASK) do { const double o = dpp_f64<CTRL, MASK>(v); v = is_max ? fmax(v, o) : v + o; } while (0)
+    KIWI_STEP(0x111, 0xf);      // row_shr:1
+    KIWI_STEP(0x112, 0xf);      // row_shr:2
+    KIWI_STEP(0x114, 0xf);      // row_shr:4
+    KIWI_STEP(0x118, 0xf);      // row_shr:8
+    KIWI_STEP(0x142, 0xa);      // row_bcast:15 -> rows 1, 3
+    KIWI_STEP(0x143, 0xc);      // row_bcast:31 -> rows 2, 3
+#undef KIWI_STEP
+    return v;
+}
+
 template <int NG, int T, bool FUSE, bool RUNS>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void accumulate_grouped_kernel(
     const float *__restrict__ G, const int2 *__restrict__ span, int pitch,
@@ -1234,12 +1259,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
                 default: { const double x = (double)(1.f * a), y = (double)(fp.syn_factor * vt); acc = fmax(acc, sqrt(x * x + y * y)); break; }
                 }
             }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const double other = __shfl_down(acc, off, 64);
-                acc = (fp.method == 6) ? fmax(acc, other) : acc + other;
-            }
-            if (lane == 0)
+            acc = wave_reduce_f64(acc, fp.method == 6);                 // total in lane 63
+            if (lane == 63)
                 fp.partial[((size_t)js * fp.nmis + rv.slot0 + k) * fp.nparts + tile * (T / 64) + (tid >> 6)] = acc;
         }
     };
@@ -1749,12 +1770,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_CELL_WAV
                 default: { const double x = (double)(1.f * a), y = (double)(fp.syn_factor * vt); acc = fmax(acc, sqrt(x * x + y * y)); break; }
                 }
             }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const double other = __shfl_down(acc, off, 64);
-                acc = (fp.method == 6) ? fmax(acc, other) : acc + other;
-            }
-            if (lane == 0)
+            acc = wave_reduce_f64(acc, fp.method == 6);                 // total in lane 63
+            if (lane == 63)
                 fp.partial[((size_t)js * fp.nmis + rv.slot0 + k) * fp.nparts + tile * (T / 64) + (tid >> 6)] = acc;
         }
     }
