@@ -1143,6 +1143,10 @@ __device__ __forceinline__ void centroid_apply_hd(f2v (&ar1)[NP], f2v (&ar2)[NP]
     }
 }
 
+// acc + d * d in fp64: the square of an fp32 value is exact in fp64 (48 significant bits), so the fused form rounds once,
+// exactly like the exact product followed by the add (comparator.f90:650-659 accumulates in real*8)
+__device__ __forceinline__ double sq_acc(double acc, float d) { return fma((double)d, (double)d, acc); }
+
 // Sum (or maximum of non-negative values) over the 64 lanes of a wave in fp64, through DPP moves instead of LDS permutes:
 // inclusive scan inside each row of 16 lanes (row_shr 1, 2, 4, 8; lanes shifted in from outside the row read 0), then the
 // row totals travel up (row_bcast 15 into rows 1 and 3, row_bcast 31 into rows 2 and 3).  The result is valid in lane 63;
@@ -1253,7 +1257,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
                 const float vt = v * tp[64 * i];
                 const float a = rt[64 * i];
                 switch (fp.method) {
-                case 1: { const float d = unit ? (a - vt) : (1.f * a - fp.syn_factor * vt); acc += (double)d * (double)d; break; }
+                case 1: { const float d = unit ? (a - vt) : (1.f * a - fp.syn_factor * vt); acc = sq_acc(acc, d); break; }
                 case 2: { const float d = unit ? fabsf(a - vt) : fabsf(1.f * a - fp.syn_factor * vt); acc += (double)d; break; }
                 case 5: acc += unit ? (double)(a * vt) : (double)(a * 1.f * vt * fp.syn_factor); break;
                 default: { const double x = (double)(1.f * a), y = (double)(fp.syn_factor * vt); acc = fmax(acc, sqrt(x * x + y * y)); break; }
@@ -1764,7 +1768,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_CELL_WAV
                 const float vt = v * tp[64 * i];
                 const float a = rt[64 * i];
                 switch (fp.method) {
-                case 1: { const float d = unit ? (a - vt) : (1.f * a - fp.syn_factor * vt); acc += (double)d * (double)d; break; }
+                case 1: { const float d = unit ? (a - vt) : (1.f * a - fp.syn_factor * vt); acc = sq_acc(acc, d); break; }
                 case 2: { const float d = unit ? fabsf(a - vt) : fabsf(1.f * a - fp.syn_factor * vt); acc += (double)d; break; }
                 case 5: acc += unit ? (double)(a * vt) : (double)(a * 1.f * vt * fp.syn_factor); break;
                 default: { const double x = (double)(1.f * a), y = (double)(fp.syn_factor * vt); acc = fmax(acc, sqrt(x * x + y * y)); break; }
@@ -1904,7 +1908,7 @@ __global__ __launch_bounds__(256) void misfit_kernel(
         switch (mp.method) {
         case 1: {                                 // l2norm_func, comparator.f90:650-659
             const float d = unit ? (a - vt) : (1.f * a - mp.syn_factor * vt);
-            acc += (double)d * (double)d; break; }
+            acc = sq_acc(acc, d); break; }
         case 2: {                                 // l1norm_func, :639-648
             const float d = unit ? fabsf(a - vt) : fabsf(1.f * a - mp.syn_factor * vt);
             acc += (double)d; break; }
@@ -1981,7 +1985,7 @@ __global__ __launch_bounds__(256) void spec_norm_kernel(
         const float a = ra[k];                            // reference, already filtered
         if (sp.method == 3) {                             // l2norm_func on amplitude spectra
             const float d = unit ? (a - b) : (1.f * a - sp.syn_factor * b);
-            acc += (double)d * (double)d;
+            acc = sq_acc(acc, d);
         } else {
             const float d = unit ? fabsf(a - b) : fabsf(1.f * a - sp.syn_factor * b);
             acc += (double)d;
@@ -2272,7 +2276,7 @@ __global__ __launch_bounds__(256) void spec_fft_norm_kernel(
         const float a = ra[k];                                           // reference, already filtered
         if (sp.method == 3) {                                            // l2norm_func on amplitude spectra
             const float d = unit ? (a - b) : (1.f * a - sp.syn_factor * b);
-            acc += (double)d * (double)d;
+            acc = sq_acc(acc, d);
         } else {
             const float d = unit ? fabsf(a - b) : fabsf(1.f * a - sp.syn_factor * b);
             acc += (double)d;
@@ -2393,7 +2397,7 @@ __global__ __launch_bounds__(256) void spec_fft_filter_norm_kernel(
         v = v * zm_[i];                                                  // :1254-1258
         const float a = rf[i];
         switch (sp.method) {
-        case 1: { const float d = unit ? (a - v) : (1.f * a - sp.syn_factor * v); acc += (double)d * (double)d; break; }
+        case 1: { const float d = unit ? (a - v) : (1.f * a - sp.syn_factor * v); acc = sq_acc(acc, d); break; }
         case 2: { const float d = unit ? fabsf(a - v) : fabsf(1.f * a - sp.syn_factor * v); acc += (double)d; break; }
         case 5: acc += unit ? (double)(a * v) : (double)(a * 1.f * v * sp.syn_factor); break;
         default: { const double x = (double)(1.f * a), y = (double)(sp.syn_factor * v); peak = fmax(peak, sqrt(x * x + y * y)); break; }
@@ -2462,7 +2466,7 @@ __global__ __launch_bounds__(256) void filtered_norm_kernel(
         if (proc) proc[(size_t)s * syn_stride + cd.synofs + cd.halo + i] = v;
         const float a = rf[i];
         switch (sp.method) {
-        case 1: { const float d = unit ? (a - v) : (1.f * a - sp.syn_factor * v); acc += (double)d * (double)d; break; }
+        case 1: { const float d = unit ? (a - v) : (1.f * a - sp.syn_factor * v); acc = sq_acc(acc, d); break; }
         case 2: { const float d = unit ? fabsf(a - v) : fabsf(1.f * a - sp.syn_factor * v); acc += (double)d; break; }
         case 5: acc += unit ? (double)(a * v) : (double)(a * 1.f * v * sp.syn_factor); break;
         default: { const double x = (double)(1.f * a), y = (double)(sp.syn_factor * v); peak = fmax(peak, sqrt(x * x + y * y)); break; }
@@ -2584,7 +2588,7 @@ __global__ __launch_bounds__(256) void floating_norm_kernel(
             const float b = sy[i];
             if (method == 1) {
                 const float d = unit ? (a - b) : (1.f * a - syn_factor * b);
-                acc += (double)d * (double)d;
+                acc = sq_acc(acc, d);
             } else {
                 const float d = unit ? fabsf(a - b) : fabsf(1.f * a - syn_factor * b);
                 acc += (double)d;
