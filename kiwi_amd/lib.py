@@ -56,7 +56,7 @@ def load():
     if "torch" not in sys.modules and os.environ.get("KIWI_HIP_WITHOUT_TORCH", "0") != "1":
         try:
             import torch  # noqa: F401
-        except ImportError:
+        except Exception:      # no torch here (or one that does not import): nothing to order
             pass
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
