@@ -2023,7 +2023,18 @@ __host__ __device__ inline size_t fused_fft_table_size(int ntrans)
     return n + (size_t)M + 1;
 }
 
-__device__ __forceinline__ float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// complex product and product-sum with fused multiply-adds: these transforms are compared with the reference's to a
+// tolerance (its FFTW rounds differently anyway), so the fewer roundings the better -- unlike the accumulate path, which
+// must round every operation as the reference does
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b)
+{
+    return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
+}
+// e + w o
+__device__ __forceinline__ float2 cmaddf(float2 e, float2 w, float2 o)
+{
+    return make_float2(fmaf(w.x, o.x, fmaf(-w.y, o.y, e.x)), fmaf(w.x, o.y, fmaf(w.y, o.x, e.y)));
+}
 
 // one radix-4 decimation-in-frequency butterfly: a, b, c, d a quarter block apart, w1..w3 = w^pos, w^2pos, w^3pos
 __device__ __forceinline__ void fused_fft_r4(float2 &a, float2 &b, float2 &c, float2 &d, float2 w1, float2 w2, float2 w3)
@@ -2291,9 +2302,10 @@ __global__ __launch_bounds__(256) void spec_fft_norm_kernel(
         zm.y = -zm.y;                                                    // conj Z[M - k]
         const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y + zm.y));
         const float2 o = make_float2(0.5f * (zk.y - zm.y), -0.5f * (zk.x - zm.x));
-        const float2 wo = cmulf(tw[k], o);
-        bin(k, e.x + wo.x, e.y + wo.y);
-        if (2 * k != M) bin(M - k, e.x - wo.x, e.y - wo.y);
+        const float2 w = tw[k];
+        const float2 xp = cmaddf(e, w, o), xm = cmaddf(e, make_float2(-w.x, -w.y), o);
+        bin(k, xp.x, xp.y);
+        if (2 * k != M) bin(M - k, xm.x, xm.y);
     }
     if (MODE == 1) return;
     const double tot = block_sum(acc, red);
@@ -2368,10 +2380,10 @@ __global__ __launch_bounds__(256) void spec_fft_filter_norm_kernel(
         const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y + zm.y));
         const float2 o = make_float2(0.5f * (zk.y - zm.y), -0.5f * (zk.x - zm.x));
         const float2 w = tw[k];
-        const float2 wo = cmulf(w, o);
+        const float2 xp = cmaddf(e, w, o), xm = cmaddf(e, make_float2(-w.x, -w.y), o);
         const float fk = fwt[k], fm = fwt[M - k];
-        const float2 yk = make_float2((e.x + wo.x) * fk, (e.y + wo.y) * fk);          // spectrum * filter, comparator.f90:1224-1225
-        const float2 ym = make_float2((e.x - wo.x) * fm, (e.y - wo.y) * fm);          // conj of bin M - k, filtered
+        const float2 yk = make_float2(xp.x * fk, xp.y * fk);                          // spectrum * filter, comparator.f90:1224-1225
+        const float2 ym = make_float2(xm.x * fm, xm.y * fm);                          // conj of bin M - k, filtered
         const float2 A = make_float2(yk.x + ym.x, yk.y + ym.y);
         const float2 B = cmulf(make_float2(yk.x - ym.x, yk.y - ym.y), make_float2(w.x, -w.y));
         zf[pk] = make_float2(A.x - B.y, A.y + B.x);                                   // A + i B

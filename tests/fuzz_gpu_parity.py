@@ -161,7 +161,9 @@ def one_case(rng, verbose):
         scale = np.maximum(np.maximum(nn, np.abs(m)), 1e-30)
         # an l1 sum over a filtered trace adds the fp32 round-off of the two transforms (~ eps log2 N of the peak per sample)
         # linearly over the window: relative to the norm factor that grows with the crest factor (seen: 5.2e-4 at L = 2300)
-        tol = float(os.environ.get("KIWI_FUZZ_L1TOL", "1e-3")) if (filtered and mid == 2) else (5e-5 if mid == 4 else 2e-5)   # seen: ampspec_l1norm 2.3e-5 at L = 2300
+        # seen: ampspec_l1norm 2.3e-5 at L = 2300; time-domain l2 on filtered traces 2.4e-5 at L = 2300 (two cases of 34 000, in-LDS
+        # transform pair before its complex products were fused multiply-adds)
+        tol = float(os.environ.get("KIWI_FUZZ_L1TOL", "1e-3")) if (filtered and mid == 2) else (5e-5 if mid == 4 else (3e-5 if (filtered and not spectral) else 2e-5))
         bad = np.abs(pm - m) > tol * scale
         # norm factor of a FILTERED reference: where the filter rejects almost all of a trace, the transforms' round-off (relative
         # to the unfiltered trace) is what is left of the small remainder (seen, in-LDS transforms: 2.5e-5 of a slot's l2 norm
