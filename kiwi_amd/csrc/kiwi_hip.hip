@@ -169,6 +169,8 @@ struct kiwi_hip_ctx {
     int group_threads_env = 0;
     int group_threads = 128;          // workgroup size of the grouped kernel (tile = 4x); env KIWI_HIP_GROUP_THREADS
     int accum_mode = 0;               // 0 grouped (LDS-staged), 1 direct; env KIWI_HIP_ACCUM
+    int pipe = 0;                     // accumulate_pipe_kernel (loads of the next group under the arithmetic of the present one, register
+                                      // pairs carried between time steps) for the pairs it takes; env KIWI_HIP_PIPE=0: accumulate_grouped_kernel only
     // cell groups (accumulate_cell_kernel: raw node traces fetched once per run of centroids in the same GF cell):
     // -1 decided per batch -- sources whose centroids are mostly different points --, 0 off, 1 on; env KIWI_HIP_CELL
     int cell_mode = -1;
@@ -929,6 +931,8 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
     // cell groups pay where most centroids are points of their own (no blended tile to share between time steps)
     // (with nearest-neighbour interpolation there is nothing to blend: same-point groups do)
     const bool cell = c->accum_mode == 0 && (c->cell_mode == 1 || (c->cell_mode < 0 && c->bilinear && c->points_per_centroid > 0.5));
+    // pipelined kernel: tiles of 512 samples; windows shorter than 384 samples stay with the 256-sample tiles of the grouped kernel
+    const bool pipe = c->accum_mode == 0 && c->pipe && !cell && c->max_wlen >= 384 && !c->group_threads_env;
     EvalParams ep{ c->bilinear, c->xus, c->zus, nrec, isrc0, cell ? 1 : 0 };
     int *spansrc = nullptr;
     if (c->any_untapered || c->want_spansrc || c->fft_needed) {     // per-source strip spans, initialised empty
@@ -941,12 +945,12 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
     record(c, 0, e0);
     if (maxnc > 0) {
         dim3 grid((unsigned)((maxnc * nrec + 255) / 256), (unsigned)nsrc);
-        if (cell) {
+        if (cell || pipe) {
             c->pairflag_d.ensure((size_t)nsrc * nrec, &c->dev_bytes);
             HIPCHECK(hipMemsetAsync(c->pairflag_d.p, 0, (size_t)nsrc * nrec * sizeof(int), c->stream));
         }
         hipLaunchKernelGGL(geometry_kernel, grid, dim3(256), 0, c->stream, c->cent_d.p, c->centofs_d.p, ep, c->gm,
-                           c->span.p, c->recv_d.p, c->recs_d.p, tab, (int *)nullptr, spansrc, cell ? c->pairflag_d.p : (int *)nullptr, c->endz.p, (const int *)nullptr);
+                           c->span.p, c->recv_d.p, c->recs_d.p, tab, (int *)nullptr, spansrc, (cell || pipe) ? c->pairflag_d.p : (int *)nullptr, c->endz.p, (const int *)nullptr);
         if (cell)
             hipLaunchKernelGGL(cellgroup_kernel, grid, dim3(256), 0, c->stream, c->centofs_d.p, ep, c->gm, c->span.p, c->recv_d.p,
                                c->recs_d.p, tab, c->pairflag_d.p, c->endz.p, (const int *)nullptr);
@@ -963,7 +967,7 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
         HIPCHECK(hipEventRecord(c->size_event, c->stream));
     }
     record(c, 0, e1);
-    int fuse_T = 0, fuse_ntiles = 0, fuse_nparts = 0;
+    int fuse_T = 0, fuse_tile = 0, fuse_ntiles = 0, fuse_nparts = 0;
     bool fuse_all = false;
     {
         dim3 grid((unsigned)((c->max_wlen + kTile - 1) / kTile), (unsigned)nrec, (unsigned)nsrc);
@@ -978,6 +982,7 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
             // workgroup size: env override, else by window length (halo overhead vs tile fit)
             const int T = c->group_threads_env ? c->group_threads : (c->max_wlen >= 2048 ? 256 : (c->max_wlen >= 384 ? 128 : 64));
             const int ntiles = (c->max_wlen + 4 * T - 1) / (4 * T);
+            const int ntiles_p = (c->max_wlen + 511) / 512;              // accumulate_pipe_kernel: 256 threads, 512 samples
             // cell mode: accumulate_cell_kernel (256 threads, tile = spl x 256 samples) takes the pairs of cell_pair(), the
             // grouped kernel behind it the others
             const int spl = c->cell_spl, Tc = 256;
@@ -1009,25 +1014,33 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
                 }
             }
             dim3 ggrid(gx, (unsigned)(ntiles * nrec));                   // source index fastest (L2 sharing)
+            dim3 pgrid(gx, (unsigned)(ntiles_p * nrec));
             dim3 cgrid((unsigned)nsrc, (unsigned)(ntiles_c * nrec));
             FuseParams fp{ nullptr, nullptr, nullptr, nullptr, 0, 1.f, 0, 0, 0 };
             if (fuse) {
                 // partial sums per (source, slot): [tile][wave] of the kernel that evaluated the pair.  In cell mode two
                 // kernels with different tilings share the buffer: it is cleared and misfit_finish_kernel sums all of it
-                const int nparts = cell ? std::max(ntiles * (T / 64), ntiles_c * (Tc / 64)) : ntiles * (T / 64);
+                const int nparts = cell ? std::max(ntiles * (T / 64), ntiles_c * (Tc / 64)) : (pipe ? std::max(ntiles * (T / 64), ntiles_p * 4) : ntiles * (T / 64));
                 c->fusepart_d.ensure((size_t)nsrc * c->nmis * nparts, &c->dev_bytes);
-                if (cell) HIPCHECK(hipMemsetAsync(c->fusepart_d.p, 0, (size_t)nsrc * c->nmis * nparts * sizeof(double), c->stream));
+                if (cell || pipe) HIPCHECK(hipMemsetAsync(c->fusepart_d.p, 0, (size_t)nsrc * c->nmis * nparts * sizeof(double), c->stream));
                 fp = FuseParams{ c->reft_d.p, c->tw_d.p, c->moment_d.p, c->fusepart_d.p, c->method, c->syn_factor, c->nmis, nparts, isrc0 };
                 fuse_nparts = nparts;
             }
-            fuse_T = T; fuse_ntiles = ntiles; fuse_all = cell;
+            fuse_T = T; fuse_tile = 4 * T; fuse_ntiles = ntiles; fuse_all = cell || pipe;
 #define KIWI_LAUNCH_G2(NGV, TV, FV, RV)                                                                     \
     hipLaunchKernelGGL((accumulate_grouped_kernel<NGV, TV, FV, RV>), ggrid, dim3(TV), 0, c->stream, c->G.p, c->span.p,   \
                        c->gm.pitch, c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p,          \
-                       c->syn_stride, ntiles, c->tab_d.p, runs, fp, cell ? c->pairflag_d.p : (const int *)nullptr, synrow, famofs, famlist)
+                       c->syn_stride, ntiles, c->tab_d.p, runs, fp, (cell || pipe) ? c->pairflag_d.p : (const int *)nullptr, cell ? 1 : (pipe ? 2 : 0), synrow, famofs, famlist)
 #define KIWI_LAUNCH_GROUPED(NGV, TV)                                                                        \
     do { if (fuse) { if (runs) KIWI_LAUNCH_G2(NGV, TV, true, true); else KIWI_LAUNCH_G2(NGV, TV, true, false); }   \
          else      { if (runs) KIWI_LAUNCH_G2(NGV, TV, false, true); else KIWI_LAUNCH_G2(NGV, TV, false, false); } } while (0)
+#define KIWI_LAUNCH_P2(NGV, FV, RV)                                                                         \
+    hipLaunchKernelGGL((accumulate_pipe_kernel<NGV, FV, RV>), pgrid, dim3(256), 0, c->stream, c->G.p, c->span.p,   \
+                       c->gm.pitch, c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p,          \
+                       c->syn_stride, ntiles_p, c->tab_d.p, runs, fp, c->pairflag_d.p, synrow, famofs, famlist)
+#define KIWI_LAUNCH_PIPE(NGV)                                                                               \
+    do { if (fuse) { if (runs) KIWI_LAUNCH_P2(NGV, true, true); else KIWI_LAUNCH_P2(NGV, true, false); }   \
+         else      { if (runs) KIWI_LAUNCH_P2(NGV, false, true); else KIWI_LAUNCH_P2(NGV, false, false); } } while (0)
 #define KIWI_LAUNCH_C3(NGV, SV, PV, FV)                                                                     \
     hipLaunchKernelGGL((accumulate_cell_kernel<NGV, 256, SV, PV, FV>), cgrid, dim3(256), 0, c->stream, c->G.p, c->span.p,   \
                        c->gm.pitch, c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p,          \
@@ -1037,11 +1050,15 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
 #define KIWI_LAUNCH_CELL(NGV) do { if (spl == 2) { if (fuse) KIWI_LAUNCH_C2(NGV, 2, true); else KIWI_LAUNCH_C2(NGV, 2, false); } \
                                    else          { if (fuse) KIWI_LAUNCH_C2(NGV, 4, true); else KIWI_LAUNCH_C2(NGV, 4, false); } } while (0)
             if (cell) { if (c->gm.ng == 10) KIWI_LAUNCH_CELL(10); else KIWI_LAUNCH_CELL(8); }
+            // the pairs accumulate_pipe_kernel takes (pipe_pair()); the grouped kernel behind it returns at once for those
+            if (pipe) { if (c->gm.ng == 10) KIWI_LAUNCH_PIPE(10); else KIWI_LAUNCH_PIPE(8); }
             if (c->gm.ng == 10) {
                 if (T == 64) KIWI_LAUNCH_GROUPED(10, 64); else if (T == 256) KIWI_LAUNCH_GROUPED(10, 256); else KIWI_LAUNCH_GROUPED(10, 128);
             } else {
                 if (T == 64) KIWI_LAUNCH_GROUPED(8, 64); else if (T == 256) KIWI_LAUNCH_GROUPED(8, 256); else KIWI_LAUNCH_GROUPED(8, 128);
             }
+#undef KIWI_LAUNCH_PIPE
+#undef KIWI_LAUNCH_P2
 #undef KIWI_LAUNCH_CELL
 #undef KIWI_LAUNCH_C2
 #undef KIWI_LAUNCH_C3
@@ -1069,7 +1086,7 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
             const int nth = nsrc * c->nmis;
             hipLaunchKernelGGL(misfit_finish_kernel, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, c->stream,
                                c->fusepart_d.p, c->comps_d.p, c->nmis, fuse_all ? fuse_nparts : fuse_ntiles * (fuse_T / 64), fuse_T / 64,
-                               fuse_all ? 0 : 4 * fuse_T,
+                               fuse_all ? 0 : fuse_tile,
                                c->method, c->gm.dt, isrc0, nsrc, c->misfit_d.p);
         }
         // amplitude-spectrum norms whose transforms fit spec_fft_norm_kernel: that kernel takes the plain synthetics itself
@@ -1207,6 +1224,7 @@ int kiwi_hip_init(int device, kiwi_hip_ctx **out)
         }
         if (const char *m = std::getenv("KIWI_HIP_ACCUM")) c->accum_mode = (std::strcmp(m, "direct") == 0) ? 1 : 0;
         if (const char *m = std::getenv("KIWI_HIP_FUSE")) c->fuse_enabled = std::atoi(m);
+        if (const char *m = std::getenv("KIWI_HIP_PIPE")) c->pipe = std::atoi(m) != 0;
         if (const char *m = std::getenv("KIWI_HIP_CELL")) c->cell_mode = std::atoi(m) ? 1 : 0;
         if (const char *m = std::getenv("KIWI_HIP_DEDUPE")) c->dedupe_enabled = std::atoi(m);      // 0 off, 1 default, 2 also for point sources
         if (const char *m = std::getenv("KIWI_HIP_FUSED_FFT")) c->fused_fft = std::atoi(m) != 0;   // 0: amplitude spectra through hipFFT

@@ -18,6 +18,7 @@
 // Built with -ffp-contract=off: the reference rounds every multiply and add separately.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "kiwi_libm32.hpp"
 
 namespace kiwi {
@@ -208,9 +209,10 @@ __device__ __forceinline__ bool starts_group(const float *__restrict__ cent, int
 // out as consecutive 16-byte stores, so that a line is complete in L2 before it leaves it (interleaving the stores
 // with the look-ups left every line open for microseconds: partial-line write-backs, 0.32 ms per 1.3 M records).
 template <int NG>
-__device__ __forceinline__ void write_tab(int *__restrict__ tb, const GeoRec &g, const int2 *__restrict__ span, int pitch, float sd,
+__device__ __forceinline__ bool write_tab(int *__restrict__ tb, const GeoRec &g, const int2 *__restrict__ span, int pitch, float sd,
                                           bool full, const unsigned char *__restrict__ endz)
 {
+    bool all_endzero = true;          // returned: (full rows) every row of the cell ends in an exact zero -- no tail rule for this group
     // full: this centroid starts a group and the kernel reads the whole row; otherwise only its coefficients (they
     // share the row's last 128-byte line with the clamp floors of components 9 and 10, which are then not needed)
     const int nn = (g.flags & 1) ? 1 : 4;
@@ -244,6 +246,7 @@ __device__ __forceinline__ void write_tab(int *__restrict__ tb, const GeoRec &g,
     for (int ig = NG; ig < 10; ig++) jend[ig] = 0;
     jend[10] = endzero ? 0x7fffffff : jmin_h;
     jend[11] = endzero ? 0x7fffffff : jmin_d;
+    all_endzero = endzero;
     }
     float cf[20];
     {
@@ -278,13 +281,16 @@ __device__ __forceinline__ void write_tab(int *__restrict__ tb, const GeoRec &g,
     float4 *f4 = reinterpret_cast<float4 *>(tb);
 #pragma unroll
     for (int q = 0; q < (NG == 10 ? 5 : 4); q++) f4[26 + q] = make_float4(cf[4 * q], cf[4 * q + 1], cf[4 * q + 2], cf[4 * q + 3]);
+    return all_endzero;
 }
 
 __global__ __launch_bounds__(256) void geometry_kernel(
     const float *__restrict__ cent, const int *__restrict__ cent_ofs, EvalParams ep, GfMeta gm,
     const int2 *__restrict__ span, const RecvDev *__restrict__ recv, GeoRec *__restrict__ out,
     int *__restrict__ tab, int *__restrict__ spanbuf, int *__restrict__ spansrc /* optional [source][receiver][kSpanInts] */,
-    int *__restrict__ pairflag /* optional [source][receiver]: some centroid of the pair misses a trace (cell mode) */,
+    int *__restrict__ pairflag /* optional [source][receiver]: bit 0 some centroid of the pair is added in part (a trace is missing),
+                                  bit 1 some centroid is left out (a trace missing or outside the database), bit 2 some group's rows do
+                                  not all end in zero (the tail rule can apply); see cell_pair(), pipe_pair() */,
     const unsigned char *__restrict__ endz /* per GF row: its end value is zero (write_tab) */,
     const int *__restrict__ synrow /* optional [source]: source whose synthetics this one shares; != own index: nothing to do */)
 {
@@ -430,6 +436,7 @@ __global__ __launch_bounds__(256) void geometry_kernel(
         }
         if (!ok) g.row[0] = -1;
     }
+    if (pairflag && live && g.row[0] < 0) atomicOr(&pairflag[(size_t)s * ep.nrec + r], 2);
     // group hint (used by accumulate_grouped_kernel when a group STARTS at this centroid): how many
     // following centroids sit at this same point with their integer shifts within the LDS halo, and
     // the spread of those shifts.  pad = len | (smax - ishift) << 8 | (ishift - smin) << 16
@@ -502,8 +509,10 @@ __global__ __launch_bounds__(256) void geometry_kernel(
     if (tab && g.row[0] >= 0) {
         // cell mode: only the coefficient line here, cellgroup_kernel completes the rows of the group starts it finds
         const bool full = !ep.cellmode && (!(g.flags & 4) || starts_group(cent, c0, nc, c, gm.dt));
-        if (gm.ng == 10) write_tab<10>(tab + base * 128, g, span, gm.pitch, rv.sd, full, endz);
-        else write_tab<8>(tab + base * 128, g, span, gm.pitch, rv.sd, full, endz);
+        bool ez;
+        if (gm.ng == 10) ez = write_tab<10>(tab + base * 128, g, span, gm.pitch, rv.sd, full, endz);
+        else ez = write_tab<8>(tab + base * 128, g, span, gm.pitch, rv.sd, full, endz);
+        if (pairflag && !ez) atomicOr(&pairflag[(size_t)s * ep.nrec + r], 4);
     }
 }
 
@@ -524,6 +533,14 @@ __device__ __forceinline__ bool same_cell(const GeoRec *__restrict__ a, const in
 __device__ __forceinline__ bool cell_pair(const RecvDev &rv, const int *__restrict__ pairflag, int s, int nrec, int r)
 {
     return rv.need_h && rv.has_d && !(pairflag[(size_t)s * nrec + r] & 1);
+}
+
+// Which (trial source, receiver) pairs accumulate_pipe_kernel takes: receivers with horizontal AND vertical components whose
+// centroids all find all their traces (no `cycle`, geometry_kernel: pairflag bits 0 and 1) and whose rows all end in an exact
+// zero (no `factor * last` rule, bit 2).  accumulate_grouped_kernel runs behind it for the other pairs.
+__device__ __forceinline__ bool pipe_pair(const RecvDev &rv, const int *__restrict__ pairflag, int s, int nrec, int r)
+{
+    return rv.need_h && rv.has_d && pairflag[(size_t)s * nrec + r] == 0;
 }
 
 __global__ __launch_bounds__(256) void cellgroup_kernel(const int *__restrict__ cent_ofs, EvalParams ep, GfMeta gm,
@@ -967,6 +984,7 @@ __device__ __forceinline__ void halo_finish(bool active, const HaloRegs &h, floa
 }
 
 typedef float f2v __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) float *lds_cfp;
 
 // Apply-phase mapping of samples to lanes: lane l of wave w owns the four tile samples 256 w + l + 64 q, q = 0..3 (stride
 // 64, not four consecutive ones).  The two blended samples an output needs, b[j-1] and b[j], then sit at LDS dwords
@@ -1001,7 +1019,11 @@ __device__ __forceinline__ TileRegsN<NP> tile_load(const TileBase &b, int ofs)
 #pragma unroll
     for (int h = 0; h < NP; h++) {
         t.lo[h] = f2v{ b.lo[ofs + 128 * h], b.lo[ofs + 128 * h + 64] };
+#ifdef KIWI_X_FAKECARRY
+        t.hi[h] = t.lo[h];
+#else
         t.hi[h] = f2v{ b.hi[ofs + 128 * h], b.hi[ofs + 128 * h + 64] };
+#endif
     }
     return t;
 }
@@ -1172,13 +1194,187 @@ __device__ __forceinline__ double wave_reduce_f64(double v, bool is_max)
     return v;
 }
 
+#ifndef KIWI_GROUPED_WAVES
+#define KIWI_GROUPED_WAVES 3
+#endif
+#ifndef KIWI_X_FULL
+#define KIWI_X_FULL(x) (x)
+#endif
+// ------------------------------------------------------------------------------------------------
+// Register pairs carried between the centroids of a group (round 3), accumulate_grouped_kernel with 256 threads.
+//
+// The centroids of a group are the time steps of ONE sub-fault: the same blended traces, read at an integer shift that
+// usually moves by exactly one sample from step to step (effective_dt == dt of the database: source_bilat.f90:443-457 with
+// seismogram.f90:139).  With the stride-64 lane mapping b[j] of step k+1 IS b[j-1] of step k -- the register pairs the lane
+// already holds.  The apply keeps the pairs of ALL components of the previous centroid in registers (two sets that swap
+// roles at every centroid) and reads only what the new shift needs:
+//     shift + 1 -> the old b[j-1] set serves as b[j], only b[j-1] is read        (20 reads instead of 40)
+//     shift - 1 -> the old b[j] set serves as b[j-1], only b[j] is read
+//     anything else -> both are read.
+// The reads are ONE asm statement per set with the pairs as read-modify-write operands: a set that is not read keeps its
+// registers, and the compiler sees no merge of a loaded and a kept value (which it answers with a copy per pair, or --
+// with the sets as arrays -- by promoting a whole set to one 32-register tuple that is copied and spilled as a whole).
+// The compiler's wait-count bookkeeping does not see these reads: set2_wait / set2_dep make the pairs operands of the
+// wait, so that the arithmetic cannot be scheduled in front of it.
+// ---- (generated text) carried register sets of accumulate_grouped_kernel, 4 outputs per lane, component stride 17 x 64 dwords
+struct Set2_10 { f2v &a0, &a1, &a2, &a3, &a4, &a5, &a6, &a7, &a8, &a9, &b0, &b1, &b2, &b3, &b4, &b5, &b6, &b7, &b8, &b9; };
+__device__ __forceinline__ void set2_read_10(int on, unsigned a, const Set2_10 &S)
+{
+    asm volatile("s_cmp_eq_u32 %21, 0\n\ts_cbranch_scc1 .Lkiwi_skip%=\n\t"
+                 "ds_read2st64_b32 %0, %20 offset1:1\n\t"
+                 "ds_read2st64_b32 %1, %20 offset0:17 offset1:18\n\t"
+                 "ds_read2st64_b32 %2, %20 offset0:34 offset1:35\n\t"
+                 "ds_read2st64_b32 %3, %20 offset0:136 offset1:137\n\t"
+                 "ds_read2st64_b32 %4, %20 offset0:51 offset1:52\n\t"
+                 "ds_read2st64_b32 %5, %20 offset0:68 offset1:69\n\t"
+                 "ds_read2st64_b32 %6, %20 offset0:85 offset1:86\n\t"
+                 "ds_read2st64_b32 %7, %20 offset0:102 offset1:103\n\t"
+                 "ds_read2st64_b32 %8, %20 offset0:119 offset1:120\n\t"
+                 "ds_read2st64_b32 %9, %20 offset0:153 offset1:154\n\t"
+                 "ds_read2st64_b32 %10, %20 offset0:2 offset1:3\n\t"
+                 "ds_read2st64_b32 %11, %20 offset0:19 offset1:20\n\t"
+                 "ds_read2st64_b32 %12, %20 offset0:36 offset1:37\n\t"
+                 "ds_read2st64_b32 %13, %20 offset0:138 offset1:139\n\t"
+                 "ds_read2st64_b32 %14, %20 offset0:53 offset1:54\n\t"
+                 "ds_read2st64_b32 %15, %20 offset0:70 offset1:71\n\t"
+                 "ds_read2st64_b32 %16, %20 offset0:87 offset1:88\n\t"
+                 "ds_read2st64_b32 %17, %20 offset0:104 offset1:105\n\t"
+                 "ds_read2st64_b32 %18, %20 offset0:121 offset1:122\n\t"
+                 "ds_read2st64_b32 %19, %20 offset0:155 offset1:156\n\t"
+                 "\n.Lkiwi_skip%=:"
+                 : "+v"(S.a0), "+v"(S.a1), "+v"(S.a2), "+v"(S.a3), "+v"(S.a4), "+v"(S.a5), "+v"(S.a6), "+v"(S.a7), "+v"(S.a8), "+v"(S.a9), "+v"(S.b0), "+v"(S.b1), "+v"(S.b2), "+v"(S.b3), "+v"(S.b4), "+v"(S.b5), "+v"(S.b6), "+v"(S.b7), "+v"(S.b8), "+v"(S.b9) : "v"(a), "s"(on) : "memory", "scc");
+}
+__device__ __forceinline__ void set2_wait_10(const Set2_10 &S)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(S.a0), "+v"(S.a1), "+v"(S.a2), "+v"(S.a3), "+v"(S.a4), "+v"(S.a5), "+v"(S.a6), "+v"(S.a7), "+v"(S.a8), "+v"(S.a9), "+v"(S.b0), "+v"(S.b1), "+v"(S.b2), "+v"(S.b3), "+v"(S.b4), "+v"(S.b5), "+v"(S.b6), "+v"(S.b7), "+v"(S.b8), "+v"(S.b9) :: "memory");
+}
+__device__ __forceinline__ void set2_dep_10(const Set2_10 &S)
+{
+    asm volatile("" : "+v"(S.a0), "+v"(S.a1), "+v"(S.a2), "+v"(S.a3), "+v"(S.a4), "+v"(S.a5), "+v"(S.a6), "+v"(S.a7), "+v"(S.a8), "+v"(S.a9), "+v"(S.b0), "+v"(S.b1), "+v"(S.b2), "+v"(S.b3), "+v"(S.b4), "+v"(S.b5), "+v"(S.b6), "+v"(S.b7), "+v"(S.b8), "+v"(S.b9) :: "memory");
+}
+__device__ __forceinline__ void set2_dead_10(const Set2_10 &S)
+{
+    asm volatile("" : "=v"(S.a0), "=v"(S.a1), "=v"(S.a2), "=v"(S.a3), "=v"(S.a4), "=v"(S.a5), "=v"(S.a6), "=v"(S.a7), "=v"(S.a8), "=v"(S.a9), "=v"(S.b0), "=v"(S.b1), "=v"(S.b2), "=v"(S.b3), "=v"(S.b4), "=v"(S.b5), "=v"(S.b6), "=v"(S.b7), "=v"(S.b8), "=v"(S.b9));
+}
+template <int I> __device__ __forceinline__ f2v &s2a(const Set2_10 &s) { if constexpr (I == 0) return s.a0; else if constexpr (I == 1) return s.a1; else if constexpr (I == 2) return s.a2; else if constexpr (I == 3) return s.a3; else if constexpr (I == 4) return s.a4; else if constexpr (I == 5) return s.a5; else if constexpr (I == 6) return s.a6; else if constexpr (I == 7) return s.a7; else if constexpr (I == 8) return s.a8; else return s.a9; }
+template <int I> __device__ __forceinline__ f2v &s2b(const Set2_10 &s) { if constexpr (I == 0) return s.b0; else if constexpr (I == 1) return s.b1; else if constexpr (I == 2) return s.b2; else if constexpr (I == 3) return s.b3; else if constexpr (I == 4) return s.b4; else if constexpr (I == 5) return s.b5; else if constexpr (I == 6) return s.b6; else if constexpr (I == 7) return s.b7; else if constexpr (I == 8) return s.b8; else return s.b9; }
+struct Set2_8 { f2v &a0, &a1, &a2, &a3, &a4, &a5, &a6, &a7, &b0, &b1, &b2, &b3, &b4, &b5, &b6, &b7; };
+__device__ __forceinline__ void set2_read_8(int on, unsigned a, const Set2_8 &S)
+{
+    asm volatile("s_cmp_eq_u32 %17, 0\n\ts_cbranch_scc1 .Lkiwi_skip%=\n\t"
+                 "ds_read2st64_b32 %0, %16 offset1:1\n\t"
+                 "ds_read2st64_b32 %1, %16 offset0:17 offset1:18\n\t"
+                 "ds_read2st64_b32 %2, %16 offset0:34 offset1:35\n\t"
+                 "ds_read2st64_b32 %3, %16 offset0:51 offset1:52\n\t"
+                 "ds_read2st64_b32 %4, %16 offset0:68 offset1:69\n\t"
+                 "ds_read2st64_b32 %5, %16 offset0:85 offset1:86\n\t"
+                 "ds_read2st64_b32 %6, %16 offset0:102 offset1:103\n\t"
+                 "ds_read2st64_b32 %7, %16 offset0:119 offset1:120\n\t"
+                 "ds_read2st64_b32 %8, %16 offset0:2 offset1:3\n\t"
+                 "ds_read2st64_b32 %9, %16 offset0:19 offset1:20\n\t"
+                 "ds_read2st64_b32 %10, %16 offset0:36 offset1:37\n\t"
+                 "ds_read2st64_b32 %11, %16 offset0:53 offset1:54\n\t"
+                 "ds_read2st64_b32 %12, %16 offset0:70 offset1:71\n\t"
+                 "ds_read2st64_b32 %13, %16 offset0:87 offset1:88\n\t"
+                 "ds_read2st64_b32 %14, %16 offset0:104 offset1:105\n\t"
+                 "ds_read2st64_b32 %15, %16 offset0:121 offset1:122\n\t"
+                 "\n.Lkiwi_skip%=:"
+                 : "+v"(S.a0), "+v"(S.a1), "+v"(S.a2), "+v"(S.a3), "+v"(S.a4), "+v"(S.a5), "+v"(S.a6), "+v"(S.a7), "+v"(S.b0), "+v"(S.b1), "+v"(S.b2), "+v"(S.b3), "+v"(S.b4), "+v"(S.b5), "+v"(S.b6), "+v"(S.b7) : "v"(a), "s"(on) : "memory", "scc");
+}
+__device__ __forceinline__ void set2_wait_8(const Set2_8 &S)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(S.a0), "+v"(S.a1), "+v"(S.a2), "+v"(S.a3), "+v"(S.a4), "+v"(S.a5), "+v"(S.a6), "+v"(S.a7), "+v"(S.b0), "+v"(S.b1), "+v"(S.b2), "+v"(S.b3), "+v"(S.b4), "+v"(S.b5), "+v"(S.b6), "+v"(S.b7) :: "memory");
+}
+__device__ __forceinline__ void set2_dep_8(const Set2_8 &S)
+{
+    asm volatile("" : "+v"(S.a0), "+v"(S.a1), "+v"(S.a2), "+v"(S.a3), "+v"(S.a4), "+v"(S.a5), "+v"(S.a6), "+v"(S.a7), "+v"(S.b0), "+v"(S.b1), "+v"(S.b2), "+v"(S.b3), "+v"(S.b4), "+v"(S.b5), "+v"(S.b6), "+v"(S.b7) :: "memory");
+}
+__device__ __forceinline__ void set2_dead_8(const Set2_8 &S)
+{
+    asm volatile("" : "=v"(S.a0), "=v"(S.a1), "=v"(S.a2), "=v"(S.a3), "=v"(S.a4), "=v"(S.a5), "=v"(S.a6), "=v"(S.a7), "=v"(S.b0), "=v"(S.b1), "=v"(S.b2), "=v"(S.b3), "=v"(S.b4), "=v"(S.b5), "=v"(S.b6), "=v"(S.b7));
+}
+template <int I> __device__ __forceinline__ f2v &s2a(const Set2_8 &s) { if constexpr (I == 0) return s.a0; else if constexpr (I == 1) return s.a1; else if constexpr (I == 2) return s.a2; else if constexpr (I == 3) return s.a3; else if constexpr (I == 4) return s.a4; else if constexpr (I == 5) return s.a5; else if constexpr (I == 6) return s.a6; else return s.a7; }
+template <int I> __device__ __forceinline__ f2v &s2b(const Set2_8 &s) { if constexpr (I == 0) return s.b0; else if constexpr (I == 1) return s.b1; else if constexpr (I == 2) return s.b2; else if constexpr (I == 3) return s.b3; else if constexpr (I == 4) return s.b4; else if constexpr (I == 5) return s.b5; else if constexpr (I == 6) return s.b6; else return s.b7; }
+
+template <int NG> struct Set2Sel;
+template <> struct Set2Sel<10> { typedef Set2_10 type; };
+template <> struct Set2Sel<8> { typedef Set2_8 type; };
+__device__ __forceinline__ void set2_read(int on, unsigned a, const Set2_10 &S) { set2_read_10(on, a, S); }
+__device__ __forceinline__ void set2_read(int on, unsigned a, const Set2_8 &S) { set2_read_8(on, a, S); }
+__device__ __forceinline__ void set2_wait(const Set2_10 &S) { set2_wait_10(S); }
+__device__ __forceinline__ void set2_wait(const Set2_8 &S) { set2_wait_8(S); }
+__device__ __forceinline__ void set2_dep(const Set2_10 &S) { set2_dep_10(S); }
+__device__ __forceinline__ void set2_dep(const Set2_8 &S) { set2_dep_8(S); }
+__device__ __forceinline__ void set2_dead(const Set2_10 &S) { set2_dead_10(S); }
+__device__ __forceinline__ void set2_dead(const Set2_8 &S) { set2_dead_8(S); }
+
+template <int N, int I = 0, class F> __device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<N, I + 1>(f); }
+}
+
+// All GF components of one centroid from the register sets L (b[j-1]) and H (b[j]), reference order (centroid_apply_hd's
+// operations); a: LDS byte address of b[j-1] of the lane's first output in component 0; coef: the centroid's coefficient line
+// (wave-uniform pointer: scalar loads, SGPR operands of the packed multiplies).
+template <int NG, bool ROT>
+__device__ __forceinline__ void carry2_apply(f2v (&ar1)[2], f2v (&ar2)[2], f2v (&dz)[2], const typename Set2Sel<NG>::type &L,
+                                             const typename Set2Sel<NG>::type &H, unsigned a, int load_lo, int load_hi,
+                                             const float *__restrict__ coef, float cl, float sl)
+{
+    constexpr int nH1 = (NG == 10) ? 4 : 3;      // components summed into the radial trace
+    float cw[2 * NG];
+#pragma unroll
+    for (int i = 0; i < 2 * NG; i++) cw[i] = coef[i];
+    set2_read(load_hi, a + 4, H);
+    set2_read(load_lo, a, L);
+    set2_wait(H);
+    set2_dep(L);
+    f2v t1[2], t2[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) { t1[k] = ROT ? f2v{ 0.f, 0.f } : ar1[k]; t2[k] = ROT ? f2v{ 0.f, 0.f } : ar2[k]; }
+    static_for<NG>([&](auto I) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value;
+        const f2v c1 = { cw[2 * i], cw[2 * i] }, c2 = { cw[2 * i + 1], cw[2 * i + 1] };
+        if constexpr (i < nH1) {
+            t1[0] = t1[0] + c1 * s2a<i>(H); t1[0] = t1[0] + c2 * s2a<i>(L);
+            t1[1] = t1[1] + c1 * s2b<i>(H); t1[1] = t1[1] + c2 * s2b<i>(L);
+        } else if constexpr (i < nH1 + 2) {
+            t2[0] = t2[0] + c1 * s2a<i>(H); t2[0] = t2[0] + c2 * s2a<i>(L);
+            t2[1] = t2[1] + c1 * s2b<i>(H); t2[1] = t2[1] + c2 * s2b<i>(L);
+        } else {
+            dz[0] = dz[0] + c1 * s2a<i>(H); dz[0] = dz[0] + c2 * s2a<i>(L);
+            dz[1] = dz[1] + c1 * s2b<i>(H); dz[1] = dz[1] + c2 * s2b<i>(L);
+        }
+        if constexpr (i == nH1 + 1) {
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                if (ROT) {
+                    ar1[k] = ar1[k] + cl * t1[k] - sl * t2[k];
+                    ar2[k] = ar2[k] + cl * t2[k] + sl * t1[k];
+                } else {
+                    ar1[k] = t1[k]; ar2[k] = t2[k];
+                }
+            }
+        }
+    });
+}
+
+template <int NG>
+__device__ __forceinline__ typename Set2Sel<NG>::type make_set2(f2v &a0, f2v &a1, f2v &a2, f2v &a3, f2v &a4, f2v &a5, f2v &a6, f2v &a7, f2v &a8, f2v &a9,
+                                                                f2v &b0, f2v &b1, f2v &b2, f2v &b3, f2v &b4, f2v &b5, f2v &b6, f2v &b7, f2v &b8, f2v &b9)
+{
+    if constexpr (NG == 10) return Set2_10{ a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, b0, b1, b2, b3, b4, b5, b6, b7, b8, b9 };
+    else return Set2_8{ a0, a1, a2, a3, a4, a5, a6, a7, b0, b1, b2, b3, b4, b5, b6, b7 };
+}
+
 template <int NG, int T, bool FUSE, bool RUNS>
-__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void accumulate_grouped_kernel(
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_GROUPED_WAVES))) void accumulate_grouped_kernel(
     const float *__restrict__ G, const int2 *__restrict__ span, int pitch,
     const GeoRec *__restrict__ recs, const int *__restrict__ cent_ofs, int isrc0, int nrec,
     const RecvDev *__restrict__ recv, float *__restrict__ syn, size_t syn_stride, int ntiles,
     const int *__restrict__ tab, const int *__restrict__ run_first, FuseParams fp,
-    const int *__restrict__ pairflag /* cell mode: only the (source, receiver) pairs accumulate_cell_kernel leaves out */,
+    const int *__restrict__ pairflag /* see geometry_kernel */,
+    int pairsel /* 0 all pairs, 1 not the cell kernel's, 2 not the pipe kernel's */,
     const int *__restrict__ synrow /* optional: sources that share another source's synthetics are not synthesised */,
     const int *__restrict__ fam_ofs, const int *__restrict__ fam_list /* FUSE with synrow: the sources that share source s's
                                           synthetics, fam_list[fam_ofs[s] .. fam_ofs[s + 1]): compared here with their moments */)
@@ -1205,7 +1401,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
     const RecvDev &rv = recv[r];
     if (!rv.enabled) return;
     if (tile * TILE >= rv.wlen) return;
-    if (pairflag && cell_pair(rv, pairflag, s, nrec, r)) return;
+    if (pairsel == 1 && cell_pair(rv, pairflag, s, nrec, r)) return;
+    if (pairsel == 2 && pipe_pair(rv, pairflag, s, nrec, r)) return;
     if (synrow && !multi && synrow[s] != s) return;  // (in a run the sources that share synthetics are left out one by one)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1281,6 +1478,13 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
     int cur = rec_load(rc, 0, nc, lane);                 // record c, lane-distributed
     int ta = 0, tb = 0;                                  // load descriptors of record c (a rejected trial source has no centroids, no rows)
     if (nc > 0) { ta = tc[lane]; tb = tc[64 + lane]; }
+    // carried register sets (see set2_read): the common case of 256-thread workgroups
+    constexpr bool kCarry = (T == 256) && !RUNS;
+    f2v xa0, xa1, xa2, xa3, xa4, xa5, xa6, xa7, xa8, xa9, xb0, xb1, xb2, xb3, xb4, xb5, xb6, xb7, xb8, xb9;
+    f2v ya0, ya1, ya2, ya3, ya4, ya5, ya6, ya7, ya8, ya9, yb0, yb1, yb2, yb3, yb4, yb5, yb6, yb7, yb8, yb9;
+    typedef typename Set2Sel<NG>::type SetT;
+    const SetT X = make_set2<NG>(xa0, xa1, xa2, xa3, xa4, xa5, xa6, xa7, xa8, xa9, xb0, xb1, xb2, xb3, xb4, xb5, xb6, xb7, xb8, xb9);
+    const SetT Y = make_set2<NG>(ya0, ya1, ya2, ya3, ya4, ya5, ya6, ya7, ya8, ya9, yb0, yb1, yb2, yb3, yb4, yb5, yb6, yb7, yb8, yb9);
     while (c < nc) {
         GeoRec g0;
         rec_head(cur, 0, g0);
@@ -1291,6 +1495,9 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
             continue;
         }
         // ---- the group starting here (hint computed by geometry_kernel)
+#ifdef KIWI_X_PRIO_BUILD
+        __builtin_amdgcn_s_setprio(KIWI_X_PRIO_BUILD);
+#endif
         const int cend = c + (g0.pad & 0xff);
         const int smax = g0.ishift + ((g0.pad >> 8) & 0xff), smin = g0.ishift - ((g0.pad >> 16) & 0xff);
         // LDS position p holds blended trace sample jb + p
@@ -1304,6 +1511,20 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
         for (int ig = 0; ig < NG; ig++) jend[ig] = REC_I(ta, 40 + ig);
         const int jend_h = REC_I(ta, 50), jend_d = REC_I(ta, 51);
         const int jend_min = min(need_h ? jend_h : 0x7fffffff, has_d ? jend_d : 0x7fffffff);
+        // carried register sets: receivers with horizontal and vertical components, every component added, no tail rule
+        // anywhere in the tile for any shift of the group; the group's cos / sin of the back-azimuth change and its flags are
+        // those of its head record (same point, same receiver), its integer shifts come in one load (lane k = centroid c + k)
+        bool carry_grp = false;
+        int ishv = 0, cur_next = 0;
+        float gcl = 0.f, gsl = 0.f;
+        if constexpr (kCarry) {
+            carry_grp = need_h && has_d && !(g0.flags & 8) && !((jb + (smax - smin) + TILE) > jend_min);
+            if (carry_grp) {
+                if (lane < (g0.pad & 0xff)) ishv = rc[c + lane].ishift;
+                cur_next = rec_load(rc, cend, nc, lane);
+                gcl = REC_F(cur, 16); gsl = REC_F(cur, 17);
+            }
+        }
         {
             float *tile0 = &tiles[0][0];
             // descriptors are relative to the first row of the group's cell (64-bit base, see write_tab)
@@ -1387,6 +1608,39 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
         // descriptors of the NEXT group: in flight while this group is applied
         if (cend < nc) { ta = tc[(size_t)cend * 128 + lane]; tb = tc[(size_t)cend * 128 + 64 + lane]; }
         __syncthreads();
+#ifdef KIWI_X_PRIO_APPLY
+        __builtin_amdgcn_s_setprio(KIWI_X_PRIO_APPLY);
+#endif
+        if (kCarry && carry_grp) {
+            // ---- apply with carried register sets: the two sets swap roles at EVERY centroid (pairs of centroids, roles
+            // static): after a centroid L holds its b[j-1] and H its b[j]; with the roles swapped, shift + 1 finds b[j] in place
+            // and reads b[j-1], shift - 1 finds b[j-1] in place and reads b[j]; every other step reads both.  The rotating /
+            // plain branch (seismogram.f90:160-203 / :205-231) is the same for the whole group: two copies of the loop.
+            const size_t crow = ((size_t)(c0 - cb) * nrec + (size_t)r * nc + c) * 128 + 64 + 40;
+            const unsigned clo = __builtin_amdgcn_readfirstlane((unsigned)crow), chi = __builtin_amdgcn_readfirstlane((unsigned)(crow >> 32));
+            const float *__restrict__ coef_grp = (const float *)(tab + (((size_t)chi << 32) | clo));
+            const unsigned abase = (unsigned)(size_t)(lds_cfp)&tiles[0][4 * (tid & ~63) + lane];
+            int cc = c, eprev = 0;
+            bool have = false;
+#define KIWI_C2STEP(LL, HH, RV, CC) do { \
+                const int e = smax - __builtin_amdgcn_readlane(ishv, (CC) - c);      /* LDS position of b[j-1] of the tile's first sample */ \
+                const int d = have ? eprev - e : 0x7fff; \
+                carry2_apply<NG, RV>(ar1, ar2, dz, LL, HH, abase + 4u * (unsigned)e, __builtin_amdgcn_readfirstlane((int)KIWI_X_FULL(d != -1)), \
+                                     __builtin_amdgcn_readfirstlane((int)KIWI_X_FULL(d != 1)), coef_grp + (size_t)((CC) - c) * 128, gcl, gsl); \
+                have = true; eprev = e; } while (0)
+            // (nothing is carried into a group, its first centroid reads both sets: set2_dead tells the register allocator so)
+            if (g0.flags & 2) {
+                set2_dead(X); set2_dead(Y);
+                for (; cc + 1 < cend; cc += 2) { KIWI_C2STEP(X, Y, true, cc); KIWI_C2STEP(Y, X, true, cc + 1); }
+                if (cc < cend) KIWI_C2STEP(X, Y, true, cc);
+            } else {
+                set2_dead(X); set2_dead(Y);
+                for (; cc + 1 < cend; cc += 2) { KIWI_C2STEP(X, Y, false, cc); KIWI_C2STEP(Y, X, false, cc + 1); }
+                if (cc < cend) KIWI_C2STEP(X, Y, false, cc);
+            }
+#undef KIWI_C2STEP
+            cur = cur_next;
+        } else
         // ---- apply: every centroid of the group, in table order (seismogram.f90:131); in a run, source after source
         for (int js = s; js < s_end; js++) {
         const GeoRec *__restrict__ rcj = multi ? recs + ((size_t)(cent_ofs[isrc0 + js] - cb) * nrec + (size_t)r * nc) : rc;
@@ -1437,6 +1691,562 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(3))) void acc
         for (int js = s; js < s_end; js++)
             if (!(synrow && synrow[js] != js)) store_family(js);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// accumulate, grouped, with the blended samples CARRIED between the centroids of a group (round 3)
+//
+// accumulate_grouped_kernel reads b[j-1] and b[j] of every output from LDS for every centroid and component; its LDS pipe
+// is then as busy as its vector pipe (40 ds_read2st64_b32 against 96 packed operations per wave and centroid, 4.3 LDS
+// cycles per read for the whole CU against 4 issue cycles per packed operation on one of four SIMDs) and the two overlap
+// only in part.  But the centroids of a group are the time steps of ONE sub-fault: the same blended traces, read at an
+// integer shift that usually moves by exactly one sample from step to step (effective_dt == dt of the database:
+// source_bilat.f90:443-457 with seismogram.f90:139).  With the stride-64 lane mapping, b[j] of step k+1 IS b[j-1] of
+// step k -- the register pair the lane already holds.  This kernel keeps the pairs of ALL components of the previous
+// centroid in registers (two sets that swap roles) and loads only what the new shift needs:
+//     shift + 1 -> the old b[j-1] set serves as b[j], only b[j-1] is read        (10 reads instead of 20)
+//     shift - 1 -> the old b[j] set serves as b[j-1], only b[j] is read          (runs of point sources: last step -> first step)
+//     same shift -> nothing is read;  anything else -> both are read.
+// To pay for the 2 x NG carried pairs the lane owns TWO outputs (samples 128 w + l and 128 w + l + 64 of the tile,
+// one register pair per quantity) and the workgroup has T = TILE / 2 threads (512 for the 1024-sample tile): per wave
+// the kernel then needs about half the registers of accumulate_grouped_kernel and twice the waves fit a SIMD.
+// What else changed on the way:
+//   * the group's cos / sin of the back-azimuth change and its flags are taken once per group (same point, same
+//     receiver: they are equal for every centroid of a group), the integer shifts of the group's centroids come in ONE
+//     vector load per group and reach the scalar unit with one v_readlane per centroid -- no per-centroid record fetch;
+//   * rotating / plain branch (seismogram.f90:160-203 / :205-231) chosen per group, outside the centroid loop: no
+//     v_cndmask selection and no copies per centroid;
+//   * the build is shared by the two halves of the workgroup (components 1-5 / 6-10), three components of loads in flight.
+// Per-sample operations and their order are those of accumulate_grouped_kernel / accumulate_kernel: bit-identical results
+// (tests/test_gpu_parity.py runs the three against each other).
+
+template <int NG, int HALF> struct CarryHalf;       // GF components (storage index) built by each half of the workgroup
+template <> struct CarryHalf<10, 0> { static constexpr int n = 5; __device__ static constexpr int ig(int i) { return i; } };
+template <> struct CarryHalf<10, 1> { static constexpr int n = 5; __device__ static constexpr int ig(int i) { return 5 + i; } };
+template <> struct CarryHalf<8, 0>  { static constexpr int n = 4; __device__ static constexpr int ig(int i) { return i; } };
+template <> struct CarryHalf<8, 1>  { static constexpr int n = 4; __device__ static constexpr int ig(int i) { return 4 + i; } };
+
+template <bool BLEND, bool FAST>
+__device__ __forceinline__ void one_issue(f4u (&v)[BLEND ? 4 : 1], int ig, int p, int jb, const float *__restrict__ G,
+                                          int pitch, int ta, int tb)
+{
+    const int j = jb + p;
+#pragma unroll
+    for (int k = 0; k < (BLEND ? 4 : 1); k++) {
+        const int base = REC_I(ta, 4 * ig + k);
+        if constexpr (FAST) {
+            v[k] = buf_load4(gf_rsrc(G), p, base + jb);
+        } else {
+            const int lo = REC_I(tb, 4 * ig + k);
+            const int idx = min(max(base + j, lo), lo + pitch - 4);
+            v[k] = *(const f4u *)(G + (size_t)(unsigned)idx);
+        }
+    }
+}
+
+template <bool BLEND>
+__device__ __forceinline__ void one_finish(const f4u (&v)[BLEND ? 4 : 1], float *__restrict__ tile0, int lds_tile, int ig, int p,
+                                           const GeoRec &g)
+{
+    f4u b;
+    if constexpr (BLEND) {
+        b = g.w[0] * v[0];                    // gfdb.f90:946-949, summed in this order
+        b = b + g.w[1] * v[1];
+        b = b + g.w[2] * v[2];
+        b = b + g.w[3] * v[3];
+    } else {
+        b = v[0];
+    }
+    *(float4 *)(tile0 + ig * lds_tile + p) = make_float4(b.x, b.y, b.z, b.w);
+}
+
+// main chunk (LDS positions [p, p + 4)) of the components of one half of the workgroup; loads of DEPTH components in flight
+template <int NG, int HALF, bool BLEND, bool FAST>
+__device__ __forceinline__ void carry_build(float *__restrict__ tile0, int lds_tile, int p, int jb, const float *__restrict__ G,
+                                            int pitch, int ta, int tb, const GeoRec &g)
+{
+    typedef CarryHalf<NG, HALF> H;
+    constexpr int N = H::n, DEPTH = 3;
+    f4u v[N][BLEND ? 4 : 1];
+#pragma unroll
+    for (int i = 0; i < DEPTH && i < N; i++) one_issue<BLEND, FAST>(v[i], H::ig(i), p, jb, G, pitch, ta, tb);
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        __builtin_amdgcn_sched_barrier(0);
+        one_finish<BLEND>(v[i], tile0, lds_tile, H::ig(i), p, g);
+        if (i + DEPTH < N) one_issue<BLEND, FAST>(v[i + DEPTH], H::ig(i + DEPTH), p, jb, G, pitch, ta, tb);
+    }
+}
+
+
+// one quantity (b[j-1] or b[j]) of the lane's 2 NP outputs of one component: NP ds_read2st64_b32
+template <int NP>
+__device__ __forceinline__ void tile_load_half(f2v (&d)[NP], lds_cfp b, int ofs)
+{
+#pragma unroll
+    for (int h = 0; h < NP; h++) d[h] = f2v{ b[ofs + 128 * h], b[ofs + 128 * h + 64] };
+}
+
+// A carried register set: one register pair per GF component (application order), each a variable of its own.  (As an
+// array the compiler's scalar-replacement pass promotes the whole set to ONE <20 x float> value -- a 32-register tuple
+// that is copied and spilled as a whole at every conditional load.)
+struct CarrySet { f2v &c0, &c1, &c2, &c3, &c4, &c5, &c6, &c7, &c8, &c9; };
+template <int I> __device__ __forceinline__ f2v &cs_get(const CarrySet &s)
+{
+    if constexpr (I == 0) return s.c0; else if constexpr (I == 1) return s.c1; else if constexpr (I == 2) return s.c2;
+    else if constexpr (I == 3) return s.c3; else if constexpr (I == 4) return s.c4; else if constexpr (I == 5) return s.c5;
+    else if constexpr (I == 6) return s.c6; else if constexpr (I == 7) return s.c7; else if constexpr (I == 8) return s.c8;
+    else return s.c9;
+}
+
+// All GF components of one centroid from the two register sets L (b[j-1]) and H (b[j]), reference order.  load_lo /
+// load_hi: which of the sets this centroid's shift makes it read (see the head of this section).  coef: the centroid's
+// 2 NG interpolation coefficients (wave-uniform pointer: scalar loads, SGPR operands of the packed multiplies).
+// TAIL: the `factor * last` rule needs the factors and the fraction; they are read from the record then (rare).
+template <int NG, int LDS_TILE, bool TAIL, bool ROT>
+__device__ __forceinline__ void carry_apply(f2v &ar1, f2v &ar2, f2v &dz, const CarrySet &L, const CarrySet &H,
+                                            const TileBase &cb, bool load_lo, bool load_hi, const float *__restrict__ coef,
+                                            int jl, const int *__restrict__ jendp, const GeoRec *__restrict__ rec, float sd,
+                                            float cl, float sl)
+{
+    constexpr int seq10[10] = { 0, 1, 2, 8, 3, 4, 5, 6, 7, 9 }, seq8[8] = { 0, 1, 2, 3, 4, 5, 6, 7 };
+    constexpr int nH1 = (NG == 10) ? 4 : 3;      // components summed into the radial trace
+    if (load_hi)
+        static_for<NG>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value, o = ((NG == 10) ? seq10[i] : seq8[i]) * LDS_TILE;
+            cs_get<i>(H) = f2v{ cb.hi[o], cb.hi[o + 64] };
+        });
+    if (load_lo)
+        static_for<NG>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value, o = ((NG == 10) ? seq10[i] : seq8[i]) * LDS_TILE;
+            cs_get<i>(L) = f2v{ cb.lo[o], cb.lo[o + 64] };
+        });
+    float cw[2 * NG];
+#pragma unroll
+    for (int i = 0; i < 2 * NG; i++) cw[i] = coef[i];
+    float fac[NG];
+    int jend[NG];
+    if constexpr (TAIL) {
+        const float f0 = rec->f[0], f1 = rec->f[1], f2 = rec->f[2], f3 = rec->f[3], f4 = rec->f[4], f5 = rec->f[5];
+        const float fac10[10] = { f0, f1, f2, f5, f3, f4, f0 * sd, f1 * sd, f2 * sd, f5 * sd };
+        const float fac8[8] = { f0, f1, f2, f3, f4, f0 * sd, f1 * sd, f2 * sd };
+#pragma unroll
+        for (int i = 0; i < NG; i++) { fac[i] = (NG == 10) ? fac10[i] : fac8[i]; jend[i] = jendp[(NG == 10) ? seq10[i] : seq8[i]]; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NG; i++) { fac[i] = 0.f; jend[i] = 0; }
+    }
+    f2v t1[1], t2[1], dd[1];
+    t1[0] = ROT ? f2v{ 0.f, 0.f } : ar1; t2[0] = ROT ? f2v{ 0.f, 0.f } : ar2; dd[0] = dz;
+    static_for<NG>([&](auto I) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value;
+        TileRegsN<1> tr;
+        tr.lo[0] = cs_get<i>(L); tr.hi[0] = cs_get<i>(H);
+        const float wl = cw[2 * i], wr = cw[2 * i + 1];
+        if constexpr (i < nH1) tile_fma<TAIL, 1>(t1, tr, jl, jend[i], fac[i], wl, wr);
+        else if constexpr (i < nH1 + 2) tile_fma<TAIL, 1>(t2, tr, jl, jend[i], fac[i], wl, wr);
+        else tile_fma<TAIL, 1>(dd, tr, jl, jend[i], fac[i], wl, wr);
+        if constexpr (i == nH1 + 1) {
+            if (ROT) {
+                ar1 = ar1 + cl * t1[0] - sl * t2[0];
+                ar2 = ar2 + cl * t2[0] + sl * t1[0];
+            } else {
+                ar1 = t1[0]; ar2 = t2[0];
+            }
+        }
+    });
+    dz = dd[0];
+}
+
+// In-place conditional LDS reads of one register set (one pair per GF component of a pass), as ONE asm statement: for the
+// compiler the pairs are read-modify-write operands, so a set that is NOT read this time simply keeps its registers -- no
+// merge of a "loaded" and a "kept" value, which the register allocator answered with a copy per pair and centroid.
+// Offsets in units of 64 dwords for component stride LDS_TILE = 576 = 9 x 64 (pass H: components 0 1 2 [8] 3 4 in
+// application order, pass D: 5 6 7 [9]).  The reads are NOT known to the compiler's wait-count bookkeeping: lds_wait()
+// before the first use.
+__device__ __forceinline__ void cond_read_h10(int on, unsigned a, f2v &r0, f2v &r1, f2v &r2, f2v &r3, f2v &r4, f2v &r5)
+{
+    asm volatile("s_cmp_eq_u32 %7, 0\n\ts_cbranch_scc1 .Lkiwi_skip%=\n\t"
+                 "ds_read2st64_b32 %0, %6 offset1:1\n\tds_read2st64_b32 %1, %6 offset0:9 offset1:10\n\t"
+                 "ds_read2st64_b32 %2, %6 offset0:18 offset1:19\n\tds_read2st64_b32 %3, %6 offset0:72 offset1:73\n\t"
+                 "ds_read2st64_b32 %4, %6 offset0:27 offset1:28\n\tds_read2st64_b32 %5, %6 offset0:36 offset1:37\n"
+                 ".Lkiwi_skip%=:"
+                 : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5) : "v"(a), "s"(on) : "memory", "scc");
+}
+__device__ __forceinline__ void cond_read_d10(int on, unsigned a, f2v &r0, f2v &r1, f2v &r2, f2v &r3)
+{
+    asm volatile("s_cmp_eq_u32 %5, 0\n\ts_cbranch_scc1 .Lkiwi_skip%=\n\t"
+                 "ds_read2st64_b32 %0, %4 offset0:45 offset1:46\n\tds_read2st64_b32 %1, %4 offset0:54 offset1:55\n\t"
+                 "ds_read2st64_b32 %2, %4 offset0:63 offset1:64\n\tds_read2st64_b32 %3, %4 offset0:81 offset1:82\n"
+                 ".Lkiwi_skip%=:"
+                 : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "v"(a), "s"(on) : "memory", "scc");
+}
+__device__ __forceinline__ void cond_read_h8(int on, unsigned a, f2v &r0, f2v &r1, f2v &r2, f2v &r3, f2v &r4)
+{
+    asm volatile("s_cmp_eq_u32 %6, 0\n\ts_cbranch_scc1 .Lkiwi_skip%=\n\t"
+                 "ds_read2st64_b32 %0, %5 offset1:1\n\tds_read2st64_b32 %1, %5 offset0:9 offset1:10\n\t"
+                 "ds_read2st64_b32 %2, %5 offset0:18 offset1:19\n\tds_read2st64_b32 %3, %5 offset0:27 offset1:28\n\t"
+                 "ds_read2st64_b32 %4, %5 offset0:36 offset1:37\n"
+                 ".Lkiwi_skip%=:"
+                 : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4) : "v"(a), "s"(on) : "memory", "scc");
+}
+__device__ __forceinline__ void cond_read_d8(int on, unsigned a, f2v &r0, f2v &r1, f2v &r2)
+{
+    asm volatile("s_cmp_eq_u32 %4, 0\n\ts_cbranch_scc1 .Lkiwi_skip%=\n\t"
+                 "ds_read2st64_b32 %0, %3 offset0:45 offset1:46\n\tds_read2st64_b32 %1, %3 offset0:54 offset1:55\n\t"
+                 "ds_read2st64_b32 %2, %3 offset0:63 offset1:64\n"
+                 ".Lkiwi_skip%=:"
+                 : "+v"(r0), "+v"(r1), "+v"(r2) : "v"(a), "s"(on) : "memory", "scc");
+}
+// (the pairs are operands of the wait: the arithmetic that uses them cannot be scheduled in front of it)
+__device__ __forceinline__ void lds_wait(f2v &a0, f2v &a1, f2v &a2, f2v &a3, f2v &a4, f2v &a5, f2v &b0, f2v &b1, f2v &b2, f2v &b3, f2v &b4, f2v &b5)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5),
+                 "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5) :: "memory");
+}
+__device__ __forceinline__ void lds_wait(f2v &a0, f2v &a1, f2v &a2, f2v &a3, f2v &b0, f2v &b1, f2v &b2, f2v &b3)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3) :: "memory");
+}
+
+// one register set of a pass: up to six pairs, each a variable of its own (see CarrySet)
+struct PassSet { f2v &c0, &c1, &c2, &c3, &c4, &c5; };
+template <int I> __device__ __forceinline__ f2v &ps_get(const PassSet &s)
+{
+    if constexpr (I == 0) return s.c0; else if constexpr (I == 1) return s.c1; else if constexpr (I == 2) return s.c2;
+    else if constexpr (I == 3) return s.c3; else if constexpr (I == 4) return s.c4; else return s.c5;
+}
+template <int NG, bool HPASS>
+__device__ __forceinline__ void pass_read(int on, unsigned a, const PassSet &S)
+{
+    if constexpr (NG == 10 && HPASS) cond_read_h10(on, a, S.c0, S.c1, S.c2, S.c3, S.c4, S.c5);
+    else if constexpr (NG == 10) cond_read_d10(on, a, S.c0, S.c1, S.c2, S.c3);
+    else if constexpr (HPASS) cond_read_h8(on, a, S.c0, S.c1, S.c2, S.c3, S.c4);
+    else cond_read_d8(on, a, S.c0, S.c1, S.c2);
+}
+
+// One centroid of one pass (HPASS: the horizontal components into ar1 / ar2, seismogram.f90:158-231; else the vertical ones
+// into dz, :236-253) from the register sets L (b[j-1]) and H (b[j]); a: LDS byte address of b[j-1] of the lane's first output in
+// component 0; coef: the centroid's coefficient line (scalar loads).  Same operations in the same order as centroid_apply.
+template <int NG, bool HPASS, bool ROT>
+__device__ __forceinline__ void pass_apply(f2v &ar1, f2v &ar2, f2v &dz, const PassSet &L, const PassSet &H, unsigned a,
+                                           bool load_lo, bool load_hi, const float *__restrict__ coef, float cl, float sl)
+{
+    constexpr int nH = (NG == 10) ? 6 : 5, nD = (NG == 10) ? 4 : 3, nH1 = nH - 2;
+    constexpr int N = HPASS ? nH : nD, C0 = HPASS ? 0 : 2 * nH;
+    float cw[2 * N];
+#pragma unroll
+    for (int i = 0; i < 2 * N; i++) cw[i] = coef[C0 + i];
+    pass_read<NG, HPASS>(__builtin_amdgcn_readfirstlane((int)load_hi), a + 4, H);
+    pass_read<NG, HPASS>(__builtin_amdgcn_readfirstlane((int)load_lo), a, L);
+    if constexpr (HPASS) lds_wait(L.c0, L.c1, L.c2, L.c3, L.c4, L.c5, H.c0, H.c1, H.c2, H.c3, H.c4, H.c5);
+    else lds_wait(L.c0, L.c1, L.c2, L.c3, H.c0, H.c1, H.c2, H.c3);
+    if constexpr (HPASS) {
+        f2v t1 = ROT ? f2v{ 0.f, 0.f } : ar1, t2 = ROT ? f2v{ 0.f, 0.f } : ar2;
+        static_for<nH>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            const f2v c1 = { cw[2 * i], cw[2 * i] }, c2 = { cw[2 * i + 1], cw[2 * i + 1] };
+            if constexpr (i < nH1) { t1 = t1 + c1 * ps_get<i>(H); t1 = t1 + c2 * ps_get<i>(L); }
+            else                   { t2 = t2 + c1 * ps_get<i>(H); t2 = t2 + c2 * ps_get<i>(L); }
+        });
+        if (ROT) {
+            ar1 = ar1 + cl * t1 - sl * t2;
+            ar2 = ar2 + cl * t2 + sl * t1;
+        } else {
+            ar1 = t1; ar2 = t2;
+        }
+    } else {
+        static_for<nD>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            const f2v c1 = { cw[2 * i], cw[2 * i] }, c2 = { cw[2 * i + 1], cw[2 * i + 1] };
+            dz = dz + c1 * ps_get<i>(H); dz = dz + c2 * ps_get<i>(L);
+        });
+    }
+}
+
+#ifndef KIWI_X_COEFIDX
+#define KIWI_X_COEFIDX(x) (x)
+#endif
+#ifndef KIWI_PIPE_WAVES
+#define KIWI_PIPE_WAVES 3
+#endif
+
+// The kernel.  T = 256 threads, tile = 512 samples, two tile sets in LDS (2 x 23 KB: three workgroups per CU):
+//
+//     issue the global loads of group g+1 (they stay in registers)  ->  apply group g from tile set g & 1
+//     ->  blend the loaded rows into tile set (g+1) & 1  ->  ONE barrier  ->  ...
+//
+// What bounded accumulate_grouped_kernel (measured, round 3: build only 29 ms + apply only 33 ms -> 42 ms per 1024 sources at
+// cfg3, 60 % of the vector issue slots) is that every group starts with an L2 round trip nothing hides but the other two
+// workgroups of the CU: its workgroup issues the loads, waits, blends, synchronises, applies, synchronises.  Here the
+// round trip of group g+1 lies under the arithmetic of group g.
+template <int NG, bool FUSE, bool RUNS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIWI_PIPE_WAVES))) void accumulate_pipe_kernel(
+    const float *__restrict__ G, const int2 *__restrict__ span, int pitch,
+    const GeoRec *__restrict__ recs, const int *__restrict__ cent_ofs, int isrc0, int nrec,
+    const RecvDev *__restrict__ recv, float *__restrict__ syn, size_t syn_stride, int ntiles,
+    const int *__restrict__ tab, const int *__restrict__ run_first, FuseParams fp,
+    const int *__restrict__ pairflag, const int *__restrict__ synrow,
+    const int *__restrict__ fam_ofs, const int *__restrict__ fam_list)
+{
+    // arguments, grid (source index or run fastest) and semantics: accumulate_grouped_kernel
+    constexpr int T = 256, NP = 1;
+    constexpr int TILE = 2 * NP * T;
+    constexpr int LDS_TILE = TILE + kHalo;
+    static_assert(LDS_TILE % 64 == 0, "tile layout");
+    __shared__ __attribute__((aligned(16))) float tiles[2][NG][LDS_TILE];
+    const int s = RUNS ? run_first[blockIdx.x] : (int)blockIdx.x;
+    const int s_end = RUNS ? run_first[blockIdx.x + 1] : s + 1;
+    const bool multi = RUNS && s_end - s > 1;
+    const int tile = blockIdx.y % ntiles, r = blockIdx.y / ntiles;
+    const RecvDev &rv = recv[r];
+    if (!rv.enabled) return;
+    if (tile * TILE >= rv.wlen) return;
+    if (!pipe_pair(rv, pairflag, s, nrec, r)) return;
+    if (synrow && !multi && synrow[s] != s) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int half = __builtin_amdgcn_readfirstlane(tid / (T / 2));      // which components this wave builds
+    const int t_tile0 = rv.wbeg + tile * TILE;
+    const int cb = cent_ofs[isrc0], c0 = cent_ofs[isrc0 + s], nc = cent_ofs[isrc0 + s + 1] - c0;
+    const GeoRec *__restrict__ rc = recs + ((size_t)(c0 - cb) * nrec + (size_t)r * nc);
+    const int *__restrict__ tc = tab + ((size_t)(c0 - cb) * nrec + (size_t)r * nc) * 128;
+    const float sd = rv.sd;
+    const int u0 = 2 * NP * (tid & ~63) + lane;          // the lane's first tile sample (the other: + 64)
+    const int p = 4 * (tid % (T / 2));                   // the lane's main chunk of the build
+    // halo: one lane per (component, 4-sample chunk)
+    const int hslot = tid >> 4, hig = min(hslot, NG - 1), hph = TILE + 4 * (tid & 15);
+    static_assert(16 * NG <= T, "one halo pass");
+
+    f2v ar1[NP], ar2[NP], dz[NP];
+#pragma unroll
+    for (int k = 0; k < NP; k++) ar1[k] = ar2[k] = dz[k] = f2v{ 0.f, 0.f };
+    // rotation to N/E, signs and store of one source's accumulators (seismogram.f90:256-283)
+    auto store = [&](int js) {
+        constexpr int NO = 2 * NP;
+        const int tl = tile * TILE + u0;                 // window sample of the lane's output q = 0; q-th: + 64 q
+        if (!FUSE && tl >= rv.wlen) return;
+        float *__restrict__ so = syn + (size_t)js * syn_stride + tl;
+        float a1[NO], a2[NO], ad[NO];
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            a1[2 * k] = ar1[k].x; a1[2 * k + 1] = ar1[k].y; a2[2 * k] = ar2[k].x; a2[2 * k + 1] = ar2[k].y;
+            ad[2 * k] = dz[k].x; ad[2 * k + 1] = dz[k].y;
+        }
+        float mom = 0.f;
+        if constexpr (FUSE) mom = fp.moment[fp.isrc0 + js];
+        const bool unit = (fp.syn_factor == 1.f);
+        for (int k = 0; k < rv.ncomp; k++) {
+            const float sg = rv.sign[k];
+            float o[NO];
+#pragma unroll
+            for (int i = 0; i < NO; i++) {
+                switch (rv.comp[k]) {
+                case 1: o[i] = a1[i] * sg; break;
+                case 2: o[i] = a2[i] * sg; break;
+                case 3: o[i] = ad[i]; break;
+                case 4: o[i] = (rv.cl0 * a1[i] - rv.sl0 * a2[i]) * sg; break;
+                default: o[i] = (rv.cl0 * a2[i] + rv.sl0 * a1[i]) * sg; break;
+                }
+            }
+            if constexpr (!FUSE) {
+#pragma unroll
+                for (int i = 0; i < NO; i++)
+                    if (tl + 64 * i < rv.wlen) so[rv.synofs[k] + 64 * i] = o[i];
+                continue;
+            }
+            // fused comparator (see accumulate_grouped_kernel): partial of (source, slot, tile, wave)
+            double acc = 0.0;
+            const float *__restrict__ rt = fp.reft + rv.refofs[k] + tl, *__restrict__ tp = fp.tw + rv.refofs[k] + tl;
+#pragma unroll
+            for (int i = 0; i < NO; i++) {
+                if (tl + 64 * i >= rv.wlen) break;
+                const float v = o[i] * mom;
+                const float vt = v * tp[64 * i];
+                const float a = rt[64 * i];
+                switch (fp.method) {
+                case 1: { const float d = unit ? (a - vt) : (1.f * a - fp.syn_factor * vt); acc = sq_acc(acc, d); break; }
+                case 2: { const float d = unit ? fabsf(a - vt) : fabsf(1.f * a - fp.syn_factor * vt); acc += (double)d; break; }
+                case 5: acc += unit ? (double)(a * vt) : (double)(a * 1.f * vt * fp.syn_factor); break;
+                default: { const double x = (double)(1.f * a), y = (double)(fp.syn_factor * vt); acc = fmax(acc, sqrt(x * x + y * y)); break; }
+                }
+            }
+            acc = wave_reduce_f64(acc, fp.method == 6);                 // total in lane 63
+            if (lane == 63)
+                fp.partial[((size_t)js * fp.nmis + rv.slot0 + k) * fp.nparts + tile * (T / 64) + (tid >> 6)] = acc;
+        }
+    };
+    auto store_family = [&](int js) {
+        store(js);
+        if constexpr (FUSE) {
+            if (fam_ofs)
+                for (int q = fam_ofs[js]; q < fam_ofs[js + 1]; q++) store(fam_list[q]);
+        }
+    };
+    if (nc <= 0) {                                       // (a rejected trial source has no centroids: zero synthetics)
+        for (int js = s; js < s_end; js++)
+            if (!(synrow && multi && synrow[js] != js)) store_family(js);
+        return;
+    }
+
+    // ---- what the apply of a group needs (from its head record; equal for all its centroids: same point, same receiver)
+    struct Grp { int c, cend, smax, jb; float cl, sl; bool rot; };
+    // ---- what the build of a group leaves in flight: the raw rows of the lane's chunk (and halo chunk), the blend weights
+    f4u V[CarryHalf<NG, 0>::n][4];
+    HaloRegs HV;
+    float bw0 = 0.f, bw1 = 0.f, bw2 = 0.f, bw3 = 0.f;
+    bool bdirect = false, bhact = false;
+    int ishv = 0, ishv_next = 0;                         // integer shifts of the group's centroids, lane k = centroid c + k
+
+    // decode the head record of the group starting at centroid c (cur / ta / tb: its record and descriptors, lane-
+    // distributed), issue its loads; returns what its apply needs
+    auto issue = [&](int c, int cur, int ta, int tb, int &ish) -> Grp {
+        GeoRec g0;
+        rec_head(cur, 0, g0);
+        Grp g;
+        const int glen = g0.pad & 0xff;
+        g.c = c; g.cend = c + glen;
+        g.smax = g0.ishift + ((g0.pad >> 8) & 0xff);
+        const int smin = g0.ishift - ((g0.pad >> 16) & 0xff);
+        g.jb = t_tile0 - g.smax - 1;                     // LDS position q holds blended trace sample jb + q
+        g.cl = REC_F(cur, 16); g.sl = REC_F(cur, 17);
+        g.rot = (g0.flags & 2) != 0;
+        const int npos = TILE + (g.smax - smin) + 8;     // positions read by the group (<= LDS_TILE)
+        bdirect = (g0.flags & 1) != 0;
+        bw0 = g0.w[0]; bw1 = g0.w[1]; bw2 = g0.w[2]; bw3 = g0.w[3];
+        bhact = hslot < NG && hph < npos;
+        ish = 0;
+        if (lane < glen) ish = rc[c + lane].ishift;
+        const float *__restrict__ Gg = G + (size_t)g0.row[0] * (size_t)pitch;
+        const int jb = g.jb;
+        const bool lane_ok = lane >= 4 * NG || (ta + jb >= tb && ta + jb + LDS_TILE <= tb + pitch);
+        const bool fast = __builtin_amdgcn_ballot_w64(lane_ok) == ~0ull;
+#define KIWI_ISS(HF, BL, FA) do { \
+            _Pragma("unroll") for (int i = 0; i < CarryHalf<NG, HF>::n; i++) { \
+                f4u t[BL ? 4 : 1]; \
+                one_issue<BL, FA>(t, CarryHalf<NG, HF>::ig(i), p, jb, Gg, pitch, ta, tb); \
+                _Pragma("unroll") for (int k = 0; k < (BL ? 4 : 1); k++) V[i][k] = t[k]; \
+            } \
+            HV = halo_issue<BL, FA>(bhact, hig, hph, jb, Gg, pitch, ta, tb); } while (0)
+#ifdef KIWI_X_ONEVAR
+#define KIWI_ISS2(HF) do { (void)fast; KIWI_ISS(HF, true, true); } while (0)
+#else
+#define KIWI_ISS2(HF) do { if (fast) KIWI_ISS(HF, true, true); else KIWI_ISS(HF, true, false); } while (0)
+#endif
+#ifndef KIWI_X_NOBUILD
+        if (half == 0) KIWI_ISS2(0); else KIWI_ISS2(1);
+#else
+        (void)fast; (void)Gg;
+#endif
+#undef KIWI_ISS2
+#undef KIWI_ISS
+        return g;
+    };
+    // blend what issue() left in flight into tile set `buf`
+    auto finish = [&](int buf) {
+        float *tile0 = &tiles[buf][0][0];
+        GeoRec gw;
+        gw.w[0] = bw0; gw.w[1] = bw1; gw.w[2] = bw2; gw.w[3] = bw3;
+#define KIWI_FIN(HF, BL) do { \
+            _Pragma("unroll") for (int i = 0; i < CarryHalf<NG, HF>::n; i++) { \
+                f4u t[BL ? 4 : 1]; \
+                _Pragma("unroll") for (int k = 0; k < (BL ? 4 : 1); k++) t[k] = V[i][k]; \
+                one_finish<BL>(t, tile0, LDS_TILE, CarryHalf<NG, HF>::ig(i), p, gw); \
+            } \
+            halo_finish<BL>(bhact, HV, tile0, LDS_TILE, hig, hph, gw); } while (0)
+#ifdef KIWI_X_ONEVAR
+        if (half == 0) KIWI_FIN(0, true); else KIWI_FIN(1, true);
+#else
+        if (half == 0) KIWI_FIN(0, true); else KIWI_FIN(1, true);
+#endif
+#undef KIWI_FIN
+    };
+
+    // the two carried register sets of a pass
+    f2v x0, x1, x2, x3, x4, x5, y0, y1, y2, y3, y4, y5;
+    const PassSet X{ x0, x1, x2, x3, x4, x5 }, Y{ y0, y1, y2, y3, y4, y5 };
+    static_assert(LDS_TILE == 576, "cond_read_*: component stride 9 x 64 dwords");
+
+    // ---- prologue: group 0 into tile set 0; head of group 1 in flight
+    Grp g, gn;
+    int cur, ta, tb;
+    {
+        const int cur0 = rec_load(rc, 0, nc, lane);
+        const int ta0 = tc[lane], tb0 = tc[64 + lane];
+        g = issue(0, cur0, ta0, tb0, ishv);
+        cur = rec_load(rc, g.cend, nc, lane);
+        ta = 0; tb = 0;
+        if (g.cend < nc) { ta = tc[(size_t)g.cend * 128 + lane]; tb = tc[(size_t)g.cend * 128 + 64 + lane]; }
+        finish(0);
+        __syncthreads();
+    }
+    bool stored = false;
+    int buf = 0;
+    for (;;) {
+        const bool more = g.cend < nc;
+        if (more) {
+            gn = issue(g.cend, cur, ta, tb, ishv_next);
+            // head of the group after that
+            cur = rec_load(rc, gn.cend, nc, lane);
+            if (gn.cend < nc) { ta = tc[(size_t)gn.cend * 128 + lane]; tb = tc[(size_t)gn.cend * 128 + 64 + lane]; }
+        }
+        // ---- apply group g from tile set buf: every centroid, in table order (seismogram.f90:131); in a run, source after
+        // source.  Two passes over the group's centroids: the horizontal components into ar1 / ar2, then the vertical ones into
+        // dz -- independent accumulators, so each keeps the reference's order of additions -- because the carried register sets
+        // of ALL components (40 registers) do not fit next to the loads of the next group that are in flight meanwhile.
+        {
+            const int c = g.c, cend = g.cend, smax = g.smax;
+            const float cl = g.cl, sl = g.sl;
+            const unsigned abase = (unsigned)(size_t)(lds_cfp)&tiles[buf][0][u0];
+            for (int js = s; js < s_end; js++) {
+                if (multi) {
+#pragma unroll
+                    for (int k = 0; k < NP; k++) ar1[k] = ar2[k] = dz[k] = f2v{ 0.f, 0.f };
+                    if (synrow && synrow[js] != js) continue;           // evaluated with the source it shares synthetics with
+                }
+                const size_t crow = ((size_t)(cent_ofs[isrc0 + js] - cb) * nrec + (size_t)r * nc + c) * 128 + 64 + 40;
+                const unsigned clo = __builtin_amdgcn_readfirstlane((unsigned)crow), chi = __builtin_amdgcn_readfirstlane((unsigned)(crow >> 32));
+                const float *__restrict__ coef_grp = (const float *)(tab + (((size_t)chi << 32) | clo));
+                // The two register sets swap roles at EVERY centroid (pairs of centroids, roles static): after a centroid L holds
+                // its b[j-1] and H its b[j]; with the roles swapped, shift + 1 finds b[j] in place and reads b[j-1], shift - 1
+                // finds b[j-1] in place and reads b[j]; every other step reads both.  The rotating / plain branch
+                // (seismogram.f90:160-203 / :205-231) is the same for the whole group: two copies of the horizontal loop.
+#define KIWI_PSTEP(LL, HH, HP, RV, CC) do { \
+                    const int ishift = __builtin_amdgcn_readlane(ishv, (CC) - c); \
+                    const float *__restrict__ coef = coef_grp + (size_t)KIWI_X_COEFIDX((CC) - c) * 128; \
+                    const int e = smax - ishift;                 /* LDS position of b[j-1] of the tile's first sample */ \
+                    const int d = have ? eprev - e : 0x7fff; \
+                    const bool load_lo = KIWI_X_FULL(d != -1), load_hi = KIWI_X_FULL(d != 1); \
+                    pass_apply<NG, HP, RV>(ar1[0], ar2[0], dz[0], LL, HH, abase + 4u * (unsigned)e, load_lo, load_hi, coef, cl, sl); \
+                    have = true; eprev = e; } while (0)
+#define KIWI_DEAD(v) asm volatile("" : "=v"(v))
+#define KIWI_PLOOP(HP, RV) do { \
+                    int cc = c, eprev = 0; \
+                    bool have = false; \
+                    /* nothing is carried into a pass (its first centroid reads both sets): tell the register allocator so */ \
+                    KIWI_DEAD(x0); KIWI_DEAD(x1); KIWI_DEAD(x2); KIWI_DEAD(x3); KIWI_DEAD(x4); KIWI_DEAD(x5); \
+                    KIWI_DEAD(y0); KIWI_DEAD(y1); KIWI_DEAD(y2); KIWI_DEAD(y3); KIWI_DEAD(y4); KIWI_DEAD(y5); \
+                    for (; cc + 1 < cend; cc += 2) { KIWI_PSTEP(X, Y, HP, RV, cc); KIWI_PSTEP(Y, X, HP, RV, cc + 1); } \
+                    if (cc < cend) KIWI_PSTEP(X, Y, HP, RV, cc); } while (0)
+#ifndef KIWI_X_NOAPPLY
+                if (g.rot) KIWI_PLOOP(true, true); else KIWI_PLOOP(true, false);
+                KIWI_PLOOP(false, false);
+#endif
+#undef KIWI_PLOOP
+#undef KIWI_PSTEP
+#undef KIWI_DEAD
+                if (multi) store_family(js);
+            }
+            stored = multi;
+        }
+        if (!more) break;
+        finish(buf ^ 1);
+        __syncthreads();                                 // tile set buf ^ 1 complete; nobody reads set buf any more
+        buf ^= 1;
+        g = gn; ishv = ishv_next;
+    }
+    if (!multi) store_family(s);
+    (void)stored;
 }
 
 // ------------------------------------------------------------------------------------------------
