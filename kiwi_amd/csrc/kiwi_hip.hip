@@ -144,6 +144,9 @@ struct kiwi_hip_ctx {
     DevBuf<int> synrow_d, famofs_d, famlist_d;
     int dedupe_enabled = 1;           // env KIWI_HIP_DEDUPE=0 switches it off
     std::vector<unsigned long long> geo_hash;
+    std::vector<unsigned long long> struct_hash;   // per source: number of centroids, pattern of repeated points, integer shifts (accumulate_duo_kernel's pairing)
+    DevBuf<int> mate_d;
+    int duo = 1;                      // accumulate_duo_kernel for pairs of consecutive sources of equal structure; env KIWI_HIP_DUO=0 switches it off
     std::vector<char> single_group;
     DevBuf<int> runfirst_d;
     int share_runs = 1, max_run = 64;
@@ -933,6 +936,8 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
     const bool cell = c->accum_mode == 0 && (c->cell_mode == 1 || (c->cell_mode < 0 && c->bilinear && c->points_per_centroid > 0.5));
     // pipelined kernel: tiles of 512 samples; windows shorter than 384 samples stay with the 256-sample tiles of the grouped kernel
     const bool pipe = c->accum_mode == 0 && c->pipe && !cell && c->max_wlen >= 384 && !c->group_threads_env;
+    // two sources per workgroup (accumulate_duo_kernel, 512-sample tiles); decided below, once the runs and the shared synthetics are known
+    const bool duo_maybe = c->accum_mode == 0 && c->duo && !pipe && !cell && c->max_wlen >= 384 && !c->group_threads_env && nsrc >= 2;
     EvalParams ep{ c->bilinear, c->xus, c->zus, nrec, isrc0, cell ? 1 : 0 };
     int *spansrc = nullptr;
     if (c->any_untapered || c->want_spansrc || c->fft_needed) {     // per-source strip spans, initialised empty
@@ -945,12 +950,12 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
     record(c, 0, e0);
     if (maxnc > 0) {
         dim3 grid((unsigned)((maxnc * nrec + 255) / 256), (unsigned)nsrc);
-        if (cell || pipe) {
+        if (cell || pipe || duo_maybe) {
             c->pairflag_d.ensure((size_t)nsrc * nrec, &c->dev_bytes);
             HIPCHECK(hipMemsetAsync(c->pairflag_d.p, 0, (size_t)nsrc * nrec * sizeof(int), c->stream));
         }
         hipLaunchKernelGGL(geometry_kernel, grid, dim3(256), 0, c->stream, c->cent_d.p, c->centofs_d.p, ep, c->gm,
-                           c->span.p, c->recv_d.p, c->recs_d.p, tab, (int *)nullptr, spansrc, (cell || pipe) ? c->pairflag_d.p : (int *)nullptr, c->endz.p, (const int *)nullptr);
+                           c->span.p, c->recv_d.p, c->recs_d.p, tab, (int *)nullptr, spansrc, (cell || pipe || duo_maybe) ? c->pairflag_d.p : (int *)nullptr, c->endz.p, (const int *)nullptr);
         if (cell)
             hipLaunchKernelGGL(cellgroup_kernel, grid, dim3(256), 0, c->stream, c->centofs_d.p, ep, c->gm, c->span.p, c->recv_d.p,
                                c->recs_d.p, tab, c->pairflag_d.p, c->endz.p, (const int *)nullptr);
@@ -1013,24 +1018,44 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
                     gx = (unsigned)rf.size() - 1;
                 }
             }
+            // pairs of consecutive sources of equal structure (see accumulate_duo_kernel)
+            bool duo = duo_maybe && !runs && !synrow && maxnc > 0;
+            if (duo) {
+                std::vector<int> mt((size_t)(nsrc + 1) / 2, 0);
+                bool any = false;
+                for (int k = 0; 2 * k + 1 < nsrc; k++) {
+                    const int a = isrc0 + 2 * k, b = a + 1;
+                    const int na = c->cent_ofs[a + 1] - c->cent_ofs[a], nb = c->cent_ofs[b + 1] - c->cent_ofs[b];
+                    mt[k] = (na > 0 && na == nb && c->struct_hash[a] == c->struct_hash[b]) ? 1 : 0;
+                    any = any || mt[k];
+                }
+                duo = any;
+                if (duo) {
+                    c->mate_d.ensure(mt.size(), &c->dev_bytes);
+                    HIPCHECK(hipMemcpyAsync(c->mate_d.p, mt.data(), mt.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+                    HIPCHECK(hipStreamSynchronize(c->stream));         // mt goes out of scope
+                }
+            }
             dim3 ggrid(gx, (unsigned)(ntiles * nrec));                   // source index fastest (L2 sharing)
+            dim3 dgrid((unsigned)((nsrc + 1) / 2), (unsigned)(ntiles_p * nrec));
             dim3 pgrid(gx, (unsigned)(ntiles_p * nrec));
             dim3 cgrid((unsigned)nsrc, (unsigned)(ntiles_c * nrec));
             FuseParams fp{ nullptr, nullptr, nullptr, nullptr, 0, 1.f, 0, 0, 0 };
             if (fuse) {
                 // partial sums per (source, slot): [tile][wave] of the kernel that evaluated the pair.  In cell mode two
                 // kernels with different tilings share the buffer: it is cleared and misfit_finish_kernel sums all of it
-                const int nparts = cell ? std::max(ntiles * (T / 64), ntiles_c * (Tc / 64)) : (pipe ? std::max(ntiles * (T / 64), ntiles_p * 4) : ntiles * (T / 64));
+                const int nparts = cell ? std::max(ntiles * (T / 64), ntiles_c * (Tc / 64))
+                                        : (pipe ? std::max(ntiles * (T / 64), ntiles_p * 4) : (duo ? std::max(ntiles * (T / 64), ntiles_p * 2) : ntiles * (T / 64)));
                 c->fusepart_d.ensure((size_t)nsrc * c->nmis * nparts, &c->dev_bytes);
-                if (cell || pipe) HIPCHECK(hipMemsetAsync(c->fusepart_d.p, 0, (size_t)nsrc * c->nmis * nparts * sizeof(double), c->stream));
+                if (cell || pipe || duo) HIPCHECK(hipMemsetAsync(c->fusepart_d.p, 0, (size_t)nsrc * c->nmis * nparts * sizeof(double), c->stream));
                 fp = FuseParams{ c->reft_d.p, c->tw_d.p, c->moment_d.p, c->fusepart_d.p, c->method, c->syn_factor, c->nmis, nparts, isrc0 };
                 fuse_nparts = nparts;
             }
-            fuse_T = T; fuse_tile = 4 * T; fuse_ntiles = ntiles; fuse_all = cell || pipe;
+            fuse_T = T; fuse_tile = 4 * T; fuse_ntiles = ntiles; fuse_all = cell || pipe || duo;
 #define KIWI_LAUNCH_G2(NGV, TV, FV, RV)                                                                     \
     hipLaunchKernelGGL((accumulate_grouped_kernel<NGV, TV, FV, RV>), ggrid, dim3(TV), 0, c->stream, c->G.p, c->span.p,   \
                        c->gm.pitch, c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p,          \
-                       c->syn_stride, ntiles, c->tab_d.p, runs, fp, (cell || pipe) ? c->pairflag_d.p : (const int *)nullptr, cell ? 1 : (pipe ? 2 : 0), synrow, famofs, famlist)
+                       c->syn_stride, ntiles, c->tab_d.p, runs, fp, (cell || pipe || duo) ? c->pairflag_d.p : (const int *)nullptr, cell ? 1 : (pipe ? 2 : (duo ? 3 : 0)), duo ? c->mate_d.p : (const int *)nullptr, synrow, famofs, famlist)
 #define KIWI_LAUNCH_GROUPED(NGV, TV)                                                                        \
     do { if (fuse) { if (runs) KIWI_LAUNCH_G2(NGV, TV, true, true); else KIWI_LAUNCH_G2(NGV, TV, true, false); }   \
          else      { if (runs) KIWI_LAUNCH_G2(NGV, TV, false, true); else KIWI_LAUNCH_G2(NGV, TV, false, false); } } while (0)
@@ -1052,6 +1077,15 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
             if (cell) { if (c->gm.ng == 10) KIWI_LAUNCH_CELL(10); else KIWI_LAUNCH_CELL(8); }
             // the pairs accumulate_pipe_kernel takes (pipe_pair()); the grouped kernel behind it returns at once for those
             if (pipe) { if (c->gm.ng == 10) KIWI_LAUNCH_PIPE(10); else KIWI_LAUNCH_PIPE(8); }
+#define KIWI_LAUNCH_D2(NGV, FV)                                                                             \
+    hipLaunchKernelGGL((accumulate_duo_kernel<NGV, FV>), dgrid, dim3(256), 0, c->stream, c->G.p, c->span.p,           \
+                       c->gm.pitch, c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p,          \
+                       c->syn_stride, ntiles_p, c->tab_d.p, fp, c->pairflag_d.p, c->mate_d.p)
+            if (duo) {
+                if (c->gm.ng == 10) { if (fuse) KIWI_LAUNCH_D2(10, true); else KIWI_LAUNCH_D2(10, false); }
+                else                { if (fuse) KIWI_LAUNCH_D2(8, true); else KIWI_LAUNCH_D2(8, false); }
+            }
+#undef KIWI_LAUNCH_D2
             if (c->gm.ng == 10) {
                 if (T == 64) KIWI_LAUNCH_GROUPED(10, 64); else if (T == 256) KIWI_LAUNCH_GROUPED(10, 256); else KIWI_LAUNCH_GROUPED(10, 128);
             } else {
@@ -1225,6 +1259,7 @@ int kiwi_hip_init(int device, kiwi_hip_ctx **out)
         if (const char *m = std::getenv("KIWI_HIP_ACCUM")) c->accum_mode = (std::strcmp(m, "direct") == 0) ? 1 : 0;
         if (const char *m = std::getenv("KIWI_HIP_FUSE")) c->fuse_enabled = std::atoi(m);
         if (const char *m = std::getenv("KIWI_HIP_PIPE")) c->pipe = std::atoi(m) != 0;
+        if (const char *m = std::getenv("KIWI_HIP_DUO")) c->duo = std::atoi(m) != 0;
         if (const char *m = std::getenv("KIWI_HIP_CELL")) c->cell_mode = std::atoi(m) ? 1 : 0;
         if (const char *m = std::getenv("KIWI_HIP_DEDUPE")) c->dedupe_enabled = std::atoi(m);      // 0 off, 1 default, 2 also for point sources
         if (const char *m = std::getenv("KIWI_HIP_FUSED_FFT")) c->fused_fft = std::atoi(m) != 0;   // 0: amplitude spectra through hipFFT
@@ -1611,6 +1646,7 @@ int kiwi_hip_set_sources(kiwi_hip_ctx *c, int nsrc, const int *cent_ofs, const f
     if (2 * fold_halfwidth(maxrise, c->gm.dt) + 1 > kMaxFold) throw std::runtime_error("rise time too long for the fold kernel");
     c->cent_ofs.assign(cent_ofs, cent_ofs + nsrc + 1);
     c->geo_hash.assign((size_t)nsrc, 0ull);
+    c->struct_hash.assign((size_t)nsrc, 0ull);
     c->single_group.assign((size_t)nsrc, 0);
     {
         const float dt = c->gm.dt;
@@ -1619,12 +1655,19 @@ int kiwi_hip_set_sources(kiwi_hip_ctx *c, int nsrc, const int *cent_ofs, const f
             const float *ce = cent + (size_t)cent_ofs[s] * 10;
             const int nc = cent_ofs[s + 1] - cent_ofs[s];
             unsigned long long h = 1469598103934665603ull ^ (unsigned long long)nc;        // FNV-1a over the bit patterns of (north, east, depth, time)
+            unsigned long long hs = 1469598103934665603ull ^ (unsigned long long)nc;       // ... over what decides the centroid groups (group_len)
             bool one = nc >= 1 && nc <= kMaxGroup;
             int smin = 0, smax = 0;
             for (int k = 0; k < nc; k++) {
                 unsigned int w[4];
                 std::memcpy(w, ce + (size_t)k * 10, sizeof(w));
                 for (int q = 0; q < 4; q++) { h ^= w[q]; h *= 1099511628211ull; }
+                {
+                    const float *p = ce + (size_t)k * 10, *q = p - 10;
+                    const unsigned same = (k > 0 && p[0] == q[0] && p[1] == q[1] && p[2] == q[2]) ? 1u : 0u;
+                    const unsigned sh = (unsigned)(int)std::floor(p[3] / dt);             // as geometry_kernel: floorf(time / dt) in fp32
+                    hs ^= same; hs *= 1099511628211ull; hs ^= sh; hs *= 1099511628211ull;
+                }
                 if (one) {
                     const float *p = ce + (size_t)k * 10;
                     if (!(p[0] == ce[0] && p[1] == ce[1] && p[2] == ce[2])) one = false;
@@ -1634,6 +1677,7 @@ int kiwi_hip_set_sources(kiwi_hip_ctx *c, int nsrc, const int *cent_ofs, const f
                 }
             }
             c->geo_hash[s] = h;
+            c->struct_hash[s] = hs;
             c->single_group[s] = one ? 1 : 0;
         }
         // identical tables (hash over all ten columns, confirmed by comparison)

@@ -543,6 +543,14 @@ __device__ __forceinline__ bool pipe_pair(const RecvDev &rv, const int *__restri
     return rv.need_h && rv.has_d && pairflag[(size_t)s * nrec + r] == 0;
 }
 
+// (pairs accumulate_duo_kernel takes; the same rule as duo_pair() further down)
+__device__ __forceinline__ bool duo_pair_fwd(const RecvDev &rv, const int *__restrict__ pairflag, const int *__restrict__ mate,
+                                             int s, int nrec, int r)
+{
+    const int a = s & ~1;
+    return mate[a >> 1] && rv.need_h && rv.has_d && (pairflag[(size_t)a * nrec + r] | pairflag[(size_t)(a + 1) * nrec + r]) == 0;
+}
+
 __global__ __launch_bounds__(256) void cellgroup_kernel(const int *__restrict__ cent_ofs, EvalParams ep, GfMeta gm,
                                                         const int2 *__restrict__ span, const RecvDev *__restrict__ recv,
                                                         GeoRec *__restrict__ recs, int *__restrict__ tab,
@@ -1194,6 +1202,9 @@ __device__ __forceinline__ double wave_reduce_f64(double v, bool is_max)
     return v;
 }
 
+#ifndef KIWI_X_COEFIDX
+#define KIWI_X_COEFIDX(x) (x)
+#endif
 #ifndef KIWI_GROUPED_WAVES
 #define KIWI_GROUPED_WAVES 3
 #endif
@@ -1296,11 +1307,60 @@ __device__ __forceinline__ void set2_dead_8(const Set2_8 &S)
 template <int I> __device__ __forceinline__ f2v &s2a(const Set2_8 &s) { if constexpr (I == 0) return s.a0; else if constexpr (I == 1) return s.a1; else if constexpr (I == 2) return s.a2; else if constexpr (I == 3) return s.a3; else if constexpr (I == 4) return s.a4; else if constexpr (I == 5) return s.a5; else if constexpr (I == 6) return s.a6; else return s.a7; }
 template <int I> __device__ __forceinline__ f2v &s2b(const Set2_8 &s) { if constexpr (I == 0) return s.b0; else if constexpr (I == 1) return s.b1; else if constexpr (I == 2) return s.b2; else if constexpr (I == 3) return s.b3; else if constexpr (I == 4) return s.b4; else if constexpr (I == 5) return s.b5; else if constexpr (I == 6) return s.b6; else return s.b7; }
 
+// ---- the same for a component stride of 9 x 64 dwords (512-sample tiles of accumulate_duo_kernel)
+__device__ __forceinline__ void set2_read_10_k9(int on, unsigned a, const Set2_10 &S)
+{
+    asm volatile("s_cmp_eq_u32 %21, 0\n\ts_cbranch_scc1 .Lkiwi_skip%=\n\t"
+                 "ds_read2st64_b32 %0, %20 offset1:1\n\t"
+                 "ds_read2st64_b32 %1, %20 offset0:9 offset1:10\n\t"
+                 "ds_read2st64_b32 %2, %20 offset0:18 offset1:19\n\t"
+                 "ds_read2st64_b32 %3, %20 offset0:72 offset1:73\n\t"
+                 "ds_read2st64_b32 %4, %20 offset0:27 offset1:28\n\t"
+                 "ds_read2st64_b32 %5, %20 offset0:36 offset1:37\n\t"
+                 "ds_read2st64_b32 %6, %20 offset0:45 offset1:46\n\t"
+                 "ds_read2st64_b32 %7, %20 offset0:54 offset1:55\n\t"
+                 "ds_read2st64_b32 %8, %20 offset0:63 offset1:64\n\t"
+                 "ds_read2st64_b32 %9, %20 offset0:81 offset1:82\n\t"
+                 "ds_read2st64_b32 %10, %20 offset0:2 offset1:3\n\t"
+                 "ds_read2st64_b32 %11, %20 offset0:11 offset1:12\n\t"
+                 "ds_read2st64_b32 %12, %20 offset0:20 offset1:21\n\t"
+                 "ds_read2st64_b32 %13, %20 offset0:74 offset1:75\n\t"
+                 "ds_read2st64_b32 %14, %20 offset0:29 offset1:30\n\t"
+                 "ds_read2st64_b32 %15, %20 offset0:38 offset1:39\n\t"
+                 "ds_read2st64_b32 %16, %20 offset0:47 offset1:48\n\t"
+                 "ds_read2st64_b32 %17, %20 offset0:56 offset1:57\n\t"
+                 "ds_read2st64_b32 %18, %20 offset0:65 offset1:66\n\t"
+                 "ds_read2st64_b32 %19, %20 offset0:83 offset1:84\n\t"
+                 "\n.Lkiwi_skip%=:"
+                 : "+v"(S.a0), "+v"(S.a1), "+v"(S.a2), "+v"(S.a3), "+v"(S.a4), "+v"(S.a5), "+v"(S.a6), "+v"(S.a7), "+v"(S.a8), "+v"(S.a9), "+v"(S.b0), "+v"(S.b1), "+v"(S.b2), "+v"(S.b3), "+v"(S.b4), "+v"(S.b5), "+v"(S.b6), "+v"(S.b7), "+v"(S.b8), "+v"(S.b9) : "v"(a), "s"(on) : "memory", "scc");
+}
+__device__ __forceinline__ void set2_read_8_k9(int on, unsigned a, const Set2_8 &S)
+{
+    asm volatile("s_cmp_eq_u32 %17, 0\n\ts_cbranch_scc1 .Lkiwi_skip%=\n\t"
+                 "ds_read2st64_b32 %0, %16 offset1:1\n\t"
+                 "ds_read2st64_b32 %1, %16 offset0:9 offset1:10\n\t"
+                 "ds_read2st64_b32 %2, %16 offset0:18 offset1:19\n\t"
+                 "ds_read2st64_b32 %3, %16 offset0:27 offset1:28\n\t"
+                 "ds_read2st64_b32 %4, %16 offset0:36 offset1:37\n\t"
+                 "ds_read2st64_b32 %5, %16 offset0:45 offset1:46\n\t"
+                 "ds_read2st64_b32 %6, %16 offset0:54 offset1:55\n\t"
+                 "ds_read2st64_b32 %7, %16 offset0:63 offset1:64\n\t"
+                 "ds_read2st64_b32 %8, %16 offset0:2 offset1:3\n\t"
+                 "ds_read2st64_b32 %9, %16 offset0:11 offset1:12\n\t"
+                 "ds_read2st64_b32 %10, %16 offset0:20 offset1:21\n\t"
+                 "ds_read2st64_b32 %11, %16 offset0:29 offset1:30\n\t"
+                 "ds_read2st64_b32 %12, %16 offset0:38 offset1:39\n\t"
+                 "ds_read2st64_b32 %13, %16 offset0:47 offset1:48\n\t"
+                 "ds_read2st64_b32 %14, %16 offset0:56 offset1:57\n\t"
+                 "ds_read2st64_b32 %15, %16 offset0:65 offset1:66\n\t"
+                 "\n.Lkiwi_skip%=:"
+                 : "+v"(S.a0), "+v"(S.a1), "+v"(S.a2), "+v"(S.a3), "+v"(S.a4), "+v"(S.a5), "+v"(S.a6), "+v"(S.a7), "+v"(S.b0), "+v"(S.b1), "+v"(S.b2), "+v"(S.b3), "+v"(S.b4), "+v"(S.b5), "+v"(S.b6), "+v"(S.b7) : "v"(a), "s"(on) : "memory", "scc");
+}
 template <int NG> struct Set2Sel;
 template <> struct Set2Sel<10> { typedef Set2_10 type; };
 template <> struct Set2Sel<8> { typedef Set2_8 type; };
-__device__ __forceinline__ void set2_read(int on, unsigned a, const Set2_10 &S) { set2_read_10(on, a, S); }
-__device__ __forceinline__ void set2_read(int on, unsigned a, const Set2_8 &S) { set2_read_8(on, a, S); }
+template <int K> __device__ __forceinline__ void set2_read(int on, unsigned a, const Set2_10 &S) { if constexpr (K == 17) set2_read_10(on, a, S); else set2_read_10_k9(on, a, S); }
+template <int K> __device__ __forceinline__ void set2_read(int on, unsigned a, const Set2_8 &S) { if constexpr (K == 17) set2_read_8(on, a, S); else set2_read_8_k9(on, a, S); }
 __device__ __forceinline__ void set2_wait(const Set2_10 &S) { set2_wait_10(S); }
 __device__ __forceinline__ void set2_wait(const Set2_8 &S) { set2_wait_8(S); }
 __device__ __forceinline__ void set2_dep(const Set2_10 &S) { set2_dep_10(S); }
@@ -1316,7 +1376,7 @@ template <int N, int I = 0, class F> __device__ __forceinline__ void static_for(
 // All GF components of one centroid from the register sets L (b[j-1]) and H (b[j]), reference order (centroid_apply_hd's
 // operations); a: LDS byte address of b[j-1] of the lane's first output in component 0; coef: the centroid's coefficient line
 // (wave-uniform pointer: scalar loads, SGPR operands of the packed multiplies).
-template <int NG, bool ROT>
+template <int NG, bool ROT, int K = 17>
 __device__ __forceinline__ void carry2_apply(f2v (&ar1)[2], f2v (&ar2)[2], f2v (&dz)[2], const typename Set2Sel<NG>::type &L,
                                              const typename Set2Sel<NG>::type &H, unsigned a, int load_lo, int load_hi,
                                              const float *__restrict__ coef, float cl, float sl)
@@ -1325,8 +1385,9 @@ __device__ __forceinline__ void carry2_apply(f2v (&ar1)[2], f2v (&ar2)[2], f2v (
     float cw[2 * NG];
 #pragma unroll
     for (int i = 0; i < 2 * NG; i++) cw[i] = coef[i];
-    set2_read(load_hi, a + 4, H);
-    set2_read(load_lo, a, L);
+    static_assert(K == 17 || K == 9, "component stride in units of 64 dwords");
+    set2_read<K>(load_hi, a + 4, H);
+    set2_read<K>(load_lo, a, L);
     set2_wait(H);
     set2_dep(L);
     f2v t1[2], t2[2];
@@ -1374,7 +1435,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_GROUPED_
     const RecvDev *__restrict__ recv, float *__restrict__ syn, size_t syn_stride, int ntiles,
     const int *__restrict__ tab, const int *__restrict__ run_first, FuseParams fp,
     const int *__restrict__ pairflag /* see geometry_kernel */,
-    int pairsel /* 0 all pairs, 1 not the cell kernel's, 2 not the pipe kernel's */,
+    int pairsel /* 0 all pairs, 1 not the cell kernel's, 2 not the pipe kernel's, 3 not the duo kernel's */,
+    const int *__restrict__ mate /* pairsel 3: see duo_pair() */,
     const int *__restrict__ synrow /* optional: sources that share another source's synthetics are not synthesised */,
     const int *__restrict__ fam_ofs, const int *__restrict__ fam_list /* FUSE with synrow: the sources that share source s's
                                           synthetics, fam_list[fam_ofs[s] .. fam_ofs[s + 1]): compared here with their moments */)
@@ -1403,6 +1465,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_GROUPED_
     if (tile * TILE >= rv.wlen) return;
     if (pairsel == 1 && cell_pair(rv, pairflag, s, nrec, r)) return;
     if (pairsel == 2 && pipe_pair(rv, pairflag, s, nrec, r)) return;
+    if (pairsel == 3 && duo_pair_fwd(rv, pairflag, mate, s, nrec, r)) return;
     if (synrow && !multi && synrow[s] != s) return;  // (in a run the sources that share synthetics are left out one by one)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1573,7 +1636,13 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_GROUPED_
 #define HALO_FINISH() do { _Pragma("unroll") for (int it = 0; it < kHaloIter; it++) { \
                 if (direct) halo_finish<false>(hact[it], hr[it], tile0, LDS_TILE, hig[it], hph[it], g0); \
                 else        halo_finish<true>(hact[it], hr[it], tile0, LDS_TILE, hig[it], hph[it], g0); } } while (0)
+#ifdef KIWI_X_NOBUILD
+            if (false) {
+#elif defined(KIWI_X_HALFBUILD)
+            if (!((c / 5) & 1)) { } else if (need_h && has_d) {
+#else
             if (need_h && has_d) {
+#endif
                 // streamed: NG / 2 sub-batches of two components, two in flight (see pair_issue)
                 constexpr int NP = NG / 2;
 #define STREAM(BL, FA) do { \
@@ -1592,11 +1661,19 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_GROUPED_
                 else      { if (direct) STREAM(false, false); else STREAM(true, false); }
 #undef STREAM
                 HALO_FINISH();
+#ifdef KIWI_X_NOBUILD
+            } else if (false) {
+#else
             } else if (need_h) {
+#endif
                 HALO_ISSUE();
                 if constexpr (NG == 10) BUILD_B(igH10, 4 * tid); else BUILD_B(igH8, 4 * tid);
                 HALO_FINISH();
+#ifdef KIWI_X_NOBUILD
+            } else if (false) {
+#else
             } else {
+#endif
                 HALO_ISSUE();
                 if constexpr (NG == 10) BUILD_B(igD10, 4 * tid); else BUILD_B(igD8, 4 * tid);
                 HALO_FINISH();
@@ -1610,6 +1687,9 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_GROUPED_
         __syncthreads();
 #ifdef KIWI_X_PRIO_APPLY
         __builtin_amdgcn_s_setprio(KIWI_X_PRIO_APPLY);
+#endif
+#ifdef KIWI_X_NOAPPLY
+        if (kCarry && carry_grp) { cur = cur_next; } else
 #endif
         if (kCarry && carry_grp) {
             // ---- apply with carried register sets: the two sets swap roles at EVERY centroid (pairs of centroids, roles
@@ -1626,7 +1706,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_GROUPED_
                 const int e = smax - __builtin_amdgcn_readlane(ishv, (CC) - c);      /* LDS position of b[j-1] of the tile's first sample */ \
                 const int d = have ? eprev - e : 0x7fff; \
                 carry2_apply<NG, RV>(ar1, ar2, dz, LL, HH, abase + 4u * (unsigned)e, __builtin_amdgcn_readfirstlane((int)KIWI_X_FULL(d != -1)), \
-                                     __builtin_amdgcn_readfirstlane((int)KIWI_X_FULL(d != 1)), coef_grp + (size_t)((CC) - c) * 128, gcl, gsl); \
+                                     __builtin_amdgcn_readfirstlane((int)KIWI_X_FULL(d != 1)), coef_grp + (size_t)KIWI_X_COEFIDX((CC) - c) * 128, gcl, gsl); \
                 have = true; eprev = e; } while (0)
             // (nothing is carried into a group, its first centroid reads both sets: set2_dead tells the register allocator so)
             if (g0.flags & 2) {
@@ -1964,9 +2044,240 @@ __device__ __forceinline__ void pass_apply(f2v &ar1, f2v &ar2, f2v &dz, const Pa
     }
 }
 
-#ifndef KIWI_X_COEFIDX
-#define KIWI_X_COEFIDX(x) (x)
-#endif
+// Build of accumulate_duo_kernel: wave w blends components 2 i + (w >> 1) for the 64 chunks of slab w & 1 (chunk = 4 samples;
+// the 128 main chunks of the 512-sample tile), threads 0 .. 16 NG - 1 the halo chunks; every chunk's four node rows are loaded
+// once and blended with the weights of gw0 into tile set 0 (W0) and with those of gw1 into tile set 1 (W1)
+// (gfdb.f90:946-949, summed in this order).  A centroid exactly on a node carries the weights (1, 0, 0, 0) over four copies of
+// its row: 1 v + 0 v + 0 v + 0 v is v bit for bit, so there is no unblended variant.
+template <int NG, bool FAST, bool W0, bool W1>
+__device__ __forceinline__ void duo_build(float *__restrict__ tile0, int wv, int lane, int tid, int jb, const float *__restrict__ G,
+                                          int pitch, int ta, int tb, const GeoRec &gw0, const GeoRec &gw1, bool hact, int hig, int hph)
+{
+    constexpr int LDS_TILE = 512 + kHalo, N = NG / 2, DEPTH = 3;
+    const int p = 4 * (64 * (wv & 1) + lane), cg = wv >> 1;
+    float *__restrict__ tile1 = tile0 + NG * LDS_TILE;
+    f4u v[N][4];
+    HaloRegs hv = halo_issue<true, FAST>(true, hig, hph, jb, G, pitch, ta, tb);        // (inactive lanes load a valid chunk too: no merge of registers)
+#pragma unroll
+    for (int i = 0; i < DEPTH && i < N; i++) one_issue<true, FAST>(v[i], 2 * i + cg, p, jb, G, pitch, ta, tb);
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (W0) one_finish<true>(v[i], tile0, LDS_TILE, 2 * i + cg, p, gw0);
+        if (W1) one_finish<true>(v[i], tile1, LDS_TILE, 2 * i + cg, p, gw1);
+        if (i + DEPTH < N) one_issue<true, FAST>(v[i + DEPTH], 2 * (i + DEPTH) + cg, p, jb, G, pitch, ta, tb);
+    }
+    if (W0) halo_finish<true>(hact, hv, tile0, LDS_TILE, hig, hph, gw0);
+    if (W1) halo_finish<true>(hact, hv, tile1, LDS_TILE, hig, hph, gw1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// accumulate, two trial sources per workgroup (round 3)
+//
+// Measured on accumulate_grouped_kernel (cfg3, 1024 sources per launch): build phase alone 22.8 ms, apply phase alone
+// 22.7 ms, together 38.6 ms -- and the build alone moves 713 GB from the L2s to the CUs (40 node rows of 1088 samples per
+// group and workgroup) in those 22.8 ms: 31 TB/s of the ~34.5 TB/s the L2s deliver.  The build is bound by L2 bandwidth,
+// the apply by vector issue, and a workgroup alternates between the two.  What shrinks the first: NEIGHBOURING trial sources
+// of a grid search put their sub-faults into the same cells of the Green's function grid (a strike step of 0.1 degree moves a
+// sub-fault by metres, the nodes are kilometres apart): the 40 node rows a group needs are the same for both, only the
+// four blend weights differ.  This kernel gives a workgroup the same (receiver, 512-sample tile) of TWO consecutive trial
+// sources: every group's node rows are loaded ONCE and blended twice, into a tile set per source (2 x 23 KB of LDS); waves
+// 0-1 then apply the centroids of the first source from its tile set, waves 2-3 those of the second.  Per output sample:
+// half the L2 traffic, about half the build's instructions (addresses, descriptors and loads are shared), the apply as
+// before (carry2_apply).  Where the two sources' groups do NOT sit in the same cell the workgroup builds the two tile sets
+// one after the other.
+//
+// Pairing (host, kiwi_hip_set_sources): sources 2k and 2k+1 of a chunk whose centroid tables have the same STRUCTURE --
+// same number of centroids, same pattern of repeated points, same integer shifts -- so that both have the same groups
+// (group_len) and walk them in lockstep; `mate[k]` says so.  Of those the kernel takes the (pair, receiver) combinations
+// where both sources are "clean" for the receiver (pipe_pair(): horizontal and vertical components, no missing trace, no
+// tail rule); accumulate_grouped_kernel runs behind it for everything else (pairsel 3).
+__device__ __forceinline__ bool duo_pair(const RecvDev &rv, const int *__restrict__ pairflag, const int *__restrict__ mate,
+                                         int s, int nrec, int r)
+{
+    const int a = s & ~1;
+    return mate[a >> 1] && rv.need_h && rv.has_d && (pairflag[(size_t)a * nrec + r] | pairflag[(size_t)(a + 1) * nrec + r]) == 0;
+}
+
+template <int NG, bool FUSE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void accumulate_duo_kernel(
+    const float *__restrict__ G, const int2 *__restrict__ span, int pitch,
+    const GeoRec *__restrict__ recs, const int *__restrict__ cent_ofs, int isrc0, int nrec,
+    const RecvDev *__restrict__ recv, float *__restrict__ syn, size_t syn_stride, int ntiles,
+    const int *__restrict__ tab, FuseParams fp, const int *__restrict__ pairflag, const int *__restrict__ mate)
+{
+    constexpr int TILE = 512, LDS_TILE = TILE + kHalo, K = LDS_TILE / 64;
+    static_assert(K == 9, "component stride of set2_read_*_k9");
+    __shared__ __attribute__((aligned(16))) float tiles[2][NG][LDS_TILE];
+    const int s0 = 2 * (int)blockIdx.x;                  // the pair: chunk-local sources s0, s0 + 1
+    const int tile = blockIdx.y % ntiles, r = blockIdx.y / ntiles;
+    const RecvDev &rv = recv[r];
+    if (!rv.enabled) return;
+    if (tile * TILE >= rv.wlen) return;
+    if (!duo_pair(rv, pairflag, mate, s0, nrec, r)) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sh = wv >> 1;                              // which source this wave applies
+    const int me = s0 + sh;
+    const int t_tile0 = rv.wbeg + tile * TILE;
+    const int cb = cent_ofs[isrc0];
+    const int cA = cent_ofs[isrc0 + s0], cB = cent_ofs[isrc0 + s0 + 1], nc = cB - cA;      // (both have nc centroids)
+    const GeoRec *__restrict__ rcA = recs + ((size_t)(cA - cb) * nrec + (size_t)r * nc);
+    const GeoRec *__restrict__ rcB = recs + ((size_t)(cB - cb) * nrec + (size_t)r * nc);
+    const int *__restrict__ tcA = tab + ((size_t)(cA - cb) * nrec + (size_t)r * nc) * 128;
+    const int *__restrict__ tcB = tab + ((size_t)(cB - cb) * nrec + (size_t)r * nc) * 128;
+    const GeoRec *__restrict__ rc = sh ? rcB : rcA;      // this wave's source
+    const int *__restrict__ tc = sh ? tcB : tcA;
+    const float sd = rv.sd;
+    const int u0 = 256 * (wv & 1) + lane;                // the lane's first sample of its source's tile (the others: + 64 q)
+
+    f2v ar1[2] = { { 0.f, 0.f }, { 0.f, 0.f } }, ar2[2] = { { 0.f, 0.f }, { 0.f, 0.f } }, dz[2] = { { 0.f, 0.f }, { 0.f, 0.f } };
+    f2v xa0, xa1, xa2, xa3, xa4, xa5, xa6, xa7, xa8, xa9, xb0, xb1, xb2, xb3, xb4, xb5, xb6, xb7, xb8, xb9;
+    f2v ya0, ya1, ya2, ya3, ya4, ya5, ya6, ya7, ya8, ya9, yb0, yb1, yb2, yb3, yb4, yb5, yb6, yb7, yb8, yb9;
+    typedef typename Set2Sel<NG>::type SetT;
+    const SetT X = make_set2<NG>(xa0, xa1, xa2, xa3, xa4, xa5, xa6, xa7, xa8, xa9, xb0, xb1, xb2, xb3, xb4, xb5, xb6, xb7, xb8, xb9);
+    const SetT Y = make_set2<NG>(ya0, ya1, ya2, ya3, ya4, ya5, ya6, ya7, ya8, ya9, yb0, yb1, yb2, yb3, yb4, yb5, yb6, yb7, yb8, yb9);
+
+    // head records and load descriptors of the group starting at c, of BOTH sources, lane-distributed
+    int c = 0;
+    int curA = rec_load(rcA, 0, nc, lane), curB = rec_load(rcB, 0, nc, lane);
+    int taA = tcA[lane], tbA = tcA[64 + lane], taB = tcB[lane], tbB = tcB[64 + lane];
+    // halo: one lane per (component, 4-sample chunk)
+    const int hslot = tid >> 4, hig = min(hslot, NG - 1), hph = TILE + 4 * (tid & 15);
+    while (c < nc) {
+        GeoRec gA, gB;
+        rec_head(curA, 0, gA);
+        rec_head(curB, 0, gB);
+        const int glen = gA.pad & 0xff;                  // (same structure: equal for both)
+        const int cend = c + glen;
+        const int smax = gA.ishift + ((gA.pad >> 8) & 0xff), smin = gA.ishift - ((gA.pad >> 16) & 0xff);
+        const int jb = t_tile0 - smax - 1;               // LDS position p holds blended trace sample jb + p
+        const int npos = TILE + (smax - smin) + 8;
+        const bool hact = hslot < NG && hph < npos;
+        // this wave's source: what its apply needs
+        const int flags = sh ? gB.flags : gA.flags;
+        const float gcl = sh ? REC_F(curB, 16) : REC_F(curA, 16), gsl = sh ? REC_F(curB, 17) : REC_F(curA, 17);
+        const int jmin_me = sh ? min(REC_I(taB, 50), REC_I(taB, 51)) : min(REC_I(taA, 50), REC_I(taA, 51));
+        const bool carry_grp = !((jb + (smax - smin) + TILE) > jmin_me);      // (clean pairs: no tail rule -> always)
+        int ishv = 0;
+        if (lane < glen) ishv = rc[c + lane].ishift;
+        // ---- build: the node rows of the cell once, blended for both sources -- if both sit in the same cell
+        const bool shared = gA.row[0] == gB.row[0] && gA.row[1] == gB.row[1] && gA.row[2] == gB.row[2] && gA.row[3] == gB.row[3];
+#define KIWI_DUO_BUILD(TA, TB, GR, W0, W1, WR0, WR1) do { \
+            const float *__restrict__ Gg = G + (size_t)(GR).row[0] * (size_t)pitch; \
+            const bool lane_ok = lane >= 4 * NG || ((TA) + jb >= (TB) && (TA) + jb + LDS_TILE <= (TB) + pitch); \
+            const bool fast = __builtin_amdgcn_ballot_w64(lane_ok) == ~0ull; \
+            if (fast) duo_build<NG, true, WR0, WR1>(&tiles[0][0][0], wv, lane, tid, jb, Gg, pitch, TA, TB, W0, W1, hact, hig, hph); \
+            else      duo_build<NG, false, WR0, WR1>(&tiles[0][0][0], wv, lane, tid, jb, Gg, pitch, TA, TB, W0, W1, hact, hig, hph); } while (0)
+        if (shared) KIWI_DUO_BUILD(taA, tbA, gA, gA, gB, true, true);
+        else { KIWI_DUO_BUILD(taA, tbA, gA, gA, gA, true, false); KIWI_DUO_BUILD(taB, tbB, gB, gB, gB, false, true); }
+#undef KIWI_DUO_BUILD
+        // head records and descriptors of the NEXT group: in flight while this group is applied
+        curA = rec_load(rcA, cend, nc, lane); curB = rec_load(rcB, cend, nc, lane);
+        if (cend < nc) {
+            taA = tcA[(size_t)cend * 128 + lane]; tbA = tcA[(size_t)cend * 128 + 64 + lane];
+            taB = tcB[(size_t)cend * 128 + lane]; tbB = tcB[(size_t)cend * 128 + 64 + lane];
+        }
+        __syncthreads();
+        // ---- apply: this wave's source from its tile set
+        {
+            const size_t crow = ((size_t)((sh ? cB : cA) - cb) * nrec + (size_t)r * nc + c) * 128 + 64 + 40;
+            const unsigned clo = __builtin_amdgcn_readfirstlane((unsigned)crow), chi = __builtin_amdgcn_readfirstlane((unsigned)(crow >> 32));
+            const float *__restrict__ coef_grp = (const float *)(tab + (((size_t)chi << 32) | clo));
+            const unsigned abase = (unsigned)(size_t)(lds_cfp)&tiles[sh][0][u0];
+            int cc = c, eprev = 0;
+            bool have = false;
+            if (carry_grp) {
+#define KIWI_C2STEP(LL, HH, RV, CC) do { \
+                    const int e = smax - __builtin_amdgcn_readlane(ishv, (CC) - c); \
+                    const int d = have ? eprev - e : 0x7fff; \
+                    carry2_apply<NG, RV, K>(ar1, ar2, dz, LL, HH, abase + 4u * (unsigned)e, __builtin_amdgcn_readfirstlane((int)KIWI_X_FULL(d != -1)), \
+                                            __builtin_amdgcn_readfirstlane((int)KIWI_X_FULL(d != 1)), coef_grp + (size_t)((CC) - c) * 128, gcl, gsl); \
+                    have = true; eprev = e; } while (0)
+                if (flags & 2) {
+                    set2_dead(X); set2_dead(Y);
+                    for (; cc + 1 < cend; cc += 2) { KIWI_C2STEP(X, Y, true, cc); KIWI_C2STEP(Y, X, true, cc + 1); }
+                    if (cc < cend) KIWI_C2STEP(X, Y, true, cc);
+                } else {
+                    set2_dead(X); set2_dead(Y);
+                    for (; cc + 1 < cend; cc += 2) { KIWI_C2STEP(X, Y, false, cc); KIWI_C2STEP(Y, X, false, cc + 1); }
+                    if (cc < cend) KIWI_C2STEP(X, Y, false, cc);
+                }
+#undef KIWI_C2STEP
+            } else {
+                // (not reached for the pairs duo_pair() admits; kept so that a change of that rule cannot silently drop a tail)
+                int jend[NG];
+#pragma unroll
+                for (int ig = 0; ig < NG; ig++) jend[ig] = tc[(size_t)c * 128 + 40 + ig];
+                for (; cc < cend; cc++) {
+                    const GeoRec *__restrict__ rr = rc + cc;
+                    const int e = smax - rr->ishift;
+                    const TileBase chunk0 = tile_base(&tiles[sh][0][e + u0]);
+                    const int jl = jb + e + u0;
+                    const bool tail = (jb + e + TILE) > jmin_me;
+                    if (!tail) centroid_apply<NG, LDS_TILE, false, 2>(ar1, ar2, dz, chunk0, jl, jend, true, true, flags, rr->wfrac, sd,
+                                                                      rr->f[0], rr->f[1], rr->f[2], rr->f[3], rr->f[4], rr->f[5], gcl, gsl);
+                    else       centroid_apply<NG, LDS_TILE, true, 2>(ar1, ar2, dz, chunk0, jl, jend, true, true, flags, rr->wfrac, sd,
+                                                                     rr->f[0], rr->f[1], rr->f[2], rr->f[3], rr->f[4], rr->f[5], gcl, gsl);
+                }
+            }
+        }
+        __syncthreads();                                 // tiles are rebuilt by the next group
+        c = cend;
+    }
+    // ---- rotation to N/E, signs and store (or fused comparison) of this wave's source (seismogram.f90:256-283)
+    {
+        const int js = me;
+        const int tl = tile * TILE + u0;                 // window sample of the lane's output q = 0; q-th: + 64 q
+        if (!FUSE && tl >= rv.wlen) return;
+        float *__restrict__ so = syn + (size_t)js * syn_stride + tl;
+        const float a1[4] = { ar1[0].x, ar1[0].y, ar1[1].x, ar1[1].y }, a2[4] = { ar2[0].x, ar2[0].y, ar2[1].x, ar2[1].y },
+                    ad[4] = { dz[0].x, dz[0].y, dz[1].x, dz[1].y };
+        float mom = 0.f;
+        if constexpr (FUSE) mom = fp.moment[fp.isrc0 + js];
+        const bool unit = (fp.syn_factor == 1.f);
+        for (int k = 0; k < rv.ncomp; k++) {
+            const float sg = rv.sign[k];
+            float o[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                switch (rv.comp[k]) {
+                case 1: o[i] = a1[i] * sg; break;
+                case 2: o[i] = a2[i] * sg; break;
+                case 3: o[i] = ad[i]; break;
+                case 4: o[i] = (rv.cl0 * a1[i] - rv.sl0 * a2[i]) * sg; break;
+                default: o[i] = (rv.cl0 * a2[i] + rv.sl0 * a1[i]) * sg; break;
+                }
+            }
+            if constexpr (!FUSE) {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (tl + 64 * i < rv.wlen) so[rv.synofs[k] + 64 * i] = o[i];
+                continue;
+            }
+            double acc = 0.0;
+            const float *__restrict__ rt = fp.reft + rv.refofs[k] + tl, *__restrict__ tp = fp.tw + rv.refofs[k] + tl;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (tl + 64 * i >= rv.wlen) break;
+                const float v = o[i] * mom;
+                const float vt = v * tp[64 * i];
+                const float a = rt[64 * i];
+                switch (fp.method) {
+                case 1: { const float d = unit ? (a - vt) : (1.f * a - fp.syn_factor * vt); acc = sq_acc(acc, d); break; }
+                case 2: { const float d = unit ? fabsf(a - vt) : fabsf(1.f * a - fp.syn_factor * vt); acc += (double)d; break; }
+                case 5: acc += unit ? (double)(a * vt) : (double)(a * 1.f * vt * fp.syn_factor); break;
+                default: { const double x = (double)(1.f * a), y = (double)(fp.syn_factor * vt); acc = fmax(acc, sqrt(x * x + y * y)); break; }
+                }
+            }
+            acc = wave_reduce_f64(acc, fp.method == 6);                 // total in lane 63
+            if (lane == 63)
+                fp.partial[((size_t)js * fp.nmis + rv.slot0 + k) * fp.nparts + tile * 2 + (wv & 1)] = acc;
+        }
+    }
+}
+
 #ifndef KIWI_PIPE_WAVES
 #define KIWI_PIPE_WAVES 3
 #endif
