@@ -144,7 +144,7 @@ struct kiwi_hip_ctx {
     DevBuf<int> synrow_d, famofs_d, famlist_d;
     int dedupe_enabled = 1;           // env KIWI_HIP_DEDUPE=0 switches it off
     std::vector<unsigned long long> geo_hash;
-    std::vector<unsigned long long> struct_hash;   // per source: number of centroids, pattern of repeated points, integer shifts (accumulate_duo_kernel's pairing)
+    std::vector<unsigned long long> struct_hash;   // per source: number of centroids and boundaries of its centroid groups (accumulate_duo_kernel's pairing)
     DevBuf<int> mate_d;
     int duo = 1;                      // accumulate_duo_kernel for pairs of consecutive sources of equal structure; env KIWI_HIP_DUO=0 switches it off
     std::vector<char> single_group;
@@ -172,8 +172,6 @@ struct kiwi_hip_ctx {
     int group_threads_env = 0;
     int group_threads = 128;          // workgroup size of the grouped kernel (tile = 4x); env KIWI_HIP_GROUP_THREADS
     int accum_mode = 0;               // 0 grouped (LDS-staged), 1 direct; env KIWI_HIP_ACCUM
-    int pipe = 0;                     // accumulate_pipe_kernel (loads of the next group under the arithmetic of the present one, register
-                                      // pairs carried between time steps) for the pairs it takes; env KIWI_HIP_PIPE=0: accumulate_grouped_kernel only
     // cell groups (accumulate_cell_kernel: raw node traces fetched once per run of centroids in the same GF cell):
     // -1 decided per batch -- sources whose centroids are mostly different points --, 0 off, 1 on; env KIWI_HIP_CELL
     int cell_mode = -1;
@@ -934,10 +932,8 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
     // cell groups pay where most centroids are points of their own (no blended tile to share between time steps)
     // (with nearest-neighbour interpolation there is nothing to blend: same-point groups do)
     const bool cell = c->accum_mode == 0 && (c->cell_mode == 1 || (c->cell_mode < 0 && c->bilinear && c->points_per_centroid > 0.5));
-    // pipelined kernel: tiles of 512 samples; windows shorter than 384 samples stay with the 256-sample tiles of the grouped kernel
-    const bool pipe = c->accum_mode == 0 && c->pipe && !cell && c->max_wlen >= 384 && !c->group_threads_env;
     // two sources per workgroup (accumulate_duo_kernel, 512-sample tiles); decided below, once the runs and the shared synthetics are known
-    const bool duo_maybe = c->accum_mode == 0 && c->duo && !pipe && !cell && c->max_wlen >= 384 && !c->group_threads_env && nsrc >= 2;
+    const bool duo_maybe = c->accum_mode == 0 && c->duo && !cell && c->max_wlen >= 384 && !c->group_threads_env && nsrc >= 2;
     EvalParams ep{ c->bilinear, c->xus, c->zus, nrec, isrc0, cell ? 1 : 0 };
     int *spansrc = nullptr;
     if (c->any_untapered || c->want_spansrc || c->fft_needed) {     // per-source strip spans, initialised empty
@@ -950,12 +946,12 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
     record(c, 0, e0);
     if (maxnc > 0) {
         dim3 grid((unsigned)((maxnc * nrec + 255) / 256), (unsigned)nsrc);
-        if (cell || pipe || duo_maybe) {
+        if (cell || duo_maybe) {
             c->pairflag_d.ensure((size_t)nsrc * nrec, &c->dev_bytes);
             HIPCHECK(hipMemsetAsync(c->pairflag_d.p, 0, (size_t)nsrc * nrec * sizeof(int), c->stream));
         }
         hipLaunchKernelGGL(geometry_kernel, grid, dim3(256), 0, c->stream, c->cent_d.p, c->centofs_d.p, ep, c->gm,
-                           c->span.p, c->recv_d.p, c->recs_d.p, tab, (int *)nullptr, spansrc, (cell || pipe || duo_maybe) ? c->pairflag_d.p : (int *)nullptr, c->endz.p, (const int *)nullptr);
+                           c->span.p, c->recv_d.p, c->recs_d.p, tab, (int *)nullptr, spansrc, (cell || duo_maybe) ? c->pairflag_d.p : (int *)nullptr, c->endz.p, (const int *)nullptr);
         if (cell)
             hipLaunchKernelGGL(cellgroup_kernel, grid, dim3(256), 0, c->stream, c->centofs_d.p, ep, c->gm, c->span.p, c->recv_d.p,
                                c->recs_d.p, tab, c->pairflag_d.p, c->endz.p, (const int *)nullptr);
@@ -987,7 +983,7 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
             // workgroup size: env override, else by window length (halo overhead vs tile fit)
             const int T = c->group_threads_env ? c->group_threads : (c->max_wlen >= 2048 ? 256 : (c->max_wlen >= 384 ? 128 : 64));
             const int ntiles = (c->max_wlen + 4 * T - 1) / (4 * T);
-            const int ntiles_p = (c->max_wlen + 511) / 512;              // accumulate_pipe_kernel: 256 threads, 512 samples
+            const int ntiles_p = (c->max_wlen + 511) / 512;              // accumulate_duo_kernel: 512 samples per source
             // cell mode: accumulate_cell_kernel (256 threads, tile = spl x 256 samples) takes the pairs of cell_pair(), the
             // grouped kernel behind it the others
             const int spl = c->cell_spl, Tc = 256;
@@ -1020,6 +1016,8 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
             }
             // pairs of consecutive sources of equal structure (see accumulate_duo_kernel)
             bool duo = duo_maybe && !runs && !synrow && maxnc > 0;
+            if (std::getenv("KIWI_HIP_DEBUG"))
+                std::fprintf(stderr, "[kiwi_hip] duo_maybe %d runs %d synrow %d cell %d max_wlen %d\n", (int)duo_maybe, runs != nullptr, synrow != nullptr, (int)cell, c->max_wlen);
             if (duo) {
                 std::vector<int> mt((size_t)(nsrc + 1) / 2, 0);
                 bool any = false;
@@ -1030,6 +1028,10 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
                     any = any || mt[k];
                 }
                 duo = any;
+                if (std::getenv("KIWI_HIP_DEBUG")) {
+                    int nm = 0; for (int v : mt) nm += v;
+                    std::fprintf(stderr, "[kiwi_hip] chunk of %d sources: %d of %d pairs of equal structure\n", nsrc, nm, (int)mt.size());
+                }
                 if (duo) {
                     c->mate_d.ensure(mt.size(), &c->dev_bytes);
                     HIPCHECK(hipMemcpyAsync(c->mate_d.p, mt.data(), mt.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
@@ -1038,34 +1040,25 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
             }
             dim3 ggrid(gx, (unsigned)(ntiles * nrec));                   // source index fastest (L2 sharing)
             dim3 dgrid((unsigned)((nsrc + 1) / 2), (unsigned)(ntiles_p * nrec));
-            dim3 pgrid(gx, (unsigned)(ntiles_p * nrec));
             dim3 cgrid((unsigned)nsrc, (unsigned)(ntiles_c * nrec));
             FuseParams fp{ nullptr, nullptr, nullptr, nullptr, 0, 1.f, 0, 0, 0 };
             if (fuse) {
                 // partial sums per (source, slot): [tile][wave] of the kernel that evaluated the pair.  In cell mode two
                 // kernels with different tilings share the buffer: it is cleared and misfit_finish_kernel sums all of it
-                const int nparts = cell ? std::max(ntiles * (T / 64), ntiles_c * (Tc / 64))
-                                        : (pipe ? std::max(ntiles * (T / 64), ntiles_p * 4) : (duo ? std::max(ntiles * (T / 64), ntiles_p * 2) : ntiles * (T / 64)));
+                const int nparts = cell ? std::max(ntiles * (T / 64), ntiles_c * (Tc / 64)) : (duo ? std::max(ntiles * (T / 64), ntiles_p * 2) : ntiles * (T / 64));
                 c->fusepart_d.ensure((size_t)nsrc * c->nmis * nparts, &c->dev_bytes);
-                if (cell || pipe || duo) HIPCHECK(hipMemsetAsync(c->fusepart_d.p, 0, (size_t)nsrc * c->nmis * nparts * sizeof(double), c->stream));
+                if (cell || duo) HIPCHECK(hipMemsetAsync(c->fusepart_d.p, 0, (size_t)nsrc * c->nmis * nparts * sizeof(double), c->stream));
                 fp = FuseParams{ c->reft_d.p, c->tw_d.p, c->moment_d.p, c->fusepart_d.p, c->method, c->syn_factor, c->nmis, nparts, isrc0 };
                 fuse_nparts = nparts;
             }
-            fuse_T = T; fuse_tile = 4 * T; fuse_ntiles = ntiles; fuse_all = cell || pipe || duo;
+            fuse_T = T; fuse_tile = 4 * T; fuse_ntiles = ntiles; fuse_all = cell || duo;
 #define KIWI_LAUNCH_G2(NGV, TV, FV, RV)                                                                     \
     hipLaunchKernelGGL((accumulate_grouped_kernel<NGV, TV, FV, RV>), ggrid, dim3(TV), 0, c->stream, c->G.p, c->span.p,   \
                        c->gm.pitch, c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p,          \
-                       c->syn_stride, ntiles, c->tab_d.p, runs, fp, (cell || pipe || duo) ? c->pairflag_d.p : (const int *)nullptr, cell ? 1 : (pipe ? 2 : (duo ? 3 : 0)), duo ? c->mate_d.p : (const int *)nullptr, synrow, famofs, famlist)
+                       c->syn_stride, ntiles, c->tab_d.p, runs, fp, (cell || duo) ? c->pairflag_d.p : (const int *)nullptr, cell ? 1 : (duo ? 3 : 0), duo ? c->mate_d.p : (const int *)nullptr, synrow, famofs, famlist)
 #define KIWI_LAUNCH_GROUPED(NGV, TV)                                                                        \
     do { if (fuse) { if (runs) KIWI_LAUNCH_G2(NGV, TV, true, true); else KIWI_LAUNCH_G2(NGV, TV, true, false); }   \
          else      { if (runs) KIWI_LAUNCH_G2(NGV, TV, false, true); else KIWI_LAUNCH_G2(NGV, TV, false, false); } } while (0)
-#define KIWI_LAUNCH_P2(NGV, FV, RV)                                                                         \
-    hipLaunchKernelGGL((accumulate_pipe_kernel<NGV, FV, RV>), pgrid, dim3(256), 0, c->stream, c->G.p, c->span.p,   \
-                       c->gm.pitch, c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p,          \
-                       c->syn_stride, ntiles_p, c->tab_d.p, runs, fp, c->pairflag_d.p, synrow, famofs, famlist)
-#define KIWI_LAUNCH_PIPE(NGV)                                                                               \
-    do { if (fuse) { if (runs) KIWI_LAUNCH_P2(NGV, true, true); else KIWI_LAUNCH_P2(NGV, true, false); }   \
-         else      { if (runs) KIWI_LAUNCH_P2(NGV, false, true); else KIWI_LAUNCH_P2(NGV, false, false); } } while (0)
 #define KIWI_LAUNCH_C3(NGV, SV, PV, FV)                                                                     \
     hipLaunchKernelGGL((accumulate_cell_kernel<NGV, 256, SV, PV, FV>), cgrid, dim3(256), 0, c->stream, c->G.p, c->span.p,   \
                        c->gm.pitch, c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p,          \
@@ -1075,12 +1068,11 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
 #define KIWI_LAUNCH_CELL(NGV) do { if (spl == 2) { if (fuse) KIWI_LAUNCH_C2(NGV, 2, true); else KIWI_LAUNCH_C2(NGV, 2, false); } \
                                    else          { if (fuse) KIWI_LAUNCH_C2(NGV, 4, true); else KIWI_LAUNCH_C2(NGV, 4, false); } } while (0)
             if (cell) { if (c->gm.ng == 10) KIWI_LAUNCH_CELL(10); else KIWI_LAUNCH_CELL(8); }
-            // the pairs accumulate_pipe_kernel takes (pipe_pair()); the grouped kernel behind it returns at once for those
-            if (pipe) { if (c->gm.ng == 10) KIWI_LAUNCH_PIPE(10); else KIWI_LAUNCH_PIPE(8); }
 #define KIWI_LAUNCH_D2(NGV, FV)                                                                             \
     hipLaunchKernelGGL((accumulate_duo_kernel<NGV, FV>), dgrid, dim3(256), 0, c->stream, c->G.p, c->span.p,           \
                        c->gm.pitch, c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p,          \
                        c->syn_stride, ntiles_p, c->tab_d.p, fp, c->pairflag_d.p, c->mate_d.p)
+            // the (pair, receiver) combinations accumulate_duo_kernel takes; the grouped kernel behind it returns at once for those
             if (duo) {
                 if (c->gm.ng == 10) { if (fuse) KIWI_LAUNCH_D2(10, true); else KIWI_LAUNCH_D2(10, false); }
                 else                { if (fuse) KIWI_LAUNCH_D2(8, true); else KIWI_LAUNCH_D2(8, false); }
@@ -1091,8 +1083,6 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
             } else {
                 if (T == 64) KIWI_LAUNCH_GROUPED(8, 64); else if (T == 256) KIWI_LAUNCH_GROUPED(8, 256); else KIWI_LAUNCH_GROUPED(8, 128);
             }
-#undef KIWI_LAUNCH_PIPE
-#undef KIWI_LAUNCH_P2
 #undef KIWI_LAUNCH_CELL
 #undef KIWI_LAUNCH_C2
 #undef KIWI_LAUNCH_C3
@@ -1258,7 +1248,6 @@ int kiwi_hip_init(int device, kiwi_hip_ctx **out)
         }
         if (const char *m = std::getenv("KIWI_HIP_ACCUM")) c->accum_mode = (std::strcmp(m, "direct") == 0) ? 1 : 0;
         if (const char *m = std::getenv("KIWI_HIP_FUSE")) c->fuse_enabled = std::atoi(m);
-        if (const char *m = std::getenv("KIWI_HIP_PIPE")) c->pipe = std::atoi(m) != 0;
         if (const char *m = std::getenv("KIWI_HIP_DUO")) c->duo = std::atoi(m) != 0;
         if (const char *m = std::getenv("KIWI_HIP_CELL")) c->cell_mode = std::atoi(m) ? 1 : 0;
         if (const char *m = std::getenv("KIWI_HIP_DEDUPE")) c->dedupe_enabled = std::atoi(m);      // 0 off, 1 default, 2 also for point sources
@@ -1662,12 +1651,7 @@ int kiwi_hip_set_sources(kiwi_hip_ctx *c, int nsrc, const int *cent_ofs, const f
                 unsigned int w[4];
                 std::memcpy(w, ce + (size_t)k * 10, sizeof(w));
                 for (int q = 0; q < 4; q++) { h ^= w[q]; h *= 1099511628211ull; }
-                {
-                    const float *p = ce + (size_t)k * 10, *q = p - 10;
-                    const unsigned same = (k > 0 && p[0] == q[0] && p[1] == q[1] && p[2] == q[2]) ? 1u : 0u;
-                    const unsigned sh = (unsigned)(int)std::floor(p[3] / dt);             // as geometry_kernel: floorf(time / dt) in fp32
-                    hs ^= same; hs *= 1099511628211ull; hs ^= sh; hs *= 1099511628211ull;
-                }
+
                 if (one) {
                     const float *p = ce + (size_t)k * 10;
                     if (!(p[0] == ce[0] && p[1] == ce[1] && p[2] == ce[2])) one = false;
@@ -1675,6 +1659,22 @@ int kiwi_hip_set_sources(kiwi_hip_ctx *c, int nsrc, const int *cent_ofs, const f
                     if (k == 0) smin = smax = sh; else { smin = std::min(smin, sh); smax = std::max(smax, sh); }
                     if (smax - smin > kHalo - 10) one = false;
                 }
+            }
+            // boundaries of the centroid groups as geometry_kernel's group_len / starts_group cut them: runs of centroids at the
+            // same point (compared with the group's FIRST centroid), integer shifts within the LDS halo, at most kMaxGroup
+            for (int k = 0; k < nc;) {
+                const float *g0 = ce + (size_t)k * 10;
+                int len = 1, lo = (int)std::floor(g0[3] / dt), hi = lo;
+                for (int q = k + 1; q < nc && len < kMaxGroup; q++) {
+                    const float *p = ce + (size_t)q * 10;
+                    if (!(p[0] == g0[0] && p[1] == g0[1] && p[2] == g0[2])) break;
+                    const int sh = (int)std::floor(p[3] / dt);
+                    const int nlo = std::min(lo, sh), nhi = std::max(hi, sh);
+                    if (nhi - nlo > kHalo - 10) break;
+                    lo = nlo; hi = nhi; len++;
+                }
+                hs ^= (unsigned)len; hs *= 1099511628211ull;
+                k += len;
             }
             c->geo_hash[s] = h;
             c->struct_hash[s] = hs;

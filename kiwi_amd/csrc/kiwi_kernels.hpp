@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void geometry_kernel(
     int *__restrict__ tab, int *__restrict__ spanbuf, int *__restrict__ spansrc /* optional [source][receiver][kSpanInts] */,
     int *__restrict__ pairflag /* optional [source][receiver]: bit 0 some centroid of the pair is added in part (a trace is missing),
                                   bit 1 some centroid is left out (a trace missing or outside the database), bit 2 some group's rows do
-                                  not all end in zero (the tail rule can apply); see cell_pair(), pipe_pair() */,
+                                  not all end in zero (the tail rule can apply); see cell_pair(), duo_pair() */,
     const unsigned char *__restrict__ endz /* per GF row: its end value is zero (write_tab) */,
     const int *__restrict__ synrow /* optional [source]: source whose synthetics this one shares; != own index: nothing to do */)
 {
@@ -533,14 +533,6 @@ __device__ __forceinline__ bool same_cell(const GeoRec *__restrict__ a, const in
 __device__ __forceinline__ bool cell_pair(const RecvDev &rv, const int *__restrict__ pairflag, int s, int nrec, int r)
 {
     return rv.need_h && rv.has_d && !(pairflag[(size_t)s * nrec + r] & 1);
-}
-
-// Which (trial source, receiver) pairs accumulate_pipe_kernel takes: receivers with horizontal AND vertical components whose
-// centroids all find all their traces (no `cycle`, geometry_kernel: pairflag bits 0 and 1) and whose rows all end in an exact
-// zero (no `factor * last` rule, bit 2).  accumulate_grouped_kernel runs behind it for the other pairs.
-__device__ __forceinline__ bool pipe_pair(const RecvDev &rv, const int *__restrict__ pairflag, int s, int nrec, int r)
-{
-    return rv.need_h && rv.has_d && pairflag[(size_t)s * nrec + r] == 0;
 }
 
 // (pairs accumulate_duo_kernel takes; the same rule as duo_pair() further down)
@@ -1027,11 +1019,7 @@ __device__ __forceinline__ TileRegsN<NP> tile_load(const TileBase &b, int ofs)
 #pragma unroll
     for (int h = 0; h < NP; h++) {
         t.lo[h] = f2v{ b.lo[ofs + 128 * h], b.lo[ofs + 128 * h + 64] };
-#ifdef KIWI_X_FAKECARRY
-        t.hi[h] = t.lo[h];
-#else
         t.hi[h] = f2v{ b.hi[ofs + 128 * h], b.hi[ofs + 128 * h + 64] };
-#endif
     }
     return t;
 }
@@ -1202,9 +1190,6 @@ __device__ __forceinline__ double wave_reduce_f64(double v, bool is_max)
     return v;
 }
 
-#ifndef KIWI_X_COEFIDX
-#define KIWI_X_COEFIDX(x) (x)
-#endif
 #ifndef KIWI_GROUPED_WAVES
 #define KIWI_GROUPED_WAVES 3
 #endif
@@ -1435,7 +1420,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_GROUPED_
     const RecvDev *__restrict__ recv, float *__restrict__ syn, size_t syn_stride, int ntiles,
     const int *__restrict__ tab, const int *__restrict__ run_first, FuseParams fp,
     const int *__restrict__ pairflag /* see geometry_kernel */,
-    int pairsel /* 0 all pairs, 1 not the cell kernel's, 2 not the pipe kernel's, 3 not the duo kernel's */,
+    int pairsel /* 0 all pairs, 1 not the cell kernel's, 3 not the duo kernel's */,
     const int *__restrict__ mate /* pairsel 3: see duo_pair() */,
     const int *__restrict__ synrow /* optional: sources that share another source's synthetics are not synthesised */,
     const int *__restrict__ fam_ofs, const int *__restrict__ fam_list /* FUSE with synrow: the sources that share source s's
@@ -1464,7 +1449,6 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_GROUPED_
     if (!rv.enabled) return;
     if (tile * TILE >= rv.wlen) return;
     if (pairsel == 1 && cell_pair(rv, pairflag, s, nrec, r)) return;
-    if (pairsel == 2 && pipe_pair(rv, pairflag, s, nrec, r)) return;
     if (pairsel == 3 && duo_pair_fwd(rv, pairflag, mate, s, nrec, r)) return;
     if (synrow && !multi && synrow[s] != s) return;  // (in a run the sources that share synthetics are left out one by one)
     const int tid = threadIdx.x;
@@ -1558,9 +1542,6 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_GROUPED_
             continue;
         }
         // ---- the group starting here (hint computed by geometry_kernel)
-#ifdef KIWI_X_PRIO_BUILD
-        __builtin_amdgcn_s_setprio(KIWI_X_PRIO_BUILD);
-#endif
         const int cend = c + (g0.pad & 0xff);
         const int smax = g0.ishift + ((g0.pad >> 8) & 0xff), smin = g0.ishift - ((g0.pad >> 16) & 0xff);
         // LDS position p holds blended trace sample jb + p
@@ -1638,8 +1619,6 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_GROUPED_
                 else        halo_finish<true>(hact[it], hr[it], tile0, LDS_TILE, hig[it], hph[it], g0); } } while (0)
 #ifdef KIWI_X_NOBUILD
             if (false) {
-#elif defined(KIWI_X_HALFBUILD)
-            if (!((c / 5) & 1)) { } else if (need_h && has_d) {
 #else
             if (need_h && has_d) {
 #endif
@@ -1685,9 +1664,6 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_GROUPED_
         // descriptors of the NEXT group: in flight while this group is applied
         if (cend < nc) { ta = tc[(size_t)cend * 128 + lane]; tb = tc[(size_t)cend * 128 + 64 + lane]; }
         __syncthreads();
-#ifdef KIWI_X_PRIO_APPLY
-        __builtin_amdgcn_s_setprio(KIWI_X_PRIO_APPLY);
-#endif
 #ifdef KIWI_X_NOAPPLY
         if (kCarry && carry_grp) { cur = cur_next; } else
 #endif
@@ -1706,7 +1682,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_GROUPED_
                 const int e = smax - __builtin_amdgcn_readlane(ishv, (CC) - c);      /* LDS position of b[j-1] of the tile's first sample */ \
                 const int d = have ? eprev - e : 0x7fff; \
                 carry2_apply<NG, RV>(ar1, ar2, dz, LL, HH, abase + 4u * (unsigned)e, __builtin_amdgcn_readfirstlane((int)KIWI_X_FULL(d != -1)), \
-                                     __builtin_amdgcn_readfirstlane((int)KIWI_X_FULL(d != 1)), coef_grp + (size_t)KIWI_X_COEFIDX((CC) - c) * 128, gcl, gsl); \
+                                     __builtin_amdgcn_readfirstlane((int)KIWI_X_FULL(d != 1)), coef_grp + (size_t)((CC) - c) * 128, gcl, gsl); \
                 have = true; eprev = e; } while (0)
             // (nothing is carried into a group, its first centroid reads both sets: set2_dead tells the register allocator so)
             if (g0.flags & 2) {
@@ -1773,39 +1749,6 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_GROUPED_
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// accumulate, grouped, with the blended samples CARRIED between the centroids of a group (round 3)
-//
-// accumulate_grouped_kernel reads b[j-1] and b[j] of every output from LDS for every centroid and component; its LDS pipe
-// is then as busy as its vector pipe (40 ds_read2st64_b32 against 96 packed operations per wave and centroid, 4.3 LDS
-// cycles per read for the whole CU against 4 issue cycles per packed operation on one of four SIMDs) and the two overlap
-// only in part.  But the centroids of a group are the time steps of ONE sub-fault: the same blended traces, read at an
-// integer shift that usually moves by exactly one sample from step to step (effective_dt == dt of the database:
-// source_bilat.f90:443-457 with seismogram.f90:139).  With the stride-64 lane mapping, b[j] of step k+1 IS b[j-1] of
-// step k -- the register pair the lane already holds.  This kernel keeps the pairs of ALL components of the previous
-// centroid in registers (two sets that swap roles) and loads only what the new shift needs:
-//     shift + 1 -> the old b[j-1] set serves as b[j], only b[j-1] is read        (10 reads instead of 20)
-//     shift - 1 -> the old b[j] set serves as b[j-1], only b[j] is read          (runs of point sources: last step -> first step)
-//     same shift -> nothing is read;  anything else -> both are read.
-// To pay for the 2 x NG carried pairs the lane owns TWO outputs (samples 128 w + l and 128 w + l + 64 of the tile,
-// one register pair per quantity) and the workgroup has T = TILE / 2 threads (512 for the 1024-sample tile): per wave
-// the kernel then needs about half the registers of accumulate_grouped_kernel and twice the waves fit a SIMD.
-// What else changed on the way:
-//   * the group's cos / sin of the back-azimuth change and its flags are taken once per group (same point, same
-//     receiver: they are equal for every centroid of a group), the integer shifts of the group's centroids come in ONE
-//     vector load per group and reach the scalar unit with one v_readlane per centroid -- no per-centroid record fetch;
-//   * rotating / plain branch (seismogram.f90:160-203 / :205-231) chosen per group, outside the centroid loop: no
-//     v_cndmask selection and no copies per centroid;
-//   * the build is shared by the two halves of the workgroup (components 1-5 / 6-10), three components of loads in flight.
-// Per-sample operations and their order are those of accumulate_grouped_kernel / accumulate_kernel: bit-identical results
-// (tests/test_gpu_parity.py runs the three against each other).
-
-template <int NG, int HALF> struct CarryHalf;       // GF components (storage index) built by each half of the workgroup
-template <> struct CarryHalf<10, 0> { static constexpr int n = 5; __device__ static constexpr int ig(int i) { return i; } };
-template <> struct CarryHalf<10, 1> { static constexpr int n = 5; __device__ static constexpr int ig(int i) { return 5 + i; } };
-template <> struct CarryHalf<8, 0>  { static constexpr int n = 4; __device__ static constexpr int ig(int i) { return i; } };
-template <> struct CarryHalf<8, 1>  { static constexpr int n = 4; __device__ static constexpr int ig(int i) { return 4 + i; } };
-
 template <bool BLEND, bool FAST>
 __device__ __forceinline__ void one_issue(f4u (&v)[BLEND ? 4 : 1], int ig, int p, int jb, const float *__restrict__ G,
                                           int pitch, int ta, int tb)
@@ -1838,210 +1781,6 @@ __device__ __forceinline__ void one_finish(const f4u (&v)[BLEND ? 4 : 1], float 
         b = v[0];
     }
     *(float4 *)(tile0 + ig * lds_tile + p) = make_float4(b.x, b.y, b.z, b.w);
-}
-
-// main chunk (LDS positions [p, p + 4)) of the components of one half of the workgroup; loads of DEPTH components in flight
-template <int NG, int HALF, bool BLEND, bool FAST>
-__device__ __forceinline__ void carry_build(float *__restrict__ tile0, int lds_tile, int p, int jb, const float *__restrict__ G,
-                                            int pitch, int ta, int tb, const GeoRec &g)
-{
-    typedef CarryHalf<NG, HALF> H;
-    constexpr int N = H::n, DEPTH = 3;
-    f4u v[N][BLEND ? 4 : 1];
-#pragma unroll
-    for (int i = 0; i < DEPTH && i < N; i++) one_issue<BLEND, FAST>(v[i], H::ig(i), p, jb, G, pitch, ta, tb);
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        __builtin_amdgcn_sched_barrier(0);
-        one_finish<BLEND>(v[i], tile0, lds_tile, H::ig(i), p, g);
-        if (i + DEPTH < N) one_issue<BLEND, FAST>(v[i + DEPTH], H::ig(i + DEPTH), p, jb, G, pitch, ta, tb);
-    }
-}
-
-
-// one quantity (b[j-1] or b[j]) of the lane's 2 NP outputs of one component: NP ds_read2st64_b32
-template <int NP>
-__device__ __forceinline__ void tile_load_half(f2v (&d)[NP], lds_cfp b, int ofs)
-{
-#pragma unroll
-    for (int h = 0; h < NP; h++) d[h] = f2v{ b[ofs + 128 * h], b[ofs + 128 * h + 64] };
-}
-
-// A carried register set: one register pair per GF component (application order), each a variable of its own.  (As an
-// array the compiler's scalar-replacement pass promotes the whole set to ONE <20 x float> value -- a 32-register tuple
-// that is copied and spilled as a whole at every conditional load.)
-struct CarrySet { f2v &c0, &c1, &c2, &c3, &c4, &c5, &c6, &c7, &c8, &c9; };
-template <int I> __device__ __forceinline__ f2v &cs_get(const CarrySet &s)
-{
-    if constexpr (I == 0) return s.c0; else if constexpr (I == 1) return s.c1; else if constexpr (I == 2) return s.c2;
-    else if constexpr (I == 3) return s.c3; else if constexpr (I == 4) return s.c4; else if constexpr (I == 5) return s.c5;
-    else if constexpr (I == 6) return s.c6; else if constexpr (I == 7) return s.c7; else if constexpr (I == 8) return s.c8;
-    else return s.c9;
-}
-
-// All GF components of one centroid from the two register sets L (b[j-1]) and H (b[j]), reference order.  load_lo /
-// load_hi: which of the sets this centroid's shift makes it read (see the head of this section).  coef: the centroid's
-// 2 NG interpolation coefficients (wave-uniform pointer: scalar loads, SGPR operands of the packed multiplies).
-// TAIL: the `factor * last` rule needs the factors and the fraction; they are read from the record then (rare).
-template <int NG, int LDS_TILE, bool TAIL, bool ROT>
-__device__ __forceinline__ void carry_apply(f2v &ar1, f2v &ar2, f2v &dz, const CarrySet &L, const CarrySet &H,
-                                            const TileBase &cb, bool load_lo, bool load_hi, const float *__restrict__ coef,
-                                            int jl, const int *__restrict__ jendp, const GeoRec *__restrict__ rec, float sd,
-                                            float cl, float sl)
-{
-    constexpr int seq10[10] = { 0, 1, 2, 8, 3, 4, 5, 6, 7, 9 }, seq8[8] = { 0, 1, 2, 3, 4, 5, 6, 7 };
-    constexpr int nH1 = (NG == 10) ? 4 : 3;      // components summed into the radial trace
-    if (load_hi)
-        static_for<NG>([&](auto I) __attribute__((always_inline)) {
-            constexpr int i = decltype(I)::value, o = ((NG == 10) ? seq10[i] : seq8[i]) * LDS_TILE;
-            cs_get<i>(H) = f2v{ cb.hi[o], cb.hi[o + 64] };
-        });
-    if (load_lo)
-        static_for<NG>([&](auto I) __attribute__((always_inline)) {
-            constexpr int i = decltype(I)::value, o = ((NG == 10) ? seq10[i] : seq8[i]) * LDS_TILE;
-            cs_get<i>(L) = f2v{ cb.lo[o], cb.lo[o + 64] };
-        });
-    float cw[2 * NG];
-#pragma unroll
-    for (int i = 0; i < 2 * NG; i++) cw[i] = coef[i];
-    float fac[NG];
-    int jend[NG];
-    if constexpr (TAIL) {
-        const float f0 = rec->f[0], f1 = rec->f[1], f2 = rec->f[2], f3 = rec->f[3], f4 = rec->f[4], f5 = rec->f[5];
-        const float fac10[10] = { f0, f1, f2, f5, f3, f4, f0 * sd, f1 * sd, f2 * sd, f5 * sd };
-        const float fac8[8] = { f0, f1, f2, f3, f4, f0 * sd, f1 * sd, f2 * sd };
-#pragma unroll
-        for (int i = 0; i < NG; i++) { fac[i] = (NG == 10) ? fac10[i] : fac8[i]; jend[i] = jendp[(NG == 10) ? seq10[i] : seq8[i]]; }
-    } else {
-#pragma unroll
-        for (int i = 0; i < NG; i++) { fac[i] = 0.f; jend[i] = 0; }
-    }
-    f2v t1[1], t2[1], dd[1];
-    t1[0] = ROT ? f2v{ 0.f, 0.f } : ar1; t2[0] = ROT ? f2v{ 0.f, 0.f } : ar2; dd[0] = dz;
-    static_for<NG>([&](auto I) __attribute__((always_inline)) {
-        constexpr int i = decltype(I)::value;
-        TileRegsN<1> tr;
-        tr.lo[0] = cs_get<i>(L); tr.hi[0] = cs_get<i>(H);
-        const float wl = cw[2 * i], wr = cw[2 * i + 1];
-        if constexpr (i < nH1) tile_fma<TAIL, 1>(t1, tr, jl, jend[i], fac[i], wl, wr);
-        else if constexpr (i < nH1 + 2) tile_fma<TAIL, 1>(t2, tr, jl, jend[i], fac[i], wl, wr);
-        else tile_fma<TAIL, 1>(dd, tr, jl, jend[i], fac[i], wl, wr);
-        if constexpr (i == nH1 + 1) {
-            if (ROT) {
-                ar1 = ar1 + cl * t1[0] - sl * t2[0];
-                ar2 = ar2 + cl * t2[0] + sl * t1[0];
-            } else {
-                ar1 = t1[0]; ar2 = t2[0];
-            }
-        }
-    });
-    dz = dd[0];
-}
-
-// In-place conditional LDS reads of one register set (one pair per GF component of a pass), as ONE asm statement: for the
-// compiler the pairs are read-modify-write operands, so a set that is NOT read this time simply keeps its registers -- no
-// merge of a "loaded" and a "kept" value, which the register allocator answered with a copy per pair and centroid.
-// Offsets in units of 64 dwords for component stride LDS_TILE = 576 = 9 x 64 (pass H: components 0 1 2 [8] 3 4 in
-// application order, pass D: 5 6 7 [9]).  The reads are NOT known to the compiler's wait-count bookkeeping: lds_wait()
-// before the first use.
-__device__ __forceinline__ void cond_read_h10(int on, unsigned a, f2v &r0, f2v &r1, f2v &r2, f2v &r3, f2v &r4, f2v &r5)
-{
-    asm volatile("s_cmp_eq_u32 %7, 0\n\ts_cbranch_scc1 .Lkiwi_skip%=\n\t"
-                 "ds_read2st64_b32 %0, %6 offset1:1\n\tds_read2st64_b32 %1, %6 offset0:9 offset1:10\n\t"
-                 "ds_read2st64_b32 %2, %6 offset0:18 offset1:19\n\tds_read2st64_b32 %3, %6 offset0:72 offset1:73\n\t"
-                 "ds_read2st64_b32 %4, %6 offset0:27 offset1:28\n\tds_read2st64_b32 %5, %6 offset0:36 offset1:37\n"
-                 ".Lkiwi_skip%=:"
-                 : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5) : "v"(a), "s"(on) : "memory", "scc");
-}
-__device__ __forceinline__ void cond_read_d10(int on, unsigned a, f2v &r0, f2v &r1, f2v &r2, f2v &r3)
-{
-    asm volatile("s_cmp_eq_u32 %5, 0\n\ts_cbranch_scc1 .Lkiwi_skip%=\n\t"
-                 "ds_read2st64_b32 %0, %4 offset0:45 offset1:46\n\tds_read2st64_b32 %1, %4 offset0:54 offset1:55\n\t"
-                 "ds_read2st64_b32 %2, %4 offset0:63 offset1:64\n\tds_read2st64_b32 %3, %4 offset0:81 offset1:82\n"
-                 ".Lkiwi_skip%=:"
-                 : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "v"(a), "s"(on) : "memory", "scc");
-}
-__device__ __forceinline__ void cond_read_h8(int on, unsigned a, f2v &r0, f2v &r1, f2v &r2, f2v &r3, f2v &r4)
-{
-    asm volatile("s_cmp_eq_u32 %6, 0\n\ts_cbranch_scc1 .Lkiwi_skip%=\n\t"
-                 "ds_read2st64_b32 %0, %5 offset1:1\n\tds_read2st64_b32 %1, %5 offset0:9 offset1:10\n\t"
-                 "ds_read2st64_b32 %2, %5 offset0:18 offset1:19\n\tds_read2st64_b32 %3, %5 offset0:27 offset1:28\n\t"
-                 "ds_read2st64_b32 %4, %5 offset0:36 offset1:37\n"
-                 ".Lkiwi_skip%=:"
-                 : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4) : "v"(a), "s"(on) : "memory", "scc");
-}
-__device__ __forceinline__ void cond_read_d8(int on, unsigned a, f2v &r0, f2v &r1, f2v &r2)
-{
-    asm volatile("s_cmp_eq_u32 %4, 0\n\ts_cbranch_scc1 .Lkiwi_skip%=\n\t"
-                 "ds_read2st64_b32 %0, %3 offset0:45 offset1:46\n\tds_read2st64_b32 %1, %3 offset0:54 offset1:55\n\t"
-                 "ds_read2st64_b32 %2, %3 offset0:63 offset1:64\n"
-                 ".Lkiwi_skip%=:"
-                 : "+v"(r0), "+v"(r1), "+v"(r2) : "v"(a), "s"(on) : "memory", "scc");
-}
-// (the pairs are operands of the wait: the arithmetic that uses them cannot be scheduled in front of it)
-__device__ __forceinline__ void lds_wait(f2v &a0, f2v &a1, f2v &a2, f2v &a3, f2v &a4, f2v &a5, f2v &b0, f2v &b1, f2v &b2, f2v &b3, f2v &b4, f2v &b5)
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5),
-                 "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5) :: "memory");
-}
-__device__ __forceinline__ void lds_wait(f2v &a0, f2v &a1, f2v &a2, f2v &a3, f2v &b0, f2v &b1, f2v &b2, f2v &b3)
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3) :: "memory");
-}
-
-// one register set of a pass: up to six pairs, each a variable of its own (see CarrySet)
-struct PassSet { f2v &c0, &c1, &c2, &c3, &c4, &c5; };
-template <int I> __device__ __forceinline__ f2v &ps_get(const PassSet &s)
-{
-    if constexpr (I == 0) return s.c0; else if constexpr (I == 1) return s.c1; else if constexpr (I == 2) return s.c2;
-    else if constexpr (I == 3) return s.c3; else if constexpr (I == 4) return s.c4; else return s.c5;
-}
-template <int NG, bool HPASS>
-__device__ __forceinline__ void pass_read(int on, unsigned a, const PassSet &S)
-{
-    if constexpr (NG == 10 && HPASS) cond_read_h10(on, a, S.c0, S.c1, S.c2, S.c3, S.c4, S.c5);
-    else if constexpr (NG == 10) cond_read_d10(on, a, S.c0, S.c1, S.c2, S.c3);
-    else if constexpr (HPASS) cond_read_h8(on, a, S.c0, S.c1, S.c2, S.c3, S.c4);
-    else cond_read_d8(on, a, S.c0, S.c1, S.c2);
-}
-
-// One centroid of one pass (HPASS: the horizontal components into ar1 / ar2, seismogram.f90:158-231; else the vertical ones
-// into dz, :236-253) from the register sets L (b[j-1]) and H (b[j]); a: LDS byte address of b[j-1] of the lane's first output in
-// component 0; coef: the centroid's coefficient line (scalar loads).  Same operations in the same order as centroid_apply.
-template <int NG, bool HPASS, bool ROT>
-__device__ __forceinline__ void pass_apply(f2v &ar1, f2v &ar2, f2v &dz, const PassSet &L, const PassSet &H, unsigned a,
-                                           bool load_lo, bool load_hi, const float *__restrict__ coef, float cl, float sl)
-{
-    constexpr int nH = (NG == 10) ? 6 : 5, nD = (NG == 10) ? 4 : 3, nH1 = nH - 2;
-    constexpr int N = HPASS ? nH : nD, C0 = HPASS ? 0 : 2 * nH;
-    float cw[2 * N];
-#pragma unroll
-    for (int i = 0; i < 2 * N; i++) cw[i] = coef[C0 + i];
-    pass_read<NG, HPASS>(__builtin_amdgcn_readfirstlane((int)load_hi), a + 4, H);
-    pass_read<NG, HPASS>(__builtin_amdgcn_readfirstlane((int)load_lo), a, L);
-    if constexpr (HPASS) lds_wait(L.c0, L.c1, L.c2, L.c3, L.c4, L.c5, H.c0, H.c1, H.c2, H.c3, H.c4, H.c5);
-    else lds_wait(L.c0, L.c1, L.c2, L.c3, H.c0, H.c1, H.c2, H.c3);
-    if constexpr (HPASS) {
-        f2v t1 = ROT ? f2v{ 0.f, 0.f } : ar1, t2 = ROT ? f2v{ 0.f, 0.f } : ar2;
-        static_for<nH>([&](auto I) __attribute__((always_inline)) {
-            constexpr int i = decltype(I)::value;
-            const f2v c1 = { cw[2 * i], cw[2 * i] }, c2 = { cw[2 * i + 1], cw[2 * i + 1] };
-            if constexpr (i < nH1) { t1 = t1 + c1 * ps_get<i>(H); t1 = t1 + c2 * ps_get<i>(L); }
-            else                   { t2 = t2 + c1 * ps_get<i>(H); t2 = t2 + c2 * ps_get<i>(L); }
-        });
-        if (ROT) {
-            ar1 = ar1 + cl * t1 - sl * t2;
-            ar2 = ar2 + cl * t2 + sl * t1;
-        } else {
-            ar1 = t1; ar2 = t2;
-        }
-    } else {
-        static_for<nD>([&](auto I) __attribute__((always_inline)) {
-            constexpr int i = decltype(I)::value;
-            const f2v c1 = { cw[2 * i], cw[2 * i] }, c2 = { cw[2 * i + 1], cw[2 * i + 1] };
-            dz = dz + c1 * ps_get<i>(H); dz = dz + c2 * ps_get<i>(L);
-        });
-    }
 }
 
 // Build of accumulate_duo_kernel: wave w blends components 2 i + (w >> 1) for the 64 chunks of slab w & 1 (chunk = 4 samples;
@@ -2088,10 +1827,10 @@ __device__ __forceinline__ void duo_build(float *__restrict__ tile0, int wv, int
 // one after the other.
 //
 // Pairing (host, kiwi_hip_set_sources): sources 2k and 2k+1 of a chunk whose centroid tables have the same STRUCTURE --
-// same number of centroids, same pattern of repeated points, same integer shifts -- so that both have the same groups
-// (group_len) and walk them in lockstep; `mate[k]` says so.  Of those the kernel takes the (pair, receiver) combinations
-// where both sources are "clean" for the receiver (pipe_pair(): horizontal and vertical components, no missing trace, no
-// tail rule); accumulate_grouped_kernel runs behind it for everything else (pairsel 3).
+// same number of centroids, same boundaries of the centroid groups (group_len) -- so that both walk their groups in
+// lockstep; `mate[k]` says so.  Of those the kernel takes the (pair, receiver) combinations
+// where both sources are "clean" for the receiver (horizontal and vertical components, no missing trace, no tail rule:
+// pairflag of geometry_kernel); accumulate_grouped_kernel runs behind it for everything else (pairsel 3).
 __device__ __forceinline__ bool duo_pair(const RecvDev &rv, const int *__restrict__ pairflag, const int *__restrict__ mate,
                                          int s, int nrec, int r)
 {
@@ -2151,10 +1890,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
         rec_head(curB, 0, gB);
         const int glen = gA.pad & 0xff;                  // (same structure: equal for both)
         const int cend = c + glen;
-        const int smax = gA.ishift + ((gA.pad >> 8) & 0xff), smin = gA.ishift - ((gA.pad >> 16) & 0xff);
-        const int jb = t_tile0 - smax - 1;               // LDS position p holds blended trace sample jb + p
-        const int npos = TILE + (smax - smin) + 8;
-        const bool hact = hslot < NG && hph < npos;
+        // integer shifts may differ between the two (a time sweep): each has its own range and tile origin
+        const int smaxA = gA.ishift + ((gA.pad >> 8) & 0xff), sminA = gA.ishift - ((gA.pad >> 16) & 0xff);
+        const int smaxB = gB.ishift + ((gB.pad >> 8) & 0xff), sminB = gB.ishift - ((gB.pad >> 16) & 0xff);
+        const int jbA = t_tile0 - smaxA - 1, jbB = t_tile0 - smaxB - 1;      // LDS position p of a source's tile set holds its blended trace sample jb + p
+        const int nposA = TILE + (smaxA - sminA) + 8, nposB = TILE + (smaxB - sminB) + 8;
+        const int smax = sh ? smaxB : smaxA, smin = sh ? sminB : sminA, jb = sh ? jbB : jbA;
         // this wave's source: what its apply needs
         const int flags = sh ? gB.flags : gA.flags;
         const float gcl = sh ? REC_F(curB, 16) : REC_F(curA, 16), gsl = sh ? REC_F(curB, 17) : REC_F(curA, 17);
@@ -2162,16 +1903,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
         const bool carry_grp = !((jb + (smax - smin) + TILE) > jmin_me);      // (clean pairs: no tail rule -> always)
         int ishv = 0;
         if (lane < glen) ishv = rc[c + lane].ishift;
-        // ---- build: the node rows of the cell once, blended for both sources -- if both sit in the same cell
-        const bool shared = gA.row[0] == gB.row[0] && gA.row[1] == gB.row[1] && gA.row[2] == gB.row[2] && gA.row[3] == gB.row[3];
-#define KIWI_DUO_BUILD(TA, TB, GR, W0, W1, WR0, WR1) do { \
+        // ---- build: the node rows of the cell once, blended for both sources -- if both sit in the same cell and read it
+        // from the same tile origin
+        const bool shared = gA.row[0] == gB.row[0] && gA.row[1] == gB.row[1] && gA.row[2] == gB.row[2] && gA.row[3] == gB.row[3] && jbA == jbB;
+#define KIWI_DUO_BUILD(TA, TB, GR, JB, NPOS, W0, W1, WR0, WR1) do { \
             const float *__restrict__ Gg = G + (size_t)(GR).row[0] * (size_t)pitch; \
-            const bool lane_ok = lane >= 4 * NG || ((TA) + jb >= (TB) && (TA) + jb + LDS_TILE <= (TB) + pitch); \
+            const bool lane_ok = lane >= 4 * NG || ((TA) + (JB) >= (TB) && (TA) + (JB) + LDS_TILE <= (TB) + pitch); \
             const bool fast = __builtin_amdgcn_ballot_w64(lane_ok) == ~0ull; \
-            if (fast) duo_build<NG, true, WR0, WR1>(&tiles[0][0][0], wv, lane, tid, jb, Gg, pitch, TA, TB, W0, W1, hact, hig, hph); \
-            else      duo_build<NG, false, WR0, WR1>(&tiles[0][0][0], wv, lane, tid, jb, Gg, pitch, TA, TB, W0, W1, hact, hig, hph); } while (0)
-        if (shared) KIWI_DUO_BUILD(taA, tbA, gA, gA, gB, true, true);
-        else { KIWI_DUO_BUILD(taA, tbA, gA, gA, gA, true, false); KIWI_DUO_BUILD(taB, tbB, gB, gB, gB, false, true); }
+            const bool hact = hslot < NG && hph < (NPOS); \
+            if (fast) duo_build<NG, true, WR0, WR1>(&tiles[0][0][0], wv, lane, tid, JB, Gg, pitch, TA, TB, W0, W1, hact, hig, hph); \
+            else      duo_build<NG, false, WR0, WR1>(&tiles[0][0][0], wv, lane, tid, JB, Gg, pitch, TA, TB, W0, W1, hact, hig, hph); } while (0)
+#ifndef KIWI_X_NOBUILD
+        if (shared) KIWI_DUO_BUILD(taA, tbA, gA, jbA, max(nposA, nposB), gA, gB, true, true);
+        else { KIWI_DUO_BUILD(taA, tbA, gA, jbA, nposA, gA, gA, true, false); KIWI_DUO_BUILD(taB, tbB, gB, jbB, nposB, gB, gB, false, true); }
+#else
+        (void)shared;
+#endif
 #undef KIWI_DUO_BUILD
         // head records and descriptors of the NEXT group: in flight while this group is applied
         curA = rec_load(rcA, cend, nc, lane); curB = rec_load(rcB, cend, nc, lane);
@@ -2188,6 +1935,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
             const unsigned abase = (unsigned)(size_t)(lds_cfp)&tiles[sh][0][u0];
             int cc = c, eprev = 0;
             bool have = false;
+#ifdef KIWI_X_NOAPPLY
+            cc = cend;
+#endif
             if (carry_grp) {
 #define KIWI_C2STEP(LL, HH, RV, CC) do { \
                     const int e = smax - __builtin_amdgcn_readlane(ishv, (CC) - c); \
@@ -2276,288 +2026,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
                 fp.partial[((size_t)js * fp.nmis + rv.slot0 + k) * fp.nparts + tile * 2 + (wv & 1)] = acc;
         }
     }
-}
-
-#ifndef KIWI_PIPE_WAVES
-#define KIWI_PIPE_WAVES 3
-#endif
-
-// The kernel.  T = 256 threads, tile = 512 samples, two tile sets in LDS (2 x 23 KB: three workgroups per CU):
-//
-//     issue the global loads of group g+1 (they stay in registers)  ->  apply group g from tile set g & 1
-//     ->  blend the loaded rows into tile set (g+1) & 1  ->  ONE barrier  ->  ...
-//
-// What bounded accumulate_grouped_kernel (measured, round 3: build only 29 ms + apply only 33 ms -> 42 ms per 1024 sources at
-// cfg3, 60 % of the vector issue slots) is that every group starts with an L2 round trip nothing hides but the other two
-// workgroups of the CU: its workgroup issues the loads, waits, blends, synchronises, applies, synchronises.  Here the
-// round trip of group g+1 lies under the arithmetic of group g.
-template <int NG, bool FUSE, bool RUNS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIWI_PIPE_WAVES))) void accumulate_pipe_kernel(
-    const float *__restrict__ G, const int2 *__restrict__ span, int pitch,
-    const GeoRec *__restrict__ recs, const int *__restrict__ cent_ofs, int isrc0, int nrec,
-    const RecvDev *__restrict__ recv, float *__restrict__ syn, size_t syn_stride, int ntiles,
-    const int *__restrict__ tab, const int *__restrict__ run_first, FuseParams fp,
-    const int *__restrict__ pairflag, const int *__restrict__ synrow,
-    const int *__restrict__ fam_ofs, const int *__restrict__ fam_list)
-{
-    // arguments, grid (source index or run fastest) and semantics: accumulate_grouped_kernel
-    constexpr int T = 256, NP = 1;
-    constexpr int TILE = 2 * NP * T;
-    constexpr int LDS_TILE = TILE + kHalo;
-    static_assert(LDS_TILE % 64 == 0, "tile layout");
-    __shared__ __attribute__((aligned(16))) float tiles[2][NG][LDS_TILE];
-    const int s = RUNS ? run_first[blockIdx.x] : (int)blockIdx.x;
-    const int s_end = RUNS ? run_first[blockIdx.x + 1] : s + 1;
-    const bool multi = RUNS && s_end - s > 1;
-    const int tile = blockIdx.y % ntiles, r = blockIdx.y / ntiles;
-    const RecvDev &rv = recv[r];
-    if (!rv.enabled) return;
-    if (tile * TILE >= rv.wlen) return;
-    if (!pipe_pair(rv, pairflag, s, nrec, r)) return;
-    if (synrow && !multi && synrow[s] != s) return;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int half = __builtin_amdgcn_readfirstlane(tid / (T / 2));      // which components this wave builds
-    const int t_tile0 = rv.wbeg + tile * TILE;
-    const int cb = cent_ofs[isrc0], c0 = cent_ofs[isrc0 + s], nc = cent_ofs[isrc0 + s + 1] - c0;
-    const GeoRec *__restrict__ rc = recs + ((size_t)(c0 - cb) * nrec + (size_t)r * nc);
-    const int *__restrict__ tc = tab + ((size_t)(c0 - cb) * nrec + (size_t)r * nc) * 128;
-    const float sd = rv.sd;
-    const int u0 = 2 * NP * (tid & ~63) + lane;          // the lane's first tile sample (the other: + 64)
-    const int p = 4 * (tid % (T / 2));                   // the lane's main chunk of the build
-    // halo: one lane per (component, 4-sample chunk)
-    const int hslot = tid >> 4, hig = min(hslot, NG - 1), hph = TILE + 4 * (tid & 15);
-    static_assert(16 * NG <= T, "one halo pass");
-
-    f2v ar1[NP], ar2[NP], dz[NP];
-#pragma unroll
-    for (int k = 0; k < NP; k++) ar1[k] = ar2[k] = dz[k] = f2v{ 0.f, 0.f };
-    // rotation to N/E, signs and store of one source's accumulators (seismogram.f90:256-283)
-    auto store = [&](int js) {
-        constexpr int NO = 2 * NP;
-        const int tl = tile * TILE + u0;                 // window sample of the lane's output q = 0; q-th: + 64 q
-        if (!FUSE && tl >= rv.wlen) return;
-        float *__restrict__ so = syn + (size_t)js * syn_stride + tl;
-        float a1[NO], a2[NO], ad[NO];
-#pragma unroll
-        for (int k = 0; k < NP; k++) {
-            a1[2 * k] = ar1[k].x; a1[2 * k + 1] = ar1[k].y; a2[2 * k] = ar2[k].x; a2[2 * k + 1] = ar2[k].y;
-            ad[2 * k] = dz[k].x; ad[2 * k + 1] = dz[k].y;
-        }
-        float mom = 0.f;
-        if constexpr (FUSE) mom = fp.moment[fp.isrc0 + js];
-        const bool unit = (fp.syn_factor == 1.f);
-        for (int k = 0; k < rv.ncomp; k++) {
-            const float sg = rv.sign[k];
-            float o[NO];
-#pragma unroll
-            for (int i = 0; i < NO; i++) {
-                switch (rv.comp[k]) {
-                case 1: o[i] = a1[i] * sg; break;
-                case 2: o[i] = a2[i] * sg; break;
-                case 3: o[i] = ad[i]; break;
-                case 4: o[i] = (rv.cl0 * a1[i] - rv.sl0 * a2[i]) * sg; break;
-                default: o[i] = (rv.cl0 * a2[i] + rv.sl0 * a1[i]) * sg; break;
-                }
-            }
-            if constexpr (!FUSE) {
-#pragma unroll
-                for (int i = 0; i < NO; i++)
-                    if (tl + 64 * i < rv.wlen) so[rv.synofs[k] + 64 * i] = o[i];
-                continue;
-            }
-            // fused comparator (see accumulate_grouped_kernel): partial of (source, slot, tile, wave)
-            double acc = 0.0;
-            const float *__restrict__ rt = fp.reft + rv.refofs[k] + tl, *__restrict__ tp = fp.tw + rv.refofs[k] + tl;
-#pragma unroll
-            for (int i = 0; i < NO; i++) {
-                if (tl + 64 * i >= rv.wlen) break;
-                const float v = o[i] * mom;
-                const float vt = v * tp[64 * i];
-                const float a = rt[64 * i];
-                switch (fp.method) {
-                case 1: { const float d = unit ? (a - vt) : (1.f * a - fp.syn_factor * vt); acc = sq_acc(acc, d); break; }
-                case 2: { const float d = unit ? fabsf(a - vt) : fabsf(1.f * a - fp.syn_factor * vt); acc += (double)d; break; }
-                case 5: acc += unit ? (double)(a * vt) : (double)(a * 1.f * vt * fp.syn_factor); break;
-                default: { const double x = (double)(1.f * a), y = (double)(fp.syn_factor * vt); acc = fmax(acc, sqrt(x * x + y * y)); break; }
-                }
-            }
-            acc = wave_reduce_f64(acc, fp.method == 6);                 // total in lane 63
-            if (lane == 63)
-                fp.partial[((size_t)js * fp.nmis + rv.slot0 + k) * fp.nparts + tile * (T / 64) + (tid >> 6)] = acc;
-        }
-    };
-    auto store_family = [&](int js) {
-        store(js);
-        if constexpr (FUSE) {
-            if (fam_ofs)
-                for (int q = fam_ofs[js]; q < fam_ofs[js + 1]; q++) store(fam_list[q]);
-        }
-    };
-    if (nc <= 0) {                                       // (a rejected trial source has no centroids: zero synthetics)
-        for (int js = s; js < s_end; js++)
-            if (!(synrow && multi && synrow[js] != js)) store_family(js);
-        return;
-    }
-
-    // ---- what the apply of a group needs (from its head record; equal for all its centroids: same point, same receiver)
-    struct Grp { int c, cend, smax, jb; float cl, sl; bool rot; };
-    // ---- what the build of a group leaves in flight: the raw rows of the lane's chunk (and halo chunk), the blend weights
-    f4u V[CarryHalf<NG, 0>::n][4];
-    HaloRegs HV;
-    float bw0 = 0.f, bw1 = 0.f, bw2 = 0.f, bw3 = 0.f;
-    bool bdirect = false, bhact = false;
-    int ishv = 0, ishv_next = 0;                         // integer shifts of the group's centroids, lane k = centroid c + k
-
-    // decode the head record of the group starting at centroid c (cur / ta / tb: its record and descriptors, lane-
-    // distributed), issue its loads; returns what its apply needs
-    auto issue = [&](int c, int cur, int ta, int tb, int &ish) -> Grp {
-        GeoRec g0;
-        rec_head(cur, 0, g0);
-        Grp g;
-        const int glen = g0.pad & 0xff;
-        g.c = c; g.cend = c + glen;
-        g.smax = g0.ishift + ((g0.pad >> 8) & 0xff);
-        const int smin = g0.ishift - ((g0.pad >> 16) & 0xff);
-        g.jb = t_tile0 - g.smax - 1;                     // LDS position q holds blended trace sample jb + q
-        g.cl = REC_F(cur, 16); g.sl = REC_F(cur, 17);
-        g.rot = (g0.flags & 2) != 0;
-        const int npos = TILE + (g.smax - smin) + 8;     // positions read by the group (<= LDS_TILE)
-        bdirect = (g0.flags & 1) != 0;
-        bw0 = g0.w[0]; bw1 = g0.w[1]; bw2 = g0.w[2]; bw3 = g0.w[3];
-        bhact = hslot < NG && hph < npos;
-        ish = 0;
-        if (lane < glen) ish = rc[c + lane].ishift;
-        const float *__restrict__ Gg = G + (size_t)g0.row[0] * (size_t)pitch;
-        const int jb = g.jb;
-        const bool lane_ok = lane >= 4 * NG || (ta + jb >= tb && ta + jb + LDS_TILE <= tb + pitch);
-        const bool fast = __builtin_amdgcn_ballot_w64(lane_ok) == ~0ull;
-#define KIWI_ISS(HF, BL, FA) do { \
-            _Pragma("unroll") for (int i = 0; i < CarryHalf<NG, HF>::n; i++) { \
-                f4u t[BL ? 4 : 1]; \
-                one_issue<BL, FA>(t, CarryHalf<NG, HF>::ig(i), p, jb, Gg, pitch, ta, tb); \
-                _Pragma("unroll") for (int k = 0; k < (BL ? 4 : 1); k++) V[i][k] = t[k]; \
-            } \
-            HV = halo_issue<BL, FA>(bhact, hig, hph, jb, Gg, pitch, ta, tb); } while (0)
-#ifdef KIWI_X_ONEVAR
-#define KIWI_ISS2(HF) do { (void)fast; KIWI_ISS(HF, true, true); } while (0)
-#else
-#define KIWI_ISS2(HF) do { if (fast) KIWI_ISS(HF, true, true); else KIWI_ISS(HF, true, false); } while (0)
-#endif
-#ifndef KIWI_X_NOBUILD
-        if (half == 0) KIWI_ISS2(0); else KIWI_ISS2(1);
-#else
-        (void)fast; (void)Gg;
-#endif
-#undef KIWI_ISS2
-#undef KIWI_ISS
-        return g;
-    };
-    // blend what issue() left in flight into tile set `buf`
-    auto finish = [&](int buf) {
-        float *tile0 = &tiles[buf][0][0];
-        GeoRec gw;
-        gw.w[0] = bw0; gw.w[1] = bw1; gw.w[2] = bw2; gw.w[3] = bw3;
-#define KIWI_FIN(HF, BL) do { \
-            _Pragma("unroll") for (int i = 0; i < CarryHalf<NG, HF>::n; i++) { \
-                f4u t[BL ? 4 : 1]; \
-                _Pragma("unroll") for (int k = 0; k < (BL ? 4 : 1); k++) t[k] = V[i][k]; \
-                one_finish<BL>(t, tile0, LDS_TILE, CarryHalf<NG, HF>::ig(i), p, gw); \
-            } \
-            halo_finish<BL>(bhact, HV, tile0, LDS_TILE, hig, hph, gw); } while (0)
-#ifdef KIWI_X_ONEVAR
-        if (half == 0) KIWI_FIN(0, true); else KIWI_FIN(1, true);
-#else
-        if (half == 0) KIWI_FIN(0, true); else KIWI_FIN(1, true);
-#endif
-#undef KIWI_FIN
-    };
-
-    // the two carried register sets of a pass
-    f2v x0, x1, x2, x3, x4, x5, y0, y1, y2, y3, y4, y5;
-    const PassSet X{ x0, x1, x2, x3, x4, x5 }, Y{ y0, y1, y2, y3, y4, y5 };
-    static_assert(LDS_TILE == 576, "cond_read_*: component stride 9 x 64 dwords");
-
-    // ---- prologue: group 0 into tile set 0; head of group 1 in flight
-    Grp g, gn;
-    int cur, ta, tb;
-    {
-        const int cur0 = rec_load(rc, 0, nc, lane);
-        const int ta0 = tc[lane], tb0 = tc[64 + lane];
-        g = issue(0, cur0, ta0, tb0, ishv);
-        cur = rec_load(rc, g.cend, nc, lane);
-        ta = 0; tb = 0;
-        if (g.cend < nc) { ta = tc[(size_t)g.cend * 128 + lane]; tb = tc[(size_t)g.cend * 128 + 64 + lane]; }
-        finish(0);
-        __syncthreads();
-    }
-    bool stored = false;
-    int buf = 0;
-    for (;;) {
-        const bool more = g.cend < nc;
-        if (more) {
-            gn = issue(g.cend, cur, ta, tb, ishv_next);
-            // head of the group after that
-            cur = rec_load(rc, gn.cend, nc, lane);
-            if (gn.cend < nc) { ta = tc[(size_t)gn.cend * 128 + lane]; tb = tc[(size_t)gn.cend * 128 + 64 + lane]; }
-        }
-        // ---- apply group g from tile set buf: every centroid, in table order (seismogram.f90:131); in a run, source after
-        // source.  Two passes over the group's centroids: the horizontal components into ar1 / ar2, then the vertical ones into
-        // dz -- independent accumulators, so each keeps the reference's order of additions -- because the carried register sets
-        // of ALL components (40 registers) do not fit next to the loads of the next group that are in flight meanwhile.
-        {
-            const int c = g.c, cend = g.cend, smax = g.smax;
-            const float cl = g.cl, sl = g.sl;
-            const unsigned abase = (unsigned)(size_t)(lds_cfp)&tiles[buf][0][u0];
-            for (int js = s; js < s_end; js++) {
-                if (multi) {
-#pragma unroll
-                    for (int k = 0; k < NP; k++) ar1[k] = ar2[k] = dz[k] = f2v{ 0.f, 0.f };
-                    if (synrow && synrow[js] != js) continue;           // evaluated with the source it shares synthetics with
-                }
-                const size_t crow = ((size_t)(cent_ofs[isrc0 + js] - cb) * nrec + (size_t)r * nc + c) * 128 + 64 + 40;
-                const unsigned clo = __builtin_amdgcn_readfirstlane((unsigned)crow), chi = __builtin_amdgcn_readfirstlane((unsigned)(crow >> 32));
-                const float *__restrict__ coef_grp = (const float *)(tab + (((size_t)chi << 32) | clo));
-                // The two register sets swap roles at EVERY centroid (pairs of centroids, roles static): after a centroid L holds
-                // its b[j-1] and H its b[j]; with the roles swapped, shift + 1 finds b[j] in place and reads b[j-1], shift - 1
-                // finds b[j-1] in place and reads b[j]; every other step reads both.  The rotating / plain branch
-                // (seismogram.f90:160-203 / :205-231) is the same for the whole group: two copies of the horizontal loop.
-#define KIWI_PSTEP(LL, HH, HP, RV, CC) do { \
-                    const int ishift = __builtin_amdgcn_readlane(ishv, (CC) - c); \
-                    const float *__restrict__ coef = coef_grp + (size_t)KIWI_X_COEFIDX((CC) - c) * 128; \
-                    const int e = smax - ishift;                 /* LDS position of b[j-1] of the tile's first sample */ \
-                    const int d = have ? eprev - e : 0x7fff; \
-                    const bool load_lo = KIWI_X_FULL(d != -1), load_hi = KIWI_X_FULL(d != 1); \
-                    pass_apply<NG, HP, RV>(ar1[0], ar2[0], dz[0], LL, HH, abase + 4u * (unsigned)e, load_lo, load_hi, coef, cl, sl); \
-                    have = true; eprev = e; } while (0)
-#define KIWI_DEAD(v) asm volatile("" : "=v"(v))
-#define KIWI_PLOOP(HP, RV) do { \
-                    int cc = c, eprev = 0; \
-                    bool have = false; \
-                    /* nothing is carried into a pass (its first centroid reads both sets): tell the register allocator so */ \
-                    KIWI_DEAD(x0); KIWI_DEAD(x1); KIWI_DEAD(x2); KIWI_DEAD(x3); KIWI_DEAD(x4); KIWI_DEAD(x5); \
-                    KIWI_DEAD(y0); KIWI_DEAD(y1); KIWI_DEAD(y2); KIWI_DEAD(y3); KIWI_DEAD(y4); KIWI_DEAD(y5); \
-                    for (; cc + 1 < cend; cc += 2) { KIWI_PSTEP(X, Y, HP, RV, cc); KIWI_PSTEP(Y, X, HP, RV, cc + 1); } \
-                    if (cc < cend) KIWI_PSTEP(X, Y, HP, RV, cc); } while (0)
-#ifndef KIWI_X_NOAPPLY
-                if (g.rot) KIWI_PLOOP(true, true); else KIWI_PLOOP(true, false);
-                KIWI_PLOOP(false, false);
-#endif
-#undef KIWI_PLOOP
-#undef KIWI_PSTEP
-#undef KIWI_DEAD
-                if (multi) store_family(js);
-            }
-            stored = multi;
-        }
-        if (!more) break;
-        finish(buf ^ 1);
-        __syncthreads();                                 // tile set buf ^ 1 complete; nobody reads set buf any more
-        buf ^= 1;
-        g = gn; ishv = ishv_next;
-    }
-    if (!multi) store_family(s);
-    (void)stored;
 }
 
 // ------------------------------------------------------------------------------------------------

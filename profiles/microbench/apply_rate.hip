@@ -1,5 +1,5 @@
-// Apply-phase microbenchmark (round 3): cycles per wave and centroid of the carried-register apply step of
-// accumulate_pipe_kernel in isolation -- LDS tile filled once, no global loads but the coefficient lines -- by variant and
+// Apply-phase microbenchmark (round 3): cycles per wave and centroid of a carried-register apply step (two outputs per
+// lane, as the experimental pipelined kernel of that round had it) in isolation -- LDS tile filled once, no global loads but the coefficient lines -- by variant and
 // by waves per SIMD.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize
 //        -I../../kiwi_amd/csrc apply_rate.hip -o apply_rate
 #include <hip/hip_runtime.h>
@@ -7,6 +7,80 @@
 #include <vector>
 #include "kiwi_kernels.hpp"
 using namespace kiwi;
+
+// ---- the compiler-scheduled form of the carried apply step this file measures (two outputs per lane; the product's
+// carry2_apply has four and reads its sets through one asm statement per set -- DESIGN.md section 3 says why)
+// A carried register set: one register pair per GF component (application order), each a variable of its own.  (As an
+// array the compiler's scalar-replacement pass promotes the whole set to ONE <20 x float> value -- a 32-register tuple
+// that is copied and spilled as a whole at every conditional load.)
+struct CarrySet { f2v &c0, &c1, &c2, &c3, &c4, &c5, &c6, &c7, &c8, &c9; };
+template <int I> __device__ __forceinline__ f2v &cs_get(const CarrySet &s)
+{
+    if constexpr (I == 0) return s.c0; else if constexpr (I == 1) return s.c1; else if constexpr (I == 2) return s.c2;
+    else if constexpr (I == 3) return s.c3; else if constexpr (I == 4) return s.c4; else if constexpr (I == 5) return s.c5;
+    else if constexpr (I == 6) return s.c6; else if constexpr (I == 7) return s.c7; else if constexpr (I == 8) return s.c8;
+    else return s.c9;
+}
+
+// All GF components of one centroid from the two register sets L (b[j-1]) and H (b[j]), reference order.  load_lo /
+// load_hi: which of the sets this centroid's shift makes it read (see the head of this section).  coef: the centroid's
+// 2 NG interpolation coefficients (wave-uniform pointer: scalar loads, SGPR operands of the packed multiplies).
+// TAIL: the `factor * last` rule needs the factors and the fraction; they are read from the record then (rare).
+template <int NG, int LDS_TILE, bool TAIL, bool ROT>
+__device__ __forceinline__ void carry_apply(f2v &ar1, f2v &ar2, f2v &dz, const CarrySet &L, const CarrySet &H,
+                                            const TileBase &cb, bool load_lo, bool load_hi, const float *__restrict__ coef,
+                                            int jl, const int *__restrict__ jendp, const GeoRec *__restrict__ rec, float sd,
+                                            float cl, float sl)
+{
+    constexpr int seq10[10] = { 0, 1, 2, 8, 3, 4, 5, 6, 7, 9 }, seq8[8] = { 0, 1, 2, 3, 4, 5, 6, 7 };
+    constexpr int nH1 = (NG == 10) ? 4 : 3;      // components summed into the radial trace
+    if (load_hi)
+        static_for<NG>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value, o = ((NG == 10) ? seq10[i] : seq8[i]) * LDS_TILE;
+            cs_get<i>(H) = f2v{ cb.hi[o], cb.hi[o + 64] };
+        });
+    if (load_lo)
+        static_for<NG>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value, o = ((NG == 10) ? seq10[i] : seq8[i]) * LDS_TILE;
+            cs_get<i>(L) = f2v{ cb.lo[o], cb.lo[o + 64] };
+        });
+    float cw[2 * NG];
+#pragma unroll
+    for (int i = 0; i < 2 * NG; i++) cw[i] = coef[i];
+    float fac[NG];
+    int jend[NG];
+    if constexpr (TAIL) {
+        const float f0 = rec->f[0], f1 = rec->f[1], f2 = rec->f[2], f3 = rec->f[3], f4 = rec->f[4], f5 = rec->f[5];
+        const float fac10[10] = { f0, f1, f2, f5, f3, f4, f0 * sd, f1 * sd, f2 * sd, f5 * sd };
+        const float fac8[8] = { f0, f1, f2, f3, f4, f0 * sd, f1 * sd, f2 * sd };
+#pragma unroll
+        for (int i = 0; i < NG; i++) { fac[i] = (NG == 10) ? fac10[i] : fac8[i]; jend[i] = jendp[(NG == 10) ? seq10[i] : seq8[i]]; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NG; i++) { fac[i] = 0.f; jend[i] = 0; }
+    }
+    f2v t1[1], t2[1], dd[1];
+    t1[0] = ROT ? f2v{ 0.f, 0.f } : ar1; t2[0] = ROT ? f2v{ 0.f, 0.f } : ar2; dd[0] = dz;
+    static_for<NG>([&](auto I) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value;
+        TileRegsN<1> tr;
+        tr.lo[0] = cs_get<i>(L); tr.hi[0] = cs_get<i>(H);
+        const float wl = cw[2 * i], wr = cw[2 * i + 1];
+        if constexpr (i < nH1) tile_fma<TAIL, 1>(t1, tr, jl, jend[i], fac[i], wl, wr);
+        else if constexpr (i < nH1 + 2) tile_fma<TAIL, 1>(t2, tr, jl, jend[i], fac[i], wl, wr);
+        else tile_fma<TAIL, 1>(dd, tr, jl, jend[i], fac[i], wl, wr);
+        if constexpr (i == nH1 + 1) {
+            if (ROT) {
+                ar1 = ar1 + cl * t1[0] - sl * t2[0];
+                ar2 = ar2 + cl * t2[0] + sl * t1[0];
+            } else {
+                ar1 = t1[0]; ar2 = t2[0];
+            }
+        }
+    });
+    dz = dd[0];
+}
+
 
 // MODE bit0: coefficient line of every centroid from memory (scalar loads) / 0: one line for all (cache hits)
 //      bit1: carry (shift pattern +1 per step, groups of 5) / 0: every step reads both sets

@@ -1382,3 +1382,54 @@ def test_reference_probes_plain_tapered_filtered():
                 assert np.max(np.abs(do[a - lo_o:b - lo_o] - dp[a - lo_p:b - lo_p])) <= tol * np.max(np.abs(do)) + 0.0
     with pytest.raises(KiwiHipError):
         p.get_reference(1, 9, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L", [700, 1500])
+def test_two_sources_per_workgroup_is_bit_identical(monkeypatch, L):
+    """accumulate_duo_kernel (two consecutive trial sources of equal structure per workgroup: node rows loaded once,
+    blended twice) against the one-source kernels, synthetics bit for bit: neighbours in the same cells (fine strike
+    steps), neighbours in different cells (coarse steps: the two tile sets are built one after the other), a time sweep
+    (integer shifts differ between the two: other tile origin), an odd number of sources, a source of another structure
+    in between (no mate), receivers the kernel does not take (one component block only) and traces missing from the
+    database (those pairs go to the grouped kernel)."""
+    sc = Scenario(nrec=6, L=L, comps_list=["ned", "ned", "d", "ne", "ned", "ar"], variant="probe")
+    _knock_out(sc, [(4, iz, 6) for iz in range(5)])
+    fine = synthetic.bilat_strike_sweep(6, step=0.05)
+    coarse = synthetic.bilat_strike_sweep(4, step=9.0)
+    coarse[:, 1] += 2500.0 * np.arange(4)                      # north-shift: other cells of the database
+    times = synthetic.bilat_strike_sweep(4, step=0.0)
+    times[:, 0] += np.array([0.0, 0.3, 0.55, 1.3], np.float32)
+    other = synthetic.bilat_strike_sweep(1, step=0.0)
+    other[:, 9] *= 0.5                                          # shorter rupture: another number of sub-faults
+    trials = np.vstack([fine, coarse, other, times, fine[:3]]).astype(np.float32)
+    assert len(trials) % 2 == 0 and len(trials) == 18
+    trials = np.vstack([trials, fine[:1]])                      # odd count: the last source has no mate
+    res = {}
+    sc.oracle()                                                 # (packs the database the product is handed)
+    for mode in ("duo", "single", "direct"):
+        monkeypatch.delenv("KIWI_HIP_ACCUM", raising=False)
+        monkeypatch.setenv("KIWI_HIP_DUO", "1" if mode == "duo" else "0")
+        if mode == "direct":
+            monkeypatch.setenv("KIWI_HIP_ACCUM", "direct")
+        p = sc.product()
+        p.set_source_params("bilateral", trials)
+        p.set_keep_synthetics(1)
+        p.eval()
+        res[mode] = [p.get_synthetics(s, ir, k, 1)[1] for s in range(len(trials)) for ir in range(1, 7)
+                     for k in range(1, len(sc.comps[ir - 1]) + 1)]
+        p.close()
+    assert len(res["duo"]) == len(res["single"]) == len(res["direct"]) > 200
+    for a, b, c in zip(res["duo"], res["single"], res["direct"]):
+        assert a.tobytes() == b.tobytes() == c.tobytes()
+    assert sum(1 for a in res["duo"] if np.any(a != 0)) > 150
+    # and through the fused comparator: misfits against the oracle
+    monkeypatch.setenv("KIWI_HIP_DUO", "1")
+    monkeypatch.delenv("KIWI_HIP_ACCUM", raising=False)
+    e, p = build(sc)
+    tr = trials[:15]                                            # (no repeated source: those would share synthetics instead)
+    m, n, g = oracle_misfits(e, 1, tr)
+    p.set_source_params("bilateral", tr)
+    p.eval()
+    pm, pn, pg = p.get_misfits()
+    assert misfit_close(pm, m) and misfit_close(pg, g)
