@@ -167,6 +167,14 @@ int kiwi_hip_misfits_for_params(kiwi_hip_ctx *ctx, int sourcetype, int nsrc, con
                                 float *misfit, float *norm, float *global, int *status);
 /* CPUs the host side may keep busy: allowed hardware threads cut to the cgroup CPU quota (the discretiser's thread count) */
 int kiwi_hip_effective_cpus(void);
+/* The eikonal discretiser keeps its fast-marching solves (eikonal.f90:29-199) by their complete inputs -- speed grid, grid
+ * spacing, start cell (source_mt_eikonal.f90:467-519 builds them in rupture coordinates) -- and returns the stored arrival
+ * times when ALL of them recur (hash, then comparison in full: bit-identical centroid tables).  North / east / time shifts
+ * and moment-tensor changes of a rupture leave the inputs alone: a location grid at fixed depth costs one solve.  Counters
+ * since the library was loaded (either pointer may be NULL); reset != 0 clears them, reset & 2 also drops the stored solves.
+ * Process-wide, shared by all contexts.
+ * KIWI_HIP_EIK_CACHE=0 in the environment switches the cache off. */
+int kiwi_hip_eikonal_cache_stats(long long *hits, long long *misses, int reset);
 
 /* minimize_lm (minimizer_engine.f90:728-874; sminpack/lmdif.f in fp32 with the reference's settings: ftol = xtol =
  * sqrt(spmpar(1)), gtol = 0, maxfev = 500 (n + 1), mode 2 with diag = 1, factor 0.01) over the parameters with

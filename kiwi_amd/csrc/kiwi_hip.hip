@@ -1774,6 +1774,16 @@ static int effective_cpus()
 
 int kiwi_hip_effective_cpus(void) { return effective_cpus(); }
 
+int kiwi_hip_eikonal_cache_stats(long long *hits, long long *misses, int reset)
+{
+    eik::SolveCache &sc = eik::SolveCache::get();
+    if (hits) *hits = sc.hits.load();
+    if (misses) *misses = sc.misses.load();
+    if (reset) { sc.hits = 0; sc.misses = 0; }
+    if (reset & 2) { std::lock_guard<std::mutex> lk(sc.mu); sc.slots.clear(); }
+    return 0;
+}
+
 // One batch of trial sources after the host discretiser, before anything touches the device
 struct HostBatch {
     int nsrc = 0, nbad = 0, bad = -1;

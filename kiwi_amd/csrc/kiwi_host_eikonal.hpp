@@ -9,7 +9,12 @@
 #pragma once
 #include "kiwi_host.hpp"
 #include <array>
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
 #include <limits>
+#include <memory>
+#include <mutex>
 
 namespace kiwi {
 
@@ -221,6 +226,93 @@ inline void fast_marching(const std::vector<float> &speed, int nx, int ny, const
     finish();
 }
 
+// ---- solves kept by their real inputs ------------------------------------------------------------------------------
+// The arrival times are a pure function of (speed grid, its dimensions and spacing, the start cell): north / east / time
+// shifts of a rupture and changes of its moment tensor leave all of these alone, a depth change alters the speed grid only
+// through the layer boundaries it crosses.  A location grid search therefore repeats a handful of solves over and over.
+// The cache compares the COMPLETE inputs (hash first, then memcmp of the speed grid), so a hit returns exactly the
+// array the solver would produce: bit-identical centroid tables, whatever the hit rate.  Shared by the discretiser
+// threads; a few entries (a solve's grids are a few MB each).  KIWI_HIP_EIK_CACHE=0 switches it off.
+struct SolveCache {
+    struct Entry {
+        unsigned long long hash = 0;
+        int nx = 0, ny = 0, ix = 0, iy = 0;
+        float dx = 0.f, dy = 0.f;
+        std::vector<float> speed, times;
+        unsigned long long stamp = 0;
+    };
+    static constexpr int kEntries = 24;
+    std::vector<std::shared_ptr<Entry>> slots;
+    std::mutex mu;
+    unsigned long long clock = 0;
+    std::atomic<long long> hits{ 0 }, misses{ 0 };
+    bool enabled = true;
+    SolveCache() { if (const char *m = std::getenv("KIWI_HIP_EIK_CACHE")) enabled = std::atoi(m) != 0; }
+    static SolveCache &get() { static SolveCache c; return c; }
+    static unsigned long long hash_of(const std::vector<float> &speed, int nx, int ny, int ix, int iy, float dx, float dy)
+    {
+        unsigned long long h = 1469598103934665603ull;
+        auto mix = [&h](unsigned long long v) { h ^= v; h *= 1099511628211ull; h ^= h >> 29; };
+        mix((unsigned long long)nx << 32 | (unsigned)ny);
+        mix((unsigned long long)ix << 32 | (unsigned)iy);
+        unsigned a, b;
+        std::memcpy(&a, &dx, 4); std::memcpy(&b, &dy, 4);
+        mix((unsigned long long)a << 32 | b);
+        const size_t n = speed.size();
+        size_t k = 0;
+        for (; k + 2 <= n; k += 2) { unsigned long long w; std::memcpy(&w, &speed[k], 8); mix(w); }
+        if (k < n) { unsigned w; std::memcpy(&w, &speed[k], 4); mix(w); }
+        return h;
+    }
+    std::shared_ptr<Entry> find(unsigned long long h, const std::vector<float> &speed, int nx, int ny, int ix, int iy, float dx, float dy)
+    {
+        std::vector<std::shared_ptr<Entry>> cand;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (auto &e : slots)
+                if (e && e->hash == h && e->nx == nx && e->ny == ny && e->ix == ix && e->iy == iy && e->dx == dx && e->dy == dy) {
+                    e->stamp = ++clock;
+                    cand.push_back(e);
+                }
+        }
+        for (auto &e : cand)                              // (outside the lock: entries are immutable once published)
+            if (e->speed.size() == speed.size() && std::memcmp(e->speed.data(), speed.data(), speed.size() * sizeof(float)) == 0) return e;
+        return nullptr;
+    }
+    void put(std::shared_ptr<Entry> e)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        e->stamp = ++clock;
+        if ((int)slots.size() < kEntries) { slots.push_back(std::move(e)); return; }
+        size_t old = 0;
+        for (size_t i = 1; i < slots.size(); i++) if (slots[i]->stamp < slots[old]->stamp) old = i;
+        slots[old] = std::move(e);
+    }
+};
+
+inline void fast_marching_cached(const std::vector<float> &speed, int nx, int ny, const float origin[2], const float delta[2],
+                                 const float start[2], std::vector<float> &times)
+{
+    SolveCache &sc = SolveCache::get();
+    if (!sc.enabled) { fast_marching(speed, nx, ny, origin, delta, start, times); return; }
+    // the start cell exactly as fast_marching computes it: all it takes from `origin` and `start`
+    int ix = (int)((start[0] - origin[0]) / delta[0]) + 1, iy = (int)((start[1] - origin[1]) / delta[1]) + 1;
+    ix = std::min(std::max(ix, 1), nx);
+    iy = std::min(std::max(iy, 1), ny);
+    const unsigned long long h = SolveCache::hash_of(speed, nx, ny, ix, iy, delta[0], delta[1]);
+    if (auto e = sc.find(h, speed, nx, ny, ix, iy, delta[0], delta[1])) {
+        times = e->times;
+        sc.hits++;
+        return;
+    }
+    fast_marching(speed, nx, ny, origin, delta, start, times);
+    sc.misses++;
+    auto e = std::make_shared<SolveCache::Entry>();
+    e->hash = h; e->nx = nx; e->ny = ny; e->ix = ix; e->iy = iy; e->dx = delta[0]; e->dy = delta[1];
+    e->speed = speed; e->times = times;
+    sc.put(std::move(e));
+}
+
 } // namespace eik
 
 inline int source_nparams_eikonal(int type) { return type == 4 ? 15 : (type == 5 ? 20 : -1); }
@@ -294,7 +386,7 @@ inline std::string discretize_eikonal(int type, const float *P, float doi, const
     const float invalid = minspeed * 0.5f;
     for (auto &v : speed) if (v == 0.f) v = invalid;
     const float start[2] = { nux, nuy };
-    fast_marching(speed, fx, fy, lo, fd, start, ftimes);
+    fast_marching_cached(speed, fx, fy, lo, fd, start, ftimes);      // (exact: hit = same inputs, compared in full)
     for (size_t k = 0; k < speed.size(); k++) if (speed[k] == invalid) ftimes[k] = -1.f;
 
     // coarse grid (psm_to_tdsm_size_*, psm_downsample_grid)

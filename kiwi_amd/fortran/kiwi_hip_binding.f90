@@ -249,6 +249,12 @@ module kiwi_hip_binding
             import :: c_int
         end function
 
+        integer(c_int) function kiwi_hip_eikonal_cache_stats( hits, misses, reset ) bind(C, name='kiwi_hip_eikonal_cache_stats')
+            import :: c_int, c_long_long
+            integer(c_long_long), intent(out) :: hits, misses
+            integer(c_int), value :: reset
+        end function
+
         integer(c_int) function kiwi_hip_eval( ctx, isrc0, nsrc ) bind(C, name='kiwi_hip_eval')
             import :: c_int, c_ptr
             type(c_ptr), value :: ctx

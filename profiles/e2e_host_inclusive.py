@@ -33,7 +33,17 @@ for rep in range(3):
           "%d threads at most + H2D) %.2f ms = %.1f %%" % (name, batch, dt * 1e3, batch / dt, p.L.kiwi_hip_effective_cpus(), ds * 1e3,
                                                          100 * ds / dt))
 # a trial list of nb batches: one after the other, and through the overlapped call
+import ctypes                                  # noqa: E402
 import numpy as np                             # noqa: E402
+
+
+def cache_stats(reset=0):
+    """(hits, misses) of the eikonal discretiser's solve cache; reset 3: counters and stored solves"""
+    h, m = ctypes.c_longlong(0), ctypes.c_longlong(0)
+    p.L.kiwi_hip_eikonal_cache_stats(ctypes.byref(h), ctypes.byref(m), reset)
+    return h.value, m.value
+
+
 nb = 4
 big = synthetic.workload(name, batch * nb, 0)["trials"]
 for rep in range(2):
@@ -44,10 +54,12 @@ for rep in range(2):
         p.eval()
         seq.append(p.get_misfits())
     dseq = time.perf_counter() - t0
+    cache_stats(3)                                  # the sweep starts with an empty solve cache
     t0 = time.perf_counter()
     m, n, g, st = p.misfits_for_params(wl["sourcetype"], big, batch)
     dpipe = time.perf_counter() - t0
+    hits, misses = cache_stats()
     same = np.array_equal(m, np.concatenate([x[0] for x in seq])) and np.array_equal(g, np.concatenate([x[2] for x in seq]))
     print("%s: %d trial sources in pieces of %d: one after the other %.1f ms (%.0f evals/s); one overlapped call %.1f ms "
-          "(%.0f evals/s); identical results: %s" % (name, len(big), batch, dseq * 1e3, len(big) / dseq, dpipe * 1e3,
-                                                     len(big) / dpipe, same))
+          "(%.0f evals/s); identical results: %s; fast-marching solves of that call: %d computed, %d taken from the cache"
+          % (name, len(big), batch, dseq * 1e3, len(big) / dseq, dpipe * 1e3, len(big) / dpipe, same, misses, hits))

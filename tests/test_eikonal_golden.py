@@ -90,3 +90,60 @@ def test_product_matches_oracle_on_random_cases():
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and (mo, ri) == (bmo, bri)
         done += 1
     assert done >= 20
+
+
+def _cache_stats(reset=False):
+    import ctypes as C
+    from kiwi_amd import lib as klib
+    h, m = C.c_longlong(0), C.c_longlong(0)
+    klib.load().kiwi_hip_eikonal_cache_stats(C.byref(h), C.byref(m), 1 if reset else 0)
+    return h.value, m.value
+
+
+def test_solve_cache_is_exact_and_hits_on_shifted_sources():
+    """The fast-marching solves are kept by their complete inputs (speed grid, spacing, start cell): a rupture shifted north /
+    east / in time, or given another moment tensor, takes the stored arrival times -- and its centroid table is bit for bit
+    what the oracle (which solves every time) and an un-cached product build (KIWI_HIP_EIK_CACHE=0, child process) give.
+    A depth change crosses layer boundaries: other speed grid, another solve."""
+    import subprocess
+    import sys
+    prof = G["rupture_profile"]
+    cp, cn = G["e0_con"]
+    base = np.array(G["e%d_params" % (N - 1)], np.float32)             # an mt_eikonal case of the golden set
+    assert int(G["e%d_type" % (N - 1)]) == 5
+    edt = float(G["e%d_edt" % (N - 1)])
+    trials = []
+    for dn in (0.0, 400.0, -800.0):
+        for de in (0.0, 250.0):
+            for dtm in (0.0, 0.7):
+                p = base.copy()
+                p[1] += dn; p[2] += de; p[0] += dtm
+                p[13:19] *= 1.0 + 0.1 * len(trials)                     # another moment tensor
+                trials.append(p)
+    deeper = base.copy()
+    deeper[3] += 2500.0
+    trials.append(deeper)
+    _cache_stats(reset=True)
+    tables = []
+    for p in trials:
+        a, mo, ri, _ = ko.discretize_eikonal(5, p, edt, oracle_profile(prof), cp, cn)
+        b, bmo, bri = ke.discretize_eikonal(5, p, edt, prof, cp, cn)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and (mo, ri) == (bmo, bri)
+        tables.append(b)
+    hits, misses = _cache_stats()
+    assert misses <= 3 and hits >= len(trials) - 3, (hits, misses)       # one solve for the twelve shifted ones, one for the deeper
+    # the same list through a build with the cache switched off: identical bytes
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from kiwi_amd import engine as ke; "
+            "G = np.load(%r); T = np.load(sys.argv[1]); cp, cn = G['e0_con']; "
+            "out = [ke.discretize_eikonal(5, p, %r, G['rupture_profile'], cp, cn)[0] for p in T]; "
+            "np.save(sys.argv[2], np.concatenate([o.ravel() for o in out]))") % (
+                os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                os.path.join(os.path.dirname(__file__), "golden", "eikonal_vectors.npz"), edt)
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        np.save(os.path.join(td, "t.npy"), np.array(trials, np.float32))
+        env = dict(os.environ, KIWI_HIP_EIK_CACHE="0")
+        subprocess.check_call([sys.executable, "-c", code, os.path.join(td, "t.npy"), os.path.join(td, "o.npy")], env=env)
+        ref = np.load(os.path.join(td, "o.npy"))
+    got = np.concatenate([t.ravel() for t in tables])
+    assert got.view(np.uint32).tobytes() == ref.view(np.uint32).tobytes()
