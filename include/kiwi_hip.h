@@ -53,6 +53,17 @@ typedef struct kiwi_hip_ctx kiwi_hip_ctx;
 
 /* ---- lifetime: program start / cleanup_minimizer (minimizer_engine.f90:1057-1067) ---- */
 int kiwi_hip_init(int device, kiwi_hip_ctx **ctx);
+/* SURVEY 8b's `kiwi_hip_init(int ndev_wanted, void** ctx)`: ONE context over ndev_wanted devices of this process
+ * (<= 0: every visible device; more than are visible is an error unless KIWI_HIP_MULTI_OVERSUBSCRIBE=1 stacks the contexts
+ * on the devices there are -- for tests on a one-GPU box).  The returned context is the first device's and owns the others:
+ * every setter called on it is repeated on them (Green's function tensor, receivers, references replicated: SURVEY 8e), and
+ * kiwi_hip_misfits_for_params cuts its trial list into contiguous shards in list order (the order of Source.grid,
+ * python/tunguska/source.py:119-164), one per device, each evaluated on its device by a thread of its own straight into its slice
+ * of the caller's arrays -- no collective.  Everything else (kiwi_hip_eval, getters, kiwi_hip_minimize_lm) works on the first
+ * device as with kiwi_hip_init.  Counterpart for the Fortran host of the process pool of python/tunguska/seismosizer.py:785-827;
+ * results do not depend on the number of devices (a source's evaluation does not depend on its batch). */
+int kiwi_hip_init_multi(int ndev_wanted, kiwi_hip_ctx **ctx);
+int kiwi_hip_ndevices(kiwi_hip_ctx *ctx, int *n);
 int kiwi_hip_destroy(kiwi_hip_ctx *ctx);
 /* copies the last error message (NUL terminated, truncated to buflen); ctx may be NULL for init errors */
 int kiwi_hip_last_error(kiwi_hip_ctx *ctx, char *buf, int buflen);

@@ -23,6 +23,7 @@
 #include <stdexcept>
 #include <omp.h>
 #include <future>
+#include <thread>
 #include <limits>
 
 using namespace kiwi;
@@ -144,6 +145,10 @@ struct kiwi_hip_ctx {
     DevBuf<int> synrow_d, famofs_d, famlist_d;
     int dedupe_enabled = 1;           // env KIWI_HIP_DEDUPE=0 switches it off
     std::vector<unsigned long long> geo_hash;
+    // multi-device context (kiwi_hip_init_multi): the contexts of the other devices, owned by this one; setters are
+    // repeated on them, kiwi_hip_misfits_for_params shards the trial list over all of them
+    std::vector<kiwi_hip_ctx *> mates;
+    int cpu_share = 1;                // contexts that discretise at the same time: divides the discretiser's thread team
     std::vector<unsigned long long> struct_hash;   // per source: number of centroids and boundaries of its centroid groups (accumulate_duo_kernel's pairing)
     DevBuf<int> mate_d;
     int duo = 1;                      // accumulate_duo_kernel for pairs of consecutive sources of equal structure; env KIWI_HIP_DUO=0 switches it off
@@ -230,6 +235,14 @@ int fail(kiwi_hip_ctx *ctx, const std::string &msg)
 #define GUARD_END(ctx)                                                                             \
     } catch (const std::exception &e) { return fail(ctx, e.what()); }                              \
       catch (...) { return fail(ctx, "unknown error"); }
+
+// repeat a setter on the other devices of a multi-device context (kiwi_hip_init_multi)
+template <class F> static int forward(kiwi_hip_ctx *c, F &&f)
+{
+    for (kiwi_hip_ctx *m : c->mates)
+        if (int rc = f(m)) { c->err = "device " + std::to_string(m->device) + ": " + m->err; return rc; }
+    return 0;
+}
 
 int component_id(char ch)     // receiver.f90:294-307
 {
@@ -1271,9 +1284,48 @@ int kiwi_hip_init(int device, kiwi_hip_ctx **out)
     }
 }
 
+// One context per device inside ONE process (the Fortran host and its machine of 8 GPUs; counterpart of the process pool of
+// python/tunguska/seismosizer.py:785-827): the returned context is the one of the first device and owns the others.  Every
+// setter called on it is repeated on them (the Green's function tensor is replicated); kiwi_hip_misfits_for_params
+// cuts the trial list into contiguous shards in list order, one per device, each evaluated by a thread of its own into its
+// slice of the caller's arrays -- no collective, the results are where the caller wants them.
+int kiwi_hip_init_multi(int ndev_wanted, kiwi_hip_ctx **out)
+{
+    if (!out) return fail(nullptr, "null argument");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(nullptr, std::string("no HIP device available: ") + hipGetErrorString(e));
+    int n = ndev_wanted <= 0 ? ndev : ndev_wanted;
+    // more contexts than devices: only on request (tests on a one-GPU box; KIWI_HIP_MULTI_OVERSUBSCRIBE=1)
+    const char *over = std::getenv("KIWI_HIP_MULTI_OVERSUBSCRIBE");
+    if (n > ndev && !(over && std::atoi(over) != 0))
+        return fail(nullptr, "kiwi_hip_init_multi: " + std::to_string(n) + " devices wanted, " + std::to_string(ndev) + " visible");
+    kiwi_hip_ctx *c = nullptr;
+    if (int rc = kiwi_hip_init(0, &c)) return rc;
+    for (int i = 1; i < n; i++) {
+        kiwi_hip_ctx *m = nullptr;
+        if (int rc = kiwi_hip_init(i % ndev, &m)) { kiwi_hip_destroy(c); return rc; }
+        c->mates.push_back(m);
+    }
+    c->cpu_share = n;
+    for (kiwi_hip_ctx *m : c->mates) m->cpu_share = n;
+    *out = c;
+    return 0;
+}
+
+int kiwi_hip_ndevices(kiwi_hip_ctx *c, int *n)
+{
+    if (!c || !n) return fail(c, "null argument");
+    *n = 1 + (int)c->mates.size();
+    return 0;
+}
+
 int kiwi_hip_destroy(kiwi_hip_ctx *c)
 {
     if (!c) return 0;
+    for (kiwi_hip_ctx *m : c->mates) kiwi_hip_destroy(m);
+    c->mates.clear();
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto &ev : c->events) {
@@ -1349,7 +1401,7 @@ int kiwi_hip_set_gfdb(kiwi_hip_ctx *c, int nx, int nz, int ng, int L, float dt, 
     c->gm = GfMeta{ nx, nz, ng, pitch, dt, dx, dz, firstx, firstz };
     c->have_db = true;
     c->prepared = false;            // dirtyfy_database, minimizer_engine.f90:1483
-    return 0;
+    return forward(c, [&](kiwi_hip_ctx *m) { return kiwi_hip_set_gfdb(m, nx, nz, ng, L, dt, dx, dz, firstx, firstz, G, first, nsamp); });
     GUARD_END(c)
 }
 
@@ -1364,7 +1416,7 @@ int kiwi_hip_set_interp(kiwi_hip_ctx *c, int bilinear, int xus, int zus)
     // natural-span windows, transform lengths and any kept synthetics are stale
     c->prepared = false;
     c->proc_which_held = 0;
-    return 0;
+    return forward(c, [&](kiwi_hip_ctx *m) { return kiwi_hip_set_interp(m, bilinear, xus, zus); });
 }
 
 int kiwi_hip_set_effective_dt(kiwi_hip_ctx *c, float edt)
@@ -1372,7 +1424,7 @@ int kiwi_hip_set_effective_dt(kiwi_hip_ctx *c, float edt)
     if (!c) return fail(nullptr, "null context");
     if (!(edt > 0.f)) return fail(c, "effective dt must be positive");
     c->effective_dt = edt;
-    return 0;
+    return forward(c, [&](kiwi_hip_ctx *m) { return kiwi_hip_set_effective_dt(m, edt); });
 }
 
 int kiwi_hip_set_source_location(kiwi_hip_ctx *c, float lat_deg, float lon_deg, double ref_time)
@@ -1383,7 +1435,7 @@ int kiwi_hip_set_source_location(kiwi_hip_ctx *c, float lat_deg, float lon_deg, 
     c->have_origin = true;
     update_receiver_geometry(c);
     c->prepared = false;                           // dirtyfy_source_location
-    return 0;
+    return forward(c, [&](kiwi_hip_ctx *m) { return kiwi_hip_set_source_location(m, lat_deg, lon_deg, ref_time); });
 }
 
 int kiwi_hip_set_receivers(kiwi_hip_ctx *c, int nrec, const double *lat_deg, const double *lon_deg,
@@ -1415,7 +1467,7 @@ int kiwi_hip_set_receivers(kiwi_hip_ctx *c, int nrec, const double *lat_deg, con
     c->recv.swap(rs);
     update_receiver_geometry(c);
     c->prepared = false;                           // dirtyfy_receivers
-    return 0;
+    return forward(c, [&](kiwi_hip_ctx *m) { return kiwi_hip_set_receivers(m, nrec, lat_deg, lon_deg, depth, components); });
     GUARD_END(c)
 }
 
@@ -1424,7 +1476,7 @@ int kiwi_hip_switch_receiver(kiwi_hip_ctx *c, int irec, int enabled)
     if (irec < 1 || irec > (int)c->recv.size()) return fail(c, "receiver index out of range");
     c->recv[irec - 1].enabled = enabled != 0;
     c->prepared = false;
-    return 0;
+    return forward(c, [&](kiwi_hip_ctx *m) { return kiwi_hip_switch_receiver(m, irec, enabled); });
 }
 
 int kiwi_hip_set_reference(kiwi_hip_ctx *c, int irec, int icomp, int first, int n, const float *data)
@@ -1436,7 +1488,7 @@ int kiwi_hip_set_reference(kiwi_hip_ctx *c, int irec, int icomp, int first, int 
     r.ref[icomp - 1].first = first;
     r.ref[icomp - 1].data.assign(data, data + n);
     c->prepared = false;                           // dirtyfy_ref_probes
-    return 0;
+    return forward(c, [&](kiwi_hip_ctx *m) { return kiwi_hip_set_reference(m, irec, icomp, first, n, data); });
 }
 
 static int set_plf(kiwi_hip_ctx *c, int irec, int npts, const float *x, const float *y, bool taper)
@@ -1454,12 +1506,14 @@ static int set_plf(kiwi_hip_ctx *c, int irec, int npts, const float *x, const fl
 
 int kiwi_hip_set_taper(kiwi_hip_ctx *c, int irec, int npts, const float *x, const float *y)
 {
-    return set_plf(c, irec, npts, x, y, true);
+    if (int rc = set_plf(c, irec, npts, x, y, true)) return rc;
+    return forward(c, [&](kiwi_hip_ctx *m) { return set_plf(m, irec, npts, x, y, true); });
 }
 
 int kiwi_hip_set_filter(kiwi_hip_ctx *c, int irec, int npts, const float *x, const float *y)
 {
-    return set_plf(c, irec, npts, x, y, false);
+    if (int rc = set_plf(c, irec, npts, x, y, false)) return rc;
+    return forward(c, [&](kiwi_hip_ctx *m) { return set_plf(m, irec, npts, x, y, false); });
 }
 
 int kiwi_hip_set_misfit_method(kiwi_hip_ctx *c, int method)
@@ -1467,7 +1521,7 @@ int kiwi_hip_set_misfit_method(kiwi_hip_ctx *c, int method)
     if (method < 1 || method > 8) return fail(c, "unknown misfit method");
     c->method = method;
     c->prepared = false;
-    return 0;
+    return forward(c, [&](kiwi_hip_ctx *m) { return kiwi_hip_set_misfit_method(m, method); });
 }
 
 int kiwi_hip_set_floating_shiftrange(kiwi_hip_ctx *c, int irec, float min_shift, float max_shift)
@@ -1482,7 +1536,7 @@ int kiwi_hip_set_floating_shiftrange(kiwi_hip_ctx *c, int irec, float min_shift,
         c->recv[irec - 1].float_lo = lo; c->recv[irec - 1].float_hi = hi;
     }
     c->prepared = false;
-    return 0;
+    return forward(c, [&](kiwi_hip_ctx *m) { return kiwi_hip_set_floating_shiftrange(m, irec, min_shift, max_shift); });
     GUARD_END(c)
 }
 
@@ -1502,7 +1556,7 @@ int kiwi_hip_get_floating_shifts(kiwi_hip_ctx *c, int isrc0, int nsrc, float *sh
 int kiwi_hip_set_synthetics_factor(kiwi_hip_ctx *c, float factor)
 {
     c->syn_factor = factor;
-    return 0;
+    return forward(c, [&](kiwi_hip_ctx *m) { return kiwi_hip_set_synthetics_factor(m, factor); });
 }
 
 static int nparams_any(int sourcetype)
@@ -1546,7 +1600,7 @@ int kiwi_hip_set_source_crust(kiwi_hip_ctx *c, const float *rupture_profile, con
     c->origin_profile = unpack_profile(origin_profile);
     c->have_crust = true;
     default_constraints(c);
-    return 0;
+    return forward(c, [&](kiwi_hip_ctx *m) { return kiwi_hip_set_source_crust(m, rupture_profile, origin_profile); });
     GUARD_END(c)
 }
 
@@ -1555,7 +1609,7 @@ int kiwi_hip_set_source_crustal_thickness_limit(kiwi_hip_ctx *c, float limit)
     GUARD_BEGIN
     c->crustal_thickness_limit = limit;
     if (c->have_crust) default_constraints(c);
-    return 0;
+    return forward(c, [&](kiwi_hip_ctx *m) { return kiwi_hip_set_source_crustal_thickness_limit(m, limit); });
     GUARD_END(c)
 }
 
@@ -1575,7 +1629,7 @@ int kiwi_hip_set_source_constraints(kiwi_hip_ctx *c, int n, const float *points,
     c->constraints.resize((size_t)n);
     for (int i = 0; i < n; i++)
         for (int k = 0; k < 3; k++) { c->constraints[i].point[k] = points[3 * i + k]; c->constraints[i].normal[k] = normals[3 * i + k]; }
-    return 0;
+    return forward(c, [&](kiwi_hip_ctx *m) { return kiwi_hip_set_source_constraints(m, n, points, normals); });
     GUARD_END(c)
 }
 
@@ -1813,7 +1867,7 @@ static void discretise_batch(const kiwi_hip_ctx *c, int sourcetype, int nsrc, co
     // The eikonal discretisers run a fast-marching solve per source (cfg4: a 25 m fine grid of 1200 x 360 points, 43 ms per
     // solve on a core of the GPU box): one thread per source pays, up to the CPUs this process really has -- measured
     // there, 128 solves: 5.5 s on one thread, 0.70 s on 8, 0.37 s on 16 = the container's CPU quota, 0.43-0.54 s on 32-128.
-    int ecap = std::max(1, effective_cpus() - std::max(0, spare));
+    int ecap = std::max(1, (effective_cpus() - std::max(0, spare)) / std::max(1, c->cpu_share));
     if (const char *m = std::getenv("KIWI_HIP_DISC_THREADS")) ecap = std::max(1, std::atoi(m));
     const int nthreads = std::max(1, eikonal ? std::min({ omp_get_max_threads(), nsrc, ecap })
                                              : std::min({ omp_get_max_threads(), (nsrc + 31) / 32, 16, ecap }));
@@ -2050,7 +2104,7 @@ int kiwi_hip_set_keep_synthetics(kiwi_hip_ctx *c, int which)
 {
     if (which < 0 || which > 3) return fail(c, "which must be 0 (off), 1 (plain), 2 (tapered) or 3 (filtered)");
     c->keep_which = which;
-    return 0;
+    return forward(c, [&](kiwi_hip_ctx *m) { return kiwi_hip_set_keep_synthetics(m, which); });
 }
 
 int kiwi_hip_sync(kiwi_hip_ctx *c)
@@ -2113,6 +2167,33 @@ int kiwi_hip_misfits_for_params(kiwi_hip_ctx *c, int sourcetype, int nsrc, const
     if (c->synth_only) throw std::runtime_error("misfits need a reference seismogram and a misfit taper for every enabled receiver component "
                                                 "(the device comparator evaluates norms over the taper span, comparator.f90:782-792)");
     const size_t nmis = (size_t)c->nmis;
+    if (!c->mates.empty() && nsrc >= 2) {
+        // ---- multi-device context: contiguous shards in list order (Source.grid order), shard 0 here -- this context keeps the
+        // HEAD of the list as in the one-device case --, the others each in a thread of their own on their device
+        const int ndev = std::min(nsrc, 1 + (int)c->mates.size());
+        std::vector<std::thread> th;
+        std::vector<int> rc((size_t)ndev, 0);
+        auto bound = [&](int i) { return (int)((long long)nsrc * i / ndev); };
+        for (int i = 1; i < ndev; i++) {
+            kiwi_hip_ctx *m = c->mates[(size_t)i - 1];
+            const int s0 = bound(i), n = bound(i + 1) - s0;
+            th.emplace_back([=, &rc] {
+                rc[(size_t)i] = kiwi_hip_misfits_for_params(m, sourcetype, n, params + (size_t)s0 * np, piece, misfit ? misfit + (size_t)s0 * nmis : nullptr,
+                                                            norm ? norm + (size_t)s0 * nmis : nullptr, global ? global + s0 : nullptr, status ? status + s0 : nullptr);
+            });
+        }
+        std::vector<kiwi_hip_ctx *> keep;
+        keep.swap(c->mates);                                  // (shard 0 through the one-device path of this very function)
+        rc[0] = kiwi_hip_misfits_for_params(c, sourcetype, bound(1), params, piece, misfit, norm, global, status);
+        keep.swap(c->mates);
+        for (auto &t : th) t.join();
+        for (int i = 0; i < ndev; i++)
+            if (rc[(size_t)i]) {
+                if (i > 0) c->err = "device " + std::to_string(c->mates[(size_t)i - 1]->device) + ": " + c->mates[(size_t)i - 1]->err;
+                return rc[(size_t)i];
+            }
+        return 0;
+    }
     if (piece <= 0) piece = source_nparams_eikonal(sourcetype) > 0 ? 128 : 1024;
     const int npieces = (nsrc + piece - 1) / piece;
     auto work = [c, sourcetype, np, params, piece, nsrc, npieces](int k) {
@@ -2330,7 +2411,7 @@ int kiwi_hip_shift_ref_seismogram(kiwi_hip_ctx *c, int irec, float shift)
     Receiver &r = c->recv[irec - 1];
     for (int k = 0; k < r.ncomp; k++) r.ref[k].first += ishift;                   // probe_shift, comparator.f90:273-288
     c->prepared = false;
-    return 0;
+    return forward(c, [&](kiwi_hip_ctx *m) { return kiwi_hip_shift_ref_seismogram(m, irec, shift); });
     GUARD_END(c)
 }
 
@@ -2442,7 +2523,15 @@ int kiwi_hip_autoshift_ref_seismogram(kiwi_hip_ctx *c, int irec, float min_shift
         for (int k = 0; k < r.ncomp; k++) r.ref[k].first += applied[ir - r0];
     }
     c->prepared = false;
-    return 0;
+    // the other devices of a multi-device context take the shifts found here
+    return forward(c, [&](kiwi_hip_ctx *m) {
+        for (int ir = r0; ir < r1; ir++) {
+            Receiver &r = m->recv[ir];
+            for (int k = 0; k < r.ncomp; k++) r.ref[k].first += applied[ir - r0];
+        }
+        m->prepared = false;
+        return 0;
+    });
     GUARD_END(c)
 }
 

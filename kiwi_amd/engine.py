@@ -91,16 +91,24 @@ def discretize_eikonal(sourcetype, params, effective_dt, rupture_profile, con_po
 
 
 class Engine:
-    def __init__(self, device=0):
+    def __init__(self, device=0, ndev=None):
+        """device: the GPU of a one-device engine; ndev: instead, ONE engine over that many devices of this process
+        (kiwi_hip_init_multi; 0 = all visible): setters are repeated on every device, misfits_for_params /
+        make_misfits_for_sources shard their trial list over them."""
         self.L = _lib.load()
         self.h = C.c_void_p()
-        rc = self.L.kiwi_hip_init(device, C.byref(self.h))
+        rc = self.L.kiwi_hip_init(device, C.byref(self.h)) if ndev is None else self.L.kiwi_hip_init_multi(ndev, C.byref(self.h))
         if rc != 0:
             buf = C.create_string_buffer(512)
             self.L.kiwi_hip_last_error(None, buf, 512)
             self.h = None
             raise KiwiHipError("kiwi_hip_init: " + buf.value.decode())
         self.nsrc = 0
+
+    def ndevices(self):
+        n = C.c_int(0)
+        self._ck(self.L.kiwi_hip_ndevices(self.h, C.byref(n)), "ndevices")
+        return n.value
 
     # ------------------------------------------------------------------ plumbing
     def _ck(self, rc, what):

@@ -19,6 +19,20 @@ module kiwi_hip_binding
             type(c_ptr), intent(out) :: ctx
         end function
 
+        ! one context over ndev_wanted devices of this process (<= 0: all): setters repeated on every device, the trial list of
+        ! kiwi_hip_misfits_for_params sharded over them
+        integer(c_int) function kiwi_hip_init_multi( ndev_wanted, ctx ) bind(C, name='kiwi_hip_init_multi')
+            import :: c_int, c_ptr
+            integer(c_int), value :: ndev_wanted
+            type(c_ptr), intent(out) :: ctx
+        end function
+
+        integer(c_int) function kiwi_hip_ndevices( ctx, n ) bind(C, name='kiwi_hip_ndevices')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: ctx
+            integer(c_int), intent(out) :: n
+        end function
+
         integer(c_int) function kiwi_hip_destroy( ctx ) bind(C, name='kiwi_hip_destroy')
             import :: c_int, c_ptr
             type(c_ptr), value :: ctx

@@ -162,7 +162,20 @@ program minimizer_hip
         integer(c_int) :: rc_
         need_ctx = .true.
         if (have_ctx) return
-        rc_ = kiwi_hip_init( 0_c_int, ctx )
+        ! KIWI_HIP_NDEV=n: one engine over n devices of this node (0: all of them); the trial list of eval_sources is
+        ! sharded over them inside the library, every other command works as with one device
+        block
+            character(len=32) :: env_
+            integer :: len_, stat_, ndev_
+            call get_environment_variable( 'KIWI_HIP_NDEV', env_, len_, stat_ )
+            if (stat_ == 0 .and. len_ > 0) then
+                read (env_(1:len_), *, iostat=stat_) ndev_
+                if (stat_ /= 0) ndev_ = 1
+                rc_ = kiwi_hip_init_multi( int(ndev_, c_int), ctx )
+            else
+                rc_ = kiwi_hip_init( 0_c_int, ctx )
+            end if
+        end block
         if (rc_ /= 0) then
             errstr = kiwi_hip_error_message( c_null_ptr )
             need_ctx = .false.

@@ -11,6 +11,7 @@ import pytest
 import bench
 from kiwi_amd import lib as _lib
 from kiwi_amd import synthetic
+from tests import common
 
 pytestmark = pytest.mark.gpu
 CORES = int(_lib.load().kiwi_hip_effective_cpus())      # hardware threads cut to the container's CPU quota
@@ -246,6 +247,7 @@ else:                                                   # one-GPU box: both rank
     local = 0
     dist.init_process_group("gloo", rank=rank, world_size=world)
 from kiwi_amd import synthetic
+from tests import common
 from kiwi_amd.shard import sharded_misfits_for_sources
 from tests.common import Scenario
 from tests.test_gpu_parity import build
@@ -322,3 +324,87 @@ def test_bench_gpus_flag_is_honoured():
         assert out.returncode == 0, out.stderr[-3000:]
         d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
         assert d["n_gpus"] == 2 and d["rccl_world_size"] == 2 and d["cpu_baseline"] is None
+
+
+def test_multi_device_context_equals_one_device(tmp_path, monkeypatch):
+    """kiwi_hip_init_multi: ONE context over several devices of this process -- setters repeated on every device, the trial
+    list of kiwi_hip_misfits_for_params cut into contiguous shards, each evaluated on its device by a thread of its own into its
+    slice of the caller's arrays.  Byte-identical to one device for time-domain L2, amplitude-spectrum L2 and filtered L2
+    (two transform lengths in the list), with a failing trial in the list; through the Python engine and through the Fortran
+    protocol host (KIWI_HIP_NDEV=2, eval_sources).  Real devices where the box has them, else both contexts on device 0
+    (KIWI_HIP_MULTI_OVERSUBSCRIBE=1)."""
+    import torch
+    from kiwi_amd import Engine, protocol
+    from tests.common import Scenario
+    if torch.cuda.device_count() < 2:
+        monkeypatch.setenv("KIWI_HIP_MULTI_OVERSUBSCRIBE", "1")
+    for method, with_filter in (("l2norm", False), ("ampspec_l2norm", False), ("l2norm", True)):
+        sc = Scenario()
+        e = sc.oracle(); sc.make_references(e); sc.apply_setup(e, True)
+        res = []
+        for ndev in (None, 2, 3):
+            g = sc.gf
+            first, nsamp, data = sc.odb.dense_tables()
+            p = Engine(0) if ndev is None else Engine(ndev=ndev)
+            assert p.ndevices() == (ndev or 1)
+            p.set_database(g["dt"], g["dx"], g["dz"], g["firstx"], g["firstz"], data, first, nsamp)
+            p.set_receivers(sc.lat, sc.lon, sc.depth, sc.comps)
+            p.set_source_location(40.0, 30.0, 0.0)
+            p.set_effective_dt(sc.effective_dt)
+            p.set_local_interpolation("bilinear")
+            sc.apply_setup(p, False)
+            p.set_misfit_method(method)
+            if with_filter:
+                for ir in range(1, sc.nrec + 1):
+                    p.set_misfit_filter(ir, [0.01, 0.03, 0.25, 0.4], [0., 1., 1., 0.])
+            trials = np.array([[0.3 * i, 0., 0., 9500. + 300 * i] + synthetic.mt_from_sdr(40. * i, 50. + 5 * i, -60. + 30 * i) + [1.0]
+                               for i in range(7)], np.float32)
+            trials[1, 10] = 150.0; trials[5, 10] = 170.0          # two transform lengths in the list
+            m, n, gl, st = p.misfits_for_params("moment_tensor", trials, 2)
+            res.append((m, n, gl, st))
+            p.close()
+        for other in res[1:]:
+            for a, b in zip(res[0], other):
+                assert np.asarray(a).tobytes() == np.asarray(b).tobytes(), (method, with_filter)
+        assert np.all(res[0][2] > 0)
+    # ---- the Fortran protocol host over two devices
+    if not common.HAVE_FLANG:
+        return
+    sc = Scenario(nrec=4)
+    e = sc.oracle(); sc.make_references(e); sc.apply_setup(e, True)
+    gf = dict(sc.gf)
+    first, nsamp, data = sc.odb.dense_tables()
+    gf.update(first=first, nsamp=nsamp, data=data)
+    base = str(tmp_path / "db")
+    protocol.write_flat_gfdb(base, gf)
+    protocol.write_receivers(str(tmp_path / "receivers.table"), sc.lat, sc.lon, sc.comps)
+    dt = gf["dt"]
+    for (ir, k), (lo, d) in sc.refs.items():
+        protocol.write_table(str(tmp_path / ("ref-%d-%s.table" % (ir, sc.comps[ir - 1][k - 1]))), (lo - 1) * dt, dt, d)
+    trials = synthetic.bilat_strike_sweep(9, step=1.5)
+    pf = tmp_path / "params.txt"
+    with open(pf, "w") as f:
+        for t in trials:
+            f.write(" ".join("%.9g" % v for v in t) + "\n")
+    outs = []
+    for ndev in (None, "2"):
+        env = dict(os.environ)
+        if ndev:
+            env["KIWI_HIP_NDEV"] = ndev
+        p = protocol.MinimizerProcess(env=env)
+        try:
+            p.do("set_database", base)
+            p.do("set_effective_dt", sc.effective_dt)
+            p.do("set_local_interpolation", "bilinear")
+            p.do("set_receivers", str(tmp_path / "receivers.table"))
+            p.do("set_source_location", 40.0, 30.0, 0.0)
+            p.do("set_ref_seismograms", str(tmp_path / "ref"), "table")
+            p.do("set_misfit_method", "l2norm")
+            for ir, (x, y) in sc.tapers.items():
+                p.do("set_misfit_taper", ir, *[v for xy in zip(x, y) for v in xy])
+            out = str(tmp_path / ("out%s.txt" % (ndev or "1")))
+            assert p.do("eval_sources", "bilateral", str(pf), out) == "9"
+            outs.append(open(out, "rb").read())
+        finally:
+            p.close()
+    assert outs[0] == outs[1] and len(outs[0]) > 500
