@@ -40,7 +40,7 @@ def setup_product(device, wl, L):
     from kiwi_amd import Engine, synthetic
     from kiwi_amd.engine import discretize, discretize_eikonal
     nrec = wl["nrec"]
-    gf = synthetic.make_gfdb(nx=wl["nx"], L=L)
+    gf = synthetic.make_gfdb(nx=wl["nx"], nz=wl.get("nz", 6), L=L)
     lat, lon, depth, comps, dist = synthetic.make_receivers(nrec)
     p = Engine(device)
     # the engine gets the traces as a database reader delivers them: gap-compressed spans (trace_pack), which is also
@@ -233,13 +233,31 @@ def measured_copy_bandwidth(torch, device):
     return 2.0 * n * reps / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
 
 
+def visible_gpus():
+    """GPUs of this node without initialising HIP / HSA in the calling process: KFD topology nodes with compute units
+    (CPU nodes have simd_count 0), cut by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES where set."""
+    import glob
+    n = 0
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            props = dict(l.split()[:2] for l in open(f) if len(l.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        except (OSError, ValueError):
+            pass
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def launch_ranks(n):
     """Parent of a multi-GPU run: one child process per GPU through torch.distributed.run (RCCL rendezvous on 127.0.0.1).
     Nothing is retried or restarted in place: a failing rank ends the run with a non-zero status."""
     import socket
     import subprocess
-    import torch
-    have = torch.cuda.device_count()                 # counts devices without initialising the runtime in this process
+    have = visible_gpus()                            # from sysfs: nothing in this process touches the HIP runtime
     if have < n:
         print("bench.py: --gpus %d requested but only %d GPU(s) are visible" % (n, have), file=sys.stderr)
         return 2
@@ -255,16 +273,111 @@ def launch_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+def kernel_sources_sha256():
+    """Hash of the sources the device code is built from: committed counters are attached to a bench line only when
+    they were collected on exactly these."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("kiwi_amd/csrc/kiwi_kernels.hpp", "kiwi_amd/csrc/kiwi_hip.hip", "kiwi_amd/csrc/kiwi_libm32.hpp", "kiwi_amd/csrc/Makefile"):
+        with open(os.path.join(ROOT, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def also_cfg3_100pt(p_main, device, L, batch=512, steps=6):
+    """The north star's "100 sub-faults" read literally (100 sub-fault points x 2 time steps = 200 centroids), timed the
+    same way right after the main workload: evals/s with inputs resident."""
+    from kiwi_amd import synthetic
+    p_main.close()
+    wl = synthetic.workload("cfg3-100pt", batch, 0)
+    p, gf, recv, refs, tapers, ncent = setup_product(device, wl, L)
+    for _ in range(2):
+        p.eval()
+    p.sync()
+    p.kernel_ms()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        p.eval()
+        p.sync()
+        p.get_misfits()
+    dt = time.perf_counter() - t0
+    ms, launches = p.kernel_ms()
+    npts, nrec, ng, W = wl["npoints"], wl["nrec"], gf["data"].shape[2], L
+    flops_eval = ncent * nrec * W * (4 * ng + 8) + npts * nrec * W * ng * 7
+    acc_s = float(ms[1]) * 1e-3
+    p.close()
+    return {"workload": "cfg3-100pt: %.0f centroids (%.0f sub-fault points) x %d receivers" % (ncent, npts, nrec),
+            "value": batch * steps / dt, "unit": "evals/s", "trial_sources_per_step": batch, "steps": steps,
+            "roofline_frac": flops_eval * batch * steps / acc_s / 1e12 / VALU_PEAK_TFLOPS if acc_s > 0 else None}
+
+
+def sweep(args, torch, dist, rank, local_rank, ngpus, force_dist):
+    """Strong scaling: a fixed trial list (cfg5: the 10^5-point grid of BASELINE.json configs[4]) split over the ranks in
+    list order; every rank evaluates its shard through ONE call (kiwi_hip_misfits_for_params: host discretiser of a piece
+    under the device's evaluation of another), one all-gather of the global misfits at the end.  Timed: everything from the
+    parameter list to the gathered misfits."""
+    from kiwi_amd.shard import shard_range, gather_misfits
+    from kiwi_amd import synthetic
+    N = args.sweep
+    lo, hi = shard_range(N, ngpus, rank)
+    setup_n = min(512, hi - lo)
+    wl = synthetic.workload(args.workload, setup_n, lo)
+    p, gf, recv, refs, tapers, ncent = setup_product(local_rank, wl, args.samples)
+    trials = synthetic.workload(args.workload, hi - lo, lo)["trials"]
+    counts = [shard_range(N, ngpus, r)[1] - shard_range(N, ngpus, r)[0] for r in range(ngpus)]
+    p.misfits_for_params(wl["sourcetype"], trials[:setup_n])            # warm-up: plans, buffers, clocks
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    m, n, g, st = p.misfits_for_params(wl["sourcetype"], trials)
+    allg = gather_misfits(g, dist, local_rank, counts, force=force_dist)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        allg = np.asarray(allg)
+        best = int(np.nanargmin(np.where(np.isfinite(allg), allg, np.inf)))
+        # where the list holds the source the references were made from, that is where the minimum has to be
+        full = synthetic.workload(args.workload, N, 0)
+        same = np.where(np.all(full["trials"] == full["true"][None, :], axis=1))[0]
+        out = {"metric": "trial-source misfit evals/s", "value": N / elapsed, "unit": "evals/s", "n_gpus": ngpus,
+               "rccl_world_size": dist.get_world_size() if dist is not None else None, "steps": 1, "warmup": 1,
+               "ms_per_step": elapsed * 1e3, "wall_s": elapsed, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "%s: sweep of %d trial sources (%s, %s%s), %d receivers x 3 comp x %d samples" %
+                                      (wl["name"], N, wl["sourcetype"], wl["method"], " + frequency filter" if wl["filter"] is not None else "",
+                                       wl["nrec"], args.samples),
+                          "parallelism": "trial list cut into %d contiguous shards, one all-gather of global misfits" % ngpus,
+                          "timed": "parameter list -> host discretiser -> upload -> kernels -> download -> gather (inputs NOT resident)"},
+               "argmin": best, "argmin_misfit": float(allg[best]), "true_source_index": int(same[0]) if len(same) else None,
+               "argmin_is_true_source": bool(len(same) and best == int(same[0])),
+               "failed_sources": int(np.count_nonzero(st)), "roofline": None, "cpu_baseline": None}
+        print(json.dumps(_finite(out)))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None,
                     help="ranks = GPUs of this node (default: WORLD_SIZE when started by a launcher, else 1)")
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5", "cfg5-td", "cfg3-100pt", "cfg3-scatter"],
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5", "cfg5-td", "cfg3-100pt", "cfg3-scatter", "cfg3-bigdb"],
                     help="BASELINE.json configs[1..4]; cfg3 (default) is the one the metric is quoted on")
     ap.add_argument("--batch", type=int, default=0,
-                    help="trial sources per GPU per step (default: 12960 cfg2, 1024 cfg3 / cfg3-scatter, 512 cfg3-100pt / cfg5 / cfg5-td, 128 cfg4)")
+                    help="trial sources per GPU per step (default: 12960 cfg2, 4096 cfg3, 1024 cfg3-scatter / cfg3-bigdb, 512 cfg3-100pt / cfg5 / cfg5-td, 128 cfg4)")
+    ap.add_argument("--sweep", type=int, default=0,
+                    help="strong scaling: ONE pass over a fixed trial list of this many sources (cfg5: its 10^5-point grid), split over "
+                         "the ranks, host discretiser and transfers included; reports wall seconds and evals/s")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary figure (cfg3-100pt) of the default run")
     ap.add_argument("--samples", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -275,7 +388,7 @@ def main():
         sys.exit("bench.py: --gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # `python bench.py --gpus N` without a launcher: this process becomes the launcher.  It starts N ranks (one per
-        # GPU) under torch.distributed.run BEFORE anything here has touched the GPU (device_count() only counts), relays
+        # GPU) under torch.distributed.run BEFORE anything here has touched the GPU (the devices are counted from sysfs), relays
         # their output -- rank 0 prints the JSON line -- and exits with their status.
         sys.exit(launch_ranks(args.gpus))
 
@@ -299,7 +412,11 @@ def main():
     from kiwi_amd.shard import shard_range, gather_misfits
     from kiwi_amd import synthetic
     if args.batch <= 0:
-        args.batch = {"cfg2": 12960, "cfg3": 1024, "cfg3-scatter": 1024, "cfg3-100pt": 512, "cfg4": 128, "cfg5": 512, "cfg5-td": 512}[args.workload]
+        # (cfg3: 4096 sources per step -- 0.14 s -- so that the driver's 20 steps time 2.8 s of device work)
+        args.batch = {"cfg2": 12960, "cfg3": 4096, "cfg3-scatter": 1024, "cfg3-bigdb": 1024, "cfg3-100pt": 512, "cfg4": 128, "cfg5": 512,
+                      "cfg5-td": 512}[args.workload]
+    if args.sweep > 0:
+        return sweep(args, torch, dist, rank, local_rank, ngpus, force_dist)
     lo, hi = shard_range(args.batch * ngpus, ngpus, rank)
     wl = synthetic.workload(args.workload, hi - lo, lo)
     p, gf, recv, refs, tapers, ncent = setup_product(local_rank, wl, args.samples)
@@ -360,12 +477,19 @@ def main():
         # ---- measured counters of this same command from the committed rocprofv3 passes (profiles/r*_summary.json):
         # PMC counters cannot be collected from inside this process, so these are null when no profile matches
         prof = {}
+        prof_note = "no committed profile of this workload"
         try:
             import glob
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json"))):
-                w = json.load(open(f)).get("workloads", {}).get(args.workload)
+                js = json.load(open(f))
+                w = js.get("workloads", {}).get(args.workload)
                 if w and w.get("batch") and os.environ.get("KIWI_HIP_ACCUM") != "direct":
-                    prof = dict(w, file=os.path.basename(f))
+                    # counters are quoted only when they were collected on THESE kernel sources
+                    if js.get("kernel_sources_sha256") == kernel_sources_sha256():
+                        prof = dict(w, file=os.path.basename(f), profile_head=js.get("head"))
+                        prof_note = "collected on commit %s, same kernel sources as this build" % js.get("head")
+                    else:
+                        prof_note = "%s was collected on other kernel sources (commit %s): counters not attached" % (os.path.basename(f), js.get("head"))
         except Exception:
             prof = {}
         scale = args.batch / prof["batch"] if prof else 0.0
@@ -377,7 +501,8 @@ def main():
             copy_gbs = None
         kernel = "accumulate_kernel (KIWI_HIP_ACCUM=direct)" if os.environ.get("KIWI_HIP_ACCUM") == "direct" else \
             ("accumulate_cell_kernel<10,256,2,0> (+ accumulate_grouped_kernel for the pairs it leaves)" if npts > 0.5 * ncent
-             else "accumulate_grouped_kernel<10,256>")
+             else ("accumulate_grouped_kernel<10,256> (runs of sources sharing their tiles)" if wl["sourcetype"] == "moment_tensor"
+                   else "accumulate_duo_kernel<10> (+ accumulate_grouped_kernel for the pairs it leaves)"))
         out = {
             "metric": "trial-source misfit evals/s", "value": value, "unit": "evals/s",
             "n_gpus": ngpus, "rccl_world_size": dist.get_world_size() if dist is not None else None,
@@ -401,6 +526,7 @@ def main():
                          "issue_slots": {"valu_busy_frac": prof.get("valu_issue_frac"), "lds_busy_frac": prof.get("lds_busy_frac"),
                                          "valu_insts_per_launch": prof["valu_insts_per_launch"] * scale if prof.get("valu_insts_per_launch") else None,
                                          "source": prof.get("file")},
+                         "profile_head": prof.get("profile_head"), "profile_note": prof_note,
                          "hbm": {"actual_gbs": traffic / (avg_ms * 1e-3) / 1e9 if traffic else None, "peak_gbs": HBM_PEAK_GBS,
                                  "frac": traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None,
                                  "peak_measured_copy_gbs": copy_gbs,
@@ -411,6 +537,9 @@ def main():
                                  "note": "algorithmic_no_reuse_gbs is the SURVEY 8d byte model (every centroid re-reads its 40 rows) "
                                          "over the kernel time; it exceeds the HBM peak by reuse_factor because the rows are served "
                                          "from cache and every blended tile is shared by the time steps of a sub-fault"},
+                         # second resource the kernel saturates in its build phase (measured r03: build alone = 31 TB/s of L2 -> CU reads)
+                         "l2": {"request_gbs": prof["l2_request_bytes_per_launch"] * scale / (avg_ms * 1e-3) / 1e9
+                                if prof.get("l2_request_bytes_per_launch") else None, "peak_gbs": 34500.0},
                          "other_kernels_ms_per_step": {"geometry": float(ms[0]) / args.steps,
                                                        "misfit": float(ms[2]) / args.steps}},
         }
@@ -419,6 +548,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(wl, gf, recv, refs, tapers, np.asarray(allg), gm, gn)
         else:
             out["cpu_baseline"] = None
+        if ngpus == 1 and args.workload == "cfg3" and not args.no_also:
+            out["also"] = also_cfg3_100pt(p, local_rank, args.samples)
         print(json.dumps(_finite(out)))
     if dist is not None:
         dist.barrier()

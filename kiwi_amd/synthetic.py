@@ -196,6 +196,19 @@ def workload(name, nsrc=None, trial0=0):
         tr[:, 5] = 91.0 + 0.1 * (idx // 2048)
         return dict(name="cfg3-scatter", sourcetype="bilateral", true=np.array(base, np.float32), trials=tr, nrec=50,
                     nx=128, method="l2norm", filter=None, crust=None, constraints=None)
+    if name == "cfg3-bigdb":
+        # the HBM regime: the cfg3 source over a 1 GB Green's function database (512 x 12 nodes)
+        # at unique locations 5 km apart over 2500 km of distance and ten depths, in shuffled order -- the rows a launch
+        # touches are (nearly) the whole database, four times the 256 MiB Infinity Cache
+        base = [0., 0., 0., 10000., 1e20, 91., 87., 164., 0., 4800., 2000., 2000., 3000., 2.]
+        n = 256 if nsrc is None else nsrc
+        total = 5120
+        idx = np.random.default_rng(20261003).permutation(total)[(trial0 + np.arange(n)) % total]
+        tr = np.tile(np.array(base, np.float32), (n, 1))
+        tr[:, 1] = 5000.0 * (idx % 512) - 1280e3
+        tr[:, 3] = 8000.0 + 2000.0 * (idx // 512)
+        return dict(name="cfg3-bigdb", sourcetype="bilateral", true=np.array(base, np.float32), trials=tr, nrec=50,
+                    nx=512, nz=12, method="l2norm", filter=None, crust=None, constraints=None)
     if name == "cfg4":
         grid = mt_eikonal_location_grid()
         n = 32 if nsrc is None else nsrc
