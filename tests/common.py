@@ -14,6 +14,22 @@ HAVE_HDF5 = os.path.exists("/opt/conda/include/hdf5.h")
 HAVE_FLANG = os.path.exists("/opt/rocm/bin/amdflang")
 
 
+# ---- the ONE statement of the spectral / filtered tolerances: per misfit slot, the difference between
+# device and oracle relative to max(norm factor, |misfit|) of the slot -- an amplitude-spectrum misfit is a difference of
+# nearly equal spectra, its round-off scales with the spectra, not with itself.  The oracle transforms in fp64 (FFTW's own
+# rounding is "parity unpinned"), the device in fp32 (in-LDS radix-4 or hipFFT); an L1 sum adds the transforms'
+# round-off linearly over the window.  Used by the full-size tests, the randomised sweep and its pytest slice alike.
+SPECTRAL_TOL = {("ampspec_l2norm", False): 2e-5, ("ampspec_l2norm", True): 2e-5,
+                ("ampspec_l1norm", False): 5e-5, ("ampspec_l1norm", True): 5e-5,
+                ("l2norm", True): 3e-5,           # time-domain L2 on frequency-filtered traces (forward, filter, back)
+                ("l1norm", True): 1e-3}           # ... L1 there: grows with the crest factor of the trace
+SPECTRAL_NORM_TOL = 5e-5                          # norm factors of FILTERED references, on the scale of >= 1/20 of the case's largest
+
+
+def spectral_tol(method, filtered):
+    return SPECTRAL_TOL[(method, bool(filtered))]
+
+
 class Scenario:
     """Small synthetic inversion setup (scaled down)."""
 

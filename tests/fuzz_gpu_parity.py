@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity sweep (manual: `python tests/fuzz_gpu_parity.py [seconds] [seed]` on a GPU box): random databases,
 receiver sets, interpolation modes, source types, tapers and norms, each compared with the CPU oracle at the tolerances
-of tests/test_gpu_parity.py.  Not collected by pytest; the cases it has found are pinned as regular tests."""
+of tests/test_gpu_parity.py / tests/common.py.  A fixed slice of it runs under pytest (tests/test_gpu_fuzz_slice.py); the
+cases the long runs have found are pinned as regular tests."""
 import os
 import sys
 import time
@@ -10,7 +11,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from kiwi_amd import synthetic  # noqa: E402
-from tests.common import Scenario, oracle_misfits  # noqa: E402
+from tests.common import Scenario, oracle_misfits, spectral_tol, SPECTRAL_NORM_TOL  # noqa: E402
 
 FAMILIES = ["ac", "rl", "du", "ns", "ew"]            # a component and its negated twin exclude each other (receiver.f90:255-270)
 
@@ -163,13 +164,13 @@ def one_case(rng, verbose):
         # linearly over the window: relative to the norm factor that grows with the crest factor (seen: 5.2e-4 at L = 2300)
         # seen: ampspec_l1norm 2.3e-5 at L = 2300; time-domain l2 on filtered traces 2.4e-5 at L = 2300 (two cases of 34 000, in-LDS
         # transform pair before its complex products were fused multiply-adds)
-        tol = float(os.environ.get("KIWI_FUZZ_L1TOL", "1e-3")) if (filtered and mid == 2) else (5e-5 if mid == 4 else (3e-5 if (filtered and not spectral) else 2e-5))
+        tol = spectral_tol(method, filtered)                   # tests/common.py: the one table of these tolerances
         bad = np.abs(pm - m) > tol * scale
         # norm factor of a FILTERED reference: where the filter rejects almost all of a trace, the transforms' round-off (relative
         # to the unfiltered trace) is what is left of the small remainder (seen, in-LDS transforms: 2.5e-5 of a slot's l2 norm
         # factor; 1.0e-3 of an l1 norm factor fifty times below the case's largest) -- such slots are judged on the scale of a
         # twentieth of the case's largest norm factor
-        ntol = max(tol, 5e-5) if filtered else tol
+        ntol = max(tol, SPECTRAL_NORM_TOL) if filtered else tol
         nscale = np.maximum(nn[0], 0.05 * nn[0].max()) if filtered else nn[0]
         ok = bool(np.all(np.abs(pn[0] - nn[0]) <= ntol * nscale)) and not bad.any()
     else:
