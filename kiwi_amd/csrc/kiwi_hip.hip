@@ -976,7 +976,7 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
         c->ntr_d.ensure(np, &c->dev_bytes);
         pin_ensure(c->ntr_pin, c->ntr_pin_n, np);
         hipLaunchKernelGGL(fft_size_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, c->stream, spansrc, c->comps_d.p, c->nmis,
-                           nsrc, nrec, fold_halfwidth(c->max_risetime, c->gm.dt), c->ntr_d.p);
+                           nsrc, nrec, c->risetime_d.p + isrc0, c->gm.dt, c->ntr_d.p);
         HIPCHECK(hipMemcpyAsync(c->ntr_pin, c->ntr_d.p, np * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHECK(hipEventRecord(c->size_event, c->stream));
     }
@@ -1366,11 +1366,12 @@ int kiwi_hip_set_gfdb(kiwi_hip_ctx *c, int nx, int nz, int ng, int L, float dt, 
     // >= pad + n + 5 for load5's clamp; the extra halo of repeated end values lets the grouped kernel's last
     // tile (which overhangs the window by up to kHalo samples) take its clamp-free path
     const int pitch = (kRowPad + lmax + kHalo + 32 + 3) / 4 * 4;
-    // The LDS-staged kernels address a group's rows relative to the first row of its cell with 32-bit offsets (write_tab):
-    // the tensor itself may have any size, one cell (two neighbouring distances, all depths between, all components) must
-    // stay below 2^31 floats.  set_interp checks the same with the undersampling factors.
-    if (((size_t)nz + 2) * (size_t)ng * (size_t)pitch >= ((size_t)1 << 31))
-        throw std::runtime_error("database rows too long: one distance step of the grid exceeds 2^31 samples");
+    // The LDS-staged kernels address a group's rows relative to the first row of its cell with 32-bit BYTE offsets (write_tab
+    // holds float offsets, the buffer loads take 4 x that as their unsigned scalar offset): the tensor itself may have any
+    // size, one cell (two neighbouring distances, all depths between, all components) must stay below 2^30 floats = 4 GB.
+    // set_interp checks the same with the undersampling factors.
+    if (((size_t)nz + 2) * (size_t)ng * (size_t)pitch >= ((size_t)1 << 30))
+        throw std::runtime_error("database rows too long: one distance step of the grid exceeds 2^30 samples (4 GB)");
     // host staging in slabs of rows: [kRowPad zeros | samples | repeated end value]
     c->G.alloc(nrows * (size_t)pitch, &c->dev_bytes);
     c->span.alloc(nrows, &c->dev_bytes);
@@ -1409,8 +1410,8 @@ int kiwi_hip_set_interp(kiwi_hip_ctx *c, int bilinear, int xus, int zus)
 {
     if (!c) return fail(nullptr, "null context");
     if (xus < 1 || zus < 1) return fail(c, "undersampling must be >= 1");
-    if (c->have_db && ((size_t)xus * c->gm.nz + zus + 1) * (size_t)c->gm.ng * (size_t)c->gm.pitch >= ((size_t)1 << 31))
-        return fail(c, "undersampling too coarse for this database: one interpolation cell exceeds 2^31 samples");
+    if (c->have_db && ((size_t)xus * c->gm.nz + zus + 1) * (size_t)c->gm.ng * (size_t)c->gm.pitch >= ((size_t)1 << 30))
+        return fail(c, "undersampling too coarse for this database: one interpolation cell exceeds 2^30 samples (4 GB)");
     c->bilinear = bilinear ? 1 : 0; c->xus = xus; c->zus = zus;
     // set_local_interpolation / set_spacial_undersampling dirty the seismograms (minimizer_engine.f90:1483-1493):
     // natural-span windows, transform lengths and any kept synthetics are stale

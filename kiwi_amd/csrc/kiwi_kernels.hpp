@@ -657,7 +657,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t gf_rsrc(const float *base)
 }
 __device__ __forceinline__ f4u buf_load4(__amdgpu_buffer_rsrc_t r, int voff_floats, int soff_floats)
 {
-    const v4i_t v = __builtin_amdgcn_raw_buffer_load_b128(r, 4 * voff_floats, 4 * soff_floats, 0);
+    // byte offsets as unsigned 32-bit values: the host keeps a cell below 2^30 floats (kiwi_hip_set_gfdb / kiwi_hip_set_interp),
+    // so neither wraps
+    const v4i_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(4u * (unsigned)voff_floats), (int)(4u * (unsigned)soff_floats), 0);
     return f4u{ __int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w) };
 }
 
@@ -2085,10 +2087,10 @@ __device__ __forceinline__ void raw_issue(RawArr<NG, PART, SPL> &v, int p, int j
             asm("s_sub_i32 %0, %1, %2\n\ts_add_i32 %0, %0, %3\n\ts_lshl_b32 %0, %0, 2" : "=&s"(u4) : "s"(base), "s"(lo), "s"(jb) : "scc");
             asm("v_add_u32 %0, %1, %2\n\tv_med3_i32 %0, %0, 0, %3" : "=&v"(q4) : "s"(u4), "v"(p4), "s"(hi4));
             if constexpr (SPL == 4) {
-                const v4i_t w = __builtin_amdgcn_raw_buffer_load_b128(gf_rsrc(G), q4, 4 * lo, 0);
+                const v4i_t w = __builtin_amdgcn_raw_buffer_load_b128(gf_rsrc(G), q4, (int)(4u * (unsigned)lo), 0);
                 v[i][k] = RV{ __int_as_float(w.x), __int_as_float(w.y), __int_as_float(w.z), __int_as_float(w.w) };
             } else {
-                const v2i_t w = __builtin_amdgcn_raw_buffer_load_b64(gf_rsrc(G), q4, 4 * lo, 0);
+                const v2i_t w = __builtin_amdgcn_raw_buffer_load_b64(gf_rsrc(G), q4, (int)(4u * (unsigned)lo), 0);
                 v[i][k] = RV{ __int_as_float(w.x), __int_as_float(w.y) };
             }
         }
@@ -3103,12 +3105,19 @@ __global__ __launch_bounds__(256) void filtered_norm_kernel(
 // ntrans = next_power_of_two(max(length of the union, 2 len_ref, 2 len_syn)).  spansrc: per (source, receiver) data spans
 // of the horizontal / vertical strips, reduced by geometry_kernel; fold_grow: strip_fold's growth (sparse_trace.f90:379-402).
 __global__ void fft_size_kernel(const int *__restrict__ spansrc, const CompDev *__restrict__ comps, int nmis, int nsrc, int nrec,
-                                int fold_grow, int *__restrict__ ntr_out)
+                                const float *__restrict__ risetime /* of the chunk's sources */, float dt, int *__restrict__ ntr_out)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nsrc * nmis) return;
     const int s = idx / nmis, m = idx - s * nmis;
     const CompDev cd = comps[m];
+    // strip_fold grows a strip by the taps of THIS source's rise time (receiver.f90:868-897, sparse_trace.f90:379-402), not by
+    // the batch's longest: a pair's transform length must not depend on the batch it is evaluated in
+    int fold_grow = 0;
+    {
+        const float rise = risetime[s];
+        if (rise > 0.f) fold_grow = ((1 + 2 * (int)roundf(0.5f * rise / dt)) - 1) / 2;
+    }
     int s0, s1;
     strip_span(spansrc + ((size_t)s * nrec + cd.rec) * kSpanInts, cd.spankind, s0, s1);
     if (s1 < s0) { s0 = cd.rf0; s1 = cd.rf0; }                       // no centroid reached this strip

@@ -391,12 +391,23 @@ class Engine:
         n = np.zeros((N, nm), np.float32)
         g = np.zeros(N, np.float32)
         status = np.zeros(N, np.int32)
-        self._ck(self.L.kiwi_hip_misfits_for_params(self.h, st, N, _fp(p), piece, _fp(m), _fp(n), _fp(g), _ip(status)),
-                 "get_misfits")
-        for s0 in range(0, N, piece):      # pieces are evaluated from the end of the list: the context holds its head
-            if np.any(status[s0:s0 + piece] == 0):
-                self.nsrc = min(piece, N - s0)
+        try:
+            self._ck(self.L.kiwi_hip_misfits_for_params(self.h, st, N, _fp(p), piece, _fp(m), _fp(n), _fp(g), _ip(status)),
+                     "get_misfits")
+        except KiwiHipError:
+            self.nsrc = 0                  # (a call that fails midway leaves no batch this object may index)
+            raise
+        # pieces are evaluated from the end of the list: the context holds the first piece that uploaded anything; with a
+        # multi-device engine that is shard 0's (the first device keeps the head of the list)
+        ndev = self.ndevices()
+        n0 = N if ndev == 1 else N // ndev
+        held = 0
+        for s0 in range(0, n0, piece):
+            if np.any(status[s0:min(s0 + piece, n0)] == 0):
+                held = min(piece, n0 - s0)
                 break
+        if held:
+            self.nsrc = held               # (no piece uploaded anything: the context keeps what it held)
         return m, n, g, status
 
     def make_misfits_for_sources(self, sourcetype=None, params=None, piece=0):

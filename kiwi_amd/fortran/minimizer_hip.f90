@@ -1329,7 +1329,8 @@ program minimizer_hip
             rc = kiwi_hip_set_sources_params( ctx, int(st,c_int), 1_c_int, p )      ! for its message
             ok_ = check( rc ); return
         end if
-        source_set = .true.
+        ! (a list none of whose trials could be discretised uploads nothing: the context keeps whatever it held before)
+        if (any(status == 0)) source_set = .true.
         open( newunit=unit, file=trim(ofile), status='unknown', iostat=ios )
         if (ios /= 0) then
             call fail( 'failed to open file for output: '//trim(ofile) ); return
@@ -1338,7 +1339,7 @@ program minimizer_hip
             write (unit,'(*(es16.8e3,1x))') g(s+1), (m(s*nmis+i), n(s*nmis+i), i=1,nmis)
         end do
         close( unit )
-        evaluated = .true.         ! source 0 of the batch is the "current" source
+        if (any(status == 0)) evaluated = .true.         ! source 0 of the batch is the "current" source
         write (str,'(i0)') nsrc
         answer = trim(str)
         if (any(status /= 0)) then              ! "<nsrc> failed <i1> <i2> ..." (1-based, in trial order)

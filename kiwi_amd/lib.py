@@ -53,10 +53,12 @@ def load():
     # (measured on the GPU box: this library + kiwi_hip_init, then `import torch` -> torch.cuda sees no GPU; torch's copy
     # initialised by another module, then kiwi_hip_init -> no device).  Loaded AFTER torch this library binds to torch's
     # copy and both work, so torch goes first wherever it is installed.
-    if "torch" not in sys.modules and os.environ.get("KIWI_HIP_WITHOUT_TORCH", "0") != "1":
+    # (only where torch is installed at all: the library itself needs no torch)
+    import importlib.util
+    if "torch" not in sys.modules and os.environ.get("KIWI_HIP_WITHOUT_TORCH", "0") != "1" and importlib.util.find_spec("torch") is not None:
         try:
             import torch  # noqa: F401
-        except Exception:      # no torch here (or one that does not import): nothing to order
+        except Exception:      # a torch that does not import: nothing to order
             pass
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from kiwi_amd import synthetic, KiwiHipError
-from tests.common import Scenario, oracle_misfits
+from tests.common import Scenario, oracle_misfits, spectral_tol
 
 pytestmark = pytest.mark.gpu
 
@@ -1433,3 +1433,103 @@ def test_two_sources_per_workgroup_is_bit_identical(monkeypatch, L):
     p.eval()
     pm, pn, pg = p.get_misfits()
     assert misfit_close(pm, m) and misfit_close(pg, g)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("what", ["ampspec_l2norm", "ampspec_l1norm", "filter"])
+def test_spectral_norms_without_a_taper_are_refused_not_approximated(what):
+    """The one branch of the comparator without a device path (INTEGRATION.md "limits"): amplitude-spectrum norms and
+    misfit filters on a receiver WITHOUT a misfit taper (comparator.f90:861-886 over the whole padded probes, whose spans follow
+    every source evaluated before: :222-271).  The engine says so (`nok >` with the reason, as every error) instead of
+    evaluating something else; the same setup with tapers evaluates.  python/tunguska/misfit.py always sets tapers."""
+    from kiwi_amd.lib import KiwiHipError
+    sc = Scenario(nrec=3)
+    e = sc.oracle()
+    sc.make_references(e)
+    p = sc.product()
+    for (ir, k), (lo, d) in sc.refs.items():
+        p.set_ref_seismogram(ir, k, lo, d)
+    for ir in (1, 2):                                        # receiver 3 keeps no taper
+        p.set_misfit_taper(ir, *sc.tapers[ir])
+    if what == "filter":
+        p.set_misfit_method("l2norm")
+        for ir in range(1, 4):
+            p.set_misfit_filter(ir, [0.01, 0.03, 0.25, 0.4], [0., 1., 1., 0.])
+    else:
+        p.set_misfit_method(what)
+    p.set_source_params("bilateral", synthetic.bilat_strike_sweep(2, step=2.0))
+    with pytest.raises(KiwiHipError, match="need a misfit taper on every enabled receiver"):
+        p.eval()
+    with pytest.raises(KiwiHipError, match="need a misfit taper on every enabled receiver"):
+        p.misfits_for_params("bilateral", synthetic.bilat_strike_sweep(2, step=2.0))
+    p.set_misfit_taper(3, *sc.tapers[3])                     # with the taper: evaluates
+    p.set_source_params("bilateral", synthetic.bilat_strike_sweep(2, step=2.0))
+    p.eval()
+    pm, pn, pg = p.get_misfits()
+    assert np.all(np.isfinite(pm)) and np.all(pn > 0) and np.all(pg > 0)
+    p.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method,with_filter", [("ampspec_l2norm", False), ("l2norm", True)])
+def test_spectral_results_of_folded_sources_do_not_depend_on_the_batch(method, with_filter):
+    """strip_fold grows a strip by the taps of the source's OWN rise time (receiver.f90:868-897), so the transform
+    length of a probe pair of an `mt_eikonal` source follows that rise time, not the longest one of the batch it is evaluated
+    in (fft_size_kernel): mixed rise times -- one of them long enough to change the transform length -- alone == in a batch
+    == in another order == through the one-call in pieces, bit for bit; and each agrees with a fresh oracle engine."""
+    import os
+    from oracle import ko
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "eikonal_vectors.npz"))
+    prof = G["rupture_profile"]
+    sc = Scenario(nz=6, L=200)
+    e, p = build(sc)
+    mid = {"ampspec_l2norm": 3, "l2norm": 1}[method]
+    p.set_misfit_method(method)
+    fx, fy = [0.01, 0.03, 0.25, 0.4], [0., 1., 1., 0.]
+    if with_filter:
+        for ir in range(1, sc.nrec + 1):
+            p.set_misfit_filter(ir, fx, fy)
+    rng = np.random.default_rng(11)
+    rises = [0.0, 1.5, 30.0, 0.6, 60.0]
+    trials = []
+    for i, rise in enumerate(rises):
+        common = [0.2 * i, 300.0 * i, -200.0 * i, 10500.0 + 300 * i]
+        bord = [100.0, -50.0, 2500.0 + 400 * i]
+        nukl = [500.0 - 300 * i, 200.0]
+        trials.append(common + [1.0, 80.0 + 5 * i, 70.0] + bord + nukl + [0.8] + list(rng.standard_normal(6) * 7e17) + [rise])
+    trials = np.array(trials, np.float32)
+    cp = np.array([[0, 0, 6500.0], [0, 0, 15500.0]], np.float32)
+    cn = np.array([[0, 0, -1.0], [0, 0, 1.0]], np.float32)
+    p.set_source_crust(prof, G["origin_profile"])
+    p.set_source_constraints(cp, cn)
+    p.set_source_params("mt_eikonal", trials)
+    p.eval()
+    bm, bn, bg = [x.copy() for x in p.get_misfits()]
+    assert len({x.tobytes() for x in bn}) > 1            # more than one transform length in this batch
+    for i in range(len(trials)):                          # alone
+        p.set_source_params("mt_eikonal", trials[i:i + 1])
+        p.eval()
+        am, an, ag = p.get_misfits()
+        assert am[0].tobytes() == bm[i].tobytes() and an[0].tobytes() == bn[i].tobytes() and ag[0] == bg[i], i
+    perm = [4, 0, 2, 1, 3]
+    p.set_source_params("mt_eikonal", trials[perm])
+    p.eval()
+    qm, qn, qg = p.get_misfits()
+    assert np.array_equal(qm, bm[perm]) and np.array_equal(qn, bn[perm]) and np.array_equal(qg, bg[perm])
+    rm, rn, rg, rs = p.misfits_for_params("mt_eikonal", trials, 2)
+    assert np.array_equal(rm, bm) and np.array_equal(rn, bn) and np.array_equal(rg, bg) and not rs.any()
+    oprof = ko.crust_profile(*np.split(prof, [8, 16, 24]))
+    tol = spectral_tol(method, with_filter)
+    for i in (1, 2, 4):
+        ef = sc.oracle()
+        sc.apply_setup(ef, True)
+        ef.set_misfit_method(mid)
+        if with_filter:
+            for ir in range(1, sc.nrec + 1):
+                ef.set_filter(ir, fx, fy)
+        c, mo, ri, _ = ko.discretize_eikonal(5, trials[i], sc.effective_dt, oprof, cp, cn)
+        ef.set_centroids(c, mo, ri)
+        om, on, og = ef.get_misfits()
+        assert np.all(np.abs(bn[i] - on) <= 5e-5 * on), (i, np.max(np.abs(bn[i] - on) / on))
+        assert np.all(np.abs(bm[i] - om) <= tol * np.maximum(on, np.abs(om))), (i, np.max(np.abs(bm[i] - om) / on))
+        ef.close()
