@@ -149,9 +149,12 @@ struct kiwi_hip_ctx {
     // repeated on them, kiwi_hip_misfits_for_params shards the trial list over all of them
     std::vector<kiwi_hip_ctx *> mates;
     int cpu_share = 1;                // contexts that discretise at the same time: divides the discretiser's thread team
-    std::vector<unsigned long long> struct_hash;   // per source: number of centroids and boundaries of its centroid groups (accumulate_duo_kernel's pairing)
-    DevBuf<int> mate_d;
-    int duo = 1;                      // accumulate_duo_kernel for pairs of consecutive sources of equal structure; env KIWI_HIP_DUO=0 switches it off
+    std::vector<unsigned long long> struct_hash;   // per source: number of centroids and boundaries of its centroid groups (accumulate_multi_kernel's grouping)
+    std::vector<unsigned long long> shift_hash;    // per source: its centroids' integer shifts (groups of four share a tile origin only with equal shifts)
+    std::vector<float> src_ends;                   // per source: position (north, east, depth) of its first and of its last centroid
+    DevBuf<int> mate_d, mate4_d;
+    int duo = 4;                      // accumulate_multi_kernel: up to this many consecutive sources of equal structure per workgroup
+                                      // (4, 2, or 0 = off); env KIWI_HIP_DUO
     std::vector<char> single_group;
     DevBuf<int> runfirst_d;
     int share_runs = 1, max_run = 64;
@@ -945,7 +948,7 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
     // cell groups pay where most centroids are points of their own (no blended tile to share between time steps)
     // (with nearest-neighbour interpolation there is nothing to blend: same-point groups do)
     const bool cell = c->accum_mode == 0 && (c->cell_mode == 1 || (c->cell_mode < 0 && c->bilinear && c->points_per_centroid > 0.5));
-    // two sources per workgroup (accumulate_duo_kernel, 512-sample tiles); decided below, once the runs and the shared synthetics are known
+    // several sources per workgroup (accumulate_multi_kernel); decided below, once the runs and the shared synthetics are known
     const bool duo_maybe = c->accum_mode == 0 && c->duo && !cell && c->max_wlen >= 384 && !c->group_threads_env && nsrc >= 2;
     EvalParams ep{ c->bilinear, c->xus, c->zus, nrec, isrc0, cell ? 1 : 0 };
     int *spansrc = nullptr;
@@ -996,7 +999,7 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
             // workgroup size: env override, else by window length (halo overhead vs tile fit)
             const int T = c->group_threads_env ? c->group_threads : (c->max_wlen >= 2048 ? 256 : (c->max_wlen >= 384 ? 128 : 64));
             const int ntiles = (c->max_wlen + 4 * T - 1) / (4 * T);
-            const int ntiles_p = (c->max_wlen + 511) / 512;              // accumulate_duo_kernel: 512 samples per source
+            const int ntiles_p = (c->max_wlen + 511) / 512;              // accumulate_multi_kernel: 512 samples per source with two of them
             // cell mode: accumulate_cell_kernel (256 threads, tile = spl x 256 samples) takes the pairs of cell_pair(), the
             // grouped kernel behind it the others
             const int spl = c->cell_spl, Tc = 256;
@@ -1027,38 +1030,58 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
                     gx = (unsigned)rf.size() - 1;
                 }
             }
-            // pairs of consecutive sources of equal structure (see accumulate_duo_kernel)
+            // aligned groups of four / two consecutive sources of equal structure (see accumulate_multi_kernel); four only where
+            // the integer shifts agree as well (else their groups do not share a tile origin: two at a time then)
             bool duo = duo_maybe && !runs && !synrow && maxnc > 0;
-            if (std::getenv("KIWI_HIP_DEBUG"))
-                std::fprintf(stderr, "[kiwi_hip] duo_maybe %d runs %d synrow %d cell %d max_wlen %d\n", (int)duo_maybe, runs != nullptr, synrow != nullptr, (int)cell, c->max_wlen);
+            bool any4 = false, any2 = false;
             if (duo) {
-                std::vector<int> mt((size_t)(nsrc + 1) / 2, 0);
-                bool any = false;
-                for (int k = 0; 2 * k + 1 < nsrc; k++) {
-                    const int a = isrc0 + 2 * k, b = a + 1;
+                std::vector<int> m4((size_t)(nsrc + 3) / 4, 0), m2((size_t)(nsrc + 1) / 2, 0);
+                // ... and only sources that are NEIGHBOURS in space (first and last centroid within a quarter of the database's node
+                // spacing): their groups then sit in the same cells for most receivers.  Sources further apart would have their tile
+                // sets built one after the other, from shorter tiles -- slower than the grouped kernel (measured: a shuffled
+                // location grid 53 instead of 42 ms per 1024 sources).
+                const float near_h = 0.25f * c->gm.dx * (float)c->xus, near_z = 0.25f * c->gm.dz * (float)c->zus;
+                auto same = [&](int a, int b, bool shifts) {
                     const int na = c->cent_ofs[a + 1] - c->cent_ofs[a], nb = c->cent_ofs[b + 1] - c->cent_ofs[b];
-                    mt[k] = (na > 0 && na == nb && c->struct_hash[a] == c->struct_hash[b]) ? 1 : 0;
-                    any = any || mt[k];
+                    if (!(na > 0 && na == nb && c->struct_hash[a] == c->struct_hash[b] && (!shifts || c->shift_hash[a] == c->shift_hash[b]))) return false;
+                    const float *p = c->src_ends.data() + (size_t)a * 6, *q = c->src_ends.data() + (size_t)b * 6;
+                    for (int k = 0; k < 6; k++)
+                        if (std::fabs(p[k] - q[k]) > (k % 3 == 2 ? near_z : near_h)) return false;
+                    return true;
+                };
+                if (c->duo >= 4)
+                    for (int k = 0; 4 * k + 3 < nsrc; k++) {
+                        const int a = isrc0 + 4 * k;
+                        m4[k] = (same(a, a + 1, true) && same(a, a + 2, true) && same(a, a + 3, true)) ? 1 : 0;
+                        any4 = any4 || m4[k];
+                    }
+                for (int k = 0; 2 * k + 1 < nsrc; k++) {
+                    const int a = isrc0 + 2 * k;
+                    m2[k] = (!m4[(size_t)k / 2] && same(a, a + 1, false)) ? 1 : 0;
+                    any2 = any2 || m2[k];
                 }
-                duo = any;
+                duo = any4 || any2;
                 if (std::getenv("KIWI_HIP_DEBUG")) {
-                    int nm = 0; for (int v : mt) nm += v;
-                    std::fprintf(stderr, "[kiwi_hip] chunk of %d sources: %d of %d pairs of equal structure\n", nsrc, nm, (int)mt.size());
+                    int n4 = 0, n2 = 0; for (int v : m4) n4 += v; for (int v : m2) n2 += v;
+                    std::fprintf(stderr, "[kiwi_hip] chunk of %d sources: %d groups of four, %d pairs of equal structure\n", nsrc, n4, n2);
                 }
                 if (duo) {
-                    c->mate_d.ensure(mt.size(), &c->dev_bytes);
-                    HIPCHECK(hipMemcpyAsync(c->mate_d.p, mt.data(), mt.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-                    HIPCHECK(hipStreamSynchronize(c->stream));         // mt goes out of scope
+                    c->mate4_d.ensure(m4.size(), &c->dev_bytes);
+                    c->mate_d.ensure(m2.size(), &c->dev_bytes);
+                    HIPCHECK(hipMemcpyAsync(c->mate4_d.p, m4.data(), m4.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+                    HIPCHECK(hipMemcpyAsync(c->mate_d.p, m2.data(), m2.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+                    HIPCHECK(hipStreamSynchronize(c->stream));         // m4, m2 go out of scope
                 }
             }
+            const int ntiles_q = (c->max_wlen + 255) / 256;              // ... 256 samples per source with four of them
             dim3 ggrid(gx, (unsigned)(ntiles * nrec));                   // source index fastest (L2 sharing)
-            dim3 dgrid((unsigned)((nsrc + 1) / 2), (unsigned)(ntiles_p * nrec));
+            dim3 dgrid((unsigned)((nsrc + 1) / 2), (unsigned)(ntiles_p * nrec)), qgrid((unsigned)((nsrc + 3) / 4), (unsigned)(ntiles_q * nrec));
             dim3 cgrid((unsigned)nsrc, (unsigned)(ntiles_c * nrec));
             FuseParams fp{ nullptr, nullptr, nullptr, nullptr, 0, 1.f, 0, 0, 0 };
             if (fuse) {
                 // partial sums per (source, slot): [tile][wave] of the kernel that evaluated the pair.  In cell mode two
                 // kernels with different tilings share the buffer: it is cleared and misfit_finish_kernel sums all of it
-                const int nparts = cell ? std::max(ntiles * (T / 64), ntiles_c * (Tc / 64)) : (duo ? std::max(ntiles * (T / 64), ntiles_p * 2) : ntiles * (T / 64));
+                const int nparts = cell ? std::max(ntiles * (T / 64), ntiles_c * (Tc / 64)) : (duo ? std::max({ ntiles * (T / 64), ntiles_p * 2, ntiles_q }) : ntiles * (T / 64));
                 c->fusepart_d.ensure((size_t)nsrc * c->nmis * nparts, &c->dev_bytes);
                 if (cell || duo) HIPCHECK(hipMemsetAsync(c->fusepart_d.p, 0, (size_t)nsrc * c->nmis * nparts * sizeof(double), c->stream));
                 fp = FuseParams{ c->reft_d.p, c->tw_d.p, c->moment_d.p, c->fusepart_d.p, c->method, c->syn_factor, c->nmis, nparts, isrc0 };
@@ -1068,7 +1091,8 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
 #define KIWI_LAUNCH_G2(NGV, TV, FV, RV)                                                                     \
     hipLaunchKernelGGL((accumulate_grouped_kernel<NGV, TV, FV, RV>), ggrid, dim3(TV), 0, c->stream, c->G.p, c->span.p,   \
                        c->gm.pitch, c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p,          \
-                       c->syn_stride, ntiles, c->tab_d.p, runs, fp, (cell || duo) ? c->pairflag_d.p : (const int *)nullptr, cell ? 1 : (duo ? 3 : 0), duo ? c->mate_d.p : (const int *)nullptr, synrow, famofs, famlist)
+                       c->syn_stride, ntiles, c->tab_d.p, runs, fp, (cell || duo) ? c->pairflag_d.p : (const int *)nullptr, cell ? 1 : (duo ? 3 : 0), any2 ? c->mate_d.p : (const int *)nullptr,  \
+                       any4 ? c->mate4_d.p : (const int *)nullptr, synrow, famofs, famlist)
 #define KIWI_LAUNCH_GROUPED(NGV, TV)                                                                        \
     do { if (fuse) { if (runs) KIWI_LAUNCH_G2(NGV, TV, true, true); else KIWI_LAUNCH_G2(NGV, TV, true, false); }   \
          else      { if (runs) KIWI_LAUNCH_G2(NGV, TV, false, true); else KIWI_LAUNCH_G2(NGV, TV, false, false); } } while (0)
@@ -1081,16 +1105,18 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
 #define KIWI_LAUNCH_CELL(NGV) do { if (spl == 2) { if (fuse) KIWI_LAUNCH_C2(NGV, 2, true); else KIWI_LAUNCH_C2(NGV, 2, false); } \
                                    else          { if (fuse) KIWI_LAUNCH_C2(NGV, 4, true); else KIWI_LAUNCH_C2(NGV, 4, false); } } while (0)
             if (cell) { if (c->gm.ng == 10) KIWI_LAUNCH_CELL(10); else KIWI_LAUNCH_CELL(8); }
-#define KIWI_LAUNCH_D2(NGV, FV)                                                                             \
-    hipLaunchKernelGGL((accumulate_duo_kernel<NGV, FV>), dgrid, dim3(256), 0, c->stream, c->G.p, c->span.p,           \
+            // the (group of sources, receiver) combinations accumulate_multi_kernel takes; the grouped kernel behind it returns at once for those
+#define KIWI_LAUNCH_M2(NGV, FV, NSV, GRID, NT, MATE, WIDER)                                                    \
+    hipLaunchKernelGGL((accumulate_multi_kernel<NGV, FV, NSV>), GRID, dim3(256), 0, c->stream, c->G.p, c->span.p,       \
                        c->gm.pitch, c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p,          \
-                       c->syn_stride, ntiles_p, c->tab_d.p, fp, c->pairflag_d.p, c->mate_d.p)
-            // the (pair, receiver) combinations accumulate_duo_kernel takes; the grouped kernel behind it returns at once for those
-            if (duo) {
-                if (c->gm.ng == 10) { if (fuse) KIWI_LAUNCH_D2(10, true); else KIWI_LAUNCH_D2(10, false); }
-                else                { if (fuse) KIWI_LAUNCH_D2(8, true); else KIWI_LAUNCH_D2(8, false); }
-            }
-#undef KIWI_LAUNCH_D2
+                       c->syn_stride, NT, c->tab_d.p, fp, c->pairflag_d.p, MATE, WIDER)
+#define KIWI_LAUNCH_MULTI(NSV, GRID, NT, MATE, WIDER) do {                                                  \
+                if (c->gm.ng == 10) { if (fuse) KIWI_LAUNCH_M2(10, true, NSV, GRID, NT, MATE, WIDER); else KIWI_LAUNCH_M2(10, false, NSV, GRID, NT, MATE, WIDER); } \
+                else                { if (fuse) KIWI_LAUNCH_M2(8, true, NSV, GRID, NT, MATE, WIDER); else KIWI_LAUNCH_M2(8, false, NSV, GRID, NT, MATE, WIDER); } } while (0)
+            if (any4) KIWI_LAUNCH_MULTI(4, qgrid, ntiles_q, c->mate4_d.p, (const int *)nullptr);
+            if (any2) KIWI_LAUNCH_MULTI(2, dgrid, ntiles_p, c->mate_d.p, any4 ? c->mate4_d.p : (const int *)nullptr);
+#undef KIWI_LAUNCH_MULTI
+#undef KIWI_LAUNCH_M2
             if (c->gm.ng == 10) {
                 if (T == 64) KIWI_LAUNCH_GROUPED(10, 64); else if (T == 256) KIWI_LAUNCH_GROUPED(10, 256); else KIWI_LAUNCH_GROUPED(10, 128);
             } else {
@@ -1261,7 +1287,7 @@ int kiwi_hip_init(int device, kiwi_hip_ctx **out)
         }
         if (const char *m = std::getenv("KIWI_HIP_ACCUM")) c->accum_mode = (std::strcmp(m, "direct") == 0) ? 1 : 0;
         if (const char *m = std::getenv("KIWI_HIP_FUSE")) c->fuse_enabled = std::atoi(m);
-        if (const char *m = std::getenv("KIWI_HIP_DUO")) c->duo = std::atoi(m) != 0;
+        if (const char *m = std::getenv("KIWI_HIP_DUO")) { const int v = std::atoi(m); c->duo = v >= 4 ? 4 : (v >= 1 ? 2 : 0); }
         if (const char *m = std::getenv("KIWI_HIP_CELL")) c->cell_mode = std::atoi(m) ? 1 : 0;
         if (const char *m = std::getenv("KIWI_HIP_DEDUPE")) c->dedupe_enabled = std::atoi(m);      // 0 off, 1 default, 2 also for point sources
         if (const char *m = std::getenv("KIWI_HIP_FUSED_FFT")) c->fused_fft = std::atoi(m) != 0;   // 0: amplitude spectra through hipFFT
@@ -1691,6 +1717,8 @@ int kiwi_hip_set_sources(kiwi_hip_ctx *c, int nsrc, const int *cent_ofs, const f
     c->cent_ofs.assign(cent_ofs, cent_ofs + nsrc + 1);
     c->geo_hash.assign((size_t)nsrc, 0ull);
     c->struct_hash.assign((size_t)nsrc, 0ull);
+    c->shift_hash.assign((size_t)nsrc, 0ull);
+    c->src_ends.assign((size_t)nsrc * 6, 0.f);
     c->single_group.assign((size_t)nsrc, 0);
     {
         const float dt = c->gm.dt;
@@ -1731,8 +1759,13 @@ int kiwi_hip_set_sources(kiwi_hip_ctx *c, int nsrc, const int *cent_ofs, const f
                 hs ^= (unsigned)len; hs *= 1099511628211ull;
                 k += len;
             }
+            unsigned long long hsh = 1469598103934665603ull;
+            for (int k = 0; k < nc; k++) { hsh ^= (unsigned)(int)std::floor(ce[(size_t)k * 10 + 3] / dt); hsh *= 1099511628211ull; }
             c->geo_hash[s] = h;
             c->struct_hash[s] = hs;
+            c->shift_hash[s] = hsh;
+            if (nc > 0)
+                for (int q = 0; q < 3; q++) { c->src_ends[(size_t)s * 6 + q] = ce[q]; c->src_ends[(size_t)s * 6 + 3 + q] = ce[(size_t)(nc - 1) * 10 + q]; }
             c->single_group[s] = one ? 1 : 0;
         }
         // identical tables (hash over all ten columns, confirmed by comparison)

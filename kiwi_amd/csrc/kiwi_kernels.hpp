@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void geometry_kernel(
     int *__restrict__ tab, int *__restrict__ spanbuf, int *__restrict__ spansrc /* optional [source][receiver][kSpanInts] */,
     int *__restrict__ pairflag /* optional [source][receiver]: bit 0 some centroid of the pair is added in part (a trace is missing),
                                   bit 1 some centroid is left out (a trace missing or outside the database), bit 2 some group's rows do
-                                  not all end in zero (the tail rule can apply); see cell_pair(), duo_pair() */,
+                                  not all end in zero (the tail rule can apply); see cell_pair(), multi_taken() */,
     const unsigned char *__restrict__ endz /* per GF row: its end value is zero (write_tab) */,
     const int *__restrict__ synrow /* optional [source]: source whose synthetics this one shares; != own index: nothing to do */)
 {
@@ -535,12 +535,18 @@ __device__ __forceinline__ bool cell_pair(const RecvDev &rv, const int *__restri
     return rv.need_h && rv.has_d && !(pairflag[(size_t)s * nrec + r] & 1);
 }
 
-// (pairs accumulate_duo_kernel takes; the same rule as duo_pair() further down)
-__device__ __forceinline__ bool duo_pair_fwd(const RecvDev &rv, const int *__restrict__ pairflag, const int *__restrict__ mate,
-                                             int s, int nrec, int r)
+// (the (group of NS sources, receiver) combinations accumulate_multi_kernel takes; the same rule as multi_taken() further down)
+template <int NS>
+__device__ __forceinline__ bool multi_taken_fwd(const RecvDev &rv, const int *__restrict__ pairflag, const int *__restrict__ mate,
+                                                int s, int nrec, int r)
 {
-    const int a = s & ~1;
-    return mate[a >> 1] && rv.need_h && rv.has_d && (pairflag[(size_t)a * nrec + r] | pairflag[(size_t)(a + 1) * nrec + r]) == 0;
+    if (!mate) return false;
+    const int a = s - s % NS;
+    if (!mate[a / NS] || !rv.need_h || !rv.has_d) return false;
+    int f = 0;
+#pragma unroll
+    for (int i = 0; i < NS; i++) f |= pairflag[(size_t)(a + i) * nrec + r];
+    return f == 0;
 }
 
 __global__ __launch_bounds__(256) void cellgroup_kernel(const int *__restrict__ cent_ofs, EvalParams ep, GfMeta gm,
@@ -1294,7 +1300,7 @@ __device__ __forceinline__ void set2_dead_8(const Set2_8 &S)
 template <int I> __device__ __forceinline__ f2v &s2a(const Set2_8 &s) { if constexpr (I == 0) return s.a0; else if constexpr (I == 1) return s.a1; else if constexpr (I == 2) return s.a2; else if constexpr (I == 3) return s.a3; else if constexpr (I == 4) return s.a4; else if constexpr (I == 5) return s.a5; else if constexpr (I == 6) return s.a6; else return s.a7; }
 template <int I> __device__ __forceinline__ f2v &s2b(const Set2_8 &s) { if constexpr (I == 0) return s.b0; else if constexpr (I == 1) return s.b1; else if constexpr (I == 2) return s.b2; else if constexpr (I == 3) return s.b3; else if constexpr (I == 4) return s.b4; else if constexpr (I == 5) return s.b5; else if constexpr (I == 6) return s.b6; else return s.b7; }
 
-// ---- the same for a component stride of 9 x 64 dwords (512-sample tiles of accumulate_duo_kernel)
+// ---- the same for a component stride of 9 x 64 dwords (512-sample tiles: two sources per workgroup, accumulate_multi_kernel)
 __device__ __forceinline__ void set2_read_10_k9(int on, unsigned a, const Set2_10 &S)
 {
     asm volatile("s_cmp_eq_u32 %21, 0\n\ts_cbranch_scc1 .Lkiwi_skip%=\n\t"
@@ -1343,11 +1349,66 @@ __device__ __forceinline__ void set2_read_8_k9(int on, unsigned a, const Set2_8 
                  "\n.Lkiwi_skip%=:"
                  : "+v"(S.a0), "+v"(S.a1), "+v"(S.a2), "+v"(S.a3), "+v"(S.a4), "+v"(S.a5), "+v"(S.a6), "+v"(S.a7), "+v"(S.b0), "+v"(S.b1), "+v"(S.b2), "+v"(S.b3), "+v"(S.b4), "+v"(S.b5), "+v"(S.b6), "+v"(S.b7) : "v"(a), "s"(on) : "memory", "scc");
 }
+// ---- ... and of 5 x 64 dwords (256-sample tiles: four sources per workgroup)
+__device__ __forceinline__ void set2_read_10_k5(int on, unsigned a, const Set2_10 &S)
+{
+    asm volatile("s_cmp_eq_u32 %21, 0\n\ts_cbranch_scc1 .Lkiwi_skip%=\n\t"
+                 "ds_read2st64_b32 %0, %20 offset1:1\n\t"
+                 "ds_read2st64_b32 %1, %20 offset0:5 offset1:6\n\t"
+                 "ds_read2st64_b32 %2, %20 offset0:10 offset1:11\n\t"
+                 "ds_read2st64_b32 %3, %20 offset0:40 offset1:41\n\t"
+                 "ds_read2st64_b32 %4, %20 offset0:15 offset1:16\n\t"
+                 "ds_read2st64_b32 %5, %20 offset0:20 offset1:21\n\t"
+                 "ds_read2st64_b32 %6, %20 offset0:25 offset1:26\n\t"
+                 "ds_read2st64_b32 %7, %20 offset0:30 offset1:31\n\t"
+                 "ds_read2st64_b32 %8, %20 offset0:35 offset1:36\n\t"
+                 "ds_read2st64_b32 %9, %20 offset0:45 offset1:46\n\t"
+                 "ds_read2st64_b32 %10, %20 offset0:2 offset1:3\n\t"
+                 "ds_read2st64_b32 %11, %20 offset0:7 offset1:8\n\t"
+                 "ds_read2st64_b32 %12, %20 offset0:12 offset1:13\n\t"
+                 "ds_read2st64_b32 %13, %20 offset0:42 offset1:43\n\t"
+                 "ds_read2st64_b32 %14, %20 offset0:17 offset1:18\n\t"
+                 "ds_read2st64_b32 %15, %20 offset0:22 offset1:23\n\t"
+                 "ds_read2st64_b32 %16, %20 offset0:27 offset1:28\n\t"
+                 "ds_read2st64_b32 %17, %20 offset0:32 offset1:33\n\t"
+                 "ds_read2st64_b32 %18, %20 offset0:37 offset1:38\n\t"
+                 "ds_read2st64_b32 %19, %20 offset0:47 offset1:48\n\t"
+                 "\n.Lkiwi_skip%=:"
+                 : "+v"(S.a0), "+v"(S.a1), "+v"(S.a2), "+v"(S.a3), "+v"(S.a4), "+v"(S.a5), "+v"(S.a6), "+v"(S.a7), "+v"(S.a8), "+v"(S.a9), "+v"(S.b0), "+v"(S.b1), "+v"(S.b2), "+v"(S.b3), "+v"(S.b4), "+v"(S.b5), "+v"(S.b6), "+v"(S.b7), "+v"(S.b8), "+v"(S.b9) : "v"(a), "s"(on) : "memory", "scc");
+}
+__device__ __forceinline__ void set2_read_8_k5(int on, unsigned a, const Set2_8 &S)
+{
+    asm volatile("s_cmp_eq_u32 %17, 0\n\ts_cbranch_scc1 .Lkiwi_skip%=\n\t"
+                 "ds_read2st64_b32 %0, %16 offset1:1\n\t"
+                 "ds_read2st64_b32 %1, %16 offset0:5 offset1:6\n\t"
+                 "ds_read2st64_b32 %2, %16 offset0:10 offset1:11\n\t"
+                 "ds_read2st64_b32 %3, %16 offset0:15 offset1:16\n\t"
+                 "ds_read2st64_b32 %4, %16 offset0:20 offset1:21\n\t"
+                 "ds_read2st64_b32 %5, %16 offset0:25 offset1:26\n\t"
+                 "ds_read2st64_b32 %6, %16 offset0:30 offset1:31\n\t"
+                 "ds_read2st64_b32 %7, %16 offset0:35 offset1:36\n\t"
+                 "ds_read2st64_b32 %8, %16 offset0:2 offset1:3\n\t"
+                 "ds_read2st64_b32 %9, %16 offset0:7 offset1:8\n\t"
+                 "ds_read2st64_b32 %10, %16 offset0:12 offset1:13\n\t"
+                 "ds_read2st64_b32 %11, %16 offset0:17 offset1:18\n\t"
+                 "ds_read2st64_b32 %12, %16 offset0:22 offset1:23\n\t"
+                 "ds_read2st64_b32 %13, %16 offset0:27 offset1:28\n\t"
+                 "ds_read2st64_b32 %14, %16 offset0:32 offset1:33\n\t"
+                 "ds_read2st64_b32 %15, %16 offset0:37 offset1:38\n\t"
+                 "\n.Lkiwi_skip%=:"
+                 : "+v"(S.a0), "+v"(S.a1), "+v"(S.a2), "+v"(S.a3), "+v"(S.a4), "+v"(S.a5), "+v"(S.a6), "+v"(S.a7), "+v"(S.b0), "+v"(S.b1), "+v"(S.b2), "+v"(S.b3), "+v"(S.b4), "+v"(S.b5), "+v"(S.b6), "+v"(S.b7) : "v"(a), "s"(on) : "memory", "scc");
+}
 template <int NG> struct Set2Sel;
 template <> struct Set2Sel<10> { typedef Set2_10 type; };
 template <> struct Set2Sel<8> { typedef Set2_8 type; };
-template <int K> __device__ __forceinline__ void set2_read(int on, unsigned a, const Set2_10 &S) { if constexpr (K == 17) set2_read_10(on, a, S); else set2_read_10_k9(on, a, S); }
-template <int K> __device__ __forceinline__ void set2_read(int on, unsigned a, const Set2_8 &S) { if constexpr (K == 17) set2_read_8(on, a, S); else set2_read_8_k9(on, a, S); }
+template <int K> __device__ __forceinline__ void set2_read(int on, unsigned a, const Set2_10 &S)
+{
+    if constexpr (K == 17) set2_read_10(on, a, S); else if constexpr (K == 9) set2_read_10_k9(on, a, S); else set2_read_10_k5(on, a, S);
+}
+template <int K> __device__ __forceinline__ void set2_read(int on, unsigned a, const Set2_8 &S)
+{
+    if constexpr (K == 17) set2_read_8(on, a, S); else if constexpr (K == 9) set2_read_8_k9(on, a, S); else set2_read_8_k5(on, a, S);
+}
 __device__ __forceinline__ void set2_wait(const Set2_10 &S) { set2_wait_10(S); }
 __device__ __forceinline__ void set2_wait(const Set2_8 &S) { set2_wait_8(S); }
 __device__ __forceinline__ void set2_dep(const Set2_10 &S) { set2_dep_10(S); }
@@ -1372,7 +1433,7 @@ __device__ __forceinline__ void carry2_apply(f2v (&ar1)[2], f2v (&ar2)[2], f2v (
     float cw[2 * NG];
 #pragma unroll
     for (int i = 0; i < 2 * NG; i++) cw[i] = coef[i];
-    static_assert(K == 17 || K == 9, "component stride in units of 64 dwords");
+    static_assert(K == 17 || K == 9 || K == 5, "component stride in units of 64 dwords");
     set2_read<K>(load_hi, a + 4, H);
     set2_read<K>(load_lo, a, L);
     set2_wait(H);
@@ -1423,7 +1484,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_GROUPED_
     const int *__restrict__ tab, const int *__restrict__ run_first, FuseParams fp,
     const int *__restrict__ pairflag /* see geometry_kernel */,
     int pairsel /* 0 all pairs, 1 not the cell kernel's, 3 not the duo kernel's */,
-    const int *__restrict__ mate /* pairsel 3: see duo_pair() */,
+    const int *__restrict__ mate, const int *__restrict__ mate4 /* pairsel 3: groups of two / four sources accumulate_multi_kernel takes */,
     const int *__restrict__ synrow /* optional: sources that share another source's synthetics are not synthesised */,
     const int *__restrict__ fam_ofs, const int *__restrict__ fam_list /* FUSE with synrow: the sources that share source s's
                                           synthetics, fam_list[fam_ofs[s] .. fam_ofs[s + 1]): compared here with their moments */)
@@ -1451,7 +1512,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_GROUPED_
     if (!rv.enabled) return;
     if (tile * TILE >= rv.wlen) return;
     if (pairsel == 1 && cell_pair(rv, pairflag, s, nrec, r)) return;
-    if (pairsel == 3 && duo_pair_fwd(rv, pairflag, mate, s, nrec, r)) return;
+    if (pairsel == 3 && (multi_taken_fwd<4>(rv, pairflag, mate4, s, nrec, r) || multi_taken_fwd<2>(rv, pairflag, mate, s, nrec, r))) return;
     if (synrow && !multi && synrow[s] != s) return;  // (in a run the sources that share synthetics are left out one by one)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1785,93 +1846,104 @@ __device__ __forceinline__ void one_finish(const f4u (&v)[BLEND ? 4 : 1], float 
     *(float4 *)(tile0 + ig * lds_tile + p) = make_float4(b.x, b.y, b.z, b.w);
 }
 
-// Build of accumulate_duo_kernel: wave w blends components 2 i + (w >> 1) for the 64 chunks of slab w & 1 (chunk = 4 samples;
-// the 128 main chunks of the 512-sample tile), threads 0 .. 16 NG - 1 the halo chunks; every chunk's four node rows are loaded
-// once and blended with the weights of gw0 into tile set 0 (W0) and with those of gw1 into tile set 1 (W1)
-// (gfdb.f90:946-949, summed in this order).  A centroid exactly on a node carries the weights (1, 0, 0, 0) over four copies of
-// its row: 1 v + 0 v + 0 v + 0 v is v bit for bit, so there is no unblended variant.
-template <int NG, bool FAST, bool W0, bool W1>
-__device__ __forceinline__ void duo_build(float *__restrict__ tile0, int wv, int lane, int tid, int jb, const float *__restrict__ G,
-                                          int pitch, int ta, int tb, const GeoRec &gw0, const GeoRec &gw1, bool hact, int hig, int hph)
+// Build of accumulate_multi_kernel: NS tile sets of TILE = 1024 / NS samples (+ halo).  A wave-task = one component's 64 main
+// chunks (chunk = 4 samples) of one 256-sample slab; NS = 2: wave w takes components 2 i + (w >> 1), slab w & 1; NS = 4: wave w
+// components w + 4 i (one slab); threads 0 .. 16 NG - 1 the halo chunks.  Every chunk's four node rows are loaded ONCE and
+// blended with the weights of each source into its tile set (gfdb.f90:946-949, summed in this order) -- `only` >= 0: into that
+// source's set alone.  A centroid exactly on a node carries the weights (1, 0, 0, 0) over four copies of its row:
+// 1 v + 0 v + 0 v + 0 v is v bit for bit, so there is no unblended variant.
+template <int NG, bool FAST, int NS>
+__device__ __forceinline__ void multi_build(float *__restrict__ tile0, int wv, int lane, int tid, int jb, const float *__restrict__ G,
+                                            int pitch, int ta, int tb, const GeoRec (&gw)[NS], int only, bool hact, int hig, int hph)
 {
-    constexpr int LDS_TILE = 512 + kHalo, N = NG / 2, DEPTH = 3;
-    const int p = 4 * (64 * (wv & 1) + lane), cg = wv >> 1;
-    float *__restrict__ tile1 = tile0 + NG * LDS_TILE;
+    constexpr int TILE = 1024 / NS, LDS_TILE = TILE + kHalo, DEPTH = 3;
+    constexpr int N = (NS == 2) ? NG / 2 : (NG + 3) / 4;           // wave-tasks per wave at most
+    const int p = (NS == 2) ? 4 * (64 * (wv & 1) + lane) : 4 * lane;
+    auto comp = [&](int i) { return (NS == 2) ? 2 * i + (wv >> 1) : wv + 4 * i; };
     f4u v[N][4];
     HaloRegs hv = halo_issue<true, FAST>(true, hig, hph, jb, G, pitch, ta, tb);        // (inactive lanes load a valid chunk too: no merge of registers)
 #pragma unroll
-    for (int i = 0; i < DEPTH && i < N; i++) one_issue<true, FAST>(v[i], 2 * i + cg, p, jb, G, pitch, ta, tb);
+    for (int i = 0; i < DEPTH && i < N; i++) if (comp(i) < NG) one_issue<true, FAST>(v[i], comp(i), p, jb, G, pitch, ta, tb);
 #pragma unroll
     for (int i = 0; i < N; i++) {
         __builtin_amdgcn_sched_barrier(0);
-        if (W0) one_finish<true>(v[i], tile0, LDS_TILE, 2 * i + cg, p, gw0);
-        if (W1) one_finish<true>(v[i], tile1, LDS_TILE, 2 * i + cg, p, gw1);
-        if (i + DEPTH < N) one_issue<true, FAST>(v[i + DEPTH], 2 * (i + DEPTH) + cg, p, jb, G, pitch, ta, tb);
+        if (comp(i) < NG) {
+#pragma unroll
+            for (int s = 0; s < NS; s++)
+                if (only < 0 || only == s) one_finish<true>(v[i], tile0 + s * NG * LDS_TILE, LDS_TILE, comp(i), p, gw[s]);
+        }
+        if (i + DEPTH < N && comp(i + DEPTH) < NG) one_issue<true, FAST>(v[i + DEPTH], comp(i + DEPTH), p, jb, G, pitch, ta, tb);
     }
-    if (W0) halo_finish<true>(hact, hv, tile0, LDS_TILE, hig, hph, gw0);
-    if (W1) halo_finish<true>(hact, hv, tile1, LDS_TILE, hig, hph, gw1);
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+        if (only < 0 || only == s) halo_finish<true>(hact, hv, tile0 + s * NG * LDS_TILE, LDS_TILE, hig, hph, gw[s]);
 }
 
 // ------------------------------------------------------------------------------------------------
-// accumulate, two trial sources per workgroup (round 3)
+// accumulate, several trial sources per workgroup (round 3)
 //
 // Measured on accumulate_grouped_kernel (cfg3, 1024 sources per launch): build phase alone 22.8 ms, apply phase alone
 // 22.7 ms, together 38.6 ms -- and the build alone moves 713 GB from the L2s to the CUs (40 node rows of 1088 samples per
 // group and workgroup) in those 22.8 ms: 31 TB/s of the ~34.5 TB/s the L2s deliver.  The build is bound by L2 bandwidth,
 // the apply by vector issue, and a workgroup alternates between the two.  What shrinks the first: NEIGHBOURING trial sources
 // of a grid search put their sub-faults into the same cells of the Green's function grid (a strike step of 0.1 degree moves a
-// sub-fault by metres, the nodes are kilometres apart): the 40 node rows a group needs are the same for both, only the
-// four blend weights differ.  This kernel gives a workgroup the same (receiver, 512-sample tile) of TWO consecutive trial
-// sources: every group's node rows are loaded ONCE and blended twice, into a tile set per source (2 x 23 KB of LDS); waves
-// 0-1 then apply the centroids of the first source from its tile set, waves 2-3 those of the second.  Per output sample:
-// half the L2 traffic, about half the build's instructions (addresses, descriptors and loads are shared), the apply as
-// before (carry2_apply).  Where the two sources' groups do NOT sit in the same cell the workgroup builds the two tile sets
-// one after the other.
+// sub-fault by metres, the nodes are kilometres apart): the 40 node rows a group needs are the same for all of them, only
+// the four blend weights differ.  This kernel gives a workgroup the same (receiver, tile) of NS = 2 or 4 CONSECUTIVE trial
+// sources, tiles of 1024 / NS samples: every group's node rows are loaded ONCE and blended NS times, into a tile set per
+// source (NS x (1024 / NS + 64) x NG floats of LDS: 46 / 51 KB, three workgroups per CU); each wave then applies the
+// centroids of ONE of the sources from that source's tile set (carry2_apply, as accumulate_grouped_kernel).  Per output
+// sample: 1 / NS of the L2 traffic and of the build's addresses, descriptors and loads (the blend arithmetic stays), the
+// apply as before.  Where the sources' groups do NOT all sit in the same cell with the same tile origin, the workgroup
+// builds the tile sets one after the other.
 //
-// Pairing (host, kiwi_hip_set_sources): sources 2k and 2k+1 of a chunk whose centroid tables have the same STRUCTURE --
-// same number of centroids, same boundaries of the centroid groups (group_len) -- so that both walk their groups in
-// lockstep; `mate[k]` says so.  Of those the kernel takes the (pair, receiver) combinations
-// where both sources are "clean" for the receiver (horizontal and vertical components, no missing trace, no tail rule:
-// pairflag of geometry_kernel); accumulate_grouped_kernel runs behind it for everything else (pairsel 3).
-__device__ __forceinline__ bool duo_pair(const RecvDev &rv, const int *__restrict__ pairflag, const int *__restrict__ mate,
-                                         int s, int nrec, int r)
+// Grouping (host, eval): aligned groups of NS sources of a chunk whose centroid tables have the same STRUCTURE -- same
+// number of centroids, same boundaries of the centroid groups (group_len) -- so that they walk their groups in lockstep;
+// `mate[k]` says so for group k.  Of those the kernel takes the (group, receiver) combinations where every source is "clean"
+// for the receiver (horizontal and vertical components, no missing trace, no tail rule: pairflag of geometry_kernel);
+// accumulate_grouped_kernel runs behind it for everything else (pairsel 3).
+template <int NS>
+__device__ __forceinline__ bool multi_taken(const RecvDev &rv, const int *__restrict__ pairflag, const int *__restrict__ mate,
+                                            int s, int nrec, int r)
 {
-    const int a = s & ~1;
-    return mate[a >> 1] && rv.need_h && rv.has_d && (pairflag[(size_t)a * nrec + r] | pairflag[(size_t)(a + 1) * nrec + r]) == 0;
+    if (!mate) return false;
+    const int a = s - s % NS;
+    if (!mate[a / NS] || !rv.need_h || !rv.has_d) return false;
+    int f = 0;
+#pragma unroll
+    for (int i = 0; i < NS; i++) f |= pairflag[(size_t)(a + i) * nrec + r];
+    return f == 0;
 }
 
-template <int NG, bool FUSE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void accumulate_duo_kernel(
+template <int NG, bool FUSE, int NS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void accumulate_multi_kernel(
     const float *__restrict__ G, const int2 *__restrict__ span, int pitch,
     const GeoRec *__restrict__ recs, const int *__restrict__ cent_ofs, int isrc0, int nrec,
     const RecvDev *__restrict__ recv, float *__restrict__ syn, size_t syn_stride, int ntiles,
-    const int *__restrict__ tab, FuseParams fp, const int *__restrict__ pairflag, const int *__restrict__ mate)
+    const int *__restrict__ tab, FuseParams fp, const int *__restrict__ pairflag, const int *__restrict__ mate,
+    const int *__restrict__ mate_wider /* NS = 2: the groups of four the wider launch has taken (or null) */)
 {
-    constexpr int TILE = 512, LDS_TILE = TILE + kHalo, K = LDS_TILE / 64;
-    static_assert(K == 9, "component stride of set2_read_*_k9");
-    __shared__ __attribute__((aligned(16))) float tiles[2][NG][LDS_TILE];
-    const int s0 = 2 * (int)blockIdx.x;                  // the pair: chunk-local sources s0, s0 + 1
+    static_assert(NS == 2 || NS == 4, "sources per workgroup");
+    constexpr int TILE = 1024 / NS, LDS_TILE = TILE + kHalo, K = LDS_TILE / 64, WPS = 4 / NS;       // WPS: waves per source
+    __shared__ __attribute__((aligned(16))) float tiles[NS][NG][LDS_TILE];
+    const int s0 = NS * (int)blockIdx.x;                 // chunk-local sources s0 .. s0 + NS - 1
     const int tile = blockIdx.y % ntiles, r = blockIdx.y / ntiles;
     const RecvDev &rv = recv[r];
     if (!rv.enabled) return;
     if (tile * TILE >= rv.wlen) return;
-    if (!duo_pair(rv, pairflag, mate, s0, nrec, r)) return;
+    if (!multi_taken<NS>(rv, pairflag, mate, s0, nrec, r)) return;
+    if constexpr (NS == 2) { if (multi_taken<4>(rv, pairflag, mate_wider, s0, nrec, r)) return; }
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int sh = wv >> 1;                              // which source this wave applies
-    const int me = s0 + sh;
+    const int sh = wv / WPS;                             // the source this wave applies
     const int t_tile0 = rv.wbeg + tile * TILE;
     const int cb = cent_ofs[isrc0];
-    const int cA = cent_ofs[isrc0 + s0], cB = cent_ofs[isrc0 + s0 + 1], nc = cB - cA;      // (both have nc centroids)
-    const GeoRec *__restrict__ rcA = recs + ((size_t)(cA - cb) * nrec + (size_t)r * nc);
-    const GeoRec *__restrict__ rcB = recs + ((size_t)(cB - cb) * nrec + (size_t)r * nc);
-    const int *__restrict__ tcA = tab + ((size_t)(cA - cb) * nrec + (size_t)r * nc) * 128;
-    const int *__restrict__ tcB = tab + ((size_t)(cB - cb) * nrec + (size_t)r * nc) * 128;
-    const GeoRec *__restrict__ rc = sh ? rcB : rcA;      // this wave's source
-    const int *__restrict__ tc = sh ? tcB : tcA;
+    const int nc = cent_ofs[isrc0 + s0 + 1] - cent_ofs[isrc0 + s0];      // (every source of the group has nc centroids)
+    const size_t base_me = (size_t)(cent_ofs[isrc0 + s0 + sh] - cb) * nrec + (size_t)r * nc;
+    const GeoRec *__restrict__ rc = recs + base_me;      // this wave's source
     const float sd = rv.sd;
-    const int u0 = 256 * (wv & 1) + lane;                // the lane's first sample of its source's tile (the others: + 64 q)
+    (void)sd;
+    const int u0 = 256 * (wv % WPS) + lane;              // the lane's first sample of its source's tile (the others: + 64 q)
 
     f2v ar1[2] = { { 0.f, 0.f }, { 0.f, 0.f } }, ar2[2] = { { 0.f, 0.f }, { 0.f, 0.f } }, dz[2] = { { 0.f, 0.f }, { 0.f, 0.f } };
     f2v xa0, xa1, xa2, xa3, xa4, xa5, xa6, xa7, xa8, xa9, xb0, xb1, xb2, xb3, xb4, xb5, xb6, xb7, xb8, xb9;
@@ -1880,58 +1952,73 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
     const SetT X = make_set2<NG>(xa0, xa1, xa2, xa3, xa4, xa5, xa6, xa7, xa8, xa9, xb0, xb1, xb2, xb3, xb4, xb5, xb6, xb7, xb8, xb9);
     const SetT Y = make_set2<NG>(ya0, ya1, ya2, ya3, ya4, ya5, ya6, ya7, ya8, ya9, yb0, yb1, yb2, yb3, yb4, yb5, yb6, yb7, yb8, yb9);
 
-    // head records and load descriptors of the group starting at c, of BOTH sources, lane-distributed
+    // head records of the group starting at c of EVERY source, load descriptors of the first one, lane-distributed
+    auto recs_of = [&](int i) { return recs + ((size_t)(cent_ofs[isrc0 + s0 + i] - cb) * nrec + (size_t)r * nc); };
+    auto tab_of = [&](int i) { return tab + ((size_t)(cent_ofs[isrc0 + s0 + i] - cb) * nrec + (size_t)r * nc) * 128; };
     int c = 0;
-    int curA = rec_load(rcA, 0, nc, lane), curB = rec_load(rcB, 0, nc, lane);
-    int taA = tcA[lane], tbA = tcA[64 + lane], taB = tcB[lane], tbB = tcB[64 + lane];
+    int cur[NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) cur[i] = rec_load(recs_of(i), 0, nc, lane);
+    int ta = tab_of(0)[lane], tb = tab_of(0)[64 + lane];
     // halo: one lane per (component, 4-sample chunk)
     const int hslot = tid >> 4, hig = min(hslot, NG - 1), hph = TILE + 4 * (tid & 15);
     while (c < nc) {
-        GeoRec gA, gB;
-        rec_head(curA, 0, gA);
-        rec_head(curB, 0, gB);
-        const int glen = gA.pad & 0xff;                  // (same structure: equal for both)
+        GeoRec g[NS];
+        int smaxs[NS], npos = 0;
+        bool shared = true;
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            rec_head(cur[i], 0, g[i]);
+            smaxs[i] = g[i].ishift + ((g[i].pad >> 8) & 0xff);
+            const int smin = g[i].ishift - ((g[i].pad >> 16) & 0xff);
+            npos = max(npos, TILE + (smaxs[i] - smin) + 8);
+            // the node rows once for all -- if all sit in the same cell and read it from the same tile origin (integer
+            // shifts may differ between the sources of a time sweep)
+            shared = shared && g[i].row[0] == g[0].row[0] && g[i].row[1] == g[0].row[1] && g[i].row[2] == g[0].row[2] &&
+                     g[i].row[3] == g[0].row[3] && smaxs[i] == smaxs[0];
+        }
+        const int glen = g[0].pad & 0xff;                // (same structure: equal for all)
         const int cend = c + glen;
-        // integer shifts may differ between the two (a time sweep): each has its own range and tile origin
-        const int smaxA = gA.ishift + ((gA.pad >> 8) & 0xff), sminA = gA.ishift - ((gA.pad >> 16) & 0xff);
-        const int smaxB = gB.ishift + ((gB.pad >> 8) & 0xff), sminB = gB.ishift - ((gB.pad >> 16) & 0xff);
-        const int jbA = t_tile0 - smaxA - 1, jbB = t_tile0 - smaxB - 1;      // LDS position p of a source's tile set holds its blended trace sample jb + p
-        const int nposA = TILE + (smaxA - sminA) + 8, nposB = TILE + (smaxB - sminB) + 8;
-        const int smax = sh ? smaxB : smaxA, smin = sh ? sminB : sminA, jb = sh ? jbB : jbA;
-        // this wave's source: what its apply needs
-        const int flags = sh ? gB.flags : gA.flags;
-        const float gcl = sh ? REC_F(curB, 16) : REC_F(curA, 16), gsl = sh ? REC_F(curB, 17) : REC_F(curA, 17);
-        const int jmin_me = sh ? min(REC_I(taB, 50), REC_I(taB, 51)) : min(REC_I(taA, 50), REC_I(taA, 51));
-        const bool carry_grp = !((jb + (smax - smin) + TILE) > jmin_me);      // (clean pairs: no tail rule -> always)
+        // this wave's source: what its apply needs (equal for all centroids of the group: same point, same receiver)
+        int curme = cur[0], smax = smaxs[0];
+#pragma unroll
+        for (int i = 1; i < NS; i++) if (sh == i) { curme = cur[i]; smax = smaxs[i]; }
+        const int flags = REC_I(curme, 18);
+        const float gcl = REC_F(curme, 16), gsl = REC_F(curme, 17);
         int ishv = 0;
         if (lane < glen) ishv = rc[c + lane].ishift;
-        // ---- build: the node rows of the cell once, blended for both sources -- if both sit in the same cell and read it
-        // from the same tile origin
-        const bool shared = gA.row[0] == gB.row[0] && gA.row[1] == gB.row[1] && gA.row[2] == gB.row[2] && gA.row[3] == gB.row[3] && jbA == jbB;
-#define KIWI_DUO_BUILD(TA, TB, GR, JB, NPOS, W0, W1, WR0, WR1) do { \
-            const float *__restrict__ Gg = G + (size_t)(GR).row[0] * (size_t)pitch; \
-            const bool lane_ok = lane >= 4 * NG || ((TA) + (JB) >= (TB) && (TA) + (JB) + LDS_TILE <= (TB) + pitch); \
+        // ---- build
+#define KIWI_MULTI_BUILD(TA, TB, I0, ONLY, NPOS) do { \
+            const int jb_ = t_tile0 - smaxs[I0] - 1;      /* LDS position p of a tile set holds its source's blended trace sample jb + p */ \
+            const float *__restrict__ Gg = G + (size_t)g[I0].row[0] * (size_t)pitch; \
+            const bool lane_ok = lane >= 4 * NG || ((TA) + jb_ >= (TB) && (TA) + jb_ + LDS_TILE <= (TB) + pitch); \
             const bool fast = __builtin_amdgcn_ballot_w64(lane_ok) == ~0ull; \
             const bool hact = hslot < NG && hph < (NPOS); \
-            if (fast) duo_build<NG, true, WR0, WR1>(&tiles[0][0][0], wv, lane, tid, JB, Gg, pitch, TA, TB, W0, W1, hact, hig, hph); \
-            else      duo_build<NG, false, WR0, WR1>(&tiles[0][0][0], wv, lane, tid, JB, Gg, pitch, TA, TB, W0, W1, hact, hig, hph); } while (0)
+            if (fast) multi_build<NG, true, NS>(&tiles[0][0][0], wv, lane, tid, jb_, Gg, pitch, TA, TB, g, ONLY, hact, hig, hph); \
+            else      multi_build<NG, false, NS>(&tiles[0][0][0], wv, lane, tid, jb_, Gg, pitch, TA, TB, g, ONLY, hact, hig, hph); } while (0)
 #ifndef KIWI_X_NOBUILD
-        if (shared) KIWI_DUO_BUILD(taA, tbA, gA, jbA, max(nposA, nposB), gA, gB, true, true);
-        else { KIWI_DUO_BUILD(taA, tbA, gA, jbA, nposA, gA, gA, true, false); KIWI_DUO_BUILD(taB, tbB, gB, jbB, nposB, gB, gB, false, true); }
+        if (shared) KIWI_MULTI_BUILD(ta, tb, 0, -1, npos);
+        else {
+            KIWI_MULTI_BUILD(ta, tb, 0, 0, npos);
+#pragma unroll
+            for (int i = 1; i < NS; i++) {               // (descriptors of the others only here: not kept in registers)
+                const int tai = tab_of(i)[(size_t)c * 128 + lane], tbi = tab_of(i)[(size_t)c * 128 + 64 + lane];
+                KIWI_MULTI_BUILD(tai, tbi, i, i, npos);
+            }
+        }
 #else
         (void)shared;
 #endif
-#undef KIWI_DUO_BUILD
+#undef KIWI_MULTI_BUILD
         // head records and descriptors of the NEXT group: in flight while this group is applied
-        curA = rec_load(rcA, cend, nc, lane); curB = rec_load(rcB, cend, nc, lane);
-        if (cend < nc) {
-            taA = tcA[(size_t)cend * 128 + lane]; tbA = tcA[(size_t)cend * 128 + 64 + lane];
-            taB = tcB[(size_t)cend * 128 + lane]; tbB = tcB[(size_t)cend * 128 + 64 + lane];
-        }
+#pragma unroll
+        for (int i = 0; i < NS; i++) cur[i] = rec_load(recs_of(i), cend, nc, lane);
+        if (cend < nc) { ta = tab_of(0)[(size_t)cend * 128 + lane]; tb = tab_of(0)[(size_t)cend * 128 + 64 + lane]; }
         __syncthreads();
-        // ---- apply: this wave's source from its tile set
+        // ---- apply: this wave's source from its tile set.  (No tail rule and no partly added centroid here: multi_taken()
+        // admits only pairs whose rows all end in zero and whose centroids all find all their traces.)
         {
-            const size_t crow = ((size_t)((sh ? cB : cA) - cb) * nrec + (size_t)r * nc + c) * 128 + 64 + 40;
+            const size_t crow = (base_me + c) * 128 + 64 + 40;
             const unsigned clo = __builtin_amdgcn_readfirstlane((unsigned)crow), chi = __builtin_amdgcn_readfirstlane((unsigned)(crow >> 32));
             const float *__restrict__ coef_grp = (const float *)(tab + (((size_t)chi << 32) | clo));
             const unsigned abase = (unsigned)(size_t)(lds_cfp)&tiles[sh][0][u0];
@@ -1940,47 +2027,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
 #ifdef KIWI_X_NOAPPLY
             cc = cend;
 #endif
-            if (carry_grp) {
 #define KIWI_C2STEP(LL, HH, RV, CC) do { \
-                    const int e = smax - __builtin_amdgcn_readlane(ishv, (CC) - c); \
-                    const int d = have ? eprev - e : 0x7fff; \
-                    carry2_apply<NG, RV, K>(ar1, ar2, dz, LL, HH, abase + 4u * (unsigned)e, __builtin_amdgcn_readfirstlane((int)KIWI_X_FULL(d != -1)), \
-                                            __builtin_amdgcn_readfirstlane((int)KIWI_X_FULL(d != 1)), coef_grp + (size_t)((CC) - c) * 128, gcl, gsl); \
-                    have = true; eprev = e; } while (0)
-                if (flags & 2) {
-                    set2_dead(X); set2_dead(Y);
-                    for (; cc + 1 < cend; cc += 2) { KIWI_C2STEP(X, Y, true, cc); KIWI_C2STEP(Y, X, true, cc + 1); }
-                    if (cc < cend) KIWI_C2STEP(X, Y, true, cc);
-                } else {
-                    set2_dead(X); set2_dead(Y);
-                    for (; cc + 1 < cend; cc += 2) { KIWI_C2STEP(X, Y, false, cc); KIWI_C2STEP(Y, X, false, cc + 1); }
-                    if (cc < cend) KIWI_C2STEP(X, Y, false, cc);
-                }
-#undef KIWI_C2STEP
+                const int e = smax - __builtin_amdgcn_readlane(ishv, (CC) - c);       /* LDS position of b[j-1] of the tile's first sample */ \
+                const int d = have ? eprev - e : 0x7fff; \
+                carry2_apply<NG, RV, K>(ar1, ar2, dz, LL, HH, abase + 4u * (unsigned)e, __builtin_amdgcn_readfirstlane((int)KIWI_X_FULL(d != -1)), \
+                                        __builtin_amdgcn_readfirstlane((int)KIWI_X_FULL(d != 1)), coef_grp + (size_t)((CC) - c) * 128, gcl, gsl); \
+                have = true; eprev = e; } while (0)
+            if (flags & 2) {
+                set2_dead(X); set2_dead(Y);
+                for (; cc + 1 < cend; cc += 2) { KIWI_C2STEP(X, Y, true, cc); KIWI_C2STEP(Y, X, true, cc + 1); }
+                if (cc < cend) KIWI_C2STEP(X, Y, true, cc);
             } else {
-                // (not reached for the pairs duo_pair() admits; kept so that a change of that rule cannot silently drop a tail)
-                int jend[NG];
-#pragma unroll
-                for (int ig = 0; ig < NG; ig++) jend[ig] = tc[(size_t)c * 128 + 40 + ig];
-                for (; cc < cend; cc++) {
-                    const GeoRec *__restrict__ rr = rc + cc;
-                    const int e = smax - rr->ishift;
-                    const TileBase chunk0 = tile_base(&tiles[sh][0][e + u0]);
-                    const int jl = jb + e + u0;
-                    const bool tail = (jb + e + TILE) > jmin_me;
-                    if (!tail) centroid_apply<NG, LDS_TILE, false, 2>(ar1, ar2, dz, chunk0, jl, jend, true, true, flags, rr->wfrac, sd,
-                                                                      rr->f[0], rr->f[1], rr->f[2], rr->f[3], rr->f[4], rr->f[5], gcl, gsl);
-                    else       centroid_apply<NG, LDS_TILE, true, 2>(ar1, ar2, dz, chunk0, jl, jend, true, true, flags, rr->wfrac, sd,
-                                                                     rr->f[0], rr->f[1], rr->f[2], rr->f[3], rr->f[4], rr->f[5], gcl, gsl);
-                }
+                set2_dead(X); set2_dead(Y);
+                for (; cc + 1 < cend; cc += 2) { KIWI_C2STEP(X, Y, false, cc); KIWI_C2STEP(Y, X, false, cc + 1); }
+                if (cc < cend) KIWI_C2STEP(X, Y, false, cc);
             }
+#undef KIWI_C2STEP
         }
         __syncthreads();                                 // tiles are rebuilt by the next group
         c = cend;
     }
     // ---- rotation to N/E, signs and store (or fused comparison) of this wave's source (seismogram.f90:256-283)
     {
-        const int js = me;
+        const int js = s0 + sh;
         const int tl = tile * TILE + u0;                 // window sample of the lane's output q = 0; q-th: + 64 q
         if (!FUSE && tl >= rv.wlen) return;
         float *__restrict__ so = syn + (size_t)js * syn_stride + tl;
@@ -2025,7 +2094,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
             }
             acc = wave_reduce_f64(acc, fp.method == 6);                 // total in lane 63
             if (lane == 63)
-                fp.partial[((size_t)js * fp.nmis + rv.slot0 + k) * fp.nparts + tile * 2 + (wv & 1)] = acc;
+                fp.partial[((size_t)js * fp.nmis + rv.slot0 + k) * fp.nparts + tile * WPS + (wv % WPS)] = acc;
         }
     }
 }
