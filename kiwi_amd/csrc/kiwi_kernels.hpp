@@ -1202,7 +1202,7 @@ __device__ __forceinline__ double wave_reduce_f64(double v, bool is_max)
 #define KIWI_GROUPED_WAVES 3
 #endif
 #ifndef KIWI_X_FULL
-#define KIWI_X_FULL(x) (x)
+#define KIWI_X_FULL(x) (x)       // measurement switch: -DKIWI_X_FULL(x)=0x7fff makes every centroid read both register sets
 #endif
 // ------------------------------------------------------------------------------------------------
 // Register pairs carried between the centroids of a group (round 3), accumulate_grouped_kernel with 256 threads.
@@ -1222,9 +1222,9 @@ __device__ __forceinline__ double wave_reduce_f64(double v, bool is_max)
 // wait, so that the arithmetic cannot be scheduled in front of it.
 // ---- (generated text) carried register sets of accumulate_grouped_kernel, 4 outputs per lane, component stride 17 x 64 dwords
 struct Set2_10 { f2v &a0, &a1, &a2, &a3, &a4, &a5, &a6, &a7, &a8, &a9, &b0, &b1, &b2, &b3, &b4, &b5, &b6, &b7, &b8, &b9; };
-__device__ __forceinline__ void set2_read_10(int on, unsigned a, const Set2_10 &S)
+template <int SKIP> __device__ __forceinline__ void set2_read_10(int d, unsigned a, const Set2_10 &S)
 {
-    asm volatile("s_cmp_eq_u32 %21, 0\n\ts_cbranch_scc1 .Lkiwi_skip%=\n\t"
+    asm volatile("s_cmp_eq_u32 %21, %22\n\ts_cbranch_scc1 .Lkiwi_skip%=\n\t"
                  "ds_read2st64_b32 %0, %20 offset1:1\n\t"
                  "ds_read2st64_b32 %1, %20 offset0:17 offset1:18\n\t"
                  "ds_read2st64_b32 %2, %20 offset0:34 offset1:35\n\t"
@@ -1246,7 +1246,7 @@ __device__ __forceinline__ void set2_read_10(int on, unsigned a, const Set2_10 &
                  "ds_read2st64_b32 %18, %20 offset0:121 offset1:122\n\t"
                  "ds_read2st64_b32 %19, %20 offset0:155 offset1:156\n\t"
                  "\n.Lkiwi_skip%=:"
-                 : "+v"(S.a0), "+v"(S.a1), "+v"(S.a2), "+v"(S.a3), "+v"(S.a4), "+v"(S.a5), "+v"(S.a6), "+v"(S.a7), "+v"(S.a8), "+v"(S.a9), "+v"(S.b0), "+v"(S.b1), "+v"(S.b2), "+v"(S.b3), "+v"(S.b4), "+v"(S.b5), "+v"(S.b6), "+v"(S.b7), "+v"(S.b8), "+v"(S.b9) : "v"(a), "s"(on) : "memory", "scc");
+                 : "+v"(S.a0), "+v"(S.a1), "+v"(S.a2), "+v"(S.a3), "+v"(S.a4), "+v"(S.a5), "+v"(S.a6), "+v"(S.a7), "+v"(S.a8), "+v"(S.a9), "+v"(S.b0), "+v"(S.b1), "+v"(S.b2), "+v"(S.b3), "+v"(S.b4), "+v"(S.b5), "+v"(S.b6), "+v"(S.b7), "+v"(S.b8), "+v"(S.b9) : "v"(a), "s"(d), "i"(SKIP) : "memory", "scc");
 }
 __device__ __forceinline__ void set2_wait_10(const Set2_10 &S)
 {
@@ -1263,9 +1263,9 @@ __device__ __forceinline__ void set2_dead_10(const Set2_10 &S)
 template <int I> __device__ __forceinline__ f2v &s2a(const Set2_10 &s) { if constexpr (I == 0) return s.a0; else if constexpr (I == 1) return s.a1; else if constexpr (I == 2) return s.a2; else if constexpr (I == 3) return s.a3; else if constexpr (I == 4) return s.a4; else if constexpr (I == 5) return s.a5; else if constexpr (I == 6) return s.a6; else if constexpr (I == 7) return s.a7; else if constexpr (I == 8) return s.a8; else return s.a9; }
 template <int I> __device__ __forceinline__ f2v &s2b(const Set2_10 &s) { if constexpr (I == 0) return s.b0; else if constexpr (I == 1) return s.b1; else if constexpr (I == 2) return s.b2; else if constexpr (I == 3) return s.b3; else if constexpr (I == 4) return s.b4; else if constexpr (I == 5) return s.b5; else if constexpr (I == 6) return s.b6; else if constexpr (I == 7) return s.b7; else if constexpr (I == 8) return s.b8; else return s.b9; }
 struct Set2_8 { f2v &a0, &a1, &a2, &a3, &a4, &a5, &a6, &a7, &b0, &b1, &b2, &b3, &b4, &b5, &b6, &b7; };
-__device__ __forceinline__ void set2_read_8(int on, unsigned a, const Set2_8 &S)
+template <int SKIP> __device__ __forceinline__ void set2_read_8(int d, unsigned a, const Set2_8 &S)
 {
-    asm volatile("s_cmp_eq_u32 %17, 0\n\ts_cbranch_scc1 .Lkiwi_skip%=\n\t"
+    asm volatile("s_cmp_eq_u32 %17, %18\n\ts_cbranch_scc1 .Lkiwi_skip%=\n\t"
                  "ds_read2st64_b32 %0, %16 offset1:1\n\t"
                  "ds_read2st64_b32 %1, %16 offset0:17 offset1:18\n\t"
                  "ds_read2st64_b32 %2, %16 offset0:34 offset1:35\n\t"
@@ -1283,7 +1283,7 @@ __device__ __forceinline__ void set2_read_8(int on, unsigned a, const Set2_8 &S)
                  "ds_read2st64_b32 %14, %16 offset0:104 offset1:105\n\t"
                  "ds_read2st64_b32 %15, %16 offset0:121 offset1:122\n\t"
                  "\n.Lkiwi_skip%=:"
-                 : "+v"(S.a0), "+v"(S.a1), "+v"(S.a2), "+v"(S.a3), "+v"(S.a4), "+v"(S.a5), "+v"(S.a6), "+v"(S.a7), "+v"(S.b0), "+v"(S.b1), "+v"(S.b2), "+v"(S.b3), "+v"(S.b4), "+v"(S.b5), "+v"(S.b6), "+v"(S.b7) : "v"(a), "s"(on) : "memory", "scc");
+                 : "+v"(S.a0), "+v"(S.a1), "+v"(S.a2), "+v"(S.a3), "+v"(S.a4), "+v"(S.a5), "+v"(S.a6), "+v"(S.a7), "+v"(S.b0), "+v"(S.b1), "+v"(S.b2), "+v"(S.b3), "+v"(S.b4), "+v"(S.b5), "+v"(S.b6), "+v"(S.b7) : "v"(a), "s"(d), "i"(SKIP) : "memory", "scc");
 }
 __device__ __forceinline__ void set2_wait_8(const Set2_8 &S)
 {
@@ -1301,9 +1301,9 @@ template <int I> __device__ __forceinline__ f2v &s2a(const Set2_8 &s) { if const
 template <int I> __device__ __forceinline__ f2v &s2b(const Set2_8 &s) { if constexpr (I == 0) return s.b0; else if constexpr (I == 1) return s.b1; else if constexpr (I == 2) return s.b2; else if constexpr (I == 3) return s.b3; else if constexpr (I == 4) return s.b4; else if constexpr (I == 5) return s.b5; else if constexpr (I == 6) return s.b6; else return s.b7; }
 
 // ---- the same for a component stride of 9 x 64 dwords (512-sample tiles: two sources per workgroup, accumulate_multi_kernel)
-__device__ __forceinline__ void set2_read_10_k9(int on, unsigned a, const Set2_10 &S)
+template <int SKIP> __device__ __forceinline__ void set2_read_10_k9(int d, unsigned a, const Set2_10 &S)
 {
-    asm volatile("s_cmp_eq_u32 %21, 0\n\ts_cbranch_scc1 .Lkiwi_skip%=\n\t"
+    asm volatile("s_cmp_eq_u32 %21, %22\n\ts_cbranch_scc1 .Lkiwi_skip%=\n\t"
                  "ds_read2st64_b32 %0, %20 offset1:1\n\t"
                  "ds_read2st64_b32 %1, %20 offset0:9 offset1:10\n\t"
                  "ds_read2st64_b32 %2, %20 offset0:18 offset1:19\n\t"
@@ -1325,11 +1325,11 @@ __device__ __forceinline__ void set2_read_10_k9(int on, unsigned a, const Set2_1
                  "ds_read2st64_b32 %18, %20 offset0:65 offset1:66\n\t"
                  "ds_read2st64_b32 %19, %20 offset0:83 offset1:84\n\t"
                  "\n.Lkiwi_skip%=:"
-                 : "+v"(S.a0), "+v"(S.a1), "+v"(S.a2), "+v"(S.a3), "+v"(S.a4), "+v"(S.a5), "+v"(S.a6), "+v"(S.a7), "+v"(S.a8), "+v"(S.a9), "+v"(S.b0), "+v"(S.b1), "+v"(S.b2), "+v"(S.b3), "+v"(S.b4), "+v"(S.b5), "+v"(S.b6), "+v"(S.b7), "+v"(S.b8), "+v"(S.b9) : "v"(a), "s"(on) : "memory", "scc");
+                 : "+v"(S.a0), "+v"(S.a1), "+v"(S.a2), "+v"(S.a3), "+v"(S.a4), "+v"(S.a5), "+v"(S.a6), "+v"(S.a7), "+v"(S.a8), "+v"(S.a9), "+v"(S.b0), "+v"(S.b1), "+v"(S.b2), "+v"(S.b3), "+v"(S.b4), "+v"(S.b5), "+v"(S.b6), "+v"(S.b7), "+v"(S.b8), "+v"(S.b9) : "v"(a), "s"(d), "i"(SKIP) : "memory", "scc");
 }
-__device__ __forceinline__ void set2_read_8_k9(int on, unsigned a, const Set2_8 &S)
+template <int SKIP> __device__ __forceinline__ void set2_read_8_k9(int d, unsigned a, const Set2_8 &S)
 {
-    asm volatile("s_cmp_eq_u32 %17, 0\n\ts_cbranch_scc1 .Lkiwi_skip%=\n\t"
+    asm volatile("s_cmp_eq_u32 %17, %18\n\ts_cbranch_scc1 .Lkiwi_skip%=\n\t"
                  "ds_read2st64_b32 %0, %16 offset1:1\n\t"
                  "ds_read2st64_b32 %1, %16 offset0:9 offset1:10\n\t"
                  "ds_read2st64_b32 %2, %16 offset0:18 offset1:19\n\t"
@@ -1347,12 +1347,12 @@ __device__ __forceinline__ void set2_read_8_k9(int on, unsigned a, const Set2_8 
                  "ds_read2st64_b32 %14, %16 offset0:56 offset1:57\n\t"
                  "ds_read2st64_b32 %15, %16 offset0:65 offset1:66\n\t"
                  "\n.Lkiwi_skip%=:"
-                 : "+v"(S.a0), "+v"(S.a1), "+v"(S.a2), "+v"(S.a3), "+v"(S.a4), "+v"(S.a5), "+v"(S.a6), "+v"(S.a7), "+v"(S.b0), "+v"(S.b1), "+v"(S.b2), "+v"(S.b3), "+v"(S.b4), "+v"(S.b5), "+v"(S.b6), "+v"(S.b7) : "v"(a), "s"(on) : "memory", "scc");
+                 : "+v"(S.a0), "+v"(S.a1), "+v"(S.a2), "+v"(S.a3), "+v"(S.a4), "+v"(S.a5), "+v"(S.a6), "+v"(S.a7), "+v"(S.b0), "+v"(S.b1), "+v"(S.b2), "+v"(S.b3), "+v"(S.b4), "+v"(S.b5), "+v"(S.b6), "+v"(S.b7) : "v"(a), "s"(d), "i"(SKIP) : "memory", "scc");
 }
 // ---- ... and of 5 x 64 dwords (256-sample tiles: four sources per workgroup)
-__device__ __forceinline__ void set2_read_10_k5(int on, unsigned a, const Set2_10 &S)
+template <int SKIP> __device__ __forceinline__ void set2_read_10_k5(int d, unsigned a, const Set2_10 &S)
 {
-    asm volatile("s_cmp_eq_u32 %21, 0\n\ts_cbranch_scc1 .Lkiwi_skip%=\n\t"
+    asm volatile("s_cmp_eq_u32 %21, %22\n\ts_cbranch_scc1 .Lkiwi_skip%=\n\t"
                  "ds_read2st64_b32 %0, %20 offset1:1\n\t"
                  "ds_read2st64_b32 %1, %20 offset0:5 offset1:6\n\t"
                  "ds_read2st64_b32 %2, %20 offset0:10 offset1:11\n\t"
@@ -1374,11 +1374,11 @@ __device__ __forceinline__ void set2_read_10_k5(int on, unsigned a, const Set2_1
                  "ds_read2st64_b32 %18, %20 offset0:37 offset1:38\n\t"
                  "ds_read2st64_b32 %19, %20 offset0:47 offset1:48\n\t"
                  "\n.Lkiwi_skip%=:"
-                 : "+v"(S.a0), "+v"(S.a1), "+v"(S.a2), "+v"(S.a3), "+v"(S.a4), "+v"(S.a5), "+v"(S.a6), "+v"(S.a7), "+v"(S.a8), "+v"(S.a9), "+v"(S.b0), "+v"(S.b1), "+v"(S.b2), "+v"(S.b3), "+v"(S.b4), "+v"(S.b5), "+v"(S.b6), "+v"(S.b7), "+v"(S.b8), "+v"(S.b9) : "v"(a), "s"(on) : "memory", "scc");
+                 : "+v"(S.a0), "+v"(S.a1), "+v"(S.a2), "+v"(S.a3), "+v"(S.a4), "+v"(S.a5), "+v"(S.a6), "+v"(S.a7), "+v"(S.a8), "+v"(S.a9), "+v"(S.b0), "+v"(S.b1), "+v"(S.b2), "+v"(S.b3), "+v"(S.b4), "+v"(S.b5), "+v"(S.b6), "+v"(S.b7), "+v"(S.b8), "+v"(S.b9) : "v"(a), "s"(d), "i"(SKIP) : "memory", "scc");
 }
-__device__ __forceinline__ void set2_read_8_k5(int on, unsigned a, const Set2_8 &S)
+template <int SKIP> __device__ __forceinline__ void set2_read_8_k5(int d, unsigned a, const Set2_8 &S)
 {
-    asm volatile("s_cmp_eq_u32 %17, 0\n\ts_cbranch_scc1 .Lkiwi_skip%=\n\t"
+    asm volatile("s_cmp_eq_u32 %17, %18\n\ts_cbranch_scc1 .Lkiwi_skip%=\n\t"
                  "ds_read2st64_b32 %0, %16 offset1:1\n\t"
                  "ds_read2st64_b32 %1, %16 offset0:5 offset1:6\n\t"
                  "ds_read2st64_b32 %2, %16 offset0:10 offset1:11\n\t"
@@ -1396,18 +1396,20 @@ __device__ __forceinline__ void set2_read_8_k5(int on, unsigned a, const Set2_8 
                  "ds_read2st64_b32 %14, %16 offset0:32 offset1:33\n\t"
                  "ds_read2st64_b32 %15, %16 offset0:37 offset1:38\n\t"
                  "\n.Lkiwi_skip%=:"
-                 : "+v"(S.a0), "+v"(S.a1), "+v"(S.a2), "+v"(S.a3), "+v"(S.a4), "+v"(S.a5), "+v"(S.a6), "+v"(S.a7), "+v"(S.b0), "+v"(S.b1), "+v"(S.b2), "+v"(S.b3), "+v"(S.b4), "+v"(S.b5), "+v"(S.b6), "+v"(S.b7) : "v"(a), "s"(on) : "memory", "scc");
+                 : "+v"(S.a0), "+v"(S.a1), "+v"(S.a2), "+v"(S.a3), "+v"(S.a4), "+v"(S.a5), "+v"(S.a6), "+v"(S.a7), "+v"(S.b0), "+v"(S.b1), "+v"(S.b2), "+v"(S.b3), "+v"(S.b4), "+v"(S.b5), "+v"(S.b6), "+v"(S.b7) : "v"(a), "s"(d), "i"(SKIP) : "memory", "scc");
 }
 template <int NG> struct Set2Sel;
 template <> struct Set2Sel<10> { typedef Set2_10 type; };
 template <> struct Set2Sel<8> { typedef Set2_8 type; };
-template <int K> __device__ __forceinline__ void set2_read(int on, unsigned a, const Set2_10 &S)
+// (the set is NOT read when d == SKIP: the comparison happens inside the asm statement on the scalar d -- a flag computed
+// outside reaches an "s" operand through a vector register)
+template <int K, int SKIP> __device__ __forceinline__ void set2_read(int d, unsigned a, const Set2_10 &S)
 {
-    if constexpr (K == 17) set2_read_10(on, a, S); else if constexpr (K == 9) set2_read_10_k9(on, a, S); else set2_read_10_k5(on, a, S);
+    if constexpr (K == 17) set2_read_10<SKIP>(d, a, S); else if constexpr (K == 9) set2_read_10_k9<SKIP>(d, a, S); else set2_read_10_k5<SKIP>(d, a, S);
 }
-template <int K> __device__ __forceinline__ void set2_read(int on, unsigned a, const Set2_8 &S)
+template <int K, int SKIP> __device__ __forceinline__ void set2_read(int d, unsigned a, const Set2_8 &S)
 {
-    if constexpr (K == 17) set2_read_8(on, a, S); else if constexpr (K == 9) set2_read_8_k9(on, a, S); else set2_read_8_k5(on, a, S);
+    if constexpr (K == 17) set2_read_8<SKIP>(d, a, S); else if constexpr (K == 9) set2_read_8_k9<SKIP>(d, a, S); else set2_read_8_k5<SKIP>(d, a, S);
 }
 __device__ __forceinline__ void set2_wait(const Set2_10 &S) { set2_wait_10(S); }
 __device__ __forceinline__ void set2_wait(const Set2_8 &S) { set2_wait_8(S); }
@@ -1426,7 +1428,7 @@ template <int N, int I = 0, class F> __device__ __forceinline__ void static_for(
 // (wave-uniform pointer: scalar loads, SGPR operands of the packed multiplies).
 template <int NG, bool ROT, int K = 17>
 __device__ __forceinline__ void carry2_apply(f2v (&ar1)[2], f2v (&ar2)[2], f2v (&dz)[2], const typename Set2Sel<NG>::type &L,
-                                             const typename Set2Sel<NG>::type &H, unsigned a, int load_lo, int load_hi,
+                                             const typename Set2Sel<NG>::type &H, unsigned a, int d /* previous shift position minus this one; none: 0x7fff */,
                                              const float *__restrict__ coef, float cl, float sl)
 {
     constexpr int nH1 = (NG == 10) ? 4 : 3;      // components summed into the radial trace
@@ -1434,8 +1436,8 @@ __device__ __forceinline__ void carry2_apply(f2v (&ar1)[2], f2v (&ar2)[2], f2v (
 #pragma unroll
     for (int i = 0; i < 2 * NG; i++) cw[i] = coef[i];
     static_assert(K == 17 || K == 9 || K == 5, "component stride in units of 64 dwords");
-    set2_read<K>(load_hi, a + 4, H);
-    set2_read<K>(load_lo, a, L);
+    set2_read<K, 1>(d, a + 4, H);             // shift + 1 (d == 1): the b[j] set is in place
+    set2_read<K, -1>(d, a, L);                // shift - 1: the b[j-1] set is
     set2_wait(H);
     set2_dep(L);
     f2v t1[2], t2[2];
@@ -1744,8 +1746,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_GROUPED_
 #define KIWI_C2STEP(LL, HH, RV, CC) do { \
                 const int e = smax - __builtin_amdgcn_readlane(ishv, (CC) - c);      /* LDS position of b[j-1] of the tile's first sample */ \
                 const int d = have ? eprev - e : 0x7fff; \
-                carry2_apply<NG, RV>(ar1, ar2, dz, LL, HH, abase + 4u * (unsigned)e, __builtin_amdgcn_readfirstlane((int)KIWI_X_FULL(d != -1)), \
-                                     __builtin_amdgcn_readfirstlane((int)KIWI_X_FULL(d != 1)), coef_grp + (size_t)((CC) - c) * 128, gcl, gsl); \
+                carry2_apply<NG, RV>(ar1, ar2, dz, LL, HH, abase + 4u * (unsigned)e, KIWI_X_FULL(d), coef_grp + (size_t)((CC) - c) * 128, gcl, gsl); \
                 have = true; eprev = e; } while (0)
             // (nothing is carried into a group, its first centroid reads both sets: set2_dead tells the register allocator so)
             if (g0.flags & 2) {
@@ -2030,8 +2031,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
 #define KIWI_C2STEP(LL, HH, RV, CC) do { \
                 const int e = smax - __builtin_amdgcn_readlane(ishv, (CC) - c);       /* LDS position of b[j-1] of the tile's first sample */ \
                 const int d = have ? eprev - e : 0x7fff; \
-                carry2_apply<NG, RV, K>(ar1, ar2, dz, LL, HH, abase + 4u * (unsigned)e, __builtin_amdgcn_readfirstlane((int)KIWI_X_FULL(d != -1)), \
-                                        __builtin_amdgcn_readfirstlane((int)KIWI_X_FULL(d != 1)), coef_grp + (size_t)((CC) - c) * 128, gcl, gsl); \
+                carry2_apply<NG, RV, K>(ar1, ar2, dz, LL, HH, abase + 4u * (unsigned)e, KIWI_X_FULL(d), coef_grp + (size_t)((CC) - c) * 128, gcl, gsl); \
                 have = true; eprev = e; } while (0)
             if (flags & 2) {
                 set2_dead(X); set2_dead(Y);
