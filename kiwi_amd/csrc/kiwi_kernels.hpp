@@ -1591,7 +1591,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_GROUPED_
     int ta = 0, tb = 0;                                  // load descriptors of record c (a rejected trial source has no centroids, no rows)
     if (nc > 0) { ta = tc[lane]; tb = tc[64 + lane]; }
     // carried register sets (see set2_read): the common case of 256-thread workgroups
-    constexpr bool kCarry = (T == 256) && !RUNS;
+    constexpr bool kCarry = (T == 256);
     f2v xa0, xa1, xa2, xa3, xa4, xa5, xa6, xa7, xa8, xa9, xb0, xb1, xb2, xb3, xb4, xb5, xb6, xb7, xb8, xb9;
     f2v ya0, ya1, ya2, ya3, ya4, ya5, ya6, ya7, ya8, ya9, yb0, yb1, yb2, yb3, yb4, yb5, yb6, yb7, yb8, yb9;
     typedef typename Set2Sel<NG>::type SetT;
@@ -1737,27 +1737,34 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_GROUPED_
             // static): after a centroid L holds its b[j-1] and H its b[j]; with the roles swapped, shift + 1 finds b[j] in place
             // and reads b[j-1], shift - 1 finds b[j-1] in place and reads b[j]; every other step reads both.  The rotating /
             // plain branch (seismogram.f90:160-203 / :205-231) is the same for the whole group: two copies of the loop.
-            const size_t crow = ((size_t)(c0 - cb) * nrec + (size_t)r * nc + c) * 128 + 64 + 40;
-            const unsigned clo = __builtin_amdgcn_readfirstlane((unsigned)crow), chi = __builtin_amdgcn_readfirstlane((unsigned)(crow >> 32));
-            const float *__restrict__ coef_grp = (const float *)(tab + (((size_t)chi << 32) | clo));
+            // In a run (RUNS: geometry-identical sources sharing these tiles) source after source, the carried sets passing from
+            // the last centroid of one to the first of the next (shift - k + 1 steps back: for two time steps per source the set
+            // that is in place again); accumulators and coefficient rows per source.
             const unsigned abase = (unsigned)(size_t)(lds_cfp)&tiles[0][4 * (tid & ~63) + lane];
-            int cc = c, eprev = 0;
+            int eprev = 0;
             bool have = false;
 #define KIWI_C2STEP(LL, HH, RV, CC) do { \
                 const int e = smax - __builtin_amdgcn_readlane(ishv, (CC) - c);      /* LDS position of b[j-1] of the tile's first sample */ \
                 const int d = have ? eprev - e : 0x7fff; \
                 carry2_apply<NG, RV>(ar1, ar2, dz, LL, HH, abase + 4u * (unsigned)e, KIWI_X_FULL(d), coef_grp + (size_t)((CC) - c) * 128, gcl, gsl); \
                 have = true; eprev = e; } while (0)
-            // (nothing is carried into a group, its first centroid reads both sets: set2_dead tells the register allocator so)
-            if (g0.flags & 2) {
-                set2_dead(X); set2_dead(Y);
-                for (; cc + 1 < cend; cc += 2) { KIWI_C2STEP(X, Y, true, cc); KIWI_C2STEP(Y, X, true, cc + 1); }
-                if (cc < cend) KIWI_C2STEP(X, Y, true, cc);
-            } else {
-                set2_dead(X); set2_dead(Y);
-                for (; cc + 1 < cend; cc += 2) { KIWI_C2STEP(X, Y, false, cc); KIWI_C2STEP(Y, X, false, cc + 1); }
-                if (cc < cend) KIWI_C2STEP(X, Y, false, cc);
-            }
+#define KIWI_C2SOURCES(RV) do { \
+                set2_dead(X); set2_dead(Y);       /* nothing is carried into a group, its first centroid reads both sets: tells the register allocator so */ \
+                for (int js = s; js < s_end; js++) { \
+                    if (multi) { \
+                        ar1[0] = ar1[1] = ar2[0] = ar2[1] = dz[0] = dz[1] = f2v{ 0.f, 0.f }; \
+                        if (synrow && synrow[js] != js) continue;       /* evaluated with the source it shares synthetics with */ \
+                    } \
+                    const size_t crow = ((size_t)(cent_ofs[isrc0 + js] - cb) * nrec + (size_t)r * nc + c) * 128 + 64 + 40; \
+                    const unsigned clo = __builtin_amdgcn_readfirstlane((unsigned)crow), chi = __builtin_amdgcn_readfirstlane((unsigned)(crow >> 32)); \
+                    const float *__restrict__ coef_grp = (const float *)(tab + (((size_t)chi << 32) | clo)); \
+                    int cc = c; \
+                    for (; cc + 1 < cend; cc += 2) { KIWI_C2STEP(X, Y, RV, cc); KIWI_C2STEP(Y, X, RV, cc + 1); } \
+                    if (cc < cend) { KIWI_C2STEP(X, Y, RV, cc); have = !multi && have; }      /* odd count in a run: the sets end in the roles they started in */ \
+                    if (multi) store_family(js); \
+                } } while (0)
+            if (g0.flags & 2) KIWI_C2SOURCES(true); else KIWI_C2SOURCES(false);
+#undef KIWI_C2SOURCES
 #undef KIWI_C2STEP
             cur = cur_next;
         } else
