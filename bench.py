@@ -488,7 +488,7 @@ def main():
                     if js.get("kernel_sources_sha256") == kernel_sources_sha256():
                         prof = dict(w, file=os.path.basename(f), profile_head=js.get("head"))
                         prof_note = "collected on commit %s, same kernel sources as this build" % js.get("head")
-                    else:
+                    elif not prof:
                         prof_note = "%s was collected on other kernel sources (commit %s): counters not attached" % (os.path.basename(f), js.get("head"))
         except Exception:
             prof = {}
@@ -502,7 +502,7 @@ def main():
         kernel = "accumulate_kernel (KIWI_HIP_ACCUM=direct)" if os.environ.get("KIWI_HIP_ACCUM") == "direct" else \
             ("accumulate_cell_kernel<10,256,2,0> (+ accumulate_grouped_kernel for the pairs it leaves)" if npts > 0.5 * ncent
              else ("accumulate_grouped_kernel<10,256> (runs of sources sharing their tiles)" if wl["sourcetype"] == "moment_tensor"
-                   else "accumulate_duo_kernel<10> (+ accumulate_grouped_kernel for the pairs it leaves)"))
+                   else "accumulate_multi_kernel<10,FUSE,4|2> (four / two trial sources per workgroup; + accumulate_grouped_kernel for the pairs it leaves)"))
         out = {
             "metric": "trial-source misfit evals/s", "value": value, "unit": "evals/s",
             "n_gpus": ngpus, "rccl_world_size": dist.get_world_size() if dist is not None else None,
