@@ -201,6 +201,8 @@ __device__ __forceinline__ bool starts_group(const float *__restrict__ cent, int
 //   tab[64 + 4*ig + k] = (row - row0)*pitch             (clamp floor; ceiling = floor + pitch - 4)
 //   tab[40 + ig]       = last stored sample of the blended trace (max over the nodes)
 //   tab[50], tab[51]   = minimum of those over the horizontal (1-5, 9) / vertical (6-8, 10) components
+//   tab[52], tab[53]   = minimum / maximum over the cell's rows of (kRowPad - first): where trace sample 0 sits inside its row
+//                        (accumulate_cell_kernel: a tile that stays inside every row is loaded without clamps)
 //   tab[64 + 40 + 2*i], [.. + 1] = wl, wr: per-component interpolation coefficients of THIS centroid
 //       (sparse_trace.f90:643-647 with the factors of seismogram.f90:171-250): wl = (1 - w) * factor, wr = w * factor,
 //       each rounded on its own, for the i-th component in application order 0 1 2 8 | 3 4 | 5 6 7 9 (ng = 8:
@@ -218,6 +220,7 @@ __device__ __forceinline__ bool write_tab(int *__restrict__ tb, const GeoRec &g,
     const int nn = (g.flags & 1) ? 1 : 4;
     int bases[NG][4], floors[NG][4], jend[12];
     int jmin_h = 0x7fffffff, jmin_d = 0x7fffffff;
+    int amin = 0x7fffffff, amax = -0x7fffffff;      // range of (trace sample 0 inside its row) over the cell's rows
     if (full) {
     // Rows whose stored trace ends in an exact zero (the reference's trace_pack keeps one of the zeros that follow the last
     // non-zero sample, sparse_trace.f90:535,545, so this is the normal case for traces that die out inside the database's
@@ -236,6 +239,7 @@ __device__ __forceinline__ bool write_tab(int *__restrict__ tb, const GeoRec &g,
             // base, so a tensor of any size works as long as one cell spans less than 2^31 floats (checked by the host)
             bases[ig][k] = (row - g.row[0]) * pitch + kRowPad - sp.x;
             floors[ig][k] = (row - g.row[0]) * pitch;
+            amin = min(amin, kRowPad - sp.x); amax = max(amax, kRowPad - sp.x);
             if (k < nn) { je = max(je, sp.y); endzero = endzero && endz[row]; }
         }
         jend[ig] = je;
@@ -275,6 +279,7 @@ __device__ __forceinline__ bool write_tab(int *__restrict__ tb, const GeoRec &g,
         for (int ig = 0; ig < NG; ig++) t4[ig] = make_int4(bases[ig][0], bases[ig][1], bases[ig][2], bases[ig][3]);
 #pragma unroll
         for (int q = 0; q < 3; q++) t4[10 + q] = make_int4(jend[4 * q], jend[4 * q + 1], jend[4 * q + 2], jend[4 * q + 3]);
+        t4[13] = make_int4(amin, amax, 0, 0);
 #pragma unroll
         for (int ig = 0; ig < NG; ig++) t4[16 + ig] = make_int4(floors[ig][0], floors[ig][1], floors[ig][2], floors[ig][3]);
     }
@@ -529,10 +534,11 @@ __device__ __forceinline__ bool same_cell(const GeoRec *__restrict__ a, const in
 }
 
 // is (source s, receiver r) evaluated by accumulate_cell_kernel?  Receivers with horizontal AND vertical components whose
-// centroids all find their traces; every other pair keeps same-point groups and goes through accumulate_grouped_kernel
+// centroids all find ALL their traces (pairflag bits 0 and 1: none partial, none skipped); every other pair keeps same-point
+// groups and goes through accumulate_grouped_kernel
 __device__ __forceinline__ bool cell_pair(const RecvDev &rv, const int *__restrict__ pairflag, int s, int nrec, int r)
 {
-    return rv.need_h && rv.has_d && !(pairflag[(size_t)s * nrec + r] & 1);
+    return rv.need_h && rv.has_d && !(pairflag[(size_t)s * nrec + r] & 3);
 }
 
 // (the (group of NS sources, receiver) combinations accumulate_multi_kernel takes; the same rule as multi_taken() further down)
@@ -2141,7 +2147,10 @@ template <> struct CellPart<8, 2>  { static constexpr int n = 3; static constexp
 
 template <int NG, int PART, int SPL> using RawArr = typename RawVec<SPL>::type[CellPart<NG, PART>::n][4];
 
-template <int NG, int PART, int SPL>
+// FAST: the whole tile lies inside every row of the cell (tab[52], tab[53]; the caller's test): no clamp -- the lane's
+// position is the same vector offset for all loads and the row's sample-0 position goes into the load's scalar offset: one
+// scalar instruction per load and no vector one
+template <int NG, int PART, int SPL, bool FAST = false>
 __device__ __forceinline__ void raw_issue(RawArr<NG, PART, SPL> &v, int p, int jb,
                                           const float *__restrict__ G, int pitch, int ta, int tb)
 {
@@ -2149,6 +2158,24 @@ __device__ __forceinline__ void raw_issue(RawArr<NG, PART, SPL> &v, int p, int j
     typedef CellPart<NG, PART> P;
     __builtin_assume(pitch >= 8);
     const int p4 = 4 * p, hi4 = 4 * (pitch - 4);
+    if constexpr (FAST) {
+        const unsigned jb4 = 4u * (unsigned)jb;
+#pragma unroll
+        for (int i = 0; i < P::n; i++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const unsigned so = 4u * (unsigned)REC_I(ta, 4 * P::ig(i) + k) + jb4;      // byte position of tile sample 0 in the cell
+                if constexpr (SPL == 4) {
+                    const v4i_t w = __builtin_amdgcn_raw_buffer_load_b128(gf_rsrc(G), p4, (int)so, 0);
+                    v[i][k] = RV{ __int_as_float(w.x), __int_as_float(w.y), __int_as_float(w.z), __int_as_float(w.w) };
+                } else {
+                    const v2i_t w = __builtin_amdgcn_raw_buffer_load_b64(gf_rsrc(G), p4, (int)so, 0);
+                    v[i][k] = RV{ __int_as_float(w.x), __int_as_float(w.y) };
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < P::n; i++) {
 #pragma unroll
@@ -2251,6 +2278,19 @@ __device__ __forceinline__ void cell_apply(f2v (&ar1)[NP], f2v (&ar2)[NP], f2v (
 #ifndef KIWI_CELL_WAVES
 #define KIWI_CELL_WAVES(PART) ((PART) == 0 ? 2 : 3)
 #endif
+// measurement switches (wrong results; phase timings in DESIGN.md): -DKIWI_XC_NOAPPLY / NOBLEND / NOBARRIER / NOLOAD
+#ifndef KIWI_XC_NOAPPLY
+#define KIWI_XC_NOAPPLY 0
+#endif
+#ifndef KIWI_XC_NOBLEND
+#define KIWI_XC_NOBLEND 0
+#endif
+#ifndef KIWI_XC_NOBARRIER
+#define KIWI_XC_NOBARRIER 0
+#endif
+#ifndef KIWI_XC_NOLOAD
+#define KIWI_XC_NOLOAD 0
+#endif
 // SPL: output samples per lane (tile = SPL * T samples).  With four the raw rows of a group take 160 registers per lane and
 // leave room for one wave per SIMD only; with two they take 80 and the kernel keeps the grouped kernel's three waves.
 //
@@ -2311,7 +2351,10 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_CELL_WAV
         const int smax_ = (head_ishift) + (((head_pad) >> 8) & 0xff), smin_ = (head_ishift) - (((head_pad) >> 16) & 0xff); \
         const int jb_ = t_tile0 - smax_ - 1, npos_ = TILE + (smax_ - smin_) + 8; \
         const float *__restrict__ Gg_ = G + (size_t)(head_row0) * (size_t)pitch;     /* descriptors are relative to it (write_tab) */ \
-        raw_issue<NG, PART, SPL>(raw, SPL * tid, jb_, Gg_, pitch, ta_, tb_); \
+        /* every row of the cell holds the whole tile: rows start at or before it and end behind it */ \
+        const bool inside_ = (REC_I(ta_, 52) + jb_ >= 0) && (REC_I(ta_, 53) + jb_ + SPL * (T - 1) <= pitch - 4); \
+        if (inside_) raw_issue<NG, PART, SPL, true>(raw, SPL * tid, jb_, Gg_, pitch, ta_, tb_); \
+        else         raw_issue<NG, PART, SPL, false>(raw, SPL * tid, jb_, Gg_, pitch, ta_, tb_); \
         hraw = halo_issue<true, false>(hslot && hph < npos_, hig, hph, jb_, Gg_, pitch, ta_, tb_); \
     } while (0)
     // blend the registers with the weights in lanes 4..7 of record `rec_` into tile set `buf_`
@@ -2323,22 +2366,35 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_CELL_WAV
         halo_finish<true>(hslot && hph < (npos_), hraw, tile0_, LDS_TILE, hloc, hph, gw_); \
     } while (0)
 
+    // One load site inside the loop (the NEXT group's rows, issued in front of the last apply of the group, when the raw
+    // registers are free: their L2 round trip hides behind that apply) and one in front of it for the first group.  The last
+    // centroid of a group is peeled off the loop over its centroids so that this redefinition of the raw registers is
+    // straight-line code: as a conditional inside the loop it cost ~130 register copies per group.  (Pairs with skipped
+    // centroids, row < 0, are not cell pairs: accumulate_grouped_kernel has them.)
     int c = 0;
     int cur = rec_load(rc, 0, nc, lane);                 // record c, lane-distributed; nx1: record c + 1
     int nx1 = rec_load(rc, 1, nc, lane);
     int ta = 0, tb = 0;                                  // load descriptors of record c (none for a source without centroids)
-    if (nc > 0) { ta = tc[lane]; tb = tc[64 + lane]; }
-    bool preloaded = false;                              // the loads of the group starting at c were issued during the previous apply
+    if (nc > 0) {
+        ta = tc[lane]; tb = tc[64 + lane];
+        CELL_LOAD(REC_I(cur, 0), REC_I(cur, 19), REC_I(cur, 8), ta, tb);
+    }
+    // apply centroid cc_ of the group from tile set bsel (as accumulate_grouped_kernel); its record is `cur`
+#define CELL_APPLY(cc_) do { \
+        const int flags = REC_I(cur, 18); \
+        const int ishift = REC_I(cur, 8); \
+        const float cl = REC_F(cur, 16), sl = REC_F(cur, 17); \
+        const float *__restrict__ coef = coef_grp + (size_t)((cc_) - c) * 128; \
+        const int e = smax - ishift; \
+        const TileBase chunk0 = tile_base(&tiles[bsel][0][e + u0]); \
+        const int jl = jb + e + u0; \
+        const bool tail = (jb + e + TILE) > jend_min; \
+        if (KIWI_XC_NOAPPLY) { ar1[0].x += (float)(jl + (int)tail) * cl + coef[0]; } \
+        else if (!tail) cell_apply<NG, PART, LDS_TILE, false, NP>(ar1, ar2, dz, chunk0, jl, jend, flags, coef, cur, sd, cl, sl); \
+        else       cell_apply<NG, PART, LDS_TILE, true, NP>(ar1, ar2, dz, chunk0, jl, jend, flags, coef, cur, sd, cl, sl); \
+    } while (0)
     while (c < nc) {
-        const int row0 = REC_I(cur, 0), pad0 = REC_I(cur, 19), ishift0 = REC_I(cur, 8);
-        if (row0 < 0) {                                  // nothing of this centroid is added
-            c++;
-            cur = nx1;
-            nx1 = rec_load(rc, c + 1, nc, lane);
-            if (c < nc) { ta = tc[(size_t)c * 128 + lane]; tb = tc[(size_t)c * 128 + 64 + lane]; }
-            preloaded = false;
-            continue;
-        }
+        const int pad0 = REC_I(cur, 19), ishift0 = REC_I(cur, 8);
         const int cend = c + (pad0 & 0xff);
         const int smax = ishift0 + ((pad0 >> 8) & 0xff), smin = ishift0 - ((pad0 >> 16) & 0xff);
         const int jb = t_tile0 - smax - 1;               // LDS position p holds blended trace sample jb + p
@@ -2347,7 +2403,6 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_CELL_WAV
 #pragma unroll
         for (int i = 0; i < P::n; i++) jend[i] = REC_I(ta, 40 + P::ig(i));
         const int jend_min = PART == 0 ? min(REC_I(ta, 50), REC_I(ta, 51)) : REC_I(ta, PART == 1 ? 50 : 51);
-        if (!preloaded) CELL_LOAD(row0, pad0, ishift0, ta, tb);
         // descriptors of the NEXT group
         int ta_n = 0, tb_n = 0;
         if (cend < nc) { ta_n = tc[(size_t)cend * 128 + lane]; tb_n = tc[(size_t)cend * 128 + 64 + lane]; }
@@ -2355,38 +2410,31 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_CELL_WAV
         const unsigned clo = __builtin_amdgcn_readfirstlane((unsigned)crow), chi = __builtin_amdgcn_readfirstlane((unsigned)(crow >> 32));
         const float *__restrict__ coef_grp = (const float *)(tab + (((size_t)chi << 32) | clo));
         // ---- first centroid of the group: its tile goes into set 0 (every set is free after the barrier that ended the last group)
-        CELL_BLEND(cur, 0, npos);
-        __syncthreads();
+        if (!KIWI_XC_NOBLEND) CELL_BLEND(cur, 0, npos);
+        if (!KIWI_XC_NOBARRIER) __syncthreads();
         int bsel = 0;
-        preloaded = false;
-        for (int cc = c; cc < cend; cc++) {
+        for (int cc = c; cc + 1 < cend; cc++) {
             const int nx2 = rec_load(rc, cc + 2, nc, lane);      // two records ahead: the next one is needed for its weights now
-            const int flags = REC_I(cur, 18);
             // ---- centroid cc + 1 of the group into the other tile set (a centroid at the point of its predecessor keeps the tile)
-            const bool blend_next = (cc + 1 < cend) && !(REC_I(nx1, 18) & 4);
-            if (blend_next) CELL_BLEND(nx1, bsel ^ 1, npos);
-            // ---- last centroid of the group: the raw registers are free, the next group's rows can be on their way
-            if (cc + 1 == cend && cend < nc && REC_I(nx1, 0) >= 0) {
-                CELL_LOAD(REC_I(nx1, 0), REC_I(nx1, 19), REC_I(nx1, 8), ta_n, tb_n);
-                preloaded = true;
-            }
-            // ---- apply centroid cc from tile set bsel (as accumulate_grouped_kernel)
-            const int ishift = REC_I(cur, 8);
-            const float cl = REC_F(cur, 16), sl = REC_F(cur, 17);
-            const float *__restrict__ coef = coef_grp + (size_t)(cc - c) * 128;
-            const int e = smax - ishift;
-            const TileBase chunk0 = tile_base(&tiles[bsel][0][e + u0]);
-            const int jl = jb + e + u0;
-            const bool tail = (jb + e + TILE) > jend_min;
-            if (!tail) cell_apply<NG, PART, LDS_TILE, false, NP>(ar1, ar2, dz, chunk0, jl, jend, flags, coef, cur, sd, cl, sl);
-            else       cell_apply<NG, PART, LDS_TILE, true, NP>(ar1, ar2, dz, chunk0, jl, jend, flags, coef, cur, sd, cl, sl);
-            __syncthreads();                             // set bsel may be overwritten, set bsel ^ 1 is complete
+            const bool blend_next = !(REC_I(nx1, 18) & 4);
+            if (blend_next && !KIWI_XC_NOBLEND) CELL_BLEND(nx1, bsel ^ 1, npos);
+            CELL_APPLY(cc);
+            if (!KIWI_XC_NOBARRIER) __syncthreads();     // set bsel may be overwritten, set bsel ^ 1 is complete
             if (blend_next) bsel ^= 1;
+            cur = nx1; nx1 = nx2;
+        }
+        {
+            // ---- last centroid of the group: the raw registers are free, the next group's rows can be on their way
+            const int nx2 = rec_load(rc, cend + 1, nc, lane);
+            if (cend < nc && !(KIWI_XC_NOLOAD)) CELL_LOAD(REC_I(nx1, 0), REC_I(nx1, 19), REC_I(nx1, 8), ta_n, tb_n);
+            CELL_APPLY(cend - 1);
+            if (!KIWI_XC_NOBARRIER) __syncthreads();
             cur = nx1; nx1 = nx2;
         }
         ta = ta_n; tb = tb_n;
         c = cend;
     }
+#undef CELL_APPLY
 #undef CELL_LOAD
 #undef CELL_BLEND
     // ---- rotation to N/E, signs, store or fused comparator (seismogram.f90:256-283), as accumulate_grouped_kernel; with the
