@@ -2220,8 +2220,9 @@ __device__ __forceinline__ void raw_blend_store(const RawArr<NG, PART, SPL> &v, 
 // operations in the same order as centroid_apply_hd performs for these components.
 template <int NG, int PART, int LDS_TILE, bool TAIL, int NP>
 __device__ __forceinline__ void cell_apply(f2v (&ar1)[NP], f2v (&ar2)[NP], f2v (&dz)[NP], const TileBase &chunk0, int jl,
-                                           const int (&jend)[CellPart<NG, PART>::n], int flags, const float *__restrict__ coef, int rec,
-                                           float sd, float cl, float sl)
+                                           const int (&jend)[CellPart<NG, PART>::n], int flags,
+                                           const float (&cw)[2 * CellPart<NG, PART>::n] /* (wl, wr) per component in application order */,
+                                           int rec, float sd, float cl, float sl)
 {
     typedef CellPart<NG, PART> P;
     constexpr int nH1 = (NG == 10) ? 4 : 3;      // components summed into the radial trace
@@ -2237,9 +2238,6 @@ __device__ __forceinline__ void cell_apply(f2v (&ar1)[NP], f2v (&ar2)[NP], f2v (
 #pragma unroll
         for (int i = 0; i < P::n; i++) fac[i] = (NG == 10) ? all10[g0 + i] : all8[g0 + i];
     }
-    float cw[2 * P::n];                           // scalar loads: (wl, wr) per component in application order (geometry_kernel)
-#pragma unroll
-    for (int i = 0; i < 2 * P::n; i++) cw[i] = coef[2 * g0 + i];
     constexpr int kAhead = 2;
     TileRegsN<NP> tr[P::n];
 #pragma unroll
@@ -2384,14 +2382,24 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_CELL_WAV
         const int flags = REC_I(cur, 18); \
         const int ishift = REC_I(cur, 8); \
         const float cl = REC_F(cur, 16), sl = REC_F(cur, 17); \
-        const float *__restrict__ coef = coef_grp + (size_t)((cc_) - c) * 128; \
         const int e = smax - ishift; \
         const TileBase chunk0 = tile_base(&tiles[bsel][0][e + u0]); \
         const int jl = jb + e + u0; \
         const bool tail = (jb + e + TILE) > jend_min; \
-        if (KIWI_XC_NOAPPLY) { ar1[0].x += (float)(jl + (int)tail) * cl + coef[0]; } \
-        else if (!tail) cell_apply<NG, PART, LDS_TILE, false, NP>(ar1, ar2, dz, chunk0, jl, jend, flags, coef, cur, sd, cl, sl); \
-        else       cell_apply<NG, PART, LDS_TILE, true, NP>(ar1, ar2, dz, chunk0, jl, jend, flags, coef, cur, sd, cl, sl); \
+        if (KIWI_XC_NOAPPLY) { ar1[0].x += (float)(jl + (int)tail) * cl + cw[0]; } \
+        else if (!tail) { const int nojend[P::n] = {}; cell_apply<NG, PART, LDS_TILE, false, NP>(ar1, ar2, dz, chunk0, jl, nojend, flags, cw, cur, sd, cl, sl); } \
+        else { \
+            int jend[P::n];                     /* end indices: the tail rule only (kept out of the scalar registers otherwise) */ \
+            _Pragma("unroll") for (int i = 0; i < P::n; i++) jend[i] = REC_I(tg, 40 + P::ig(i)); \
+            cell_apply<NG, PART, LDS_TILE, true, NP>(ar1, ar2, dz, chunk0, jl, jend, flags, cw, cur, sd, cl, sl); \
+        } \
+    } while (0)
+    // the coefficient line of centroid cc_ (scalar loads), issued at the top of the centroid's step: in front of the blend of
+    // the next centroid, whose arithmetic covers its round trip (the table comes from HBM).  Not a step earlier: scalar loads
+    // share the counter of the LDS operations, and the drain in front of the barrier would wait for them
+#define CELL_COEF(cc_) do { \
+        const float *__restrict__ coef_ = coef_grp + (size_t)((cc_) - c) * 128 + 2 * P::first; \
+        _Pragma("unroll") for (int i = 0; i < 2 * P::n; i++) cw[i] = coef_[i]; \
     } while (0)
     while (c < nc) {
         const int pad0 = REC_I(cur, 19), ishift0 = REC_I(cur, 8);
@@ -2399,9 +2407,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_CELL_WAV
         const int smax = ishift0 + ((pad0 >> 8) & 0xff), smin = ishift0 - ((pad0 >> 16) & 0xff);
         const int jb = t_tile0 - smax - 1;               // LDS position p holds blended trace sample jb + p
         const int npos = TILE + (smax - smin) + 8;
-        int jend[P::n];
-#pragma unroll
-        for (int i = 0; i < P::n; i++) jend[i] = REC_I(ta, 40 + P::ig(i));
+        const int tg = ta;                               // this group's descriptor row (end indices for the tail rule)
         const int jend_min = PART == 0 ? min(REC_I(ta, 50), REC_I(ta, 51)) : REC_I(ta, PART == 1 ? 50 : 51);
         // descriptors of the NEXT group
         int ta_n = 0, tb_n = 0;
@@ -2409,6 +2415,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_CELL_WAV
         const size_t crow = ((size_t)(c0 - cb) * nrec + (size_t)r * nc + c) * 128 + 64 + 40;
         const unsigned clo = __builtin_amdgcn_readfirstlane((unsigned)crow), chi = __builtin_amdgcn_readfirstlane((unsigned)(crow >> 32));
         const float *__restrict__ coef_grp = (const float *)(tab + (((size_t)chi << 32) | clo));
+        float cw[2 * P::n];
         // ---- first centroid of the group: its tile goes into set 0 (every set is free after the barrier that ended the last group)
         if (!KIWI_XC_NOBLEND) CELL_BLEND(cur, 0, npos);
         if (!KIWI_XC_NOBARRIER) __syncthreads();
@@ -2417,6 +2424,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_CELL_WAV
             const int nx2 = rec_load(rc, cc + 2, nc, lane);      // two records ahead: the next one is needed for its weights now
             // ---- centroid cc + 1 of the group into the other tile set (a centroid at the point of its predecessor keeps the tile)
             const bool blend_next = !(REC_I(nx1, 18) & 4);
+            CELL_COEF(cc);
             if (blend_next && !KIWI_XC_NOBLEND) CELL_BLEND(nx1, bsel ^ 1, npos);
             CELL_APPLY(cc);
             if (!KIWI_XC_NOBARRIER) __syncthreads();     // set bsel may be overwritten, set bsel ^ 1 is complete
@@ -2426,6 +2434,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_CELL_WAV
         {
             // ---- last centroid of the group: the raw registers are free, the next group's rows can be on their way
             const int nx2 = rec_load(rc, cend + 1, nc, lane);
+            CELL_COEF(cend - 1);
             if (cend < nc && !(KIWI_XC_NOLOAD)) CELL_LOAD(REC_I(nx1, 0), REC_I(nx1, 19), REC_I(nx1, 8), ta_n, tb_n);
             CELL_APPLY(cend - 1);
             if (!KIWI_XC_NOBARRIER) __syncthreads();
@@ -2435,6 +2444,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_CELL_WAV
         c = cend;
     }
 #undef CELL_APPLY
+#undef CELL_COEF
 #undef CELL_LOAD
 #undef CELL_BLEND
     // ---- rotation to N/E, signs, store or fused comparator (seismogram.f90:256-283), as accumulate_grouped_kernel; with the
