@@ -183,6 +183,7 @@ struct kiwi_hip_ctx {
     // cell groups (accumulate_cell_kernel: raw node traces fetched once per run of centroids in the same GF cell):
     // -1 decided per batch -- sources whose centroids are mostly different points --, 0 off, 1 on; env KIWI_HIP_CELL
     int cell_mode = -1;
+    int cell_wave = 1;                // 1: accumulate_cellw_kernel (a tile per wave, no barriers); 0: accumulate_cell_kernel; env KIWI_HIP_CELL_WAVE
     int cell_split = 0;               // 1: horizontal and vertical block in separate workgroups; env KIWI_HIP_CELL_SPLIT
     int cell_spl = 2;                 // output samples per lane of the cell kernel (2: raw rows take 80 registers, 4: 160); env KIWI_HIP_CELL_SPL
     double points_per_centroid = 0.0; // of the uploaded batch: distinct consecutive points / centroids
@@ -970,7 +971,8 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
                            c->span.p, c->recv_d.p, c->recs_d.p, tab, (int *)nullptr, spansrc, (cell || duo_maybe) ? c->pairflag_d.p : (int *)nullptr, c->endz.p, (const int *)nullptr);
         if (cell)
             hipLaunchKernelGGL(cellgroup_kernel, grid, dim3(256), 0, c->stream, c->centofs_d.p, ep, c->gm, c->span.p, c->recv_d.p,
-                               c->recs_d.p, tab, c->pairflag_d.p, c->endz.p, (const int *)nullptr);
+                               c->recs_d.p, tab, c->pairflag_d.p, c->endz.p, (const int *)nullptr,
+                               (c->cell_wave && c->cell_spl == 2 && !c->cell_split) ? kCellwRange : kHalo - 10);
     }
     if (c->fft_needed) {
         // transform length of every (source, slot) pair from the source's own strip spans; the lengths travel to the host
@@ -1104,7 +1106,15 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
                                          else KIWI_LAUNCH_C3(NGV, SV, 0, FV); } while (0)
 #define KIWI_LAUNCH_CELL(NGV) do { if (spl == 2) { if (fuse) KIWI_LAUNCH_C2(NGV, 2, true); else KIWI_LAUNCH_C2(NGV, 2, false); } \
                                    else          { if (fuse) KIWI_LAUNCH_C2(NGV, 4, true); else KIWI_LAUNCH_C2(NGV, 4, false); } } while (0)
-            if (cell) { if (c->gm.ng == 10) KIWI_LAUNCH_CELL(10); else KIWI_LAUNCH_CELL(8); }
+#define KIWI_LAUNCH_CW(NGV, FV)                                                                             \
+    hipLaunchKernelGGL((accumulate_cellw_kernel<NGV, FV>), cgrid, dim3(256), 0, c->stream, c->G.p, c->span.p,   \
+                       c->gm.pitch, c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p,          \
+                       c->syn_stride, ntiles_c, c->tab_d.p, fp, c->pairflag_d.p, synrow, famofs, famlist)
+            if (cell && c->cell_wave && spl == 2 && !c->cell_split) {
+                if (c->gm.ng == 10) { if (fuse) KIWI_LAUNCH_CW(10, true); else KIWI_LAUNCH_CW(10, false); }
+                else                { if (fuse) KIWI_LAUNCH_CW(8, true); else KIWI_LAUNCH_CW(8, false); }
+            } else if (cell) { if (c->gm.ng == 10) KIWI_LAUNCH_CELL(10); else KIWI_LAUNCH_CELL(8); }
+#undef KIWI_LAUNCH_CW
             // the (group of sources, receiver) combinations accumulate_multi_kernel takes; the grouped kernel behind it returns at once for those
 #define KIWI_LAUNCH_M2(NGV, FV, NSV, GRID, NT, MATE, WIDER)                                                    \
     hipLaunchKernelGGL((accumulate_multi_kernel<NGV, FV, NSV>), GRID, dim3(256), 0, c->stream, c->G.p, c->span.p,       \
@@ -1293,6 +1303,7 @@ int kiwi_hip_init(int device, kiwi_hip_ctx **out)
         if (const char *m = std::getenv("KIWI_HIP_FUSED_FFT")) c->fused_fft = std::atoi(m) != 0;   // 0: amplitude spectra through hipFFT
         if (const char *m = std::getenv("KIWI_HIP_CELL_SPL")) c->cell_spl = std::atoi(m) == 4 ? 4 : 2;
         if (const char *m = std::getenv("KIWI_HIP_CELL_SPLIT")) c->cell_split = std::atoi(m) ? 1 : 0;
+        if (const char *m = std::getenv("KIWI_HIP_CELL_WAVE")) c->cell_wave = std::atoi(m) ? 1 : 0;
         if (const char *m = std::getenv("KIWI_HIP_CHUNK_MB")) {      // workspace bound per launch (default 16 GiB); tests use it
             const long v = std::atol(m);
             if (v > 0) c->chunk_bytes_limit = (size_t)v << 20;

@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256) void cellgroup_kernel(const int *__restrict__ 
                                                         const int2 *__restrict__ span, const RecvDev *__restrict__ recv,
                                                         GeoRec *__restrict__ recs, int *__restrict__ tab,
                                                         const int *__restrict__ pairflag, const unsigned char *__restrict__ endz,
-                                                        const int *__restrict__ synrow)
+                                                        const int *__restrict__ synrow, int cell_range /* largest shift range of a cell group */)
 {
     const int s = blockIdx.y;
     if (synrow && synrow[s] != s) return;
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(256) void cellgroup_kernel(const int *__restrict__ 
                 if (!same_cell(rr + k, me.row) || !(cellp || (rr[k].flags & 4))) break;
                 const int sh = rr[k].ishift;
                 const int nmin = min(smin, sh), nmax = max(smax, sh);
-                if (nmax - nmin > kHalo - 10) break;
+                if (nmax - nmin > (cellp ? cell_range : kHalo - 10)) break;
                 smin = nmin; smax = nmax; len++;
             }
             if (pos == c) break;                  // this centroid starts a group
@@ -2502,6 +2502,259 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_CELL_WAV
             acc = wave_reduce_f64(acc, fp.method == 6);                 // total in lane 63
             if (lane == 63)
                 fp.partial[((size_t)js * fp.nmis + rv.slot0 + k) * fp.nparts + tile * (T / 64) + (tid >> 6)] = acc;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// accumulate, cell groups, a tile per WAVE (r03)
+//
+// accumulate_cell_kernel shares its tile among the four waves of the workgroup: a barrier per centroid, at which three
+// waves wait for the slowest (measured: 10 % of the kernel), and every wave in the same phase at the same time.  Here a wave
+// owns the 128 output samples it computes AND the blended samples they need: it blends positions 0 .. 127 of its tile from
+// the raw rows in its registers plus the few positions behind them that the group's shifts reach (one 4-sample chunk of one
+// component per lane, lanes 0 .. 59: groups are cut at a shift range of kCellwRange), and reads them back itself.  LDS
+// operations of one wave execute in order, so there is no barrier anywhere in the loop, and ONE tile set is enough: per
+// component the step reads what the apply of centroid k needs, then writes the blend of centroid k + 1 over it, then does
+// the arithmetic of both.  Waves drift apart and fill each other's stalls (loads of the next group's rows, the first blend of
+// a group, LDS round trips).  Per output sample the operations and their order are those of accumulate_cell_kernel.
+constexpr int kCellwRow = 192;      // floats per component row of a wave's tile: 128 + halo, a multiple of 64 (ds_read2st64 offsets)
+constexpr int kCellwRange = 23;     // largest shift range of a group: 24 positions behind the 128 = six chunks x 10 components = 60 lanes
+
+// One step of a wave: apply centroid k (record `rec`, coefficients cw, tile position `pos` = e + lane) and, BLEND, put centroid
+// k + 1 (weights w0 .. w3) into the tile -- component by component, the write of a component's row behind the read of it.
+template <int NG, bool TAIL, bool BLEND>
+__device__ __forceinline__ void cellw_step(f2v (&ar1)[1], f2v (&ar2)[1], f2v (&dz)[1], float *__restrict__ wt, int pos,
+                                           const RawArr<NG, 0, 2> &raw, float w0, float w1, float w2, float w3, int pl,
+                                           bool hact, const HaloRegs &hraw, int hloc, int hph,
+                                           int jl, const int (&jend)[CellPart<NG, 0>::n], int flags,
+                                           const float (&cw)[2 * CellPart<NG, 0>::n], int rec, float sd, float cl, float sl)
+{
+    typedef CellPart<NG, 0> P;
+    constexpr int nH1 = (NG == 10) ? 4 : 3;      // components summed into the radial trace
+    constexpr int nH = (NG == 10) ? 6 : 5;       // horizontal block
+    float fac[P::n];
+#pragma unroll
+    for (int i = 0; i < P::n; i++) fac[i] = 0.f;
+    if constexpr (TAIL) {                         // the tail rule needs the plain factors (sparse_trace.f90:698-703)
+        const float f0 = REC_F(rec, 10), f1 = REC_F(rec, 11), f2 = REC_F(rec, 12), f3 = REC_F(rec, 13), f4 = REC_F(rec, 14), f5 = REC_F(rec, 15);
+        const float all10[10] = { f0, f1, f2, f5, f3, f4, f0 * sd, f1 * sd, f2 * sd, f5 * sd };
+        const float all8[8] = { f0, f1, f2, f3, f4, f0 * sd, f1 * sd, f2 * sd };
+#pragma unroll
+        for (int i = 0; i < P::n; i++) fac[i] = (NG == 10) ? all10[i] : all8[i];
+    }
+    const TileBase chunk0 = tile_base(wt + pos);
+    constexpr int kAhead = 2;
+    TileRegsN<1> tr[P::n];
+#pragma unroll
+    for (int i = 0; i < kAhead && i < P::n; i++) tr[i] = tile_load<1>(chunk0, i * kCellwRow);
+    const bool rot = (flags & 2) != 0;           // seismogram.f90:160-203 vs :205-231
+    f2v t1[1], t2[1];
+    t1[0] = rot ? f2v{ 0.f, 0.f } : ar1[0]; t2[0] = rot ? f2v{ 0.f, 0.f } : ar2[0];
+#pragma unroll
+    for (int i = 0; i < P::n; i++) {
+        if (i + kAhead < P::n) tr[i + kAhead] = tile_load<1>(chunk0, (i + kAhead) * kCellwRow);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (BLEND) {                    // row i has been read (kAhead iterations ago): its next content may go in
+            f2u b = w0 * raw[i][0];               // gfdb.f90:946-949, summed in this order
+            b = b + w1 * raw[i][1];
+            b = b + w2 * raw[i][2];
+            b = b + w3 * raw[i][3];
+            *(float2 *)(wt + i * kCellwRow + pl) = make_float2(b.x, b.y);
+        }
+        if (i < nH1)     tile_fma<TAIL, 1>(t1, tr[i], jl, jend[i], fac[i], cw[2 * i], cw[2 * i + 1]);
+        else if (i < nH) tile_fma<TAIL, 1>(t2, tr[i], jl, jend[i], fac[i], cw[2 * i], cw[2 * i + 1]);
+        else             tile_fma<TAIL, 1>(dz, tr[i], jl, jend[i], fac[i], cw[2 * i], cw[2 * i + 1]);
+        if (i == nH - 1) {
+            if (rot) {
+                ar1[0] = ar1[0] + cl * t1[0] - sl * t2[0];
+                ar2[0] = ar2[0] + cl * t2[0] + sl * t1[0];
+            } else {
+                ar1[0] = t1[0]; ar2[0] = t2[0];
+            }
+        }
+    }
+    if constexpr (BLEND) {                        // behind every read of this step
+        GeoRec gw;
+        gw.w[0] = w0; gw.w[1] = w1; gw.w[2] = w2; gw.w[3] = w3;
+        halo_finish<true>(hact, hraw, wt, kCellwRow, hloc, hph, gw);
+    }
+}
+
+template <int NG, bool FUSE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void accumulate_cellw_kernel(
+    const float *__restrict__ G, const int2 *__restrict__ span, int pitch,
+    const GeoRec *__restrict__ recs, const int *__restrict__ cent_ofs, int isrc0, int nrec,
+    const RecvDev *__restrict__ recv, float *__restrict__ syn, size_t syn_stride, int ntiles,
+    const int *__restrict__ tab, FuseParams fp, const int *__restrict__ pairflag, const int *__restrict__ synrow,
+    const int *__restrict__ fam_ofs, const int *__restrict__ fam_list)
+{
+    constexpr int T = 256, SPL = 2, TILE = SPL * T;
+    typedef CellPart<NG, 0> P;
+    __shared__ __attribute__((aligned(16))) float tiles[T / 64][P::n][kCellwRow];
+    const int s = (int)blockIdx.x;                        // source index fastest (see accumulate_grouped_kernel)
+    const int tile = blockIdx.y % ntiles, r = blockIdx.y / ntiles;
+    const RecvDev &rv = recv[r];
+    if (!rv.enabled) return;
+    if (tile * TILE >= rv.wlen) return;
+    if (!cell_pair(rv, pairflag, s, nrec, r)) return;
+    if (synrow && synrow[s] != s) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    float *__restrict__ wt = &tiles[wv][0][0];            // this wave's tile
+    const int t_tile0 = rv.wbeg + tile * TILE;
+    const int cb = cent_ofs[isrc0], c0 = cent_ofs[isrc0 + s], nc = cent_ofs[isrc0 + s + 1] - c0;
+    const GeoRec *__restrict__ rc = recs + ((size_t)(c0 - cb) * nrec + (size_t)r * nc);
+    const int *__restrict__ tc = tab + ((size_t)(c0 - cb) * nrec + (size_t)r * nc) * 128;
+    const float sd = rv.sd;
+    const int w0s = 128 * wv;                             // first sample of the wave inside the workgroup's 512
+    const int u0 = w0s + lane;                            // this lane's first output sample (the other: + 64)
+    const int pl = 2 * lane;                              // the two tile positions this lane blends
+    // halo: lane q owns the 4-sample chunk q / n of component q % n behind the wave's 128 positions
+    const int hloc = lane % P::n, hch = lane / P::n, hph = 128 + 4 * hch;
+    int hig = P::ig(0);
+#pragma unroll
+    for (int i = 1; i < P::n; i++) if (hloc == i) hig = P::ig(i);
+
+    f2v ar1[1], ar2[1], dz[1];
+    ar1[0] = f2v{ 0.f, 0.f }; ar2[0] = f2v{ 0.f, 0.f }; dz[0] = f2v{ 0.f, 0.f };
+    f2u raw[P::n][4];                                     // raw rows of the current group over the wave's 128 positions
+    HaloRegs hraw;                                        // ... and over the halo chunk of this lane
+
+    // issue the loads of the group with head fields (pad, ishift) and descriptors ta_ / tb_
+#define CELLW_LOAD(head_row0, head_pad, head_ishift, ta_, tb_) do { \
+        const int smax_ = (head_ishift) + (((head_pad) >> 8) & 0xff), smin_ = (head_ishift) - (((head_pad) >> 16) & 0xff); \
+        const int jb_ = t_tile0 - smax_ - 1; \
+        const float *__restrict__ Gg_ = G + (size_t)(head_row0) * (size_t)pitch;     /* descriptors are relative to it (write_tab) */ \
+        /* every row of the cell holds the whole tile: rows start at or before it and end behind it */ \
+        const bool inside_ = (REC_I(ta_, 52) + jb_ >= 0) && (REC_I(ta_, 53) + jb_ + SPL * (T - 1) <= pitch - 4); \
+        if (inside_) raw_issue<NG, 0, SPL, true>(raw, SPL * tid, jb_, Gg_, pitch, ta_, tb_); \
+        else         raw_issue<NG, 0, SPL, false>(raw, SPL * tid, jb_, Gg_, pitch, ta_, tb_); \
+        hraw = halo_issue<true, false>(4 * hch <= smax_ - smin_, hig, w0s + hph, jb_, Gg_, pitch, ta_, tb_); \
+    } while (0)
+#define CELLW_COEF(cc_) do { \
+        const float *__restrict__ coef_ = coef_grp + (size_t)((cc_) - c) * 128; \
+        _Pragma("unroll") for (int i = 0; i < 2 * P::n; i++) cw[i] = coef_[i]; \
+    } while (0)
+    // one step: apply centroid `cur` from the tile and (blend_) put centroid nx1 into it
+#define CELLW_STEP(blend_) do { \
+        const int flags = REC_I(cur, 18); \
+        const int ishift = REC_I(cur, 8); \
+        const float cl = REC_F(cur, 16), sl = REC_F(cur, 17); \
+        const int e = smax - ishift; \
+        const int jl = jb + e + u0; \
+        const bool tail = (jb + e + w0s + 128) > jend_min; \
+        const float bw0 = REC_F(nx1, 4), bw1 = REC_F(nx1, 5), bw2 = REC_F(nx1, 6), bw3 = REC_F(nx1, 7); \
+        if (!tail) { \
+            const int nojend[P::n] = {}; \
+            if (blend_) cellw_step<NG, false, true>(ar1, ar2, dz, wt, e + lane, raw, bw0, bw1, bw2, bw3, pl, hact, hraw, hloc, hph, jl, nojend, flags, cw, cur, sd, cl, sl); \
+            else        cellw_step<NG, false, false>(ar1, ar2, dz, wt, e + lane, raw, bw0, bw1, bw2, bw3, pl, hact, hraw, hloc, hph, jl, nojend, flags, cw, cur, sd, cl, sl); \
+        } else { \
+            int jend[P::n];                     /* end indices: the tail rule only (kept out of the scalar registers otherwise) */ \
+            _Pragma("unroll") for (int i = 0; i < P::n; i++) jend[i] = REC_I(tg, 40 + P::ig(i)); \
+            if (blend_) cellw_step<NG, true, true>(ar1, ar2, dz, wt, e + lane, raw, bw0, bw1, bw2, bw3, pl, hact, hraw, hloc, hph, jl, jend, flags, cw, cur, sd, cl, sl); \
+            else        cellw_step<NG, true, false>(ar1, ar2, dz, wt, e + lane, raw, bw0, bw1, bw2, bw3, pl, hact, hraw, hloc, hph, jl, jend, flags, cw, cur, sd, cl, sl); \
+        } \
+    } while (0)
+
+    int c = 0;
+    int cur = rec_load(rc, 0, nc, lane);                 // record c, lane-distributed; nx1: record c + 1
+    int nx1 = rec_load(rc, 1, nc, lane);
+    int ta = 0, tb = 0;                                  // load descriptors of record c (none for a source without centroids)
+    if (nc > 0) {
+        ta = tc[lane]; tb = tc[64 + lane];
+        CELLW_LOAD(REC_I(cur, 0), REC_I(cur, 19), REC_I(cur, 8), ta, tb);
+    }
+    while (c < nc) {
+        const int pad0 = REC_I(cur, 19), ishift0 = REC_I(cur, 8);
+        const int cend = c + (pad0 & 0xff);
+        const int smax = ishift0 + ((pad0 >> 8) & 0xff), smin = ishift0 - ((pad0 >> 16) & 0xff);
+        const int jb = t_tile0 - smax - 1;               // tile position q of this wave holds blended trace sample jb + 128 wv + q
+        const bool hact = 4 * hch <= smax - smin;        // positions 128 .. 128 + (smax - smin) are read
+        const int tg = ta;                               // this group's descriptor row (end indices for the tail rule)
+        const int jend_min = min(REC_I(ta, 50), REC_I(ta, 51));
+        // descriptors of the NEXT group
+        int ta_n = 0, tb_n = 0;
+        if (cend < nc) { ta_n = tc[(size_t)cend * 128 + lane]; tb_n = tc[(size_t)cend * 128 + 64 + lane]; }
+        const size_t crow = ((size_t)(c0 - cb) * nrec + (size_t)r * nc + c) * 128 + 64 + 40;
+        const unsigned clo = __builtin_amdgcn_readfirstlane((unsigned)crow), chi = __builtin_amdgcn_readfirstlane((unsigned)(crow >> 32));
+        const float *__restrict__ coef_grp = (const float *)(tab + (((size_t)chi << 32) | clo));
+        float cw[2 * P::n];
+        {   // ---- first centroid of the group into the tile (behind the reads of the last step: LDS operations of a wave run in order)
+            GeoRec gw;
+            gw.w[0] = REC_F(cur, 4); gw.w[1] = REC_F(cur, 5); gw.w[2] = REC_F(cur, 6); gw.w[3] = REC_F(cur, 7);
+            raw_blend_store<NG, 0, SPL>(raw, wt, kCellwRow, pl, gw.w[0], gw.w[1], gw.w[2], gw.w[3]);
+            halo_finish<true>(hact, hraw, wt, kCellwRow, hloc, hph, gw);
+        }
+        for (int cc = c; cc + 1 < cend; cc++) {
+            const int nx2 = rec_load(rc, cc + 2, nc, lane);      // two records ahead: the next one is needed for its weights now
+            const bool blend_next = !(REC_I(nx1, 18) & 4);       // (a centroid at the point of its predecessor keeps the tile)
+            CELLW_COEF(cc);
+            CELLW_STEP(blend_next);
+            cur = nx1; nx1 = nx2;
+        }
+        {
+            // ---- last centroid of the group: the raw registers are free, the next group's rows can be on their way
+            const int nx2 = rec_load(rc, cend + 1, nc, lane);
+            CELLW_COEF(cend - 1);
+            if (cend < nc) CELLW_LOAD(REC_I(nx1, 0), REC_I(nx1, 19), REC_I(nx1, 8), ta_n, tb_n);
+            CELLW_STEP(false);
+            cur = nx1; nx1 = nx2;
+        }
+        ta = ta_n; tb = tb_n;
+        c = cend;
+    }
+#undef CELLW_LOAD
+#undef CELLW_COEF
+#undef CELLW_STEP
+    // ---- rotation to N/E, signs, store or fused comparator (seismogram.f90:256-283), as accumulate_cell_kernel
+    const int nfam = (FUSE && fam_ofs) ? fam_ofs[s + 1] - fam_ofs[s] : 0;
+    for (int qf = -1; qf < nfam; qf++) {
+        const int js = qf < 0 ? s : fam_list[fam_ofs[s] + qf];
+        const int tl = tile * TILE + u0;
+        if (!FUSE && tl >= rv.wlen) return;
+        float *__restrict__ so = syn + (size_t)js * syn_stride + tl;
+        const float a1[SPL] = { ar1[0].x, ar1[0].y }, a2[SPL] = { ar2[0].x, ar2[0].y }, ad[SPL] = { dz[0].x, dz[0].y };
+        float mom = 0.f;
+        if constexpr (FUSE) mom = fp.moment[fp.isrc0 + js];
+        const bool unit = (fp.syn_factor == 1.f);
+        for (int k = 0; k < rv.ncomp; k++) {
+            const float sg = rv.sign[k];
+            float o[SPL];
+#pragma unroll
+            for (int i = 0; i < SPL; i++) {
+                switch (rv.comp[k]) {
+                case 1: o[i] = a1[i] * sg; break;
+                case 2: o[i] = a2[i] * sg; break;
+                case 3: o[i] = ad[i]; break;
+                case 4: o[i] = (rv.cl0 * a1[i] - rv.sl0 * a2[i]) * sg; break;
+                default: o[i] = (rv.cl0 * a2[i] + rv.sl0 * a1[i]) * sg; break;
+                }
+            }
+            if constexpr (!FUSE) {
+#pragma unroll
+                for (int i = 0; i < SPL; i++)
+                    if (tl + 64 * i < rv.wlen) so[rv.synofs[k] + 64 * i] = o[i];
+                continue;
+            }
+            double acc = 0.0;
+            const float *__restrict__ rt = fp.reft + rv.refofs[k] + tl, *__restrict__ tp = fp.tw + rv.refofs[k] + tl;
+#pragma unroll
+            for (int i = 0; i < SPL; i++) {
+                if (tl + 64 * i >= rv.wlen) break;
+                const float v = o[i] * mom;
+                const float vt = v * tp[64 * i];
+                const float a = rt[64 * i];
+                switch (fp.method) {
+                case 1: { const float d = unit ? (a - vt) : (1.f * a - fp.syn_factor * vt); acc = sq_acc(acc, d); break; }
+                case 2: { const float d = unit ? fabsf(a - vt) : fabsf(1.f * a - fp.syn_factor * vt); acc += (double)d; break; }
+                case 5: acc += unit ? (double)(a * vt) : (double)(a * 1.f * vt * fp.syn_factor); break;
+                default: { const double x = (double)(1.f * a), y = (double)(fp.syn_factor * vt); acc = fmax(acc, sqrt(x * x + y * y)); break; }
+                }
+            }
+            acc = wave_reduce_f64(acc, fp.method == 6);                 // total in lane 63
+            if (lane == 63)
+                fp.partial[((size_t)js * fp.nmis + rv.slot0 + k) * fp.nparts + tile * (T / 64) + wv] = acc;
         }
     }
 }
