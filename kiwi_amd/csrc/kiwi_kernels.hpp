@@ -1862,20 +1862,24 @@ __device__ __forceinline__ void one_finish(const f4u (&v)[BLEND ? 4 : 1], float 
 
 // Build of accumulate_multi_kernel: NS tile sets of TILE = 1024 / NS samples (+ halo).  A wave-task = one component's 64 main
 // chunks (chunk = 4 samples) of one 256-sample slab; NS = 2: wave w takes components 2 i + (w >> 1), slab w & 1; NS = 4: wave w
-// components w + 4 i (one slab); threads 0 .. 16 NG - 1 the halo chunks.  Every chunk's four node rows are loaded ONCE and
+// components w + 4 i (one slab); the halo chunks go to the LAST threads, chunk-major (thread 255 - q: chunk q / NG of component
+// q % NG): a group reads only the first few chunks behind the tile (its shift range + 8 samples), so the halo is the work of the
+// last wave alone -- the one with the fewest main tasks (NS = 4: 3, 3, 2, 2) --, `whalo` says whether this wave has any.  Every chunk's four node rows are loaded ONCE and
 // blended with the weights of each source into its tile set (gfdb.f90:946-949, summed in this order) -- `only` >= 0: into that
 // source's set alone.  A centroid exactly on a node carries the weights (1, 0, 0, 0) over four copies of its row:
 // 1 v + 0 v + 0 v + 0 v is v bit for bit, so there is no unblended variant.
 template <int NG, bool FAST, int NS>
 __device__ __forceinline__ void multi_build(float *__restrict__ tile0, int wv, int lane, int tid, int jb, const float *__restrict__ G,
-                                            int pitch, int ta, int tb, const GeoRec (&gw)[NS], int only, bool hact, int hig, int hph)
+                                            int pitch, int ta, int tb, const GeoRec (&gw)[NS], int only, bool hact, bool whalo, int hig, int hph)
 {
     constexpr int TILE = 1024 / NS, LDS_TILE = TILE + kHalo, DEPTH = 3;
     constexpr int N = (NS == 2) ? NG / 2 : (NG + 3) / 4;           // wave-tasks per wave at most
     const int p = (NS == 2) ? 4 * (64 * (wv & 1) + lane) : 4 * lane;
     auto comp = [&](int i) { return (NS == 2) ? 2 * i + (wv >> 1) : wv + 4 * i; };
     f4u v[N][4];
-    HaloRegs hv = halo_issue<true, FAST>(true, hig, hph, jb, G, pitch, ta, tb);        // (inactive lanes load a valid chunk too: no merge of registers)
+    HaloRegs hv;
+    // (a wave without a halo lane skips the halo; in the others inactive lanes load a valid chunk too: no merge of registers)
+    if (whalo) hv = halo_issue<true, FAST>(true, hig, hph, jb, G, pitch, ta, tb);
 #pragma unroll
     for (int i = 0; i < DEPTH && i < N; i++) if (comp(i) < NG) one_issue<true, FAST>(v[i], comp(i), p, jb, G, pitch, ta, tb);
 #pragma unroll
@@ -1888,9 +1892,11 @@ __device__ __forceinline__ void multi_build(float *__restrict__ tile0, int wv, i
         }
         if (i + DEPTH < N && comp(i + DEPTH) < NG) one_issue<true, FAST>(v[i + DEPTH], comp(i + DEPTH), p, jb, G, pitch, ta, tb);
     }
+    if (whalo) {
 #pragma unroll
-    for (int s = 0; s < NS; s++)
-        if (only < 0 || only == s) halo_finish<true>(hact, hv, tile0 + s * NG * LDS_TILE, LDS_TILE, hig, hph, gw[s]);
+        for (int s = 0; s < NS; s++)
+            if (only < 0 || only == s) halo_finish<true>(hact, hv, tile0 + s * NG * LDS_TILE, LDS_TILE, hig, hph, gw[s]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1974,8 +1980,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
 #pragma unroll
     for (int i = 0; i < NS; i++) cur[i] = rec_load(recs_of(i), 0, nc, lane);
     int ta = tab_of(0)[lane], tb = tab_of(0)[64 + lane];
-    // halo: one lane per (component, 4-sample chunk)
-    const int hslot = tid >> 4, hig = min(hslot, NG - 1), hph = TILE + 4 * (tid & 15);
+    // halo: one lane per (4-sample chunk, component), chunk-major from the last thread down (see multi_build)
+    const int hq = 255 - tid, hch = min(hq / NG, 15), hig = hq % NG, hph = TILE + 4 * hch;
     while (c < nc) {
         GeoRec g[NS];
         int smaxs[NS], npos = 0;
@@ -2007,9 +2013,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
             const float *__restrict__ Gg = G + (size_t)g[I0].row[0] * (size_t)pitch; \
             const bool lane_ok = lane >= 4 * NG || ((TA) + jb_ >= (TB) && (TA) + jb_ + LDS_TILE <= (TB) + pitch); \
             const bool fast = __builtin_amdgcn_ballot_w64(lane_ok) == ~0ull; \
-            const bool hact = hslot < NG && hph < (NPOS); \
-            if (fast) multi_build<NG, true, NS>(&tiles[0][0][0], wv, lane, tid, jb_, Gg, pitch, TA, TB, g, ONLY, hact, hig, hph); \
-            else      multi_build<NG, false, NS>(&tiles[0][0][0], wv, lane, tid, jb_, Gg, pitch, TA, TB, g, ONLY, hact, hig, hph); } while (0)
+            const bool hact = hq < 16 * NG && hph < (NPOS); \
+            const bool whalo = __builtin_amdgcn_ballot_w64(hact) != 0ull; \
+            if (fast) multi_build<NG, true, NS>(&tiles[0][0][0], wv, lane, tid, jb_, Gg, pitch, TA, TB, g, ONLY, hact, whalo, hig, hph); \
+            else      multi_build<NG, false, NS>(&tiles[0][0][0], wv, lane, tid, jb_, Gg, pitch, TA, TB, g, ONLY, hact, whalo, hig, hph); } while (0)
 #ifndef KIWI_X_NOBUILD
         if (shared) KIWI_MULTI_BUILD(ta, tb, 0, -1, npos);
         else {
