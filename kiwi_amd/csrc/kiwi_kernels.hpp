@@ -1191,9 +1191,10 @@ __device__ __forceinline__ double dpp_f64(double v)
     return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ double wave_reduce_f64(double v, bool is_max)
+template <bool IS_MAX>
+__device__ __forceinline__ double wave_reduce_f64_t(double v)
 {
-#define KIWI_STEP(CTRL, MASK) do { const double o = dpp_f64<CTRL, MASK>(v); v = is_max ? fmax(v, o) : v + o; } while (0)
+#define KIWI_STEP(CTRL, MASK) do { const double o = dpp_f64<CTRL, MASK>(v); v = IS_MAX ? fmax(v, o) : v + o; } while (0)
     KIWI_STEP(0x111, 0xf);      // row_shr:1
     KIWI_STEP(0x112, 0xf);      // row_shr:2
     KIWI_STEP(0x114, 0xf);      // row_shr:4
@@ -1202,6 +1203,56 @@ __device__ __forceinline__ double wave_reduce_f64(double v, bool is_max)
     KIWI_STEP(0x143, 0xc);      // row_bcast:31 -> rows 2, 3
 #undef KIWI_STEP
     return v;
+}
+__device__ __forceinline__ double wave_reduce_f64(double v, bool is_max)      // (is_max is wave-uniform: one branch, not a select per step)
+{
+    return is_max ? wave_reduce_f64_t<true>(v) : wave_reduce_f64_t<false>(v);
+}
+
+// ---- epilogue of the accumulate kernels with four outputs per lane (samples tl + 64 q, q = 0 .. 3, held as two register pairs)
+// one output trace of the receiver from the accumulators: rotation to N/E and sign (seismogram.f90:256-283), packed
+__device__ __forceinline__ void out4(int comp, float sg, float cl0, float sl0, const f2v (&ar1)[2], const f2v (&ar2)[2], const f2v (&dz)[2],
+                                     f2v &o01, f2v &o23)
+{
+    const f2v s2 = { sg, sg }, c2 = { cl0, cl0 }, n2 = { sl0, sl0 };
+    switch (comp) {
+    case 1: o01 = ar1[0] * s2; o23 = ar1[1] * s2; break;
+    case 2: o01 = ar2[0] * s2; o23 = ar2[1] * s2; break;
+    case 3: o01 = dz[0]; o23 = dz[1]; break;
+    case 4: o01 = (c2 * ar1[0] - n2 * ar2[0]) * s2; o23 = (c2 * ar1[1] - n2 * ar2[1]) * s2; break;
+    default: o01 = (c2 * ar2[0] + n2 * ar1[0]) * s2; o23 = (c2 * ar2[1] + n2 * ar1[1]) * s2; break;
+    }
+}
+// the fused comparator over the lane's four samples (what misfit_kernel does per sample: comparator.f90:264,1173-1184,627-667);
+// `whole`: all of them lie inside the window (workgroup-uniform).  l2norm with unit factor, the norm of every grid search, has a
+// straight-line packed form -- the same operations in the same order as the general loop
+__device__ __forceinline__ double fused_acc4(const FuseParams &fp, f2v o01, f2v o23, float mom, const float *__restrict__ rt,
+                                             const float *__restrict__ tp, int tl, int wlen, bool whole)
+{
+    const bool unit = (fp.syn_factor == 1.f);
+    double acc = 0.0;
+    if (whole && unit && fp.method == 1) {
+        const f2v m2 = { mom, mom };
+        const f2v t01 = { tp[0], tp[64] }, t23 = { tp[128], tp[192] }, r01 = { rt[0], rt[64] }, r23 = { rt[128], rt[192] };
+        const f2v d01 = r01 - (o01 * m2) * t01, d23 = r23 - (o23 * m2) * t23;
+        acc = sq_acc(acc, d01.x); acc = sq_acc(acc, d01.y); acc = sq_acc(acc, d23.x); acc = sq_acc(acc, d23.y);
+        return acc;
+    }
+    const float o[4] = { o01.x, o01.y, o23.x, o23.y };
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (tl + 64 * i >= wlen) break;
+        const float v = o[i] * mom;
+        const float vt = v * tp[64 * i];
+        const float a = rt[64 * i];
+        switch (fp.method) {
+        case 1: { const float d = unit ? (a - vt) : (1.f * a - fp.syn_factor * vt); acc = sq_acc(acc, d); break; }
+        case 2: { const float d = unit ? fabsf(a - vt) : fabsf(1.f * a - fp.syn_factor * vt); acc += (double)d; break; }
+        case 5: acc += unit ? (double)(a * vt) : (double)(a * 1.f * vt * fp.syn_factor); break;
+        default: { const double x = (double)(1.f * a), y = (double)(fp.syn_factor * vt); acc = fmax(acc, sqrt(x * x + y * y)); break; }
+        }
+    }
+    return acc;
 }
 
 #ifndef KIWI_GROUPED_WAVES
@@ -1434,7 +1485,8 @@ template <int N, int I = 0, class F> __device__ __forceinline__ void static_for(
 // (wave-uniform pointer: scalar loads, SGPR operands of the packed multiplies).
 template <int NG, bool ROT, int K = 17>
 __device__ __forceinline__ void carry2_apply(f2v (&ar1)[2], f2v (&ar2)[2], f2v (&dz)[2], const typename Set2Sel<NG>::type &L,
-                                             const typename Set2Sel<NG>::type &H, unsigned a, int d /* previous shift position minus this one; none: 0x7fff */,
+                                             const typename Set2Sel<NG>::type &H, unsigned a,
+                                             int dh, int dl /* previous shift position minus this one (none: 0x7fff): 1 keeps H, -1 keeps L */,
                                              const float *__restrict__ coef, float cl, float sl)
 {
     constexpr int nH1 = (NG == 10) ? 4 : 3;      // components summed into the radial trace
@@ -1442,8 +1494,8 @@ __device__ __forceinline__ void carry2_apply(f2v (&ar1)[2], f2v (&ar2)[2], f2v (
 #pragma unroll
     for (int i = 0; i < 2 * NG; i++) cw[i] = coef[i];
     static_assert(K == 17 || K == 9 || K == 5, "component stride in units of 64 dwords");
-    set2_read<K, 1>(d, a + 4, H);             // shift + 1 (d == 1): the b[j] set is in place
-    set2_read<K, -1>(d, a, L);                // shift - 1: the b[j-1] set is
+    set2_read<K, 1>(dh, a + 4, H);            // shift + 1 (d == 1): the b[j] set is in place
+    set2_read<K, -1>(dl, a, L);               // shift - 1: the b[j-1] set is
     set2_wait(H);
     set2_dep(L);
     f2v t1[2], t2[2];
@@ -1537,47 +1589,22 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_GROUPED_
         const int tl = tile * TILE + 4 * (tid & ~63) + lane;     // window sample of the lane's output q = 0; q-th: + 64 q
         if (!FUSE && tl >= rv.wlen) return;
         float *__restrict__ so = syn + (size_t)js * syn_stride + tl;
-        const float a1[4] = { ar1[0].x, ar1[0].y, ar1[1].x, ar1[1].y }, a2[4] = { ar2[0].x, ar2[0].y, ar2[1].x, ar2[1].y },
-                    ad[4] = { dz[0].x, dz[0].y, dz[1].x, dz[1].y };
         float mom = 0.f;
         if constexpr (FUSE) mom = fp.moment[fp.isrc0 + js];
-        const bool unit = (fp.syn_factor == 1.f);
+        const bool whole = tile * TILE + TILE <= rv.wlen;
         for (int k = 0; k < rv.ncomp; k++) {
-            const float sg = rv.sign[k];
-            float o[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                switch (rv.comp[k]) {
-                case 1: o[i] = a1[i] * sg; break;
-                case 2: o[i] = a2[i] * sg; break;
-                case 3: o[i] = ad[i]; break;
-                case 4: o[i] = (rv.cl0 * a1[i] - rv.sl0 * a2[i]) * sg; break;
-                default: o[i] = (rv.cl0 * a2[i] + rv.sl0 * a1[i]) * sg; break;
-                }
-            }
+            f2v o01, o23;
+            out4(rv.comp[k], rv.sign[k], rv.cl0, rv.sl0, ar1, ar2, dz, o01, o23);
             if constexpr (!FUSE) {
+                const float o[4] = { o01.x, o01.y, o23.x, o23.y };
 #pragma unroll
                 for (int i = 0; i < 4; i++)
                     if (tl + 64 * i < rv.wlen) so[rv.synofs[k] + 64 * i] = o[i];      // 256 contiguous bytes per wave and store
                 continue;
             }
-            // ---- fused comparator: what misfit_kernel does per sample (comparator.f90:264,1173-1184,627-667), then a
-            // wave reduction; the partial of (source, slot, tile, wave) is summed by misfit_finish_kernel in a fixed order
-            double acc = 0.0;
-            const float *__restrict__ rt = fp.reft + rv.refofs[k] + tl, *__restrict__ tp = fp.tw + rv.refofs[k] + tl;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                if (tl + 64 * i >= rv.wlen) break;
-                const float v = o[i] * mom;
-                const float vt = v * tp[64 * i];
-                const float a = rt[64 * i];
-                switch (fp.method) {
-                case 1: { const float d = unit ? (a - vt) : (1.f * a - fp.syn_factor * vt); acc = sq_acc(acc, d); break; }
-                case 2: { const float d = unit ? fabsf(a - vt) : fabsf(1.f * a - fp.syn_factor * vt); acc += (double)d; break; }
-                case 5: acc += unit ? (double)(a * vt) : (double)(a * 1.f * vt * fp.syn_factor); break;
-                default: { const double x = (double)(1.f * a), y = (double)(fp.syn_factor * vt); acc = fmax(acc, sqrt(x * x + y * y)); break; }
-                }
-            }
+            // ---- fused comparator, then a wave reduction; the partial of (source, slot, tile, wave) is summed by
+            // misfit_finish_kernel in a fixed order
+            double acc = fused_acc4(fp, o01, o23, mom, fp.reft + rv.refofs[k] + tl, fp.tw + rv.refofs[k] + tl, tl, rv.wlen, whole);
             acc = wave_reduce_f64(acc, fp.method == 6);                 // total in lane 63
             if (lane == 63)
                 fp.partial[((size_t)js * fp.nmis + rv.slot0 + k) * fp.nparts + tile * (T / 64) + (tid >> 6)] = acc;
@@ -1752,7 +1779,11 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_GROUPED_
 #define KIWI_C2STEP(LL, HH, RV, CC) do { \
                 const int e = smax - __builtin_amdgcn_readlane(ishv, (CC) - c);      /* LDS position of b[j-1] of the tile's first sample */ \
                 const int d = have ? eprev - e : 0x7fff; \
-                carry2_apply<NG, RV>(ar1, ar2, dz, LL, HH, abase + 4u * (unsigned)e, KIWI_X_FULL(d), coef_grp + (size_t)((CC) - c) * 128, gcl, gsl); \
+                /* `same`: the sets are in the roles of the previous step (first centroid of a source behind a source with an odd \
+                   number of centroids): both are in place when the shift has not moved, none otherwise */ \
+                const int dh = same ? (d == 0 ? 1 : 0x7fff) : d, dl = same ? (d == 0 ? -1 : 0x7fff) : d; \
+                same = false; \
+                carry2_apply<NG, RV>(ar1, ar2, dz, LL, HH, abase + 4u * (unsigned)e, KIWI_X_FULL(dh), KIWI_X_FULL(dl), coef_grp + (size_t)((CC) - c) * 128, gcl, gsl); \
                 have = true; eprev = e; } while (0)
 #define KIWI_C2SOURCES(RV) do { \
                 set2_dead(X); set2_dead(Y);       /* nothing is carried into a group, its first centroid reads both sets: tells the register allocator so */ \
@@ -1765,8 +1796,11 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_GROUPED_
                     const unsigned clo = __builtin_amdgcn_readfirstlane((unsigned)crow), chi = __builtin_amdgcn_readfirstlane((unsigned)(crow >> 32)); \
                     const float *__restrict__ coef_grp = (const float *)(tab + (((size_t)chi << 32) | clo)); \
                     int cc = c; \
+                    /* odd count in a run: the sets end in the roles they started in, and the next source's first centroid finds \
+                       them so (point sources of ONE centroid: no LDS read at all behind the first source of the run) */ \
+                    bool same = RUNS && multi && have && ((cend - c) & 1); \
                     for (; cc + 1 < cend; cc += 2) { KIWI_C2STEP(X, Y, RV, cc); KIWI_C2STEP(Y, X, RV, cc + 1); } \
-                    if (cc < cend) { KIWI_C2STEP(X, Y, RV, cc); have = !multi && have; }      /* odd count in a run: the sets end in the roles they started in */ \
+                    if (cc < cend) KIWI_C2STEP(X, Y, RV, cc); \
                     if (multi) store_family(js); \
                 } } while (0)
             if (g0.flags & 2) KIWI_C2SOURCES(true); else KIWI_C2SOURCES(false);
@@ -2051,7 +2085,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
 #define KIWI_C2STEP(LL, HH, RV, CC) do { \
                 const int e = smax - __builtin_amdgcn_readlane(ishv, (CC) - c);       /* LDS position of b[j-1] of the tile's first sample */ \
                 const int d = have ? eprev - e : 0x7fff; \
-                carry2_apply<NG, RV, K>(ar1, ar2, dz, LL, HH, abase + 4u * (unsigned)e, KIWI_X_FULL(d), coef_grp + (size_t)((CC) - c) * 128, gcl, gsl); \
+                carry2_apply<NG, RV, K>(ar1, ar2, dz, LL, HH, abase + 4u * (unsigned)e, KIWI_X_FULL(d), KIWI_X_FULL(d), coef_grp + (size_t)((CC) - c) * 128, gcl, gsl); \
                 have = true; eprev = e; } while (0)
             if (flags & 2) {
                 set2_dead(X); set2_dead(Y);
@@ -2073,45 +2107,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
         const int tl = tile * TILE + u0;                 // window sample of the lane's output q = 0; q-th: + 64 q
         if (!FUSE && tl >= rv.wlen) return;
         float *__restrict__ so = syn + (size_t)js * syn_stride + tl;
-        const float a1[4] = { ar1[0].x, ar1[0].y, ar1[1].x, ar1[1].y }, a2[4] = { ar2[0].x, ar2[0].y, ar2[1].x, ar2[1].y },
-                    ad[4] = { dz[0].x, dz[0].y, dz[1].x, dz[1].y };
         float mom = 0.f;
         if constexpr (FUSE) mom = fp.moment[fp.isrc0 + js];
-        const bool unit = (fp.syn_factor == 1.f);
+        const bool whole = tile * TILE + TILE <= rv.wlen;
         for (int k = 0; k < rv.ncomp; k++) {
-            const float sg = rv.sign[k];
-            float o[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                switch (rv.comp[k]) {
-                case 1: o[i] = a1[i] * sg; break;
-                case 2: o[i] = a2[i] * sg; break;
-                case 3: o[i] = ad[i]; break;
-                case 4: o[i] = (rv.cl0 * a1[i] - rv.sl0 * a2[i]) * sg; break;
-                default: o[i] = (rv.cl0 * a2[i] + rv.sl0 * a1[i]) * sg; break;
-                }
-            }
+            f2v o01, o23;
+            out4(rv.comp[k], rv.sign[k], rv.cl0, rv.sl0, ar1, ar2, dz, o01, o23);
             if constexpr (!FUSE) {
+                const float o[4] = { o01.x, o01.y, o23.x, o23.y };
 #pragma unroll
                 for (int i = 0; i < 4; i++)
                     if (tl + 64 * i < rv.wlen) so[rv.synofs[k] + 64 * i] = o[i];
                 continue;
             }
-            double acc = 0.0;
-            const float *__restrict__ rt = fp.reft + rv.refofs[k] + tl, *__restrict__ tp = fp.tw + rv.refofs[k] + tl;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                if (tl + 64 * i >= rv.wlen) break;
-                const float v = o[i] * mom;
-                const float vt = v * tp[64 * i];
-                const float a = rt[64 * i];
-                switch (fp.method) {
-                case 1: { const float d = unit ? (a - vt) : (1.f * a - fp.syn_factor * vt); acc = sq_acc(acc, d); break; }
-                case 2: { const float d = unit ? fabsf(a - vt) : fabsf(1.f * a - fp.syn_factor * vt); acc += (double)d; break; }
-                case 5: acc += unit ? (double)(a * vt) : (double)(a * 1.f * vt * fp.syn_factor); break;
-                default: { const double x = (double)(1.f * a), y = (double)(fp.syn_factor * vt); acc = fmax(acc, sqrt(x * x + y * y)); break; }
-                }
-            }
+            double acc = fused_acc4(fp, o01, o23, mom, fp.reft + rv.refofs[k] + tl, fp.tw + rv.refofs[k] + tl, tl, rv.wlen, whole);
             acc = wave_reduce_f64(acc, fp.method == 6);                 // total in lane 63
             if (lane == 63)
                 fp.partial[((size_t)js * fp.nmis + rv.slot0 + k) * fp.nparts + tile * WPS + (wv % WPS)] = acc;
