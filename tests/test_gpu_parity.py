@@ -511,6 +511,63 @@ def test_spectral_results_do_not_depend_on_the_batch(method, with_filter, monkey
         ef.close()
 
 
+@pytest.mark.parametrize("L,edt", [(700, 0.5), (1500, 1.0)])
+def test_cell_kernels_are_bit_identical(monkeypatch, L, edt):
+    """Sources whose centroids are all different points (an eikonal rupture) through the four accumulate paths: the cell
+    kernel with a tile per wave (accumulate_cellw_kernel, the default), the one with a shared tile (KIWI_HIP_CELL_WAVE=0), the
+    grouped kernel with groups of one centroid (KIWI_HIP_CELL=0) and the direct kernel -- the same synthetics bit for bit.
+    Several tiles per window, receivers the cell kernels do not take (one component family only), a slow rupture (shift
+    ranges beyond what a per-wave halo holds: cellgroup_kernel cuts the runs) and a fast one."""
+    import os
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "eikonal_vectors.npz"))
+    comps = ["ned", "ned", "d", "ne", "aru", "ned"]
+    sc = Scenario(nz=6, L=L, nrec=6, comps_list=comps, effective_dt=edt)
+    sc.oracle()
+    trials = []
+    for i, vfac in enumerate([0.8, 0.25, 0.8]):          # relative rupture velocity: 0.25 stretches the arrival times of a cell's centroids
+        common = [0.2 * i, 300.0 * i, -200.0 * i, 10500.0 + 300 * i]
+        trials.append(common + [7e18, 80.0 + 5 * i, 70.0, -170.0 + 10 * i] + [100.0, -50.0, 2500.0 + 400 * i] + [500.0 - 300 * i, 200.0]
+                      + [vfac, 0.0])
+    trials = np.array(trials, np.float32)
+    cp = np.array([[0, 0, 6500.0], [0, 0, 15500.0], [0, -2000.0, 0]], np.float32)
+    cn = np.array([[0, 0, -1.0], [0, 0, 1.0], [0.2, -1.0, 0]], np.float32)
+    res, ranges = {}, None
+    for mode in ("cellw", "cell", "grouped", "direct"):
+        for k in ("KIWI_HIP_ACCUM", "KIWI_HIP_CELL", "KIWI_HIP_CELL_WAVE"):
+            monkeypatch.delenv(k, raising=False)
+        if mode == "direct":
+            monkeypatch.setenv("KIWI_HIP_ACCUM", "direct")
+        elif mode == "grouped":
+            monkeypatch.setenv("KIWI_HIP_CELL", "0")
+        else:
+            monkeypatch.setenv("KIWI_HIP_CELL", "1")
+            monkeypatch.setenv("KIWI_HIP_CELL_WAVE", "1" if mode == "cellw" else "0")
+        p = sc.product()
+        p.set_source_crust(G["rupture_profile"], G["origin_profile"])
+        p.set_source_constraints(cp, cn)
+        p.set_keep_synthetics(1)
+        p.set_source_params("eikonal", trials)
+        p.eval()
+        res[mode] = [p.get_synthetics(s, ir, k, 1)[1] for s in range(len(trials)) for ir in range(1, 7)
+                     for k in range(1, len(comps[ir - 1]) + 1)]
+        if mode in ("cellw", "cell"):
+            g = [p.get_geometry(s, 1) for s in range(len(trials))]
+            # group hints of the cell pass: length and shift range at the records that start a run
+            rng_ = [int(((r["pad"] >> 8) & 0xff).max() + ((r["pad"] >> 16) & 0xff).max()) for r in g]
+            lens = [int((r["pad"] & 0xff).max()) for r in g]
+            if mode == "cellw":
+                ranges = rng_
+                assert max(lens) > 3                       # runs of several centroids per cell
+                assert max(rng_) <= 2 * 23                 # (each side of the head's shift within the per-wave limit)
+            else:
+                assert max(rng_) >= max(ranges)            # the shared tile allows the longer runs
+        p.close()
+    assert any(np.any(a != 0) for a in res["direct"]) and len(res["direct"]) == 3 * 15
+    for mode in ("cellw", "cell", "grouped"):
+        for i, (a, b) in enumerate(zip(res[mode], res["direct"])):
+            assert a.tobytes() == b.tobytes(), (mode, i)
+
+
 @pytest.mark.parametrize("stype", ["eikonal", "mt_eikonal"])
 def test_eikonal_sources_with_risetime_fold(stype):
     """Variable-rupture-speed sources: discretised by the product's host code from the crust
