@@ -1963,8 +1963,7 @@ static void discretise_batch(const kiwi_hip_ctx *c, int sourcetype, int nsrc, co
     for (int s = 0; s < nsrc; s++)
         if (solve_of[s] != s) {                  // same rupture as an earlier source: its table, own moment and rise time
             const int f = solve_of[s];
-            status[s] = status[f];
-            ds[s].centroids = ds[f].centroids;
+            status[s] = status[f];               // (its table is taken from ds[f] when the batch is packed: no copy per duplicate)
             if (status[f] == 0) { ds[s].moment = params[(size_t)s * np + 4]; ds[s].risetime = params[(size_t)s * np + (sourcetype == 5 ? 19 : 14)]; }
             else { ds[s].moment = 0.f; ds[s].risetime = 0.f; nbad++; }
         }
@@ -1973,10 +1972,11 @@ static void discretise_batch(const kiwi_hip_ctx *c, int sourcetype, int nsrc, co
     // ("Empty rupture area", ...) is recorded and skipped like seismosizer.py:703-720 does (failings)
     if (bad >= 0 && !eikonal) throw std::runtime_error(why + " (source " + std::to_string(bad + 1) + ")");
     hb.ofs.assign((size_t)nsrc + 1, 0);
-    for (int s = 0; s < nsrc; s++) hb.ofs[s + 1] = hb.ofs[s] + (int)ds[s].centroids.size();
+    auto table_of = [&](int s) -> const std::vector<Centroid> & { return ds[solve_of[s]].centroids; };
+    for (int s = 0; s < nsrc; s++) hb.ofs[s + 1] = hb.ofs[s] + (int)table_of(s).size();
     hb.cent.resize((size_t)hb.ofs[nsrc] * 10); hb.mom.resize((size_t)nsrc); hb.rise.resize((size_t)nsrc);
     for (int s = 0; s < nsrc; s++) {
-        std::memcpy(hb.cent.data() + (size_t)hb.ofs[s] * 10, ds[s].centroids.data(), ds[s].centroids.size() * sizeof(Centroid));
+        std::memcpy(hb.cent.data() + (size_t)hb.ofs[s] * 10, table_of(s).data(), table_of(s).size() * sizeof(Centroid));
         hb.mom[s] = ds[s].moment; hb.rise[s] = ds[s].risetime;
     }
 }
