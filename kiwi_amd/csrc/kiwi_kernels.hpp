@@ -203,6 +203,8 @@ __device__ __forceinline__ bool starts_group(const float *__restrict__ cent, int
 //   tab[50], tab[51]   = minimum of those over the horizontal (1-5, 9) / vertical (6-8, 10) components
 //   tab[52], tab[53]   = minimum / maximum over the cell's rows of (kRowPad - first): where trace sample 0 sits inside its row
 //                        (accumulate_cell_kernel: a tile that stays inside every row is loaded without clamps)
+//   tab[54]            = 1 when the components of each node start at the same sample: the sample-0 positions of a node's rows are
+//                        then `pitch` apart and the kernel takes four descriptors instead of forty
 //   tab[64 + 40 + 2*i], [.. + 1] = wl, wr: per-component interpolation coefficients of THIS centroid
 //       (sparse_trace.f90:643-647 with the factors of seismogram.f90:171-250): wl = (1 - w) * factor, wr = w * factor,
 //       each rounded on its own, for the i-th component in application order 0 1 2 8 | 3 4 | 5 6 7 9 (ng = 8:
@@ -221,6 +223,7 @@ __device__ __forceinline__ bool write_tab(int *__restrict__ tb, const GeoRec &g,
     int bases[NG][4], floors[NG][4], jend[12];
     int jmin_h = 0x7fffffff, jmin_d = 0x7fffffff;
     int amin = 0x7fffffff, amax = -0x7fffffff;      // range of (trace sample 0 inside its row) over the cell's rows
+    bool uni = true;                                // the components of every node start at the same sample (the usual database)
     if (full) {
     // Rows whose stored trace ends in an exact zero (the reference's trace_pack keeps one of the zeros that follow the last
     // non-zero sample, sparse_trace.f90:535,545, so this is the normal case for traces that die out inside the database's
@@ -240,6 +243,7 @@ __device__ __forceinline__ bool write_tab(int *__restrict__ tb, const GeoRec &g,
             bases[ig][k] = (row - g.row[0]) * pitch + kRowPad - sp.x;
             floors[ig][k] = (row - g.row[0]) * pitch;
             amin = min(amin, kRowPad - sp.x); amax = max(amax, kRowPad - sp.x);
+            uni = uni && bases[ig][k] - floors[ig][k] == bases[0][k] - floors[0][k];
             if (k < nn) { je = max(je, sp.y); endzero = endzero && endz[row]; }
         }
         jend[ig] = je;
@@ -279,7 +283,7 @@ __device__ __forceinline__ bool write_tab(int *__restrict__ tb, const GeoRec &g,
         for (int ig = 0; ig < NG; ig++) t4[ig] = make_int4(bases[ig][0], bases[ig][1], bases[ig][2], bases[ig][3]);
 #pragma unroll
         for (int q = 0; q < 3; q++) t4[10 + q] = make_int4(jend[4 * q], jend[4 * q + 1], jend[4 * q + 2], jend[4 * q + 3]);
-        t4[13] = make_int4(amin, amax, 0, 0);
+        t4[13] = make_int4(amin, amax, uni ? 1 : 0, 0);
 #pragma unroll
         for (int ig = 0; ig < NG; ig++) t4[16 + ig] = make_int4(floors[ig][0], floors[ig][1], floors[ig][2], floors[ig][3]);
     }
@@ -2166,7 +2170,9 @@ template <int NG, int PART, int SPL> using RawArr = typename RawVec<SPL>::type[C
 // FAST: the whole tile lies inside every row of the cell (tab[52], tab[53]; the caller's test): no clamp -- the lane's
 // position is the same vector offset for all loads and the row's sample-0 position goes into the load's scalar offset: one
 // scalar instruction per load and no vector one
-template <int NG, int PART, int SPL, bool FAST = false>
+// UNI (with FAST; tab[54]): the rows of a node are `pitch` apart AND start at the same sample: the four descriptors of component 0
+// give all forty positions
+template <int NG, int PART, int SPL, bool FAST = false, bool UNI = false>
 __device__ __forceinline__ void raw_issue(RawArr<NG, PART, SPL> &v, int p, int jb,
                                           const float *__restrict__ G, int pitch, int ta, int tb)
 {
@@ -2176,11 +2182,18 @@ __device__ __forceinline__ void raw_issue(RawArr<NG, PART, SPL> &v, int p, int j
     const int p4 = 4 * p, hi4 = 4 * (pitch - 4);
     if constexpr (FAST) {
         const unsigned jb4 = 4u * (unsigned)jb;
+        unsigned node0[4] = { 0u, 0u, 0u, 0u };
+        if constexpr (UNI) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) node0[k] = 4u * (unsigned)REC_I(ta, k) + jb4;
+        }
 #pragma unroll
         for (int i = 0; i < P::n; i++) {
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const unsigned so = 4u * (unsigned)REC_I(ta, 4 * P::ig(i) + k) + jb4;      // byte position of tile sample 0 in the cell
+                // byte position of tile sample 0 in the cell
+                const unsigned so = UNI ? node0[k] + (unsigned)P::ig(i) * (4u * (unsigned)pitch)
+                                        : 4u * (unsigned)REC_I(ta, 4 * P::ig(i) + k) + jb4;
                 if constexpr (SPL == 4) {
                     const v4i_t w = __builtin_amdgcn_raw_buffer_load_b128(gf_rsrc(G), p4, (int)so, 0);
                     v[i][k] = RV{ __int_as_float(w.x), __int_as_float(w.y), __int_as_float(w.z), __int_as_float(w.w) };
@@ -2644,7 +2657,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
         const float *__restrict__ Gg_ = G + (size_t)(head_row0) * (size_t)pitch;     /* descriptors are relative to it (write_tab) */ \
         /* every row of the cell holds the whole tile: rows start at or before it and end behind it */ \
         const bool inside_ = (REC_I(ta_, 52) + jb_ >= 0) && (REC_I(ta_, 53) + jb_ + SPL * (T - 1) <= pitch - 4); \
-        if (inside_) raw_issue<NG, 0, SPL, true>(raw, SPL * tid, jb_, Gg_, pitch, ta_, tb_); \
+        if (inside_ && REC_I(ta_, 54)) raw_issue<NG, 0, SPL, true, true>(raw, SPL * tid, jb_, Gg_, pitch, ta_, tb_); \
+        else if (inside_) raw_issue<NG, 0, SPL, true>(raw, SPL * tid, jb_, Gg_, pitch, ta_, tb_); \
         else         raw_issue<NG, 0, SPL, false>(raw, SPL * tid, jb_, Gg_, pitch, ta_, tb_); \
         hraw = halo_issue<true, false>(4 * hch <= smax_ - smin_, hig, w0s + hph, jb_, Gg_, pitch, ta_, tb_); \
     } while (0)

@@ -511,18 +511,24 @@ def test_spectral_results_do_not_depend_on_the_batch(method, with_filter, monkey
         ef.close()
 
 
-@pytest.mark.parametrize("L,edt", [(700, 0.5), (1500, 1.0)])
-def test_cell_kernels_are_bit_identical(monkeypatch, L, edt):
+@pytest.mark.parametrize("L,edt,stagger", [(700, 0.5, False), (1500, 1.0, False), (1500, 0.5, True)])
+def test_cell_kernels_are_bit_identical(monkeypatch, L, edt, stagger):
     """Sources whose centroids are all different points (an eikonal rupture) through the four accumulate paths: the cell
     kernel with a tile per wave (accumulate_cellw_kernel, the default), the one with a shared tile (KIWI_HIP_CELL_WAVE=0), the
     grouped kernel with groups of one centroid (KIWI_HIP_CELL=0) and the direct kernel -- the same synthetics bit for bit.
     Several tiles per window, receivers the cell kernels do not take (one component family only), a slow rupture (shift
-    ranges beyond what a per-wave halo holds: cellgroup_kernel cuts the runs) and a fast one."""
+    ranges beyond what a per-wave halo holds: cellgroup_kernel cuts the runs) and a fast one.  `stagger`: the components of a
+    node start at different samples (the cell kernels then take forty row descriptors per run instead of four)."""
     import os
     G = np.load(os.path.join(os.path.dirname(__file__), "golden", "eikonal_vectors.npz"))
     comps = ["ned", "ned", "d", "ne", "aru", "ned"]
     sc = Scenario(nz=6, L=L, nrec=6, comps_list=comps, effective_dt=edt)
+    if stagger:
+        sc.gf["first"] = sc.gf["first"] + np.arange(sc.gf["first"].shape[2], dtype=sc.gf["first"].dtype)[None, None, :] * 3
     sc.oracle()
+    if stagger:
+        first = sc.odb.dense_tables()[0]
+        assert np.any(np.ptp(first, axis=2) > 0)
     trials = []
     for i, vfac in enumerate([0.8, 0.25, 0.8]):          # relative rupture velocity: 0.25 stretches the arrival times of a cell's centroids
         common = [0.2 * i, 300.0 * i, -200.0 * i, 10500.0 + 300 * i]
