@@ -2026,14 +2026,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
         bool shared = true;
 #pragma unroll
         for (int i = 0; i < NS; i++) {
-            rec_head(cur[i], 0, g[i]);
+            // of the head record: blend weights, integer shift and group hint of every source; the four node rows of the first
+            // one only -- the others' are compared where they lie (lanes 0 .. 3 of the lane-distributed records)
+            g[i].w[0] = REC_F(cur[i], 4); g[i].w[1] = REC_F(cur[i], 5); g[i].w[2] = REC_F(cur[i], 6); g[i].w[3] = REC_F(cur[i], 7);
+            g[i].ishift = REC_I(cur[i], 8);
+            g[i].pad = REC_I(cur[i], 19);
             smaxs[i] = g[i].ishift + ((g[i].pad >> 8) & 0xff);
             const int smin = g[i].ishift - ((g[i].pad >> 16) & 0xff);
             npos = max(npos, TILE + (smaxs[i] - smin) + 8);
             // the node rows once for all -- if all sit in the same cell and read it from the same tile origin (integer
             // shifts may differ between the sources of a time sweep)
-            shared = shared && g[i].row[0] == g[0].row[0] && g[i].row[1] == g[0].row[1] && g[i].row[2] == g[0].row[2] &&
-                     g[i].row[3] == g[0].row[3] && smaxs[i] == smaxs[0];
+            if (i == 0) g[0].row[0] = REC_I(cur[0], 0);
+            else shared = shared && (__builtin_amdgcn_ballot_w64(cur[i] != cur[0]) & 0xfull) == 0ull && smaxs[i] == smaxs[0];
         }
         const int glen = g[0].pad & 0xff;                // (same structure: equal for all)
         const int cend = c + glen;
@@ -2062,6 +2066,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
 #pragma unroll
             for (int i = 1; i < NS; i++) {               // (descriptors of the others only here: not kept in registers)
                 const int tai = tab_of(i)[(size_t)c * 128 + lane], tbi = tab_of(i)[(size_t)c * 128 + 64 + lane];
+                g[i].row[0] = REC_I(cur[i], 0);
                 KIWI_MULTI_BUILD(tai, tbi, i, i, npos);
             }
         }
