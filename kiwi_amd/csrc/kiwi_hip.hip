@@ -150,7 +150,8 @@ struct kiwi_hip_ctx {
     std::vector<kiwi_hip_ctx *> mates;
     int cpu_share = 1;                // contexts that discretise at the same time: divides the discretiser's thread team
     std::vector<unsigned long long> struct_hash;   // per source: number of centroids and boundaries of its centroid groups (accumulate_multi_kernel's grouping)
-    std::vector<unsigned long long> shift_hash;    // per source: its centroids' integer shifts (groups of four share a tile origin only with equal shifts)
+    std::vector<int> first_shift;                  // per source: integer shift of its first centroid (groups of four: within 16 samples of each other,
+                                                   // so that their groups can share a tile origin)
     std::vector<float> src_ends;                   // per source: position (north, east, depth) of its first and of its last centroid
     DevBuf<int> mate_d, mate4_d;
     int duo = 4;                      // accumulate_multi_kernel: up to this many consecutive sources of equal structure per workgroup
@@ -889,6 +890,13 @@ bool can_fuse(const kiwi_hip_ctx *c, int proc_which, int isrc0, int nsrc)
            c->halo == 0 && (c->method == KIWI_L2NORM || c->method == KIWI_L1NORM || c->method == KIWI_SCALAR_PRODUCT || c->method == KIWI_PEAK);
 }
 
+// groups of four trial sources per workgroup: largest difference of their origin times in samples (experiment switch)
+static int kiwi_quad_shift_span()
+{
+    static const int v = [] { const char *m = std::getenv("KIWI_HIP_QUAD_SPAN"); return m ? std::atoi(m) : 16; }();
+    return v;
+}
+
 void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
 {
     const int nrec = (int)c->recv.size();
@@ -1033,7 +1041,8 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
                 }
             }
             // aligned groups of four / two consecutive sources of equal structure (see accumulate_multi_kernel); four only where
-            // the integer shifts agree as well (else their groups do not share a tile origin: two at a time then)
+            // their origin times are within 16 samples of each other (their groups then share a tile origin: that of the largest
+            // shift; further apart the four tile sets would be built one after the other -- two at a time then)
             bool duo = duo_maybe && !runs && !synrow && maxnc > 0;
             bool any4 = false, any2 = false;
             if (duo) {
@@ -1045,7 +1054,7 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
                 const float near_h = 0.25f * c->gm.dx * (float)c->xus, near_z = 0.25f * c->gm.dz * (float)c->zus;
                 auto same = [&](int a, int b, bool shifts) {
                     const int na = c->cent_ofs[a + 1] - c->cent_ofs[a], nb = c->cent_ofs[b + 1] - c->cent_ofs[b];
-                    if (!(na > 0 && na == nb && c->struct_hash[a] == c->struct_hash[b] && (!shifts || c->shift_hash[a] == c->shift_hash[b]))) return false;
+                    if (!(na > 0 && na == nb && c->struct_hash[a] == c->struct_hash[b] && (!shifts || std::abs(c->first_shift[a] - c->first_shift[b]) <= kiwi_quad_shift_span()))) return false;
                     const float *p = c->src_ends.data() + (size_t)a * 6, *q = c->src_ends.data() + (size_t)b * 6;
                     for (int k = 0; k < 6; k++)
                         if (std::fabs(p[k] - q[k]) > (k % 3 == 2 ? near_z : near_h)) return false;
@@ -1728,7 +1737,7 @@ int kiwi_hip_set_sources(kiwi_hip_ctx *c, int nsrc, const int *cent_ofs, const f
     c->cent_ofs.assign(cent_ofs, cent_ofs + nsrc + 1);
     c->geo_hash.assign((size_t)nsrc, 0ull);
     c->struct_hash.assign((size_t)nsrc, 0ull);
-    c->shift_hash.assign((size_t)nsrc, 0ull);
+    c->first_shift.assign((size_t)nsrc, 0);
     c->src_ends.assign((size_t)nsrc * 6, 0.f);
     c->single_group.assign((size_t)nsrc, 0);
     {
@@ -1770,11 +1779,9 @@ int kiwi_hip_set_sources(kiwi_hip_ctx *c, int nsrc, const int *cent_ofs, const f
                 hs ^= (unsigned)len; hs *= 1099511628211ull;
                 k += len;
             }
-            unsigned long long hsh = 1469598103934665603ull;
-            for (int k = 0; k < nc; k++) { hsh ^= (unsigned)(int)std::floor(ce[(size_t)k * 10 + 3] / dt); hsh *= 1099511628211ull; }
             c->geo_hash[s] = h;
             c->struct_hash[s] = hs;
-            c->shift_hash[s] = hsh;
+            c->first_shift[s] = nc > 0 ? (int)std::floor(ce[3] / dt) : 0;
             if (nc > 0)
                 for (int q = 0; q < 3; q++) { c->src_ends[(size_t)s * 6 + q] = ce[q]; c->src_ends[(size_t)s * 6 + 3 + q] = ce[(size_t)(nc - 1) * 10 + q]; }
             c->single_group[s] = one ? 1 : 0;

@@ -1959,6 +1959,11 @@ __device__ __forceinline__ void multi_build(float *__restrict__ tile0, int wv, i
 // `mate[k]` says so for group k.  Of those the kernel takes the (group, receiver) combinations where every source is "clean"
 // for the receiver (horizontal and vertical components, no missing trace, no tail rule: pairflag of geometry_kernel);
 // accumulate_grouped_kernel runs behind it for everything else (pairsel 3).
+// maximum / minimum of wave-uniform integers on the scalar unit (left to itself the compiler moves them to the vector pipe
+// for its three-operand forms)
+__device__ __forceinline__ int smax_u(int a, int b) { int r; asm("s_max_i32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b) : "scc"); return r; }
+__device__ __forceinline__ int smin_u(int a, int b) { int r; asm("s_min_i32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b) : "scc"); return r; }
+
 template <int NS>
 __device__ __forceinline__ bool multi_taken(const RecvDev &rv, const int *__restrict__ pairflag, const int *__restrict__ mate,
                                             int s, int nrec, int r)
@@ -2022,8 +2027,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
     const int hq = 255 - tid, hch = min(hq / NG, 15), hig = hq % NG, hph = TILE + 4 * hch;
     while (c < nc) {
         GeoRec g[NS];
-        int smaxs[NS], npos = 0;
-        bool shared = true;
+        int smaxs[NS], smins[NS], npos = 0;
+        bool shared = true, same_rows = true;
 #pragma unroll
         for (int i = 0; i < NS; i++) {
             // of the head record: blend weights, integer shift and group hint of every source; the four node rows of the first
@@ -2032,12 +2037,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
             g[i].ishift = REC_I(cur[i], 8);
             g[i].pad = REC_I(cur[i], 19);
             smaxs[i] = g[i].ishift + ((g[i].pad >> 8) & 0xff);
-            const int smin = g[i].ishift - ((g[i].pad >> 16) & 0xff);
-            npos = max(npos, TILE + (smaxs[i] - smin) + 8);
-            // the node rows once for all -- if all sit in the same cell and read it from the same tile origin (integer
-            // shifts may differ between the sources of a time sweep)
+            smins[i] = g[i].ishift - ((g[i].pad >> 16) & 0xff);
+            npos = max(npos, TILE + (smaxs[i] - smins[i]) + 8);
+            // the node rows once for all -- if all sit in the same cell and read it from the same tile origin
             if (i == 0) g[0].row[0] = REC_I(cur[0], 0);
-            else shared = shared && (__builtin_amdgcn_ballot_w64(cur[i] != cur[0]) & 0xfull) == 0ull && smaxs[i] == smaxs[0];
+            else {
+                same_rows = same_rows && (__builtin_amdgcn_ballot_w64(cur[i] != cur[0]) & 0xfull) == 0ull;
+                shared = shared && smaxs[i] == smaxs[0];
+            }
+        }
+        shared = shared && same_rows;
+        if (same_rows && !shared) {
+            // the sources of a time sweep: same cell, shifts a few samples apart.  ONE tile origin all the same -- that of the
+            // largest shift -- when the shifts of all of them still fit the tile's halo; every source counts its positions from it
+            int smax_c = smaxs[0], smin_c = smins[0];
+#pragma unroll
+            for (int i = 1; i < NS; i++) { smax_c = smax_u(smax_c, smaxs[i]); smin_c = smin_u(smin_c, smins[i]); }
+            if (TILE + (smax_c - smin_c) + 8 <= LDS_TILE) {
+                shared = true;
+                npos = TILE + (smax_c - smin_c) + 8;
+#pragma unroll
+                for (int i = 0; i < NS; i++) smaxs[i] = smax_c;
+            }
         }
         const int glen = g[0].pad & 0xff;                // (same structure: equal for all)
         const int cend = c + glen;

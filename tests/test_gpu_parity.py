@@ -1467,12 +1467,17 @@ def test_two_sources_per_workgroup_is_bit_identical(monkeypatch, L):
     other[:, 9] *= 0.5                                          # shorter rupture: another number of sub-faults
     trials = np.vstack([fine, coarse, other, times, fine[:3]]).astype(np.float32)
     assert len(trials) % 2 == 0 and len(trials) == 18
-    trials = np.vstack([trials, fine[:1]])                      # odd count: the last source has no mate
+    # two aligned groups of FOUR sources of a time sweep (origin times up to seven samples apart: their groups share one tile
+    # origin, that of the largest shift), then an odd count: the last source has no mate
+    times8 = synthetic.bilat_strike_sweep(8, step=0.0)
+    times8[:, 0] += np.array([0.0, 0.3, 0.55, 1.3, 2.1, 2.15, 2.6, 3.4], np.float32)
+    trials = np.vstack([trials, fine[1:3], times8, fine[:1]]).astype(np.float32)
+    assert len(trials) == 29
     res = {}
     sc.oracle()                                                 # (packs the database the product is handed)
-    for mode in ("duo", "single", "direct"):
+    for mode in ("quad", "duo", "single", "direct"):
         monkeypatch.delenv("KIWI_HIP_ACCUM", raising=False)
-        monkeypatch.setenv("KIWI_HIP_DUO", "1" if mode == "duo" else "0")
+        monkeypatch.setenv("KIWI_HIP_DUO", {"quad": "4", "duo": "2"}.get(mode, "0"))
         if mode == "direct":
             monkeypatch.setenv("KIWI_HIP_ACCUM", "direct")
         p = sc.product()
@@ -1482,15 +1487,15 @@ def test_two_sources_per_workgroup_is_bit_identical(monkeypatch, L):
         res[mode] = [p.get_synthetics(s, ir, k, 1)[1] for s in range(len(trials)) for ir in range(1, 7)
                      for k in range(1, len(sc.comps[ir - 1]) + 1)]
         p.close()
-    assert len(res["duo"]) == len(res["single"]) == len(res["direct"]) > 200
-    for a, b, c in zip(res["duo"], res["single"], res["direct"]):
-        assert a.tobytes() == b.tobytes() == c.tobytes()
+    assert len(res["quad"]) == len(res["duo"]) == len(res["single"]) == len(res["direct"]) > 300
+    for q, a, b, c in zip(res["quad"], res["duo"], res["single"], res["direct"]):
+        assert q.tobytes() == a.tobytes() == b.tobytes() == c.tobytes()
     assert sum(1 for a in res["duo"] if np.any(a != 0)) > 150
     # and through the fused comparator: misfits against the oracle
-    monkeypatch.setenv("KIWI_HIP_DUO", "1")
+    monkeypatch.setenv("KIWI_HIP_DUO", "4")
     monkeypatch.delenv("KIWI_HIP_ACCUM", raising=False)
     e, p = build(sc)
-    tr = trials[:15]                                            # (no repeated source: those would share synthetics instead)
+    tr = np.vstack([trials[:15], times8, fine[3:5]])            # (no repeated source: those would share synthetics instead)
     m, n, g = oracle_misfits(e, 1, tr)
     p.set_source_params("bilateral", tr)
     p.eval()
