@@ -408,6 +408,10 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     ngpus = world
+    if ngpus > 1 and not os.environ.get("KIWI_HIP_DISC_THREADS"):
+        # N ranks share the box's host cores: each rank's discretiser team gets its share instead of all of them
+        from kiwi_amd import lib as _lib
+        os.environ["KIWI_HIP_DISC_THREADS"] = str(max(1, int(_lib.load().kiwi_hip_effective_cpus()) // ngpus))
 
     from kiwi_amd.shard import shard_range, gather_misfits
     from kiwi_amd import synthetic
