@@ -1671,6 +1671,9 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_GROUPED_
                 gcl = REC_F(cur, 16); gsl = REC_F(cur, 17);
             }
         }
+        // the build phase first (see accumulate_multi_kernel: cfg3-scatter 38.9 -> 37.6 ms); not in runs of sources, where one
+        // build serves many applies (cfg2: 12.46 -> 12.60 with it)
+        if constexpr (!RUNS) __builtin_amdgcn_s_setprio(1);
         {
             float *tile0 = &tiles[0][0];
             // descriptors are relative to the first row of the group's cell (64-bit base, see write_tab)
@@ -1766,6 +1769,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_GROUPED_
         // descriptors of the NEXT group: in flight while this group is applied
         if (cend < nc) { ta = tc[(size_t)cend * 128 + lane]; tb = tc[(size_t)cend * 128 + 64 + lane]; }
         __syncthreads();
+        if constexpr (!RUNS) __builtin_amdgcn_s_setprio(0);
 #ifdef KIWI_X_NOAPPLY
         if (kCarry && carry_grp) { cur = cur_next; } else
 #endif
@@ -2080,6 +2084,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
             const bool whalo = __builtin_amdgcn_ballot_w64(hact) != 0ull; \
             if (fast) multi_build<NG, true, NS>(&tiles[0][0][0], wv, lane, tid, jb_, Gg, pitch, TA, TB, g, ONLY, hact, whalo, hig, hph); \
             else      multi_build<NG, false, NS>(&tiles[0][0][0], wv, lane, tid, jb_, Gg, pitch, TA, TB, g, ONLY, hact, whalo, hig, hph); } while (0)
+        // A workgroup in its build phase is waiting for memory most of the time: its waves go first whenever they have an
+        // instruction to issue (loads out early, the blend done as soon as the rows arrive), the workgroups that are applying
+        // fill the rest of the issue slots.  Measured: cfg3 133.5 -> 127.2 ms per 4096 sources, cfg3-100pt 55.2 -> 51.3 (the
+        // other way round -- apply first -- 137.8 / 57.5; priority 1, 2 and 3 alike).
+        __builtin_amdgcn_s_setprio(1);
 #ifndef KIWI_X_NOBUILD
         if (shared) KIWI_MULTI_BUILD(ta, tb, 0, -1, npos);
         else {
@@ -2100,6 +2109,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
         for (int i = 0; i < NS; i++) cur[i] = rec_load(recs_of(i), cend, nc, lane);
         if (cend < nc) { ta = tab_of(0)[(size_t)cend * 128 + lane]; tb = tab_of(0)[(size_t)cend * 128 + 64 + lane]; }
         __syncthreads();
+        __builtin_amdgcn_s_setprio(0);
         // ---- apply: this wave's source from its tile set.  (No tail rule and no partly added centroid here: multi_taken()
         // admits only pairs whose rows all end in zero and whose centroids all find all their traces.)
         {
@@ -2742,6 +2752,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
             raw_blend_store<NG, 0, SPL>(raw, wt, kCellwRow, pl, gw.w[0], gw.w[1], gw.w[2], gw.w[3]);
             halo_finish<true>(hact, hraw, wt, kCellwRow, hloc, hph, gw);
         }
+        __builtin_amdgcn_s_setprio(0);
         for (int cc = c; cc + 1 < cend; cc++) {
             const int nx2 = rec_load(rc, cc + 2, nc, lane);      // two records ahead: the next one is needed for its weights now
             const bool blend_next = !(REC_I(nx1, 18) & 4);       // (a centroid at the point of its predecessor keeps the tile)
@@ -2753,6 +2764,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
             // ---- last centroid of the group: the raw registers are free, the next group's rows can be on their way
             const int nx2 = rec_load(rc, cend + 1, nc, lane);
             CELLW_COEF(cend - 1);
+            // from here to the first blend of the next run this wave waits for memory: it goes first whenever it can issue
+            // (accumulate_multi_kernel's rule; cfg4 171.5 -> 168.6 ms)
+            __builtin_amdgcn_s_setprio(1);
             if (cend < nc) CELLW_LOAD(REC_I(nx1, 0), REC_I(nx1, 19), REC_I(nx1, 8), ta_n, tb_n);
             CELLW_STEP(false);
             cur = nx1; nx1 = nx2;
