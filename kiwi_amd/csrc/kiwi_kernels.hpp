@@ -1616,7 +1616,9 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_GROUPED_
     };
     // a source and, with the fused comparator, the sources that share its synthetics (other moments; minimizer_engine.f90:516-521)
     auto store_family = [&](int js) {
+        __builtin_amdgcn_s_setprio(1);                   // (the epilogue's loads of reference and taper first: cfg2 12.62 -> 12.48 ms)
         store(js);
+        __builtin_amdgcn_s_setprio(0);
         if constexpr (FUSE) {
             if (fam_ofs)
                 for (int q = fam_ofs[js]; q < fam_ofs[js + 1]; q++) store(fam_list[q]);
