@@ -1926,6 +1926,10 @@ __device__ __forceinline__ void multi_build(float *__restrict__ tile0, int wv, i
     if (whalo) hv = halo_issue<true, FAST>(true, hig, hph, jb, G, pitch, ta, tb);
 #pragma unroll
     for (int i = 0; i < DEPTH && i < N; i++) if (comp(i) < NG) one_issue<true, FAST>(v[i], comp(i), p, jb, G, pitch, ta, tb);
+    // The barrier that frees the tile sets (every wave has applied the previous group) stands HERE, behind the first loads of
+    // this group and in front of its first LDS write: a wave that is done applying has its loads in flight while it waits
+    // for the others.  (Workgroup-uniform call: every wave takes the same variant of this function.)
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < N; i++) {
         __builtin_amdgcn_sched_barrier(0);
@@ -2140,8 +2144,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
             }
 #undef KIWI_C2STEP
         }
-        __syncthreads();                                 // tiles are rebuilt by the next group
-        c = cend;
+#ifdef KIWI_X_NOBUILD
+        __syncthreads();
+#endif
+        c = cend;                                        // (the barrier in front of the next group's LDS writes: multi_build)
     }
     // ---- rotation to N/E, signs and store (or fused comparison) of this wave's source (seismogram.f90:256-283)
     {
