@@ -1735,6 +1735,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_GROUPED_
                     f4u va[2][BL ? 4 : 1], vb[2][BL ? 4 : 1]; \
                     pair_issue<BL, FA>(va, 0, 4 * tid, jb, Gg, pitch, ta, tb); \
                     pair_issue<BL, FA>(vb, 2, 4 * tid, jb, Gg, pitch, ta, tb); \
+                    __syncthreads();        /* the tiles are free: every wave has applied the previous group (see multi_build) */ \
                     _Pragma("unroll") for (int i = 0; i < NP; i++) { \
                         __builtin_amdgcn_sched_barrier(0); \
                         if ((i & 1) == 0) { pair_finish<BL>(va, tile0, LDS_TILE, 2 * i, 4 * tid, g0); \
@@ -1753,6 +1754,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_GROUPED_
             } else if (need_h) {
 #endif
                 HALO_ISSUE();
+                __syncthreads();
                 if constexpr (NG == 10) BUILD_B(igH10, 4 * tid); else BUILD_B(igH8, 4 * tid);
                 HALO_FINISH();
 #ifdef KIWI_X_NOBUILD
@@ -1761,6 +1763,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_GROUPED_
             } else {
 #endif
                 HALO_ISSUE();
+                __syncthreads();
                 if constexpr (NG == 10) BUILD_B(igD10, 4 * tid); else BUILD_B(igD8, 4 * tid);
                 HALO_FINISH();
             }
@@ -1859,8 +1862,10 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KIWI_GROUPED_
         if (multi) { store_family(js); cur = cur_next_src; }
         }
         stored = multi;
-        __syncthreads();                                 // tiles are rebuilt by the next group
-        c = cend;
+#ifdef KIWI_X_NOBUILD
+        __syncthreads();
+#endif
+        c = cend;                                        // (the barrier in front of the next group's LDS writes stands in its build)
     }
     if (!multi) store_family(s);
     else if (!stored) {                                  // every centroid skipped: the run's synthetics are zero
