@@ -51,6 +51,17 @@ typedef struct kiwi_hip_ctx kiwi_hip_ctx;
 #define KIWI_SRC_MT_EIKONAL 5
 #define KIWI_SRC_MOMENT_TENSOR 6
 
+/* arithmetic contract of the accumulate kernels (kiwi_hip_set_arithmetic).
+ * EXACT (default): every fp32 multiply and add of the superposition is rounded on its own, in the reference's order
+ *   (gfdb.f90:944-949, sparse_trace.f90:684-703, seismogram.f90:171-250 on an x86-64 host without fused operations):
+ *   synthetics and misfits are bit-identical to the CPU restatement of the reference given equal geometry records.
+ * FUSED: the same operations in the same order, each multiply contracted with the add that consumes it into one fused
+ *   multiply-add (one rounding instead of two; half the vector instructions): tolerance class -- misfits within 1e-6 of the
+ *   slot's norm factor, synthetics within 2e-6 of the trace maximum (BASELINE.json north_star: "misfits within 1e-6 relative").
+ * Geometry (rows, sample shifts, weights), the comparator's fp64 sums and the host discretisers are the same in both. */
+#define KIWI_ARITH_EXACT 0
+#define KIWI_ARITH_FUSED 1
+
 /* ---- lifetime: program start / cleanup_minimizer (minimizer_engine.f90:1057-1067) ---- */
 int kiwi_hip_init(int device, kiwi_hip_ctx **ctx);
 /* SURVEY 8b's `kiwi_hip_init(int ndev_wanted, void** ctx)`: ONE context over ndev_wanted devices of this process
@@ -64,6 +75,10 @@ int kiwi_hip_init(int device, kiwi_hip_ctx **ctx);
  * results do not depend on the number of devices (a source's evaluation does not depend on its batch). */
 int kiwi_hip_init_multi(int ndev_wanted, kiwi_hip_ctx **ctx);
 int kiwi_hip_ndevices(kiwi_hip_ctx *ctx, int *n);
+/* KIWI_ARITH_EXACT / KIWI_ARITH_FUSED (above); takes effect at the next kiwi_hip_eval.  The environment variable
+ * KIWI_HIP_ARITH=exact|fused sets the initial value of every context (for the unmodified Fortran protocol host). */
+int kiwi_hip_set_arithmetic(kiwi_hip_ctx *ctx, int mode);
+int kiwi_hip_get_arithmetic(kiwi_hip_ctx *ctx, int *mode);
 int kiwi_hip_destroy(kiwi_hip_ctx *ctx);
 /* copies the last error message (NUL terminated, truncated to buflen); ctx may be NULL for init errors */
 int kiwi_hip_last_error(kiwi_hip_ctx *ctx, char *buf, int buflen);

@@ -8,7 +8,9 @@
 #include "kiwi_host.hpp"
 #include "kiwi_host_eikonal.hpp"
 #include "kiwi_host_lm.hpp"
-#include "kiwi_kernels.hpp"
+#include "kiwi_geometry.hpp"
+#include "kiwi_misfit.hpp"
+#include "kiwi_accum_api.hpp"
 
 #include <hip/hip_runtime.h>
 #include <hipfft/hipfft.h>
@@ -185,8 +187,7 @@ struct kiwi_hip_ctx {
     // -1 decided per batch -- sources whose centroids are mostly different points --, 0 off, 1 on; env KIWI_HIP_CELL
     int cell_mode = -1;
     int cell_wave = 1;                // 1: accumulate_cellw_kernel (a tile per wave, no barriers); 0: accumulate_cell_kernel; env KIWI_HIP_CELL_WAVE
-    int cell_split = 0;               // 1: horizontal and vertical block in separate workgroups; env KIWI_HIP_CELL_SPLIT
-    int cell_spl = 2;                 // output samples per lane of the cell kernel (2: raw rows take 80 registers, 4: 160); env KIWI_HIP_CELL_SPL
+    int arith = KIWI_ARITH_EXACT;     // arithmetic contract of the accumulate kernels (kiwi_hip_set_arithmetic; env KIWI_HIP_ARITH=exact|fused)
     double points_per_centroid = 0.0; // of the uploaded batch: distinct consecutive points / centroids
     int keep_which = 0;               // kiwi_hip_set_keep_synthetics
     int proc_chunk0 = 0, proc_chunkn = 0, proc_which_held = 0;   // what proc_d currently holds
@@ -237,16 +238,24 @@ int fail(kiwi_hip_ctx *ctx, const std::string &msg)
 }
 
 #define GUARD_BEGIN try {
+// entry points of a context that touch its device: the context's device is the calling thread's current one from here on
+// (a multi-device context forwards its setters to the other devices, kiwi_hip_init_multi: the caller's current device is
+// not something an entry point may rely on)
+#define GUARD_BEGIN_DEV(ctx) try { HIPCHECK(hipSetDevice((ctx)->device));
 #define GUARD_END(ctx)                                                                             \
     } catch (const std::exception &e) { return fail(ctx, e.what()); }                              \
       catch (...) { return fail(ctx, "unknown error"); }
 
 // repeat a setter on the other devices of a multi-device context (kiwi_hip_init_multi)
+// (a mate's setter may make its device current for the calling thread: the owner's device is current again afterwards)
 template <class F> static int forward(kiwi_hip_ctx *c, F &&f)
 {
+    if (c->mates.empty()) return 0;
+    int rc = 0;
     for (kiwi_hip_ctx *m : c->mates)
-        if (int rc = f(m)) { c->err = "device " + std::to_string(m->device) + ": " + m->err; return rc; }
-    return 0;
+        if ((rc = f(m))) { c->err = "device " + std::to_string(m->device) + ": " + m->err; break; }
+    if (hipSetDevice(c->device) != hipSuccess && !rc) { c->err = "hipSetDevice failed"; rc = 1; }
+    return rc;
 }
 
 int component_id(char ch)     // receiver.f90:294-307
@@ -980,7 +989,7 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
         if (cell)
             hipLaunchKernelGGL(cellgroup_kernel, grid, dim3(256), 0, c->stream, c->centofs_d.p, ep, c->gm, c->span.p, c->recv_d.p,
                                c->recs_d.p, tab, c->pairflag_d.p, c->endz.p, (const int *)nullptr,
-                               (c->cell_wave && c->cell_spl == 2 && !c->cell_split) ? kCellwRange : kHalo - 10);
+                               c->cell_wave ? exact::cellw_range() : kHalo - 10);
     }
     if (c->fft_needed) {
         // transform length of every (source, slot) pair from the source's own strip spans; the lengths travel to the host
@@ -998,13 +1007,13 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
     bool fuse_all = false;
     {
         dim3 grid((unsigned)((c->max_wlen + kTile - 1) / kTile), (unsigned)nrec, (unsigned)nsrc);
+        // the kernels of the arithmetic contract in force (kiwi_accum.inc compiled twice: kiwi::exact, kiwi::fused)
+        const bool fusedar = c->arith == KIWI_ARITH_FUSED;
+        AccumArgs aa{ c->stream, c->gm.ng, c->fuse_now, c->G.p, c->span.p, c->gm.pitch, c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p,
+                      c->syn_d.p, c->syn_stride, c->tab_d.p, FuseParams{ nullptr, nullptr, nullptr, nullptr, 0, 1.f, 0, 0, 0 },
+                      nullptr, synrow, famofs, famlist };
         if (c->accum_mode == 1) {            // KIWI_HIP_ACCUM=direct: A/B reference kernel, no LDS staging
-            if (c->gm.ng == 10)
-                hipLaunchKernelGGL(accumulate_kernel<10>, grid, dim3(256), 0, c->stream, c->G.p, c->span.p, c->gm.pitch,
-                                   c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p, c->syn_stride, synrow);
-            else
-                hipLaunchKernelGGL(accumulate_kernel<8>, grid, dim3(256), 0, c->stream, c->G.p, c->span.p, c->gm.pitch,
-                                   c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p, c->syn_stride, synrow);
+            if (fusedar) fused::launch_direct(aa, grid); else exact::launch_direct(aa, grid);
         } else {
             // workgroup size: env override, else by window length (halo overhead vs tile fit)
             const int T = c->group_threads_env ? c->group_threads : (c->max_wlen >= 2048 ? 256 : (c->max_wlen >= 384 ? 128 : 64));
@@ -1012,7 +1021,7 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
             const int ntiles_p = (c->max_wlen + 511) / 512;              // accumulate_multi_kernel: 512 samples per source with two of them
             // cell mode: accumulate_cell_kernel (256 threads, tile = spl x 256 samples) takes the pairs of cell_pair(), the
             // grouped kernel behind it the others
-            const int spl = c->cell_spl, Tc = 256;
+            const int spl = 2, Tc = 256;      // cell kernels: 256 threads, two output samples per lane
             const int ntiles_c = (c->max_wlen + spl * Tc - 1) / (spl * Tc);
             // runs of geometry-identical single-group sources (chunk-local indices); singletons otherwise
             int *runs = nullptr;
@@ -1088,64 +1097,28 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
             dim3 ggrid(gx, (unsigned)(ntiles * nrec));                   // source index fastest (L2 sharing)
             dim3 dgrid((unsigned)((nsrc + 1) / 2), (unsigned)(ntiles_p * nrec)), qgrid((unsigned)((nsrc + 3) / 4), (unsigned)(ntiles_q * nrec));
             dim3 cgrid((unsigned)nsrc, (unsigned)(ntiles_c * nrec));
-            FuseParams fp{ nullptr, nullptr, nullptr, nullptr, 0, 1.f, 0, 0, 0 };
             if (fuse) {
                 // partial sums per (source, slot): [tile][wave] of the kernel that evaluated the pair.  In cell mode two
                 // kernels with different tilings share the buffer: it is cleared and misfit_finish_kernel sums all of it
                 const int nparts = cell ? std::max(ntiles * (T / 64), ntiles_c * (Tc / 64)) : (duo ? std::max({ ntiles * (T / 64), ntiles_p * 2, ntiles_q }) : ntiles * (T / 64));
                 c->fusepart_d.ensure((size_t)nsrc * c->nmis * nparts, &c->dev_bytes);
                 if (cell || duo) HIPCHECK(hipMemsetAsync(c->fusepart_d.p, 0, (size_t)nsrc * c->nmis * nparts * sizeof(double), c->stream));
-                fp = FuseParams{ c->reft_d.p, c->tw_d.p, c->moment_d.p, c->fusepart_d.p, c->method, c->syn_factor, c->nmis, nparts, isrc0 };
+                aa.fp = FuseParams{ c->reft_d.p, c->tw_d.p, c->moment_d.p, c->fusepart_d.p, c->method, c->syn_factor, c->nmis, nparts, isrc0 };
                 fuse_nparts = nparts;
             }
             fuse_T = T; fuse_tile = 4 * T; fuse_ntiles = ntiles; fuse_all = cell || duo;
-#define KIWI_LAUNCH_G2(NGV, TV, FV, RV)                                                                     \
-    hipLaunchKernelGGL((accumulate_grouped_kernel<NGV, TV, FV, RV>), ggrid, dim3(TV), 0, c->stream, c->G.p, c->span.p,   \
-                       c->gm.pitch, c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p,          \
-                       c->syn_stride, ntiles, c->tab_d.p, runs, fp, (cell || duo) ? c->pairflag_d.p : (const int *)nullptr, cell ? 1 : (duo ? 3 : 0), any2 ? c->mate_d.p : (const int *)nullptr,  \
-                       any4 ? c->mate4_d.p : (const int *)nullptr, synrow, famofs, famlist)
-#define KIWI_LAUNCH_GROUPED(NGV, TV)                                                                        \
-    do { if (fuse) { if (runs) KIWI_LAUNCH_G2(NGV, TV, true, true); else KIWI_LAUNCH_G2(NGV, TV, true, false); }   \
-         else      { if (runs) KIWI_LAUNCH_G2(NGV, TV, false, true); else KIWI_LAUNCH_G2(NGV, TV, false, false); } } while (0)
-#define KIWI_LAUNCH_C3(NGV, SV, PV, FV)                                                                     \
-    hipLaunchKernelGGL((accumulate_cell_kernel<NGV, 256, SV, PV, FV>), cgrid, dim3(256), 0, c->stream, c->G.p, c->span.p,   \
-                       c->gm.pitch, c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p,          \
-                       c->syn_stride, ntiles_c, c->tab_d.p, fp, c->pairflag_d.p, synrow, famofs, famlist)
-#define KIWI_LAUNCH_C2(NGV, SV, FV) do { if (c->cell_split) { KIWI_LAUNCH_C3(NGV, SV, 1, FV); KIWI_LAUNCH_C3(NGV, SV, 2, FV); } \
-                                         else KIWI_LAUNCH_C3(NGV, SV, 0, FV); } while (0)
-#define KIWI_LAUNCH_CELL(NGV) do { if (spl == 2) { if (fuse) KIWI_LAUNCH_C2(NGV, 2, true); else KIWI_LAUNCH_C2(NGV, 2, false); } \
-                                   else          { if (fuse) KIWI_LAUNCH_C2(NGV, 4, true); else KIWI_LAUNCH_C2(NGV, 4, false); } } while (0)
-#define KIWI_LAUNCH_CW(NGV, FV)                                                                             \
-    hipLaunchKernelGGL((accumulate_cellw_kernel<NGV, FV>), cgrid, dim3(256), 0, c->stream, c->G.p, c->span.p,   \
-                       c->gm.pitch, c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p,          \
-                       c->syn_stride, ntiles_c, c->tab_d.p, fp, c->pairflag_d.p, synrow, famofs, famlist)
-            if (cell && c->cell_wave && spl == 2 && !c->cell_split) {
-                if (c->gm.ng == 10) { if (fuse) KIWI_LAUNCH_CW(10, true); else KIWI_LAUNCH_CW(10, false); }
-                else                { if (fuse) KIWI_LAUNCH_CW(8, true); else KIWI_LAUNCH_CW(8, false); }
-            } else if (cell) { if (c->gm.ng == 10) KIWI_LAUNCH_CELL(10); else KIWI_LAUNCH_CELL(8); }
-#undef KIWI_LAUNCH_CW
-            // the (group of sources, receiver) combinations accumulate_multi_kernel takes; the grouped kernel behind it returns at once for those
-#define KIWI_LAUNCH_M2(NGV, FV, NSV, GRID, NT, MATE, WIDER)                                                    \
-    hipLaunchKernelGGL((accumulate_multi_kernel<NGV, FV, NSV>), GRID, dim3(256), 0, c->stream, c->G.p, c->span.p,       \
-                       c->gm.pitch, c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p, c->syn_d.p,          \
-                       c->syn_stride, NT, c->tab_d.p, fp, c->pairflag_d.p, MATE, WIDER)
-#define KIWI_LAUNCH_MULTI(NSV, GRID, NT, MATE, WIDER) do {                                                  \
-                if (c->gm.ng == 10) { if (fuse) KIWI_LAUNCH_M2(10, true, NSV, GRID, NT, MATE, WIDER); else KIWI_LAUNCH_M2(10, false, NSV, GRID, NT, MATE, WIDER); } \
-                else                { if (fuse) KIWI_LAUNCH_M2(8, true, NSV, GRID, NT, MATE, WIDER); else KIWI_LAUNCH_M2(8, false, NSV, GRID, NT, MATE, WIDER); } } while (0)
-            if (any4) KIWI_LAUNCH_MULTI(4, qgrid, ntiles_q, c->mate4_d.p, (const int *)nullptr);
-            if (any2) KIWI_LAUNCH_MULTI(2, dgrid, ntiles_p, c->mate_d.p, any4 ? c->mate4_d.p : (const int *)nullptr);
-#undef KIWI_LAUNCH_MULTI
-#undef KIWI_LAUNCH_M2
-            if (c->gm.ng == 10) {
-                if (T == 64) KIWI_LAUNCH_GROUPED(10, 64); else if (T == 256) KIWI_LAUNCH_GROUPED(10, 256); else KIWI_LAUNCH_GROUPED(10, 128);
-            } else {
-                if (T == 64) KIWI_LAUNCH_GROUPED(8, 64); else if (T == 256) KIWI_LAUNCH_GROUPED(8, 256); else KIWI_LAUNCH_GROUPED(8, 128);
+            aa.pairflag = (cell || duo) ? c->pairflag_d.p : (const int *)nullptr;
+            if (cell) {
+                if (c->cell_wave) { if (fusedar) fused::launch_cellw(aa, cgrid, ntiles_c); else exact::launch_cellw(aa, cgrid, ntiles_c); }
+                else              { if (fusedar) fused::launch_cell(aa, cgrid, ntiles_c); else exact::launch_cell(aa, cgrid, ntiles_c); }
             }
-#undef KIWI_LAUNCH_CELL
-#undef KIWI_LAUNCH_C2
-#undef KIWI_LAUNCH_C3
-#undef KIWI_LAUNCH_GROUPED
-#undef KIWI_LAUNCH_G2
+            // the (group of sources, receiver) combinations accumulate_multi_kernel takes; the grouped kernel behind it returns at once for those
+            const int *m2p = any2 ? c->mate_d.p : (const int *)nullptr, *m4p = any4 ? c->mate4_d.p : (const int *)nullptr;
+            if (any4) { if (fusedar) fused::launch_multi(aa, qgrid, 4, ntiles_q, m4p, nullptr); else exact::launch_multi(aa, qgrid, 4, ntiles_q, m4p, nullptr); }
+            if (any2) { if (fusedar) fused::launch_multi(aa, dgrid, 2, ntiles_p, m2p, m4p); else exact::launch_multi(aa, dgrid, 2, ntiles_p, m2p, m4p); }
+            const int pairsel = cell ? 1 : (duo ? 3 : 0);
+            if (fusedar) fused::launch_grouped(aa, ggrid, T, ntiles, runs, pairsel, m2p, m4p);
+            else         exact::launch_grouped(aa, ggrid, T, ntiles, runs, pairsel, m2p, m4p);
         }
     }
     record(c, 1, e2);
@@ -1310,8 +1283,10 @@ int kiwi_hip_init(int device, kiwi_hip_ctx **out)
         if (const char *m = std::getenv("KIWI_HIP_CELL")) c->cell_mode = std::atoi(m) ? 1 : 0;
         if (const char *m = std::getenv("KIWI_HIP_DEDUPE")) c->dedupe_enabled = std::atoi(m);      // 0 off, 1 default, 2 also for point sources
         if (const char *m = std::getenv("KIWI_HIP_FUSED_FFT")) c->fused_fft = std::atoi(m) != 0;   // 0: amplitude spectra through hipFFT
-        if (const char *m = std::getenv("KIWI_HIP_CELL_SPL")) c->cell_spl = std::atoi(m) == 4 ? 4 : 2;
-        if (const char *m = std::getenv("KIWI_HIP_CELL_SPLIT")) c->cell_split = std::atoi(m) ? 1 : 0;
+        if (const char *m = std::getenv("KIWI_HIP_ARITH")) {
+            if (std::strcmp(m, "fused") == 0 || std::strcmp(m, "fma") == 0) c->arith = KIWI_ARITH_FUSED;
+            else if (std::strcmp(m, "exact") != 0) throw std::runtime_error("KIWI_HIP_ARITH: exact or fused");
+        }
         if (const char *m = std::getenv("KIWI_HIP_CELL_WAVE")) c->cell_wave = std::atoi(m) ? 1 : 0;
         if (const char *m = std::getenv("KIWI_HIP_CHUNK_MB")) {      // workspace bound per launch (default 16 GiB); tests use it
             const long v = std::atol(m);
@@ -1356,6 +1331,7 @@ int kiwi_hip_init_multi(int ndev_wanted, kiwi_hip_ctx **out)
     }
     c->cpu_share = n;
     for (kiwi_hip_ctx *m : c->mates) m->cpu_share = n;
+    if (hipSetDevice(c->device) != hipSuccess) { kiwi_hip_destroy(c); return fail(nullptr, "hipSetDevice failed"); }
     *out = c;
     return 0;
 }
@@ -1589,7 +1565,7 @@ int kiwi_hip_set_floating_shiftrange(kiwi_hip_ctx *c, int irec, float min_shift,
 
 int kiwi_hip_get_floating_shifts(kiwi_hip_ctx *c, int isrc0, int nsrc, float *shifts)
 {
-    GUARD_BEGIN
+    GUARD_BEGIN_DEV(c)
     if (!c->prepared || !c->floating) throw std::runtime_error("no floating norm evaluated");
     if (isrc0 < 0 || nsrc < 0 || isrc0 + nsrc > c->nsrc) throw std::runtime_error("source range out of bounds");
     HIPCHECK(hipStreamSynchronize(c->stream));
@@ -2159,9 +2135,22 @@ int kiwi_hip_set_keep_synthetics(kiwi_hip_ctx *c, int which)
     return forward(c, [&](kiwi_hip_ctx *m) { return kiwi_hip_set_keep_synthetics(m, which); });
 }
 
+int kiwi_hip_set_arithmetic(kiwi_hip_ctx *c, int mode)
+{
+    if (mode != KIWI_ARITH_EXACT && mode != KIWI_ARITH_FUSED) return fail(c, "arithmetic: 0 (exact) or 1 (fused)");
+    c->arith = mode;
+    return forward(c, [&](kiwi_hip_ctx *m) { return kiwi_hip_set_arithmetic(m, mode); });
+}
+
+int kiwi_hip_get_arithmetic(kiwi_hip_ctx *c, int *mode)
+{
+    *mode = c->arith;
+    return 0;
+}
+
 int kiwi_hip_sync(kiwi_hip_ctx *c)
 {
-    GUARD_BEGIN
+    GUARD_BEGIN_DEV(c)
     HIPCHECK(hipStreamSynchronize(c->stream));
     return 0;
     GUARD_END(c)
@@ -2179,7 +2168,7 @@ int kiwi_hip_nmisfits(kiwi_hip_ctx *c, int *nmis)
 
 int kiwi_hip_get_misfits(kiwi_hip_ctx *c, int isrc0, int nsrc, float *misfit, float *norm, float *global)
 {
-    GUARD_BEGIN
+    GUARD_BEGIN_DEV(c)
     if (!c->prepared) throw std::runtime_error("nothing evaluated yet");
     if (c->synth_only) throw std::runtime_error("misfits need a reference seismogram and a misfit taper for every enabled receiver component "
                                                 "(the device comparator evaluates norms over the taper span, comparator.f90:782-792)");
@@ -2279,7 +2268,7 @@ int kiwi_hip_misfits_for_params(kiwi_hip_ctx *c, int sourcetype, int nsrc, const
 int kiwi_hip_get_synthetics(kiwi_hip_ctx *c, int isrc, int irec, int icomp, int which, int *first, int *n,
                             float *out, int maxn)
 {
-    GUARD_BEGIN
+    GUARD_BEGIN_DEV(c)
     if (which < 1 || which > 3) throw std::runtime_error("which must be 1 (plain), 2 (tapered) or 3 (filtered)");
     if (which == 3) { prepare(c); if (!c->any_filter || c->method == KIWI_AMPSPEC_L2NORM || c->method == KIWI_AMPSPEC_L1NORM) throw std::runtime_error("filtered synthetics need a misfit filter and a time-domain norm"); }
     if (isrc < 0 || isrc >= c->nsrc) throw std::runtime_error("source index out of range");
@@ -2374,7 +2363,7 @@ static int shake_impl(kiwi_hip_ctx *c, int isrc, int kind, float *out)
 int kiwi_hip_get_amp_spectrum(kiwi_hip_ctx *c, int isrc, int irec, int icomp, int which_probe, int filtered, float *df, int *n,
                               float *out, int maxn)
 {
-    GUARD_BEGIN
+    GUARD_BEGIN_DEV(c)
     if (!df || !n || !out) throw std::runtime_error("null argument");
     if (irec < 1 || irec > (int)c->recv.size()) throw std::runtime_error("receiver index out of range");
     if (which_probe && (isrc < 0 || isrc >= c->nsrc)) throw std::runtime_error("source index out of range");
@@ -2506,7 +2495,7 @@ static void receiver_cross_correlations(kiwi_hip_ctx *c, int ir, const std::vect
 int kiwi_hip_get_cross_correlations(kiwi_hip_ctx *c, int isrc, int irec, float min_shift, float max_shift, int *first_shift,
                                     int *nshift, float *cc_out, int maxn)
 {
-    GUARD_BEGIN
+    GUARD_BEGIN_DEV(c)
     if (!first_shift || !nshift || !cc_out) throw std::runtime_error("null argument");
     if (irec < 1 || irec > (int)c->recv.size()) throw std::runtime_error("receiver index out of range");
     if (isrc < 0 || isrc >= c->nsrc) throw std::runtime_error("source index out of range");
@@ -2606,7 +2595,7 @@ int kiwi_hip_get_source_centroids(kiwi_hip_ctx *c, int isrc, int maxcent, int *n
 
 int kiwi_hip_get_reference(kiwi_hip_ctx *c, int irec, int icomp, int which, int *first, int *n, float *out, int maxn)
 {
-    GUARD_BEGIN
+    GUARD_BEGIN_DEV(c)
     if (which < 1 || which > 3) throw std::runtime_error("which must be 1 (plain), 2 (tapered) or 3 (filtered)");
     if (irec < 1 || irec > (int)c->recv.size()) throw std::runtime_error("receiver index out of range");
     const Receiver &r = c->recv[irec - 1];
@@ -2649,7 +2638,7 @@ int kiwi_hip_get_reference(kiwi_hip_ctx *c, int irec, int icomp, int which, int 
 
 int kiwi_hip_get_kernel_ms(kiwi_hip_ctx *c, float ms[4], int launches[3])
 {
-    GUARD_BEGIN
+    GUARD_BEGIN_DEV(c)
     HIPCHECK(hipStreamSynchronize(c->stream));
     for (int i = 0; i < 4; i++) ms[i] = 0.f;
     for (int i = 0; i < 3; i++) launches[i] = 0;
@@ -2670,7 +2659,7 @@ int kiwi_hip_get_kernel_ms(kiwi_hip_ctx *c, float ms[4], int launches[3])
 
 int kiwi_hip_get_geometry(kiwi_hip_ctx *c, int isrc, int irec, int maxcent, int *ncent, void *records)
 {
-    GUARD_BEGIN
+    GUARD_BEGIN_DEV(c)
     HIPCHECK(hipStreamSynchronize(c->stream));
     if (isrc < c->last_chunk0 || isrc >= c->last_chunk0 + c->last_chunkn)
         throw std::runtime_error("source not in the last evaluated chunk");

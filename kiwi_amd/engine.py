@@ -110,6 +110,20 @@ class Engine:
         self._ck(self.L.kiwi_hip_ndevices(self.h, C.byref(n)), "ndevices")
         return n.value
 
+    def set_arithmetic(self, mode):
+        """'exact' (default: every fp32 multiply and add of the superposition rounded on its own, as the reference's host does:
+        bit-identical to the CPU oracle) or 'fused' (multiply + consuming add as one fused multiply-add: misfits within 1e-6 of
+        the norm factor, half the vector instructions); include/kiwi_hip.h KIWI_ARITH_*."""
+        m = {"exact": 0, "fused": 1, 0: 0, 1: 1}.get(mode)
+        if m is None:
+            raise ValueError("arithmetic: 'exact' or 'fused'")
+        self._ck(self.L.kiwi_hip_set_arithmetic(self.h, m), "set_arithmetic")
+
+    def arithmetic(self):
+        m = C.c_int(0)
+        self._ck(self.L.kiwi_hip_get_arithmetic(self.h, C.byref(m)), "get_arithmetic")
+        return "fused" if m.value == 1 else "exact"
+
     # ------------------------------------------------------------------ plumbing
     def _ck(self, rc, what):
         if rc != 0:

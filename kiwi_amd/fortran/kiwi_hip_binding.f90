@@ -33,6 +33,19 @@ module kiwi_hip_binding
             integer(c_int), intent(out) :: n
         end function
 
+        ! arithmetic contract of the accumulate kernels: 0 exact (default, bit-identical to the reference's rounding), 1 fused
+        integer(c_int) function kiwi_hip_set_arithmetic( ctx, mode ) bind(C, name='kiwi_hip_set_arithmetic')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: mode
+        end function
+
+        integer(c_int) function kiwi_hip_get_arithmetic( ctx, mode ) bind(C, name='kiwi_hip_get_arithmetic')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: ctx
+            integer(c_int), intent(out) :: mode
+        end function
+
         integer(c_int) function kiwi_hip_destroy( ctx ) bind(C, name='kiwi_hip_destroy')
             import :: c_int, c_ptr
             type(c_ptr), value :: ctx

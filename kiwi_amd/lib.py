@@ -66,6 +66,8 @@ def load():
         "kiwi_hip_init": [C.c_int, C.POINTER(vp)],
         "kiwi_hip_init_multi": [C.c_int, C.POINTER(vp)],
         "kiwi_hip_ndevices": [vp, c_int_p],
+        "kiwi_hip_set_arithmetic": [vp, C.c_int],
+        "kiwi_hip_get_arithmetic": [vp, c_int_p],
         "kiwi_hip_destroy": [vp],
         "kiwi_hip_last_error": [vp, C.c_char_p, C.c_int],
         "kiwi_hip_set_gfdb": [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
