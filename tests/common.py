@@ -30,6 +30,43 @@ def spectral_tol(method, filtered):
     return SPECTRAL_TOL[(method, bool(filtered))]
 
 
+# ---- the two arithmetic contracts of the accumulate kernels (include/kiwi_hip.h; tests/conftest.py runs every GPU test under both)
+MISFIT_RTOL = 1e-6        # BASELINE.json north_star: misfits within 1e-6 relative
+SYN_RTOL = 2e-6           # synthetics: |device - oracle| <= SYN_RTOL * max|oracle| per trace
+
+
+def arith():
+    return os.environ.get("KIWI_HIP_ARITH", "exact")
+
+
+def misfit_close(a, b, norm=None):
+    """Device misfits a against oracle misfits b.  exact: |a - b| <= 1e-6 |b| per value.  fused: a misfit is the norm of a
+    DIFFERENCE of traces, its round-off scales with the traces (the norm factor), not with itself -- a trial next to the true
+    source has a misfit far below its norm factor --: |a - b| <= 1e-6 max(|b|, norm factor); without norm factors at hand
+    (global misfits, which are normalised already) the floor is a twentieth of the batch's largest value."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    scale = np.maximum(np.abs(b), 1e-30)
+    if arith() == "fused":
+        floor = np.abs(np.asarray(norm, np.float64)) if norm is not None else 0.05 * np.max(np.abs(b), initial=0.0)
+        scale = np.maximum(scale, floor)
+    return bool(np.all(np.abs(a - b) <= MISFIT_RTOL * scale))
+
+
+def same_bits(a, b):
+    """Two evaluations of the same trial by different kernels (or batch shapes).  exact: the same bits.  fused: each kernel
+    instantiation contracts its multiply-add pairs on its own (a variant of the same template is not bound to fuse the same
+    pairs): within SYN_RTOL of the larger array's maximum."""
+    a = np.asarray(a)
+    b = np.asarray(b)
+    if arith() == "exact":
+        return a.shape == b.shape and a.tobytes() == b.tobytes()
+    if a.shape != b.shape:
+        return False
+    top = max(float(np.max(np.abs(a), initial=0.0)), float(np.max(np.abs(b), initial=0.0)))
+    return bool(np.all(np.abs(a.astype(np.float64) - b.astype(np.float64)) <= SYN_RTOL * top))
+
+
 class Scenario:
     """Small synthetic inversion setup (scaled down)."""
 

@@ -11,7 +11,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from kiwi_amd import synthetic  # noqa: E402
-from tests.common import Scenario, oracle_misfits, spectral_tol, SPECTRAL_NORM_TOL  # noqa: E402
+from tests.common import Scenario, oracle_misfits, spectral_tol, SPECTRAL_NORM_TOL, arith  # noqa: E402
 
 FAMILIES = ["ac", "rl", "du", "ns", "ew"]            # a component and its negated twin exclude each other (receiver.f90:255-270)
 
@@ -174,7 +174,8 @@ def one_case(rng, verbose):
         nscale = np.maximum(nn[0], 0.05 * nn[0].max()) if filtered else nn[0]
         ok = bool(np.all(np.abs(pn[0] - nn[0]) <= ntol * nscale)) and not bad.any()
     else:
-        scale = np.maximum(np.abs(m), 1e-6 * np.maximum(nn, 1e-30))
+        # (fused arithmetic contract: relative to max(misfit, norm factor), tests/common.py misfit_close)
+        scale = np.maximum(np.abs(m), (1.0 if arith() == "fused" else 1e-6) * np.maximum(nn, 1e-30))
         tol = 1e-6 if mid not in (5,) else 2e-6
         bad = np.abs(pm - m) > tol * scale
         ok = np.array_equal(pn[0], nn[0]) and not bad.any()

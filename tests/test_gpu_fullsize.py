@@ -17,8 +17,22 @@ pytestmark = pytest.mark.gpu
 CORES = int(_lib.load().kiwi_hip_effective_cpus())      # hardware threads cut to the container's CPU quota
 
 
-def rel(a, b):
-    return float(np.max(np.abs(np.asarray(a, np.float64) - b) / np.maximum(np.abs(b), 1e-300)))
+def rel(a, b, n=None):
+    """largest difference of device misfits a from oracle misfits b, relative to the misfit -- under the fused arithmetic
+    contract to max(misfit, norm factor n): a misfit is the norm of a difference of traces, its round-off scales with the traces"""
+    scale = np.maximum(np.abs(b), 1e-300)
+    if common.arith() == "fused" and n is not None:
+        scale = np.maximum(scale, np.abs(n))
+    return float(np.max(np.abs(np.asarray(a, np.float64) - b) / scale))
+
+
+def reproduces(m, n, g):
+    """the source the references were made from: exact arithmetic gives identical traces and a misfit of exactly zero; under the
+    fused contract the kernel that kept the reference synthetics and the one with the comparator in its epilogue contract
+    on their own: zero within 1e-6 of the norm factor"""
+    if common.arith() == "exact":
+        return bool(np.all(m == 0.0) and g == 0.0)
+    return bool(np.all(m <= 1e-6 * n) and g <= 1e-6)
 
 
 def setup(name, batch):
@@ -42,7 +56,7 @@ def test_cfg3_bilateral_100_centroids_50_receivers():
     p.eval()
     m, n, g = p.get_misfits()
     assert m.shape == (24, 150)
-    assert np.all(m[0] == 0.0) and g[0] == 0.0           # identical traces -> exactly zero
+    assert reproduces(m[0], n[0], g[0])                  # identical traces -> exactly zero (exact arithmetic)
     s0, s1 = all_synthetics(p, 0, 50), all_synthetics(p, 1, 50)
     assert all(np.array_equal(2.0 * a, b) for a, b in zip(s0, s1))
     assert np.all(np.diff(g[2:12]) > 0)                  # strike sweep away from the true strike
@@ -51,7 +65,7 @@ def test_cfg3_bilateral_100_centroids_50_receivers():
     e, db, evaluate = bench.oracle_engine(wl, gf, recv, refs, tapers, CORES)
     for i in (2, 11, 23):
         om, on, og = evaluate(tr[i])
-        assert rel(m[i], om) <= 1e-6 and abs(g[i] - og) <= 1e-6 * og and np.array_equal(n[i], on)
+        assert rel(m[i], om, on) <= 1e-6 and abs(g[i] - og) <= 1e-6 * max(og, 0.05 if common.arith() == "fused" else 0.0) and np.array_equal(n[i], on)
     e.close(); db.close()
     # pieces == whole
     p.eval(0, 7); p.eval(7, 17)
@@ -72,13 +86,13 @@ def test_cfg3_variants_at_full_size(name, ncent_want):
     p.set_source_params("bilateral", tr)
     p.eval()
     m, n, g = p.get_misfits()
-    assert m.shape == (20, 150) and np.all(m[0] == 0.0) and g[0] == 0.0
+    assert m.shape == (20, 150) and reproduces(m[0], n[0], g[0])
     if name == "cfg3-scatter":                              # the trials really are scattered: 4 km steps north / east
         assert len(np.unique(tr[1:, 1])) > 5 and len(np.unique(tr[1:, 2])) > 5 and np.all(g[1:] > 0.1)
     e, db, evaluate = bench.oracle_engine(wl, gf, recv, refs, tapers, CORES)
     for i in (1, 7, 19):
         om, on, og = evaluate(tr[i])
-        assert rel(m[i], om) <= 1e-6 and abs(g[i] - og) <= 1e-6 * og and np.array_equal(n[i], on)
+        assert rel(m[i], om, on) <= 1e-6 and abs(g[i] - og) <= 1e-6 * max(og, 0.05 if common.arith() == "fused" else 0.0) and np.array_equal(n[i], on)
     e.close(); db.close()
 
 
@@ -92,7 +106,7 @@ def test_cfg2_moment_tensor_grid():
     p.set_source_params("moment_tensor", tr)
     p.eval()
     m, n, g = p.get_misfits()
-    assert np.all(m[0] == 0.0)
+    assert reproduces(m[0], n[0], 0.0)
     s0, s1, s2 = (all_synthetics(p, i, 50) for i in range(3))
     assert all(np.array_equal(2.0 * a, b) for a, b in zip(s0, s1))
     assert all(np.array_equal(-a, b) for a, b in zip(s0, s2))
@@ -100,7 +114,7 @@ def test_cfg2_moment_tensor_grid():
     e, db, evaluate = bench.oracle_engine(wl, gf, recv, refs, tapers, CORES)
     for i in (3, 100, 257, 511):
         om, on, og = evaluate(tr[i])
-        assert rel(m[i], om) <= 1e-6 and abs(g[i] - og) <= 1e-6 * og
+        assert rel(m[i], om, on) <= 1e-6 and abs(g[i] - og) <= 1e-6 * max(og, 0.05 if common.arith() == "fused" else 0.0)
     e.close(); db.close()
 
 
@@ -114,14 +128,14 @@ def test_cfg4_mt_eikonal_468_centroids_200_receivers():
     p.set_source_params("mt_eikonal", tr)
     p.eval()
     m, n, g = p.get_misfits()
-    assert m.shape == (4, 600) and np.all(m[0] == 0.0)
+    assert m.shape == (4, 600) and reproduces(m[0], n[0], 0.0)
     s0, s1 = all_synthetics(p, 0, 200), all_synthetics(p, 1, 200)
     assert all(np.array_equal(2.0 * a, b) for a, b in zip(s0, s1))
     p.set_keep_synthetics(0)
     e, db, evaluate = bench.oracle_engine(wl, gf, recv, refs, tapers, CORES)
     for i in (2, 3):
         om, on, og = evaluate(tr[i])
-        assert rel(m[i], om) <= 1e-6 and abs(g[i] - og) <= 1e-6 * og and np.array_equal(n[i], on)
+        assert rel(m[i], om, on) <= 1e-6 and abs(g[i] - og) <= 1e-6 * max(og, 0.05 if common.arith() == "fused" else 0.0) and np.array_equal(n[i], on)
     e.close(); db.close()
 
 
