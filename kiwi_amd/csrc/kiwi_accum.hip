@@ -31,7 +31,7 @@ template <int NG, int T>
 static void grouped_t(const AccumArgs &a, dim3 grid, int ntiles, const int *runs, int pairsel, const int *mate, const int *mate4)
 {
 #define KIWI_G(FV, RV) hipLaunchKernelGGL((accumulate_grouped_kernel<NG, T, FV, RV>), grid, dim3(T), 0, a.stream, KIWI_COMMON_ARGS, ntiles, \
-                                          a.tab, runs, a.fp, a.pairflag, pairsel, mate, mate4, a.synrow, a.fam_ofs, a.fam_list)
+                                          a.tab, a.coefs, runs, a.fp, a.pairflag, pairsel, mate, mate4, a.synrow, a.fam_ofs, a.fam_list)
     if (a.fuse) { if (runs) KIWI_G(true, true); else KIWI_G(true, false); }
     else        { if (runs) KIWI_G(false, true); else KIWI_G(false, false); }
 #undef KIWI_G
@@ -54,9 +54,9 @@ void launch_grouped(const AccumArgs &a, dim3 grid, int T, int ntiles, const int 
 template <int NG, int NS>
 static void multi_t(const AccumArgs &a, dim3 grid, int ntiles, const int *mate, const int *wider)
 {
-    if (a.fuse) hipLaunchKernelGGL((accumulate_multi_kernel<NG, true, NS>), grid, dim3(256), 0, a.stream, KIWI_COMMON_ARGS, ntiles, a.tab, a.fp,
+    if (a.fuse) hipLaunchKernelGGL((accumulate_multi_kernel<NG, true, NS>), grid, dim3(256), 0, a.stream, KIWI_COMMON_ARGS, ntiles, a.tab, a.coefs, a.fp,
                                    a.pairflag, mate, wider);
-    else        hipLaunchKernelGGL((accumulate_multi_kernel<NG, false, NS>), grid, dim3(256), 0, a.stream, KIWI_COMMON_ARGS, ntiles, a.tab, a.fp,
+    else        hipLaunchKernelGGL((accumulate_multi_kernel<NG, false, NS>), grid, dim3(256), 0, a.stream, KIWI_COMMON_ARGS, ntiles, a.tab, a.coefs, a.fp,
                                    a.pairflag, mate, wider);
 }
 void launch_multi(const AccumArgs &a, dim3 grid, int NS, int ntiles, const int *mate, const int *wider)
@@ -70,7 +70,7 @@ void launch_multi(const AccumArgs &a, dim3 grid, int NS, int ntiles, const int *
 template <int NG>
 static void cell_t(const AccumArgs &a, dim3 grid, int ntiles, bool per_wave)
 {
-#define KIWI_C(KERNEL) hipLaunchKernelGGL(KERNEL, grid, dim3(256), 0, a.stream, KIWI_COMMON_ARGS, ntiles, a.tab, a.fp, a.pairflag, a.synrow, \
+#define KIWI_C(KERNEL) hipLaunchKernelGGL(KERNEL, grid, dim3(256), 0, a.stream, KIWI_COMMON_ARGS, ntiles, a.tab, a.coefs, a.fp, a.pairflag, a.synrow, \
                                           a.fam_ofs, a.fam_list)
     if (per_wave) { if (a.fuse) KIWI_C((accumulate_cellw_kernel<NG, true>)); else KIWI_C((accumulate_cellw_kernel<NG, false>)); }
     else          { if (a.fuse) KIWI_C((accumulate_cell_kernel<NG, 256, 2, 0, true>)); else KIWI_C((accumulate_cell_kernel<NG, 256, 2, 0, false>)); }

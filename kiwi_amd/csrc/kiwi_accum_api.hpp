@@ -14,7 +14,7 @@ struct AccumArgs {
     const float *G; const int2 *span; int pitch;
     const GeoRec *recs; const int *cent_ofs; int isrc0, nrec;
     const RecvDev *recv; float *syn; size_t syn_stride;
-    const int *tab; FuseParams fp;
+    const int *tab; const float *coefs; FuseParams fp;
     const int *pairflag, *synrow, *fam_ofs, *fam_list;
 };
 

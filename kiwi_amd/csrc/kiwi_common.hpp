@@ -107,19 +107,15 @@ struct ShakeRec {
     int rec;
 };
 
-// Layout of a centroid's interpolation-coefficient line (written by geometry_kernel's write_tab, read by the accumulate
-// kernels with scalar loads): wl = (1 - w) * factor and wr = w * factor of every GF component (sparse_trace.f90:643-647 with
-// the factors of seismogram.f90:171-250).  With a = the component's index in APPLICATION order (ng = 10: 1 2 3 9 | 4 5 | 6 7 8 10,
-// ng = 8: 1 2 3 | 4 5 | 6 7 8 -- radial sum | transverse sum | vertical), the a-th radial and the a-th vertical component sit
-// next to each other: line = [wl_rad(0) wl_ver(0) wr_rad(0) wr_ver(0) | ... | wl_tra(0) wr_tra(0) wl_tra(1) wr_tra(1)], so that
-// accumulate_multi_kernel -- whose LDS tiles interleave exactly these component pairs -- takes (wl_rad, wl_ver) and (wr_rad, wr_ver)
-// as aligned scalar-register pairs of its packed multiplies.
-template <int NG> __host__ __device__ constexpr int coef_wl(int a)
-{
-    constexpr int nP = NG == 10 ? 4 : 3, nH = NG == 10 ? 6 : 5;
-    return a < nP ? 4 * a : (a < nH ? 4 * nP + 2 * (a - nP) : 4 * (a - nH) + 1);
-}
-template <int NG> __host__ __device__ constexpr int coef_wr(int a) { return coef_wl<NG>(a) + ((a >= (NG == 10 ? 4 : 3) && a < (NG == 10 ? 6 : 5)) ? 1 : 2); }
+// A centroid's interpolation-coefficient line (written by geometry_kernel's write_tab, read by the accumulate kernels with scalar
+// loads): wl = (1 - w) * factor and wr = w * factor of every GF component (sparse_trace.f90:643-647 with the factors of
+// seismogram.f90:171-250), each rounded on its own, for the a-th component in APPLICATION order (ng = 10: 1 2 3 9 | 4 5 | 6 7 8 10,
+// ng = 8: 1 2 3 | 4 5 | 6 7 8).  One line of kCoefLine floats per record, lines of consecutive centroids consecutive in memory:
+// the time steps of a sub-fault share cache lines and DRAM bursts (until round 3 each line sat alone in its record's 512-byte
+// descriptor row: 2.6 GB per cfg3 launch from HBM, and a third of geometry_kernel's writes).
+constexpr int kCoefLine = 20;      // floats per record in the coefficient array (ng = 8 uses the first 16)
+template <int NG> __host__ __device__ constexpr int coef_wl(int a) { return 2 * a; }
+template <int NG> __host__ __device__ constexpr int coef_wr(int a) { return 2 * a + 1; }
 
 // Data spans of one (source, receiver)'s synthetic strips, 8 ints: [lo, hi] of the radial sum displacement_ar(1), of the
 // transverse sum displacement_ar(2), of the vertical strip, 2 unused; lo > hi = empty.  The two horizontal sums are

@@ -77,7 +77,7 @@ __device__ __forceinline__ bool starts_group(const float *__restrict__ cent, int
 // out as consecutive 16-byte stores, so that a line is complete in L2 before it leaves it (interleaving the stores
 // with the look-ups left every line open for microseconds: partial-line write-backs, 0.32 ms per 1.3 M records).
 template <int NG>
-__device__ __forceinline__ bool write_tab(int *__restrict__ tb, const GeoRec &g, const int2 *__restrict__ span, int pitch, float sd,
+__device__ __forceinline__ bool write_tab(int *__restrict__ tb, float *__restrict__ cline, const GeoRec &g, const int2 *__restrict__ span, int pitch, float sd,
                                           bool full, const unsigned char *__restrict__ endz)
 {
     bool all_endzero = true;          // returned: (full rows) every row of the cell ends in an exact zero -- no tail rule for this group
@@ -151,16 +151,16 @@ __device__ __forceinline__ bool write_tab(int *__restrict__ tb, const GeoRec &g,
 #pragma unroll
         for (int ig = 0; ig < NG; ig++) t4[16 + ig] = make_int4(floors[ig][0], floors[ig][1], floors[ig][2], floors[ig][3]);
     }
-    float4 *f4 = reinterpret_cast<float4 *>(tb);
+    float4 *f4 = reinterpret_cast<float4 *>(cline);           // (80-byte lines: 16-byte aligned)
 #pragma unroll
-    for (int q = 0; q < (NG == 10 ? 5 : 4); q++) f4[26 + q] = make_float4(cf[4 * q], cf[4 * q + 1], cf[4 * q + 2], cf[4 * q + 3]);
+    for (int q = 0; q < (NG == 10 ? 5 : 4); q++) f4[q] = make_float4(cf[4 * q], cf[4 * q + 1], cf[4 * q + 2], cf[4 * q + 3]);
     return all_endzero;
 }
 
 __global__ __launch_bounds__(256) void geometry_kernel(
     const float *__restrict__ cent, const int *__restrict__ cent_ofs, EvalParams ep, GfMeta gm,
     const int2 *__restrict__ span, const RecvDev *__restrict__ recv, GeoRec *__restrict__ out,
-    int *__restrict__ tab, int *__restrict__ spanbuf, int *__restrict__ spansrc /* optional [source][receiver][kSpanInts] */,
+    int *__restrict__ tab, float *__restrict__ coefs /* [record][kCoefLine] interpolation coefficients, see coef_wl */, int *__restrict__ spanbuf, int *__restrict__ spansrc /* optional [source][receiver][kSpanInts] */,
     int *__restrict__ pairflag /* optional [source][receiver]: bit 0 some centroid of the pair is added in part (a trace is missing),
                                   bit 1 some centroid is left out (a trace missing or outside the database), bit 2 some group's rows do
                                   not all end in zero (the tail rule can apply); see cell_pair(), multi_taken() */,
@@ -383,8 +383,8 @@ __global__ __launch_bounds__(256) void geometry_kernel(
         // cell mode: only the coefficient line here, cellgroup_kernel completes the rows of the group starts it finds
         const bool full = !ep.cellmode && (!(g.flags & 4) || starts_group(cent, c0, nc, c, gm.dt));
         bool ez;
-        if (gm.ng == 10) ez = write_tab<10>(tab + base * 128, g, span, gm.pitch, rv.sd, full, endz);
-        else ez = write_tab<8>(tab + base * 128, g, span, gm.pitch, rv.sd, full, endz);
+        if (gm.ng == 10) ez = write_tab<10>(tab + base * 128, coefs + base * kCoefLine, g, span, gm.pitch, rv.sd, full, endz);
+        else ez = write_tab<8>(tab + base * 128, coefs + base * kCoefLine, g, span, gm.pitch, rv.sd, full, endz);
         if (pairflag && !ez) atomicOr(&pairflag[(size_t)s * ep.nrec + r], 4);
     }
 }
@@ -404,7 +404,7 @@ __device__ __forceinline__ bool same_cell(const GeoRec *__restrict__ a, const in
 
 __global__ __launch_bounds__(256) void cellgroup_kernel(const int *__restrict__ cent_ofs, EvalParams ep, GfMeta gm,
                                                         const int2 *__restrict__ span, const RecvDev *__restrict__ recv,
-                                                        GeoRec *__restrict__ recs, int *__restrict__ tab,
+                                                        GeoRec *__restrict__ recs, int *__restrict__ tab, float *__restrict__ coefs,
                                                         const int *__restrict__ pairflag, const unsigned char *__restrict__ endz,
                                                         const int *__restrict__ synrow, int cell_range /* largest shift range of a cell group */)
 {
@@ -442,8 +442,8 @@ __global__ __launch_bounds__(256) void cellgroup_kernel(const int *__restrict__ 
         }
     }
     rr[c].pad = len | ((smax - me.ishift) << 8) | ((me.ishift - smin) << 16);
-    if (gm.ng == 10) write_tab<10>(tab + (base0 + c) * 128, me, span, gm.pitch, recv[r].sd, true, endz);
-    else write_tab<8>(tab + (base0 + c) * 128, me, span, gm.pitch, recv[r].sd, true, endz);
+    if (gm.ng == 10) write_tab<10>(tab + (base0 + c) * 128, coefs + (base0 + c) * kCoefLine, me, span, gm.pitch, recv[r].sd, true, endz);
+    else write_tab<8>(tab + (base0 + c) * 128, coefs + (base0 + c) * kCoefLine, me, span, gm.pitch, recv[r].sd, true, endz);
 }
 
 } // namespace kiwi

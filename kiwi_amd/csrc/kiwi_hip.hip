@@ -169,7 +169,8 @@ struct kiwi_hip_ctx {
     // results + workspace
     DevBuf<float> misfit_d, global_d;
     DevBuf<GeoRec> recs_d;
-    DevBuf<int> tab_d;                // grouped kernel load descriptors, 128 ints per GeoRec
+    DevBuf<int> tab_d;                // grouped kernel load descriptors, 128 ints per GeoRec (written at group starts only)
+    DevBuf<float> coef_d;             // interpolation coefficients, kCoefLine floats per GeoRec, consecutive (kiwi_common.hpp coef_wl)
     DevBuf<int> pairflag_d;           // cell mode: per (source of the chunk, receiver) "some centroid misses a trace"
     DevBuf<float> syn_d, proc_d;
     // floating norms
@@ -300,7 +301,7 @@ void natural_spans(kiwi_hip_ctx *c, std::vector<int> &sb)
         EvalParams ep{ c->bilinear, c->xus, c->zus, nrec, s0 };
         dim3 grid((unsigned)((maxnc * nrec + 255) / 256), (unsigned)n);
         hipLaunchKernelGGL(geometry_kernel, grid, dim3(256), 0, c->stream, c->cent_d.p, c->centofs_d.p, ep, c->gm,
-                           c->span.p, c->recv_d.p, (GeoRec *)nullptr, (int *)nullptr, c->spanbuf_d.p, (int *)nullptr, (int *)nullptr, c->endz.p, (const int *)nullptr);
+                           c->span.p, c->recv_d.p, (GeoRec *)nullptr, (int *)nullptr, (float *)nullptr, c->spanbuf_d.p, (int *)nullptr, (int *)nullptr, c->endz.p, (const int *)nullptr);
     }
     HIPCHECK(hipMemcpyAsync(sb.data(), c->spanbuf_d.p, sb.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));
@@ -919,6 +920,7 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
         // KIWI_HIP_POISON=1 (tests): rows keep nothing from earlier evaluations -- a descriptor line the kernel reads but
         // geometry_kernel did not write shows as a wild address instead of passing by accident
         if (std::getenv("KIWI_HIP_POISON")) HIPCHECK(hipMemsetAsync(tab, 0x7f, (size_t)(cend - cbeg) * nrec * 128 * sizeof(int), c->stream));
+        c->coef_d.ensure((size_t)(cend - cbeg) * nrec * kCoefLine, &c->dev_bytes);
     }
     // ---- sources of this chunk that can take an earlier source's synthetics (same centroid table, same chunk): not
     // synthesised, compared from that source's row with their own moment and rise time.  Plain time-domain comparator only.
@@ -985,10 +987,10 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
             HIPCHECK(hipMemsetAsync(c->pairflag_d.p, 0, (size_t)nsrc * nrec * sizeof(int), c->stream));
         }
         hipLaunchKernelGGL(geometry_kernel, grid, dim3(256), 0, c->stream, c->cent_d.p, c->centofs_d.p, ep, c->gm,
-                           c->span.p, c->recv_d.p, c->recs_d.p, tab, (int *)nullptr, spansrc, (cell || duo_maybe) ? c->pairflag_d.p : (int *)nullptr, c->endz.p, (const int *)nullptr);
+                           c->span.p, c->recv_d.p, c->recs_d.p, tab, c->coef_d.p, (int *)nullptr, spansrc, (cell || duo_maybe) ? c->pairflag_d.p : (int *)nullptr, c->endz.p, (const int *)nullptr);
         if (cell)
             hipLaunchKernelGGL(cellgroup_kernel, grid, dim3(256), 0, c->stream, c->centofs_d.p, ep, c->gm, c->span.p, c->recv_d.p,
-                               c->recs_d.p, tab, c->pairflag_d.p, c->endz.p, (const int *)nullptr,
+                               c->recs_d.p, tab, c->coef_d.p, c->pairflag_d.p, c->endz.p, (const int *)nullptr,
                                c->cell_wave ? exact::cellw_range() : kHalo - 10);
     }
     if (c->fft_needed) {
@@ -1010,7 +1012,7 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
         // the kernels of the arithmetic contract in force (kiwi_accum.inc compiled twice: kiwi::exact, kiwi::fused)
         const bool fusedar = c->arith == KIWI_ARITH_FUSED;
         AccumArgs aa{ c->stream, c->gm.ng, c->fuse_now, c->G.p, c->span.p, c->gm.pitch, c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p,
-                      c->syn_d.p, c->syn_stride, c->tab_d.p, FuseParams{ nullptr, nullptr, nullptr, nullptr, 0, 1.f, 0, 0, 0 },
+                      c->syn_d.p, c->syn_stride, c->tab_d.p, c->coef_d.p, FuseParams{ nullptr, nullptr, nullptr, nullptr, 0, 1.f, 0, 0, 0 },
                       nullptr, synrow, famofs, famlist };
         if (c->accum_mode == 1) {            // KIWI_HIP_ACCUM=direct: A/B reference kernel, no LDS staging
             if (fusedar) fused::launch_direct(aa, grid); else exact::launch_direct(aa, grid);
@@ -1108,9 +1110,13 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
             }
             fuse_T = T; fuse_tile = 4 * T; fuse_ntiles = ntiles; fuse_all = cell || duo;
             aa.pairflag = (cell || duo) ? c->pairflag_d.p : (const int *)nullptr;
+            // (The cell kernels run uncontracted under either contract -- bit-identical results are inside any tolerance --:
+            // contracted, accumulate_cellw_kernel needs 189 registers for its 168 and spills in its centroid loop (cfg4: 246 ms
+            // per 128 sources against 169), and the contracted shared-tile kernel only reaches the uncontracted per-wave one
+            // (169.4 against 169.0): these kernels are bound by their descriptor / bookkeeping instructions, not by the
+            // multiplies and adds a fused operation saves.)
             if (cell) {
-                if (c->cell_wave) { if (fusedar) fused::launch_cellw(aa, cgrid, ntiles_c); else exact::launch_cellw(aa, cgrid, ntiles_c); }
-                else              { if (fusedar) fused::launch_cell(aa, cgrid, ntiles_c); else exact::launch_cell(aa, cgrid, ntiles_c); }
+                if (c->cell_wave) exact::launch_cellw(aa, cgrid, ntiles_c); else exact::launch_cell(aa, cgrid, ntiles_c);
             }
             // the (group of sources, receiver) combinations accumulate_multi_kernel takes; the grouped kernel behind it returns at once for those
             const int *m2p = any2 ? c->mate_d.p : (const int *)nullptr, *m4p = any4 ? c->mate4_d.p : (const int *)nullptr;
@@ -1240,7 +1246,7 @@ int eval_impl(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
             const size_t nc = (size_t)(c->cent_ofs[s + n + 1] - c->cent_ofs[s + n]);
             const size_t syn_bytes = c->fuse_now ? (size_t)c->nmis * 64 * sizeof(double)
                                                              : c->syn_stride * sizeof(float) * ((proc_which ? 2 : 1) + (c->floating ? 1 : 0));
-            const size_t add = nc * nrec * (sizeof(GeoRec) + (c->accum_mode == 0 ? 512 : 0)) + syn_bytes;
+            const size_t add = nc * nrec * (sizeof(GeoRec) + (c->accum_mode == 0 ? 512 + kCoefLine * sizeof(float) : 0)) + syn_bytes;
             if (n > 0 && (bytes + add > c->chunk_bytes_limit || n >= 65535)) break;
             if (c->fft_needed && n >= c->fft_cap) break;
             bytes += add; n++;
