@@ -30,9 +30,18 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-# Peak FP32 (vector) 157.3 TFLOP/s counts fused multiply-adds; the reference rounds every multiply and every add on its
-# own (the library is built with -ffp-contract=off and parity is bit-level), so a lane does one flop per packed slot:
-VALU_PEAK_TFLOPS = 157.3 / 2.0
+# Peak FP32 (vector) 157.3 TFLOP/s counts fused multiply-adds.  Under the library's default arithmetic contract ("exact": the
+# reference rounds every multiply and every add on its own, parity is bit-level) a lane does one flop per packed slot, half
+# that rate; under the "fused" contract (KIWI_HIP_ARITH=fused / kiwi_hip_set_arithmetic: multiply + consuming add as one FMA,
+# tolerance class) the kernels are priced against the full figure.
+FP32_PEAK_TFLOPS = 157.3
+
+
+def valu_peak(arith):
+    return FP32_PEAK_TFLOPS if arith == "fused" else FP32_PEAK_TFLOPS / 2.0
+
+
+VALU_PEAK_TFLOPS = FP32_PEAK_TFLOPS / 2.0
 NORM_ID = {"l2norm": 1, "l1norm": 2, "ampspec_l2norm": 3, "ampspec_l1norm": 4}
 
 
@@ -63,7 +72,12 @@ def setup_product(device, wl, L):
     for ir in range(nrec):
         for k in range(3):
             p.set_ref_seismogram(ir + 1, k + 1, firsts[ir], np.zeros(L, np.float32))
-        tapers[ir + 1] = synthetic.full_taper(firsts[ir], L, dt)
+        # misfit window: the whole trace, or (cfg3-w256 / cfg3-w600) a short taper inside it -- the window is the taper's span
+        # (comparator.f90:782-792)
+        if wl.get("window"):
+            tapers[ir + 1] = synthetic.full_taper(firsts[ir] + wl.get("window_offset", 0), wl["window"], dt, ramp=min(10.0, 0.2 * wl["window"] * dt))
+        else:
+            tapers[ir + 1] = synthetic.full_taper(firsts[ir], L, dt)
         p.set_misfit_taper(ir + 1, *tapers[ir + 1])
         if wl["filter"] is not None:
             p.set_misfit_filter(ir + 1, *wl["filter"])
@@ -286,15 +300,8 @@ def kernel_sources_sha256():
     return h.hexdigest()
 
 
-def also_cfg3_100pt(p_main, device, L, batch=512, steps=6):
-    """The north star's "100 sub-faults" read literally (100 sub-fault points x 2 time steps = 200 centroids), timed the
-    same way right after the main workload: evals/s with inputs resident."""
-    from kiwi_amd import synthetic
-    p_main.close()
-    wl = synthetic.workload("cfg3-100pt", batch, 0)
-    p, gf, recv, refs, tapers, ncent = setup_product(device, wl, L)
-    for _ in range(2):
-        p.eval()
+def timed_evals(p, steps):
+    """`steps` passes of the hot path on an engine that is set up and warm -> (wall s, accumulate-kernel ms per pass)"""
     p.sync()
     p.kernel_ms()
     t0 = time.perf_counter()
@@ -304,13 +311,56 @@ def also_cfg3_100pt(p_main, device, L, batch=512, steps=6):
         p.get_misfits()
     dt = time.perf_counter() - t0
     ms, launches = p.kernel_ms()
+    return dt, float(ms[1]) / steps          # (accumulate ms per pass: a pass over a large batch is several launches)
+
+
+def required_flops(ncent, npts, nrec, ng, W):
+    """What the accumulate kernel has to execute per trial source: fp32 multiplies and adds in the
+    reference's order -- apply: 4 per GF component, centroid and output sample + 8 for the per-centroid rotation
+    (seismogram.f90:171-250, sparse_trace.f90:684-703); blend: 7 per component and sample, once per sub-fault POINT and
+    receiver (gfdb.f90:944-949; the time steps of a point share the blended trace).  The same count under both arithmetic
+    contracts (a fused multiply-add is two of them)."""
+    return ncent * nrec * W * (4 * ng + 8) + npts * nrec * W * ng * 7
+
+
+def other_contract(p, batch, flops_eval, steps=6):
+    """The same resident batch under the OTHER arithmetic contract of the accumulate kernels (exact <-> fused), timed the same
+    way; the engine is left in the contract it came in."""
+    was = p.arithmetic()
+    oth = "exact" if was == "fused" else "fused"
+    p.set_arithmetic(oth)
+    for _ in range(2):
+        p.eval()
+    dt, acc_ms = timed_evals(p, steps)
+    p.set_arithmetic(was)
+    ach = flops_eval * batch / (acc_ms * 1e-3) / 1e12 if acc_ms > 0 else 0.0
+    return {"arithmetic": oth, "value": batch * steps / dt, "unit": "evals/s", "steps": steps, "accumulate_ms_per_step": acc_ms,
+            "roofline": {"bound": "valu_issue", "achieved": ach, "peak": valu_peak(oth), "unit": "TFLOP/s", "frac": ach / valu_peak(oth)}}
+
+
+def also_cfg3_100pt(p_main, device, L, batch=512, steps=6):
+    """The north star's "100 sub-faults" read literally (100 sub-fault points x 2 time steps = 200 centroids), timed the
+    same way right after the main workload: evals/s with inputs resident, its own roofline block, both arithmetic contracts."""
+    from kiwi_amd import synthetic
+    p_main.close()
+    wl = synthetic.workload("cfg3-100pt", batch, 0)
+    p, gf, recv, refs, tapers, ncent = setup_product(device, wl, L)
+    for _ in range(2):
+        p.eval()
+    dt, acc_ms = timed_evals(p, steps)
     npts, nrec, ng, W = wl["npoints"], wl["nrec"], gf["data"].shape[2], L
-    flops_eval = ncent * nrec * W * (4 * ng + 8) + npts * nrec * W * ng * 7
-    acc_s = float(ms[1]) * 1e-3
+    flops_eval = required_flops(ncent, npts, nrec, ng, W)
+    ar = p.arithmetic()
+    ach = flops_eval * batch / (acc_ms * 1e-3) / 1e12 if acc_ms > 0 else 0.0
+    out = {"workload": "cfg3-100pt: %.0f centroids (%.0f sub-fault points) x %d receivers x 3 comp x %d samples" % (ncent, npts, nrec, W),
+           "arithmetic": ar, "value": batch * steps / dt, "unit": "evals/s", "trial_sources_per_step": batch, "steps": steps,
+           "roofline": {"bound": "valu_issue", "achieved": ach, "peak": valu_peak(ar), "unit": "TFLOP/s", "frac": ach / valu_peak(ar),
+                        "accumulate_ms_per_step": acc_ms, "flops_per_eval": flops_eval,
+                        "kernel": "accumulate_multi_kernel<10,FUSE,4|2> (+ accumulate_grouped_kernel for the pairs it leaves)"},
+           "roofline_frac": ach / valu_peak(ar),
+           "other_contract": other_contract(p, batch, flops_eval, steps)}
     p.close()
-    return {"workload": "cfg3-100pt: %.0f centroids (%.0f sub-fault points) x %d receivers" % (ncent, npts, nrec),
-            "value": batch * steps / dt, "unit": "evals/s", "trial_sources_per_step": batch, "steps": steps,
-            "roofline_frac": flops_eval * batch * steps / acc_s / 1e12 / VALU_PEAK_TFLOPS if acc_s > 0 else None}
+    return out
 
 
 def sweep(args, torch, dist, rank, local_rank, ngpus, force_dist):
@@ -372,7 +422,7 @@ def main():
                     help="ranks = GPUs of this node (default: WORLD_SIZE when started by a launcher, else 1)")
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5", "cfg5-td", "cfg3-100pt", "cfg3-scatter", "cfg3-bigdb"],
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5", "cfg5-td", "cfg3-100pt", "cfg3-scatter", "cfg3-bigdb", "cfg3-w256", "cfg3-w600"],
                     help="BASELINE.json configs[1..4]; cfg3 (default) is the one the metric is quoted on")
     ap.add_argument("--batch", type=int, default=0,
                     help="trial sources per GPU per step (default: 12960 cfg2, 4096 cfg3, 1024 cfg3-scatter / cfg3-bigdb, 512 cfg3-100pt / cfg5 / cfg5-td, 128 cfg4)")
@@ -420,7 +470,7 @@ def main():
     if args.batch <= 0:
         # (cfg3: 4096 sources per step -- 0.14 s -- so that the driver's 20 steps time 2.8 s of device work)
         args.batch = {"cfg2": 12960, "cfg3": 4096, "cfg3-scatter": 1024, "cfg3-bigdb": 1024, "cfg3-100pt": 512, "cfg4": 128, "cfg5": 512,
-                      "cfg5-td": 512}[args.workload]
+                      "cfg5-td": 512, "cfg3-w256": 16384, "cfg3-w600": 8192}[args.workload]
     if args.sweep > 0:
         return sweep(args, torch, dist, rank, local_rank, ngpus, force_dist)
     lo, hi = shard_range(args.batch * ngpus, ngpus, rank)
@@ -467,18 +517,16 @@ def main():
     if rank == 0:
         total_evals = args.batch * ngpus * args.steps
         value = total_evals / elapsed
-        n_ip, ng, L, W = 4, gf["data"].shape[2], args.samples, args.samples
+        n_ip, ng, L, W = 4, gf["data"].shape[2], args.samples, (wl.get("window") or args.samples)
         npts = wl["npoints"]
         acc_s = float(ms[1]) * 1e-3
         launches_acc = max(int(launches[1]), 1)
-        # ---- what the accumulate kernel has to execute per trial source: separately rounded fp32
-        # multiplies and adds in the reference's order -- apply: 4 per GF component, centroid and output sample + 8 for the
-        # per-centroid rotation (seismogram.f90:171-250, sparse_trace.f90:684-703); blend: 7 per component and sample,
-        # once per sub-fault POINT and receiver (gfdb.f90:944-949; the time steps of a point share the blended trace)
-        flops_eval = ncent * nrec * W * (4 * ng + 8) + npts * nrec * W * ng * 7
+        flops_eval = required_flops(ncent, npts, nrec, ng, W)
+        arith = p.arithmetic()
+        peak_tf = valu_peak(arith)
         achieved_tflops = flops_eval * args.batch * args.steps / acc_s / 1e12 if acc_s > 0 else 0.0
         # ---- the SURVEY 8d byte model (no reuse at all: every centroid re-reads its n_g x n_ip rows over the window)
-        b_eval = int(ncent * nrec * ng * n_ip * L * 4 + nrec * 3 * W * 4 * 2)
+        b_eval = int(ncent * nrec * ng * n_ip * W * 4 + nrec * 3 * W * 4 * 2)
         no_reuse_gbs = b_eval * args.batch * args.steps / acc_s / 1e9 if acc_s > 0 else 0.0
         # ---- measured counters of this same command from the committed rocprofv3 passes (profiles/r*_summary.json):
         # PMC counters cannot be collected from inside this process, so these are null when no profile matches
@@ -515,6 +563,9 @@ def main():
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # arithmetic contract of the accumulate kernels this line was measured under (include/kiwi_hip.h KIWI_ARITH_*;
+            # `other_contract` below carries the same batch under the other one)
+            "arithmetic": arith,
             "config": {"workload": "%s: %s source, %.0f centroids (%.0f sub-fault points) x %d receivers x 3 comp x %d samples, "
                                    "ng=10, bilinear GF interpolation, %s%s, tapered %d-sample window"
                                    % (wl["name"], wl["sourcetype"], ncent, npts, nrec, L, wl["method"],
@@ -524,8 +575,8 @@ def main():
             # The dominant kernel runs against the vector ALU's issue rate, not against HBM: the Green's function tensor
             # (130-160 MB) is resident in L2 / Infinity Cache and HBM is nearly idle, by design (see `hbm` below).  `achieved`
             # = required flops / measured kernel time, `peak` = the unfused fp32 vector rate, so frac <= 1 by construction.
-            "roofline": {"bound": "valu_issue", "achieved": achieved_tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved_tflops / VALU_PEAK_TFLOPS,
+            "roofline": {"bound": "valu_issue", "achieved": achieved_tflops, "peak": peak_tf, "unit": "TFLOP/s",
+                         "frac": achieved_tflops / peak_tf, "arithmetic": arith,
                          "traffic": traffic,
                          "kernel": kernel, "launches": int(launches[1]), "avg_launch_ms": avg_ms,
                          "flops_per_eval": flops_eval,
@@ -554,6 +605,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(wl, gf, recv, refs, tapers, np.asarray(allg), gm, gn)
         else:
             out["cpu_baseline"] = None
+        if ngpus == 1 and not args.no_also:
+            out["other_contract"] = other_contract(p, args.batch, flops_eval)
         if ngpus == 1 and args.workload == "cfg3" and not args.no_also:
             out["also"] = also_cfg3_100pt(p, local_rank, args.samples)
         print(json.dumps(_finite(out)))

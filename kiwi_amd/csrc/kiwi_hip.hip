@@ -969,7 +969,7 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
     // (with nearest-neighbour interpolation there is nothing to blend: same-point groups do)
     const bool cell = c->accum_mode == 0 && (c->cell_mode == 1 || (c->cell_mode < 0 && c->bilinear && c->points_per_centroid > 0.5));
     // several sources per workgroup (accumulate_multi_kernel); decided below, once the runs and the shared synthetics are known
-    const bool duo_maybe = c->accum_mode == 0 && c->duo && !cell && c->max_wlen >= 384 && !c->group_threads_env && nsrc >= 2;
+    const bool duo_maybe = c->accum_mode == 0 && c->duo && !cell && c->max_wlen >= 128 && !c->group_threads_env && nsrc >= 2;      // (four sources: 256-sample tiles)
     EvalParams ep{ c->bilinear, c->xus, c->zus, nrec, isrc0, cell ? 1 : 0 };
     int *spansrc = nullptr;
     if (c->any_untapered || c->want_spansrc || c->fft_needed) {     // per-source strip spans, initialised empty
@@ -1077,7 +1077,8 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
                         m4[k] = (same(a, a + 1, true) && same(a, a + 2, true) && same(a, a + 3, true)) ? 1 : 0;
                         any4 = any4 || m4[k];
                     }
-                for (int k = 0; 2 * k + 1 < nsrc; k++) {
+                // (pairs work on 512-sample tiles: not for windows of one 256-sample tile, where half of their lanes would idle)
+                for (int k = 0; c->max_wlen > 256 && 2 * k + 1 < nsrc; k++) {
                     const int a = isrc0 + 2 * k;
                     m2[k] = (!m4[(size_t)k / 2] && same(a, a + 1, false)) ? 1 : 0;
                     any2 = any2 || m2[k];

@@ -173,6 +173,12 @@ def workload(name, nsrc=None, trial0=0):
         tr[:, 5] += 0.1 * trial0
         return dict(name="cfg3-bilat", sourcetype="bilateral", true=np.array(base, np.float32), trials=tr, nrec=50,
                     nx=128, method="l2norm", filter=None, crust=None, constraints=None)
+    if name in ("cfg3-w256", "cfg3-w600"):
+        # cfg3 under the short taper windows real inversions use (body-wave windows of tens to hundreds of samples,
+        # python/tunguska/misfit.py style): 256 / 600 samples inside the 4096-sample traces, 500 samples behind the first arrival
+        w = workload("cfg3", nsrc, trial0)
+        w.update(name=name, window=int(name[6:]), window_offset=500)
+        return w
     if name == "cfg3-100pt":
         # the north star's "100 sub-faults" taken literally: 25 x 4 sub-fault points of an 18 km x 4.5 km rupture, two
         # source-time-function steps each (200 centroids)
