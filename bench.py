@@ -389,7 +389,7 @@ def sweep(args, torch, dist, rank, local_rank, ngpus, force_dist):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
@@ -453,19 +453,27 @@ def main():
     dist = None
     # KIWI_BENCH_FORCE_DIST=1: go through RCCL even with one rank (self-test of the collective path on a 1-GPU box)
     force_dist = bool(os.environ.get("KIWI_BENCH_FORCE_DIST"))
+    # KIWI_BENCH_BACKEND=gloo + KIWI_BENCH_DEVICE=d: the same N-rank run with every rank's engine on device d and the collective
+    # through gloo -- the dress rehearsal of `--gpus N` on a box with one GPU (tests/test_gpu_fullsize.py); RCCL wants a device per rank
+    backend = os.environ.get("KIWI_BENCH_BACKEND", "nccl")
+    if os.environ.get("KIWI_BENCH_DEVICE") is not None:
+        local_rank = int(os.environ["KIWI_BENCH_DEVICE"])
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     ngpus = world
     if ngpus > 1 and not os.environ.get("KIWI_HIP_DISC_THREADS"):
         # N ranks share the box's host cores: each rank's discretiser team gets its share instead of all of them
         from kiwi_amd import lib as _lib
         os.environ["KIWI_HIP_DISC_THREADS"] = str(max(1, int(_lib.load().kiwi_hip_effective_cpus()) // ngpus))
 
-    from kiwi_amd.shard import shard_range, gather_misfits
+    from kiwi_amd.shard import shard_range, gather_misfits, DeviceGather
     from kiwi_amd import synthetic
     if args.batch <= 0:
         # (cfg3: 4096 sources per step -- 0.14 s -- so that the driver's 20 steps time 2.8 s of device work)
@@ -481,8 +489,14 @@ def main():
 
     counts = [shard_range(args.batch * ngpus, ngpus, r)[1] - shard_range(args.batch * ngpus, ngpus, r)[0] for r in range(ngpus)]
 
+    # the one collective of the sharded search: over RCCL straight from the engine's device buffer (DeviceGather), through the
+    # host only with a CPU backend (gloo rehearsal) or a single process
+    dgather = DeviceGather(dist, local_rank, counts) if dist is not None and backend == "nccl" else None
+
     def step():
         p.eval()
+        if dgather is not None:
+            return dgather.gather(p)                 # (synchronises the engine's stream; the result stays on the device)
         p.sync()
         _, _, g = p.get_misfits()
         return gather_misfits(g, dist, local_rank, counts, force=force_dist)
@@ -509,9 +523,11 @@ def main():
     if os.environ.get("KIWI_BENCH_VERBOSE"):
         print("rank %d step ms: %s" % (rank, " ".join("%.2f" % (1e3 * v) for v in step_s)), file=sys.stderr)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if dgather is not None:
+        allg = dgather.host()
     ms, launches = p.kernel_ms()
 
     if rank == 0:
@@ -560,6 +576,8 @@ def main():
         out = {
             "metric": "trial-source misfit evals/s", "value": value, "unit": "evals/s",
             "n_gpus": ngpus, "rccl_world_size": dist.get_world_size() if dist is not None else None,
+            "collective": None if dist is None else ("all_gather_into_tensor over %s, device to device from the engine's buffer" % backend
+                                                      if dgather is not None else "all-gather over %s through the host" % backend),
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -600,6 +618,8 @@ def main():
                          "other_kernels_ms_per_step": {"geometry": float(ms[0]) / args.steps,
                                                        "misfit": float(ms[2]) / args.steps}},
         }
+        if os.environ.get("KIWI_BENCH_DUMP_MISFITS"):        # (tests: the gathered global misfits of the last step, in trial order)
+            out["gathered_global_misfits"] = [float(x) for x in np.asarray(allg).ravel()]
         if ngpus == 1 and not args.no_cpu_baseline:
             gm, gn, gg = p.get_misfits()
             out["cpu_baseline"] = cpu_baseline(wl, gf, recv, refs, tapers, np.asarray(allg), gm, gn)

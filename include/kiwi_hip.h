@@ -231,6 +231,11 @@ int kiwi_hip_nmisfits(kiwi_hip_ctx *ctx, int *nmis);
 /* misfit[nsrc][nmis], norm[nsrc][nmis] (misfits_norm_factors), global[nsrc] =
  * sqrt(sum m^2)/sqrt(sum n^2) (minimizer_engine.f90:939-942); any pointer may be NULL.  Synchronises. */
 int kiwi_hip_get_misfits(kiwi_hip_ctx *ctx, int isrc0, int nsrc, float *misfit, float *norm, float *global);
+/* The global misfits of evaluated sources isrc0 .. isrc0 + nsrc - 1 WHERE THEY LIE: a device pointer (fp32, contiguous) on the
+ * context's device, valid until the next kiwi_hip_eval / kiwi_hip_set_sources* on the context.  For the multi-GPU exchange
+ * (one all-gather of per-source misfit scalars): a collective library takes the shard straight from device memory,
+ * no staging through the host.  Synchronises the context's stream (the values are final when the call returns). */
+int kiwi_hip_get_global_misfits_device(kiwi_hip_ctx *ctx, int isrc0, int nsrc, const float **device_ptr);
 
 /* output_seismograms (minimizer_engine.f90:980-1010): synthetic of one source of the LAST
  * kiwi_hip_eval range, over the receiver's misfit window.  which: 1 plain (scaled by moment,

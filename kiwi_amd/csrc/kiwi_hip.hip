@@ -152,6 +152,7 @@ struct kiwi_hip_ctx {
     std::vector<kiwi_hip_ctx *> mates;
     int cpu_share = 1;                // contexts that discretise at the same time: divides the discretiser's thread team
     std::vector<unsigned long long> struct_hash;   // per source: number of centroids and boundaries of its centroid groups (accumulate_multi_kernel's grouping)
+    std::vector<unsigned char> group_lens;          // per centroid: length of the centroid group that starts there, 0 inside a group (what struct_hash hashes)
     std::vector<int> first_shift;                  // per source: integer shift of its first centroid (groups of four: within 16 samples of each other,
                                                    // so that their groups can share a tile origin)
     std::vector<float> src_ends;                   // per source: position (north, east, depth) of its first and of its last centroid
@@ -209,6 +210,8 @@ struct kiwi_hip_ctx {
     DevBuf<float2> spec_d;
     DevBuf<FftPair> pairs_d;
     int *ntr_pin = nullptr; size_t ntr_pin_n = 0;               // pinned staging: transform lengths down, pair table up
+    int *mate_pin = nullptr; size_t mate_pin_n = 0;             // pinned staging of the mate flags of a chunk (groups of four, then pairs)
+    hipEvent_t mate_event = nullptr;                            // their upload has been read
     FftPair *pairs_pin = nullptr; size_t pairs_pin_n = 0;
     std::vector<FftPair> last_pairs;                             // pair table of the last chunk (diagnostic getters)
     std::vector<float> norm_src_h;                               // norm factors per (uploaded source, slot)
@@ -1057,7 +1060,14 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
             bool duo = duo_maybe && !runs && !synrow && maxnc > 0;
             bool any4 = false, any2 = false;
             if (duo) {
-                std::vector<int> m4((size_t)(nsrc + 3) / 4, 0), m2((size_t)(nsrc + 1) / 2, 0);
+                // (flags staged in pinned memory the context owns: the upload needs no stream synchronisation -- the host only waits,
+                // before it rewrites them for the next chunk, until the previous upload has been read)
+                const size_t n4 = (size_t)(nsrc + 3) / 4, n2 = (size_t)(nsrc + 1) / 2;
+                pin_ensure(c->mate_pin, c->mate_pin_n, n4 + n2);
+                if (!c->mate_event) HIPCHECK(hipEventCreateWithFlags(&c->mate_event, hipEventDisableTiming));
+                else HIPCHECK(hipEventSynchronize(c->mate_event));
+                int *m4 = c->mate_pin, *m2 = c->mate_pin + n4;
+                std::fill(m4, m4 + n4 + n2, 0);
                 // ... and only sources that are NEIGHBOURS in space (first and last centroid within a quarter of the database's node
                 // spacing): their groups then sit in the same cells for most receivers.  Sources further apart would have their tile
                 // sets built one after the other, from shorter tiles -- slower than the grouped kernel (measured: a shuffled
@@ -1066,6 +1076,8 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
                 auto same = [&](int a, int b, bool shifts) {
                     const int na = c->cent_ofs[a + 1] - c->cent_ofs[a], nb = c->cent_ofs[b + 1] - c->cent_ofs[b];
                     if (!(na > 0 && na == nb && c->struct_hash[a] == c->struct_hash[b] && (!shifts || std::abs(c->first_shift[a] - c->first_shift[b]) <= kiwi_quad_shift_span()))) return false;
+                    // (the hash only sorts out; the kernel walks all sources of a group with the group lengths of the first: compared in full)
+                    if (std::memcmp(c->group_lens.data() + c->cent_ofs[a], c->group_lens.data() + c->cent_ofs[b], (size_t)na) != 0) return false;
                     const float *p = c->src_ends.data() + (size_t)a * 6, *q = c->src_ends.data() + (size_t)b * 6;
                     for (int k = 0; k < 6; k++)
                         if (std::fabs(p[k] - q[k]) > (k % 3 == 2 ? near_z : near_h)) return false;
@@ -1085,15 +1097,15 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
                 }
                 duo = any4 || any2;
                 if (std::getenv("KIWI_HIP_DEBUG")) {
-                    int n4 = 0, n2 = 0; for (int v : m4) n4 += v; for (int v : m2) n2 += v;
-                    std::fprintf(stderr, "[kiwi_hip] chunk of %d sources: %d groups of four, %d pairs of equal structure\n", nsrc, n4, n2);
+                    int c4 = 0, c2 = 0; for (size_t i = 0; i < n4; i++) c4 += m4[i]; for (size_t i = 0; i < n2; i++) c2 += m2[i];
+                    std::fprintf(stderr, "[kiwi_hip] chunk of %d sources: %d groups of four, %d pairs of equal structure\n", nsrc, c4, c2);
                 }
                 if (duo) {
-                    c->mate4_d.ensure(m4.size(), &c->dev_bytes);
-                    c->mate_d.ensure(m2.size(), &c->dev_bytes);
-                    HIPCHECK(hipMemcpyAsync(c->mate4_d.p, m4.data(), m4.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-                    HIPCHECK(hipMemcpyAsync(c->mate_d.p, m2.data(), m2.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-                    HIPCHECK(hipStreamSynchronize(c->stream));         // m4, m2 go out of scope
+                    c->mate4_d.ensure(n4, &c->dev_bytes);
+                    c->mate_d.ensure(n2, &c->dev_bytes);
+                    HIPCHECK(hipMemcpyAsync(c->mate4_d.p, m4, n4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+                    HIPCHECK(hipMemcpyAsync(c->mate_d.p, m2, n2 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+                    HIPCHECK(hipEventRecord(c->mate_event, c->stream));
                 }
             }
             const int ntiles_q = (c->max_wlen + 255) / 256;              // ... 256 samples per source with four of them
@@ -1364,6 +1376,8 @@ int kiwi_hip_destroy(kiwi_hip_ctx *c)
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     for (auto &kv : c->plans) (void)hipfftDestroy(kv.second);
     if (c->ntr_pin) (void)hipHostFree(c->ntr_pin);
+    if (c->mate_pin) (void)hipHostFree(c->mate_pin);
+    if (c->mate_event) (void)hipEventDestroy(c->mate_event);
     if (c->pairs_pin) (void)hipHostFree(c->pairs_pin);
     if (c->size_event) (void)hipEventDestroy(c->size_event);
     (void)hipStreamDestroy(c->stream);
@@ -1720,6 +1734,7 @@ int kiwi_hip_set_sources(kiwi_hip_ctx *c, int nsrc, const int *cent_ofs, const f
     c->cent_ofs.assign(cent_ofs, cent_ofs + nsrc + 1);
     c->geo_hash.assign((size_t)nsrc, 0ull);
     c->struct_hash.assign((size_t)nsrc, 0ull);
+    c->group_lens.assign(ntot, 0);
     c->first_shift.assign((size_t)nsrc, 0);
     c->src_ends.assign((size_t)nsrc * 6, 0.f);
     c->single_group.assign((size_t)nsrc, 0);
@@ -1760,6 +1775,7 @@ int kiwi_hip_set_sources(kiwi_hip_ctx *c, int nsrc, const int *cent_ofs, const f
                     lo = nlo; hi = nhi; len++;
                 }
                 hs ^= (unsigned)len; hs *= 1099511628211ull;
+                c->group_lens[(size_t)cent_ofs[s] + k] = (unsigned char)len;
                 k += len;
             }
             c->geo_hash[s] = h;
@@ -2199,6 +2215,21 @@ int kiwi_hip_get_misfits(kiwi_hip_ctx *c, int isrc0, int nsrc, float *misfit, fl
     GUARD_END(c)
 }
 
+int kiwi_hip_get_global_misfits_device(kiwi_hip_ctx *c, int isrc0, int nsrc, const float **device_ptr)
+{
+    GUARD_BEGIN_DEV(c)
+    if (!device_ptr) throw std::runtime_error("null argument");
+    if (!c->prepared || c->synth_only) throw std::runtime_error("nothing evaluated yet");
+    if (isrc0 < 0 || nsrc < 0 || isrc0 + nsrc > c->nsrc) throw std::runtime_error("source range out of bounds");
+    for (int s = isrc0; s < isrc0 + nsrc; s++)
+        if ((size_t)s >= c->evaluated.size() || !c->evaluated[s])
+            throw std::runtime_error("nothing evaluated yet for source " + std::to_string(s + 1) + " of the uploaded batch");
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    *device_ptr = c->global_d.p + isrc0;
+    return 0;
+    GUARD_END(c)
+}
+
 // make_misfits_for_sources for a whole trial list in one call (seismosizer.py:682-722), host and device overlapped: the
 // list is cut into pieces; while the device evaluates one piece, a second host thread discretises the next.  Per piece
 // the calls are exactly kiwi_hip_set_sources_params + kiwi_hip_eval + kiwi_hip_get_misfits + kiwi_hip_get_source_status,
@@ -2219,22 +2250,25 @@ int kiwi_hip_misfits_for_params(kiwi_hip_ctx *c, int sourcetype, int nsrc, const
         // ---- multi-device context: contiguous shards in list order (Source.grid order), shard 0 here -- this context keeps the
         // HEAD of the list as in the one-device case --, the others each in a thread of their own on their device
         const int ndev = std::min(nsrc, 1 + (int)c->mates.size());
-        std::vector<std::thread> th;
+        // (futures: their destructors join -- a std::thread that is still joinable when an exception unwinds this frame, e.g.
+        // from the next emplace_back, would end the process in std::terminate)
+        std::vector<std::future<int>> th;
         std::vector<int> rc((size_t)ndev, 0);
         auto bound = [&](int i) { return (int)((long long)nsrc * i / ndev); };
         for (int i = 1; i < ndev; i++) {
             kiwi_hip_ctx *m = c->mates[(size_t)i - 1];
             const int s0 = bound(i), n = bound(i + 1) - s0;
-            th.emplace_back([=, &rc] {
-                rc[(size_t)i] = kiwi_hip_misfits_for_params(m, sourcetype, n, params + (size_t)s0 * np, piece, misfit ? misfit + (size_t)s0 * nmis : nullptr,
-                                                            norm ? norm + (size_t)s0 * nmis : nullptr, global ? global + s0 : nullptr, status ? status + s0 : nullptr);
-            });
+            th.push_back(std::async(std::launch::async, [=] {
+                return kiwi_hip_misfits_for_params(m, sourcetype, n, params + (size_t)s0 * np, piece, misfit ? misfit + (size_t)s0 * nmis : nullptr,
+                                                   norm ? norm + (size_t)s0 * nmis : nullptr, global ? global + s0 : nullptr, status ? status + s0 : nullptr);
+            }));
         }
         std::vector<kiwi_hip_ctx *> keep;
         keep.swap(c->mates);                                  // (shard 0 through the one-device path of this very function)
         rc[0] = kiwi_hip_misfits_for_params(c, sourcetype, bound(1), params, piece, misfit, norm, global, status);
         keep.swap(c->mates);
-        for (auto &t : th) t.join();
+        for (int i = 1; i < ndev; i++) rc[(size_t)i] = th[(size_t)i - 1].get();
+        HIPCHECK(hipSetDevice(c->device));
         for (int i = 0; i < ndev; i++)
             if (rc[(size_t)i]) {
                 if (i > 0) c->err = "device " + std::to_string(c->mates[(size_t)i - 1]->device) + ": " + c->mates[(size_t)i - 1]->err;

@@ -308,6 +308,18 @@ class Engine:
         self._ck(self.L.kiwi_hip_get_misfits(self.h, isrc0, nsrc, _fp(m), _fp(n), _fp(g)), "get_misfits")
         return m, n, g
 
+    def global_misfits_device(self, isrc0=0, nsrc=None):
+        """The global misfits of evaluated sources where they lie: an object with `__cuda_array_interface__` (fp32 [nsrc] on this
+        engine's device; torch.as_tensor(obj, device=...) wraps it without a copy), valid until the next eval / upload.  What the
+        multi-GPU all-gather takes (kiwi_amd/shard.py gather_global_misfits_device)."""
+        nsrc = self.nsrc - isrc0 if nsrc is None else nsrc
+        ptr = C.c_void_p()
+        self._ck(self.L.kiwi_hip_get_global_misfits_device(self.h, isrc0, nsrc, C.byref(ptr)), "get_global_misfits_device")
+
+        class _DeviceArray:
+            __cuda_array_interface__ = {"shape": (nsrc,), "typestr": "<f4", "data": (ptr.value or 0, False), "version": 2, "strides": None}
+        return _DeviceArray()
+
     def set_keep_synthetics(self, which):
         self._ck(self.L.kiwi_hip_set_keep_synthetics(self.h, which), "set_keep_synthetics")
 
@@ -413,8 +425,11 @@ class Engine:
             raise
         # pieces are evaluated from the end of the list: the context holds the first piece that uploaded anything; with a
         # multi-device engine that is shard 0's (the first device keeps the head of the list)
+        # (kiwi_hip_misfits_for_params: a list of ONE source takes the one-device path; otherwise min(N, devices) shards, shard i
+        # = [N i / k, N (i + 1) / k))
         ndev = self.ndevices()
-        n0 = N if ndev == 1 else N // ndev
+        k = 1 if (ndev == 1 or N < 2) else min(N, ndev)
+        n0 = N // k
         held = 0
         for s0 in range(0, n0, piece):
             if np.any(status[s0:min(s0 + piece, n0)] == 0):

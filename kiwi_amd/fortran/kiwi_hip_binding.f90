@@ -299,6 +299,14 @@ module kiwi_hip_binding
             integer(c_int), intent(out) :: nmis
         end function
 
+        ! device pointer of the global misfits of a source range (for a device-to-device all-gather)
+        integer(c_int) function kiwi_hip_get_global_misfits_device( ctx, isrc0, nsrc, device_ptr ) bind(C, name='kiwi_hip_get_global_misfits_device')
+            import :: c_int, c_ptr
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: isrc0, nsrc
+            type(c_ptr), intent(out) :: device_ptr
+        end function
+
         integer(c_int) function kiwi_hip_get_misfits( ctx, isrc0, nsrc, misfit, norm, global ) &
                 bind(C, name='kiwi_hip_get_misfits')
             import :: c_int, c_ptr, c_float

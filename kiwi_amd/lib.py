@@ -107,6 +107,7 @@ def load():
         "kiwi_hip_set_keep_synthetics": [vp, C.c_int],
         "kiwi_hip_nmisfits": [vp, c_int_p],
         "kiwi_hip_get_misfits": [vp, C.c_int, C.c_int, c_float_p, c_float_p, c_float_p],
+        "kiwi_hip_get_global_misfits_device": [vp, C.c_int, C.c_int, C.POINTER(C.c_void_p)],
         "kiwi_hip_get_synthetics": [vp, C.c_int, C.c_int, C.c_int, C.c_int, c_int_p, c_int_p, c_float_p, C.c_int],
         "kiwi_hip_get_source_centroids": [vp, C.c_int, C.c_int, c_int_p, c_float_p],
         "kiwi_hip_get_reference": [vp, C.c_int, C.c_int, C.c_int, c_int_p, c_int_p, c_float_p, C.c_int],

@@ -48,6 +48,36 @@ def gather_misfits(local, dist=None, device_index=None, counts=None, force=False
     return res.reshape((-1,) + local.shape[1:])
 
 
+class DeviceGather:
+    """The sharded grid search's one collective, device to device: every rank's global misfits go from the engine's own device
+    buffer (Engine.global_misfits_device) into one all-gather over RCCL; the gathered array stays on the device until somebody
+    asks for it (`host()`).  No staging through the host per step (until round 3: device -> numpy -> device -> gather -> host).
+    Shares may differ by one source: shards are padded to the largest."""
+
+    def __init__(self, dist, device_index, counts):
+        import torch
+        self.torch, self.dist, self.counts = torch, dist, list(counts)
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        if len(self.counts) != self.world:
+            raise ValueError("counts do not match the world size")
+        self.dev = torch.device("cuda", device_index)
+        self.nmax = max(self.counts)
+        self.buf = torch.zeros(self.nmax, dtype=torch.float32, device=self.dev)
+        self.out = torch.empty(self.world * self.nmax, dtype=torch.float32, device=self.dev)
+
+    def gather(self, engine, isrc0=0):
+        n = self.counts[self.rank]
+        if n:
+            src = self.torch.as_tensor(engine.global_misfits_device(isrc0, n), device=self.dev)   # (the call synchronises the engine's stream)
+            self.buf[:n].copy_(src)
+        self.dist.all_gather_into_tensor(self.out, self.buf)
+        return self.out
+
+    def host(self):
+        o = self.out.cpu().numpy().reshape(self.world, self.nmax)
+        return np.concatenate([o[r, :self.counts[r]] for r in range(self.world)])
+
+
 def best_source(global_misfits):
     """MisfitGrid's argmin over the trial list (gridsearch.py:250-266): NaNs ignored."""
     g = np.asarray(global_misfits, np.float64)

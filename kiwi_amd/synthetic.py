@@ -73,11 +73,12 @@ def make_receivers(nrec=50, lat0=40.0, lon0=30.0, dmin=150e3, dspan=400e3, comps
 TRUE_BILAT = [0., 0., 0., 10000., 1e20, 91., 87., 164., 0., 4000., 2000., 4000., 3000., 2.]
 
 
-def bilat_strike_sweep(nsrc, step=0.1, base=None):
-    """`bilateral` trial sources differing in strike by `step` degrees (kiwibench.py:136)."""
+def bilat_strike_sweep(nsrc, step=0.1, base=None, first=0):
+    """`bilateral` trial sources differing in strike by `step` degrees (kiwibench.py:136); `first`: index of the sweep's first
+    trial (a rank's shard of a longer sweep holds exactly the parameters the whole sweep holds there)."""
     base = np.array(TRUE_BILAT if base is None else base, np.float32)
     p = np.tile(base, (nsrc, 1))
-    p[:, 5] = base[5] + step * (1 + np.arange(nsrc))
+    p[:, 5] = base[5] + step * (1 + first + np.arange(nsrc))
     return p
 
 
@@ -169,8 +170,7 @@ def workload(name, nsrc=None, trial0=0):
     if name == "cfg3":
         base = [0., 0., 0., 10000., 1e20, 91., 87., 164., 0., 4800., 2000., 2000., 3000., 2.]   # 100 centroids
         n = 256 if nsrc is None else nsrc
-        tr = bilat_strike_sweep(n, step=0.1, base=base)
-        tr[:, 5] += 0.1 * trial0
+        tr = bilat_strike_sweep(n, step=0.1, base=base, first=trial0)
         return dict(name="cfg3-bilat", sourcetype="bilateral", true=np.array(base, np.float32), trials=tr, nrec=50,
                     nx=128, method="l2norm", filter=None, crust=None, constraints=None)
     if name in ("cfg3-w256", "cfg3-w600"):
@@ -184,8 +184,7 @@ def workload(name, nsrc=None, trial0=0):
         # source-time-function steps each (200 centroids)
         base = [0., 0., 0., 10000., 1e20, 91., 87., 164., 0., 12000., 6000., 4500., 3000., 0.5]
         n = 256 if nsrc is None else nsrc
-        tr = bilat_strike_sweep(n, step=0.1, base=base)
-        tr[:, 5] += 0.1 * trial0
+        tr = bilat_strike_sweep(n, step=0.1, base=base, first=trial0)
         return dict(name="cfg3-100pt", sourcetype="bilateral", true=np.array(base, np.float32), trials=tr, nrec=50,
                     nx=128, method="l2norm", filter=None, crust=None, constraints=None)
     if name == "cfg3-scatter":
