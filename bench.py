@@ -422,7 +422,7 @@ def main():
                     help="ranks = GPUs of this node (default: WORLD_SIZE when started by a launcher, else 1)")
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5", "cfg5-td", "cfg3-100pt", "cfg3-scatter", "cfg3-bigdb", "cfg3-w256", "cfg3-w600"],
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5", "cfg5-td", "cfg3-100pt", "cfg3-scatter", "cfg3-bigdb", "cfg3-bigdb4", "cfg3-bigdb4-ordered", "cfg3-w256", "cfg3-w600"],
                     help="BASELINE.json configs[1..4]; cfg3 (default) is the one the metric is quoted on")
     ap.add_argument("--batch", type=int, default=0,
                     help="trial sources per GPU per step (default: 12960 cfg2, 4096 cfg3, 1024 cfg3-scatter / cfg3-bigdb, 512 cfg3-100pt / cfg5 / cfg5-td, 128 cfg4)")
@@ -478,7 +478,7 @@ def main():
     if args.batch <= 0:
         # (cfg3: 4096 sources per step -- 0.14 s -- so that the driver's 20 steps time 2.8 s of device work)
         args.batch = {"cfg2": 12960, "cfg3": 4096, "cfg3-scatter": 1024, "cfg3-bigdb": 1024, "cfg3-100pt": 512, "cfg4": 128, "cfg5": 512,
-                      "cfg5-td": 512, "cfg3-w256": 16384, "cfg3-w600": 8192}[args.workload]
+                      "cfg5-td": 512, "cfg3-w256": 16384, "cfg3-w600": 8192, "cfg3-bigdb4": 1024, "cfg3-bigdb4-ordered": 1024}[args.workload]
     if args.sweep > 0:
         return sweep(args, torch, dist, rank, local_rank, ngpus, force_dist)
     lo, hi = shard_range(args.batch * ngpus, ngpus, rank)
@@ -552,7 +552,7 @@ def main():
             import glob
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json"))):
                 js = json.load(open(f))
-                w = js.get("workloads", {}).get(args.workload)
+                w = js.get("workloads", {}).get(args.workload + ("@fused" if arith == "fused" else ""))
                 if w and w.get("batch") and os.environ.get("KIWI_HIP_ACCUM") != "direct":
                     # counters are quoted only when they were collected on THESE kernel sources
                     if js.get("kernel_sources_sha256") == kernel_sources_sha256():

@@ -13,23 +13,32 @@ def make_gfdb(nx=128, nz=6, ng=10, L=4096, dt=0.5, dx=4000.0, dz=2000.0, firstx=
     variant "probe": the survey's probe database -- damped sinusoids, last sample forced to 0.
     variant "static": adds a non-zero static end value to components 2 and 7 and carves interior
     zero gaps of 9 samples (> maxgap = 5, sparse_trace.f90:25) so that gap-compressed traces with
-    several strips and repeated non-zero end points are exercised."""
-    ix = np.arange(nx)[:, None, None, None]
+    several strips and repeated non-zero end points are exercised.
+    (Evaluated in slabs of distances: the float64 temporaries of a multi-GB database would not fit the host.)"""
     iz = np.arange(nz)[None, :, None, None]
     ig = np.arange(1, ng + 1)[None, None, :, None]
     i = np.arange(L)[None, None, None, :].astype(np.float64)
-    x = firstx + ix * dx
-    val = (1e-20 * np.sin(0.02 * i * (1 + 0.05 * ig) + 0.37 * ig + 0.11 * (iz + 1))
-           * np.exp(-((i - center - center / 15.0 * ig) / width) ** 2) / (x / 1e5))
+    # everything that does not depend on the distance, once
+    shape = (1e-20 * np.sin(0.02 * i * (1 + 0.05 * ig) + 0.37 * ig + 0.11 * (iz + 1))
+             * np.exp(-((i - center - center / 15.0 * ig) / width) ** 2))
+    stat_ramp = None
     if variant == "static":
         ramp = 0.5 * (1 + np.tanh((i - 500.0) / 60.0))
         stat = np.zeros((1, 1, ng, 1))
         stat[0, 0, 1, 0] = 3e-22
         stat[0, 0, 6, 0] = -2e-22
-        val = val + stat * ramp / (x / 1e5)
-        val[..., 300:309] = 0.0
-        val[..., 1000:1009] = 0.0
-    data = val.astype(np.float32)
+        stat_ramp = stat * ramp
+    data = np.empty((nx, nz, ng, L), np.float32)
+    slab = max(1, (1 << 26) // (nz * ng * L))
+    for a in range(0, nx, slab):
+        b = min(nx, a + slab)
+        x = (firstx + np.arange(a, b) * dx)[:, None, None, None]
+        val = shape / (x / 1e5)
+        if variant == "static":
+            val = val + stat_ramp / (x / 1e5)
+            val[..., 300:309] = 0.0
+            val[..., 1000:1009] = 0.0
+        data[a:b] = val.astype(np.float32)
     if variant != "static":
         data[..., -1] = 0.0
     first = np.rint((firstx + np.arange(nx) * dx) / vel / dt).astype(np.int32)
@@ -42,21 +51,32 @@ def pack_gfdb(gf):
     """What a GFDB reader hands the engine for these traces: the reference stores every trace gap-compressed
     (trace_pack, sparse_trace.f90:443-560), so a stored trace begins at its first non-zero sample and ends one sample
     after its last non-zero one when a zero follows (an all-zero trace keeps ONE zero sample at its first position, :490-510).  Returns a new dict with `first`,
-    `nsamp` and left-aligned `data` of the packed traces; interior zero gaps stay as zeros of the dense row."""
+    `nsamp` and left-aligned `data` of the packed traces; interior zero gaps stay as zeros of the dense row.
+    (In slabs of distances, like make_gfdb.)"""
     data = np.ascontiguousarray(gf["data"], np.float32)
     nx, nz, ng, L = data.shape
-    nzm = data != 0
-    anyv = nzm.any(-1)
-    lo = np.where(anyv, nzm.argmax(-1), 0)
-    hi = np.where(anyv, np.minimum(L - 1 - nzm[..., ::-1].argmax(-1) + 1, L - 1), 0)    # "add one of the zeros", :535,545
-    nsamp = (hi - lo + 1).astype(np.int32)
-    first = (np.asarray(gf["first"], np.int64) + lo).astype(np.int32)
-    idx = lo[..., None] + np.arange(L)[None, None, None, :]
-    out = np.take_along_axis(data, np.minimum(idx, L - 1), -1)
-    out[np.arange(L)[None, None, None, :] >= nsamp[..., None]] = 0.0
+    out = np.empty_like(data)
+    nsamp = np.empty((nx, nz, ng), np.int32)
+    first = np.empty((nx, nz, ng), np.int32)
+    slab = max(1, (1 << 25) // (nz * ng * L))
+    ar = np.arange(L)[None, None, None, :]
+    for a in range(0, nx, slab):
+        b = min(nx, a + slab)
+        d = data[a:b]
+        nzm = d != 0
+        anyv = nzm.any(-1)
+        lo = np.where(anyv, nzm.argmax(-1), 0)
+        hi = np.where(anyv, np.minimum(L - 1 - nzm[..., ::-1].argmax(-1) + 1, L - 1), 0)    # "add one of the zeros", :535,545
+        ns = (hi - lo + 1).astype(np.int32)
+        nsamp[a:b] = ns
+        first[a:b] = (np.asarray(gf["first"][a:b], np.int64) + lo).astype(np.int32)
+        idx = lo[..., None] + ar
+        o = np.take_along_axis(d, np.minimum(idx, L - 1), -1)
+        o[ar >= ns[..., None]] = 0.0
+        out[a:b] = o
     lmax = int(nsamp.max())
     g = dict(gf)
-    g.update(data=np.ascontiguousarray(out[..., :lmax]), first=first, nsamp=nsamp)
+    g.update(data=np.ascontiguousarray(out[..., :lmax]) if lmax < L else out, first=first, nsamp=nsamp)
     return g
 
 
@@ -214,6 +234,21 @@ def workload(name, nsrc=None, trial0=0):
         tr[:, 3] = 8000.0 + 2000.0 * (idx // 512)
         return dict(name="cfg3-bigdb", sourcetype="bilateral", true=np.array(base, np.float32), trials=tr, nrec=50,
                     nx=512, nz=12, method="l2norm", filter=None, crust=None, constraints=None)
+    if name in ("cfg3-bigdb4", "cfg3-bigdb4-ordered"):
+        # the HBM regime proper: a 4.2 GB database (2048 x 12 nodes) -- sixteen times the 256 MiB
+        # Infinity Cache, so that at most a sixteenth of the memory-side traffic can be cache hits -- and trial locations 4 km
+        # apart (one per distance node) over the whole distance range and ten depths; shuffled, or ("-ordered") in the order a
+        # P3 location grid delivers them (first parameter slowest: neighbours in the list are neighbours in depth, then distance)
+        base = [0., 0., 0., 10000., 1e20, 91., 87., 164., 0., 4800., 2000., 2000., 3000., 2.]
+        n = 256 if nsrc is None else nsrc
+        total = 19000
+        k = (trial0 + np.arange(n)) % total
+        idx = np.random.default_rng(20261004).permutation(total)[k] if name == "cfg3-bigdb4" else k
+        tr = np.tile(np.array(base, np.float32), (n, 1))
+        tr[:, 1] = 4000.0 * (idx // 10) - 3900e3
+        tr[:, 3] = 8000.0 + 2000.0 * (idx % 10)
+        return dict(name=name, sourcetype="bilateral", true=np.array(base, np.float32), trials=tr, nrec=50,
+                    nx=2048, nz=12, method="l2norm", filter=None, crust=None, constraints=None)
     if name == "cfg4":
         grid = mt_eikonal_location_grid()
         n = 32 if nsrc is None else nsrc

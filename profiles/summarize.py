@@ -1,6 +1,22 @@
 #!/usr/bin/env python3
-"""Condenses rocprofv3 output directories (gpurun_out/<tag>_*) into profiles/<tag>_summary.json +
-copies of the kernel-stats CSVs.  Usage: python profiles/summarize.py r01 gpurun_out r1"""
+"""Condenses the rocprofv3 output of profiles/collect.sh into profiles/<tag>_summary.json (+ the kernel-stats CSVs).
+Usage (in the repo, after the gpurun call has merged its output): python profiles/summarize.py r04 gpurun_out/r04
+Workload keys: `<workload>` (exact arithmetic contract) and `<workload>@fused`.
+Records the commit and a hash of the kernel sources the passes were taken on: bench.py attaches these counters to its line
+only when its own build comes from the same sources (`roofline.profile_head`).
+
+Per workload the summary holds what bench.py's `roofline` block quotes (keys under "workloads"):
+  ("per launch" = per bench step: a step over a large batch is several dispatches, launches_per_step)
+  hbm_bytes_per_launch        FETCH_SIZE x 2 (gfx950: wide coalesced reads are tallied at half their bytes,
+                              MI355X_MICROARCH.md "HBM") + WRITE_SIZE, summed over the accumulate kernels of one step.
+                              These are the L2's memory-side requests: Infinity-Cache hits are included, so this is an
+                              upper bound of what reached HBM.
+  l2_request_bytes_per_launch (TCC_HIT_sum + TCC_MISS_sum) x 128 B
+  valu_insts_per_launch       SQ_INSTS_VALU (wave instructions)
+  valu_issue_frac             SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8
+  lds_busy_frac               SQ_LDS_IDX_ACTIVE / (256 CUs x kernel cycles)
+  accumulate_ms               median duration per step of the accumulate kernels (kernel trace)
+"""
 import csv
 import glob
 import json
@@ -8,66 +24,100 @@ import os
 import shutil
 import sys
 
-tag, src, prefix = sys.argv[1], sys.argv[2], sys.argv[3]
-out = {"tag": tag, "command": "rocprofv3 ... -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline",
-       "note": "counter values are per dispatch of the accumulate kernel (median over dispatches); "
-               "FETCH_SIZE / WRITE_SIZE are in KiB as rocprofv3 reports them"}
+tag, src = sys.argv[1], sys.argv[2]
+here = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(here))
+import subprocess  # noqa: E402
+import bench  # noqa: E402
+head = subprocess.run(["git", "-C", os.path.dirname(here), "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+dirty = bool(subprocess.run(["git", "-C", os.path.dirname(here), "status", "--porcelain", "kiwi_amd/csrc"], capture_output=True, text=True).stdout.strip())
+out = {"tag": tag, "command": "rocprofv3 <pass> -- python3 bench.py --workload <w> --steps 5 --warmup 2 --no-cpu-baseline --no-also",
+       "head": (head + ("+uncommitted kernel changes" if dirty else "")) if head else None, "kernel_sources_sha256": bench.kernel_sources_sha256(),
+       "note": "per step = sum over the accumulate kernels of one bench step of the per-dispatch medians; FETCH_SIZE / WRITE_SIZE "
+               "are in KiB as rocprofv3 reports them", "workloads": {}}
+# a re-collection of some workloads keeps the entries of the others
+_prev = os.path.join(here, tag + "_summary.json")
+if os.path.exists(_prev):
+    try:
+        _p = json.load(open(_prev))
+        if _p.get("kernel_sources_sha256") == out["kernel_sources_sha256"]:
+            out["workloads"].update(_p.get("workloads", {}))
+    except ValueError:
+        pass
 
 
-def counters(d, match):
-    fs = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv")) + glob.glob(os.path.join(src, d, "*_counter_collection.csv"))
-    res = {}
-    if not fs:
-        return res
+def counters(d):
+    """{kernel name: {counter: median over dispatches}}"""
+    fs = glob.glob(os.path.join(src, d, "**", "*_counter_collection.csv"), recursive=True)
     vals = {}
+    if not fs:
+        return {}
     for r in csv.DictReader(open(fs[0])):
-        if match in r["Kernel_Name"]:
-            vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-    for k, v in vals.items():
-        v.sort()
-        res[k] = {"median": v[len(v) // 2], "dispatches": len(v)}
+        if "accumulate" in r["Kernel_Name"]:
+            vals.setdefault(r["Kernel_Name"], {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    res = {}
+    for k, cs in vals.items():
+        res[k] = {"_dispatches": max(len(v) for v in cs.values())}
+        for c, v in cs.items():
+            v.sort()
+            res[k][c] = v[len(v) // 2]
     return res
 
 
-for d, key, match in ((prefix + "_fetch", "grouped", "accumulate_grouped"), (prefix + "_write", "grouped", "accumulate_grouped"),
-                      (prefix + "_l2", "grouped", "accumulate_grouped"), (prefix + "_sq", "grouped", "accumulate_grouped"),
-                      (prefix + "_sq2", "grouped", "accumulate_grouped"), (prefix + "_fetch_direct", "direct", "accumulate_kernel")):
-    out.setdefault(key, {}).update(counters(d, match))
-old = {}
-try:
-    old = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), tag + "_summary.json")))
-except Exception:
-    pass
-for k in ("direct", "kernel_stats_direct.csv"):          # the A/B baseline kernel is profiled once per round
-    if k in old:
-        out[k] = old[k]
-for d, name in ((prefix + "_kt", "kernel_stats.csv"), (prefix + "_kt_direct", "kernel_stats_direct.csv")):
-    fs = glob.glob(os.path.join(src, d, "*", "*_kernel_stats.csv")) + glob.glob(os.path.join(src, d, "*_kernel_stats.csv"))
+def total(cnt, name):
+    """sum over the accumulate kernels of a TIMED step: the instantiations dispatched every step (the set-up evaluation that
+    makes the reference traces runs the unfused instantiation once and is left out; the complement launch of the cell mode
+    is dispatched every step and nearly empty)"""
+    if not cnt:
+        return 0.0
+    most = max(c["_dispatches"] for c in cnt.values())
+    return sum(c.get(name, 0.0) for c in cnt.values() if c["_dispatches"] >= most - 1 and c["_dispatches"] > 2)
+
+
+for f in sorted(glob.glob(os.path.join(src, "bench_*.json"))):
+    w = os.path.basename(f)[len("bench_"):-len(".json")]
+    try:
+        line = json.loads([l for l in open(f).read().splitlines() if l.startswith("{")][-1])
+    except Exception:
+        continue
+    # a step over a large batch is several launches (the engine bounds its workspace): counters and durations are per-dispatch
+    # medians, a step is `lps` of them
+    lps = max(1, int(round(line["roofline"]["launches"] / float(line["steps"])))) if line.get("roofline") else 1
+    e = {"batch": line["config"]["trial_sources_per_gpu_per_step"], "launches_per_step": lps, "arithmetic": line.get("arithmetic", "exact"),
+         "bench_line_under_rocprof": line}
+    c_f, c_w, c_l2, c_sq, c_sq2 = (counters(p + "_" + w) for p in ("fetch", "write", "l2", "sq", "sq2"))
+    if c_f and c_w:
+        rd = total(c_f, "FETCH_SIZE") * 1024 * 2 * lps
+        wr = total(c_w, "WRITE_SIZE") * 1024 * lps
+        e["hbm_bytes_per_launch"] = rd + wr
+        e["fabric_read_corrected"] = rd
+        e["fabric_write"] = wr
+    if c_l2:
+        hit, miss = total(c_l2, "TCC_HIT_sum"), total(c_l2, "TCC_MISS_sum")
+        e["l2_request_bytes_per_launch"] = (hit + miss) * 128 * lps
+        e["l2_hit_rate"] = hit / (hit + miss) if hit + miss else None
+    if c_sq2:
+        cyc = total(c_sq2, "GRBM_GUI_ACTIVE") / 8.0 * lps
+        e["kernel_cycles"] = cyc
+        e["valu_insts_per_launch"] = total(c_sq2, "SQ_INSTS_VALU") * lps
+        if cyc:
+            e["valu_issue_frac"] = e["valu_insts_per_launch"] * 4.0 / (1024.0 * cyc)
+            e["lds_busy_frac"] = total(c_sq2, "SQ_LDS_IDX_ACTIVE") * lps / (256.0 * cyc)
+            e["scalar_issue_frac"] = total(c_sq2, "SQ_ACTIVE_INST_SCA") * lps / (1024.0 * cyc)
+        e["lds_bank_conflict_cycles"] = total(c_sq2, "SQ_LDS_BANK_CONFLICT") * lps
+    e["counters"] = {"sq": c_sq, "sq2": c_sq2, "l2": c_l2, "fetch": c_f, "write": c_w}
+    # kernel stats of the trace pass
+    fs = glob.glob(os.path.join(src, "kt_" + w, "**", "*_kernel_stats.csv"), recursive=True)
     if fs:
-        dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "%s_%s" % (tag, name))
-        shutil.copy(fs[0], dst)
+        shutil.copy(fs[0], os.path.join(here, "%s_kernel_stats_%s.csv" % (tag, w)))
         rows = list(csv.DictReader(open(fs[0])))
-        out[name] = [{"name": r["Name"][:60], "calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
-                      "pct": float(r["Percentage"])} for r in rows[:6]]
-# per-dispatch durations from the kernel trace: the first launches of a process run at warm-up clocks
-# (and the very first one loads the code object), so the median is the steady-state figure
-fs = glob.glob(os.path.join(src, prefix + "_kt", "*", "*_kernel_trace.csv")) + glob.glob(os.path.join(src, prefix + "_kt", "*_kernel_trace.csv"))
-if fs:
-    dur = {}
-    for r in csv.DictReader(open(fs[0])):
-        dur.setdefault(r["Kernel_Name"][:60], []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
-    out["kernel_trace_ms"] = {k: {"median": sorted(v)[len(v) // 2], "min": min(v), "max": max(v), "calls": len(v)}
-                              for k, v in dur.items() if "kiwi::" in k}
-bj = os.path.join(src, prefix + "_bench_under_rocprof.json")
-if os.path.exists(bj):
-    out["bench_line_under_rocprof"] = json.loads(open(bj).read().strip().splitlines()[-1])
-g = out.get("grouped", {})
-if "FETCH_SIZE" in g and "WRITE_SIZE" in g:
-    # gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section)
-    rd = g["FETCH_SIZE"]["median"] * 1024 * 2
-    wr = g["WRITE_SIZE"]["median"] * 1024
-    out["traffic_bytes_per_launch"] = {"read_corrected": rd, "write": wr, "total": rd + wr,
-                                       "batch": out.get("bench_line_under_rocprof", {}).get("config", {}).get("trial_sources_per_gpu_per_step"),
-                                       "workload": "cfg3"}
-json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), tag + "_summary.json"), "w"), indent=1)
-print(json.dumps(out, indent=1)[:3000])
+        e["kernel_stats"] = [{"name": r["Name"][:70], "calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
+                              "pct": float(r["Percentage"])} for r in rows[:8]]
+        acc = [r for r in rows if "accumulate" in r["Name"]]
+        if acc:                              # the timed steps' kernels (the set-up launch uses the unfused instantiation once)
+            most = max(int(r["Calls"]) for r in acc)
+            e["accumulate_ms"] = lps * sum(float(r["AverageNs"]) / 1e6 for r in acc if int(r["Calls"]) >= most - 1 and int(r["Calls"]) > 2)
+    out["workloads"][w] = e
+json.dump(out, open(os.path.join(here, tag + "_summary.json"), "w"), indent=1)
+for w, e in out["workloads"].items():
+    print(w, {k: (round(v, 4) if isinstance(v, float) else v) for k, v in e.items() if k not in ("counters", "bench_line_under_rocprof", "kernel_stats")})

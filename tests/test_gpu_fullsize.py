@@ -409,6 +409,16 @@ def test_multi_device_context_equals_one_device(tmp_path, monkeypatch):
                                for i in range(7)], np.float32)
             trials[1, 10] = 150.0; trials[5, 10] = 170.0          # two transform lengths in the list
             m, n, gl, st = p.misfits_for_params("moment_tensor", trials, 2)
+            # a setter forwarded to the other devices, then getters on the owning context: the owner's device must be the
+            # current one again (the forward left the LAST device current, prepare() then allocated the owner's tables
+            # there -- invisible with both contexts stacked on one device, a fault on two)
+            if with_filter:
+                for ir in range(1, sc.nrec + 1):
+                    p.set_misfit_filter(ir, [0.01, 0.03, 0.25, 0.4], [0., 1., 1., 0.])
+                lo_f, syn_f = p.get_synthetics(0, 1, 1, 3)
+                p.eval(0, 1)
+                gm2 = p.get_misfits(0, 1)[0]
+                assert len(syn_f) > 10 and np.all(np.isfinite(syn_f)) and np.array_equal(gm2[0], m[0])
             res.append((m, n, gl, st))
             p.close()
         for other in res[1:]:
