@@ -245,6 +245,10 @@ int ko_engine_cross_correlations(ko_engine *e, int irec1, int lo, int hi, float 
 int ko_engine_amp_spectrum(ko_engine *e, int irec1, int icomp1, int synthetic, int filtered, float *df, float *out, int maxn);
 int ko_engine_shake(ko_engine *e, int differentiate, float *out);   /* get_peak_amplitudes (1, 2) / get_arias_intensities (0) */
 void ko_engine_set_nthreads(ko_engine *e, int n);
+/* precision of the comparator's transforms: 64 (default: an exact DFT rounded once) or 32 (a textbook fp32 radix-2 FFT, the second
+ * checker of the spectral tolerances); process-wide, set before the probes are evaluated */
+void ko_set_fft_precision(int bits);
+int ko_get_fft_precision(void);
 /* the three private engine steps (minimizer_engine.f90:885-945) */
 void ko_engine_calculate_seismograms(ko_engine *e);
 void ko_engine_scale_seismograms(ko_engine *e);

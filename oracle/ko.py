@@ -227,6 +227,14 @@ def discretize(sourcetype, params, effective_dt):
     return arr, float(psm.moment), float(psm.risetime), tuple(psm.grid_size)
 
 
+def set_fft_precision(bits):
+    """64 (default): the comparator's transforms are an exact DFT rounded once; 32: a textbook fp32 radix-2 FFT (second checker of the
+    spectral tolerances).  Process-wide; engines evaluate their probes with the precision in force at that moment."""
+    L = lib()
+    L.ko_set_fft_precision.argtypes = [C.c_int]
+    L.ko_set_fft_precision(int(bits))
+
+
 class Gfdb:
     def __init__(self, nx, nz, ng, dt, dx, dz, firstx, firstz):
         self.nx, self.nz, self.ng = nx, nz, ng

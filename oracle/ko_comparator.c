@@ -204,6 +204,47 @@ static void fft_c(double *re, double *im, int n, int sign)
     }
 }
 
+/* The same radix-2 algorithm with every operation in fp32 (twiddles: cos / sin in double, rounded once): a textbook fp32 FFT,
+ * the SECOND checker of the spectral norms (tests/test_oracle_fft32.py): what it changes in a misfit is the round-off any
+ * fp32 transform of that length brings -- the device's in-LDS radix-4 and hipFFT are such transforms, FFTW's single-precision
+ * library in the reference is another --, and tests/common.py fft_roundoff_bound has to hold it.  ko_set_fft_precision(32). */
+static int g_fft_bits = 64;
+void ko_set_fft_precision(int bits) { g_fft_bits = (bits == 32) ? 32 : 64; }
+int ko_get_fft_precision(void) { return g_fft_bits; }
+
+static void fft_c32(float *re, float *im, int n, int sign)
+{
+    for (int i = 1, j = 0; i < n; i++) {
+        int bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { float t = re[i]; re[i] = re[j]; re[j] = t; t = im[i]; im[i] = im[j]; im[j] = t; }
+    }
+    for (int len = 2; len <= n; len <<= 1) {
+        double ang = sign * 2.0 * M_PI / len;
+        for (int i = 0; i < n; i += len)
+            for (int k = 0; k < len / 2; k++) {
+                const float wr = (float)cos(ang * k), wi = (float)sin(ang * k);
+                int u = i + k, v = i + k + len / 2;
+                const float a = re[v] * wr, b = im[v] * wi, c = re[v] * wi, d = im[v] * wr;
+                const float xr = a - b, xi = c + d;
+                re[v] = re[u] - xr; im[v] = im[u] - xi;
+                re[u] = re[u] + xr; im[u] = im[u] + xi;
+            }
+    }
+}
+
+/* transform of n doubles held in re / im at the precision in force */
+static void fft_any(double *re, double *im, int n, int sign)
+{
+    if (g_fft_bits == 64) { fft_c(re, im, n, sign); return; }
+    float *fr = (float *)malloc(sizeof(float) * 2 * (size_t)n), *fi = fr + n;
+    for (int i = 0; i < n; i++) { fr[i] = (float)re[i]; fi[i] = (float)im[i]; }
+    fft_c32(fr, fi, n, sign);
+    for (int i = 0; i < n; i++) { re[i] = fr[i]; im[i] = fi[i]; }
+    free(fr);
+}
+
 /* comparator.f90:1186-1216 */
 static void make_spectrum(ko_probe *p)
 {
@@ -220,7 +261,7 @@ static void make_spectrum(ko_probe *p)
     const float *src = (p->taper.n > 0) ? p->array_tapered : p->array;
     double *re = (double *)malloc(sizeof(double) * 2 * (size_t)ntrans), *im = re + ntrans;
     for (int i = 0; i < ntrans; i++) { re[i] = src[i]; im[i] = 0.0; }
-    fft_c(re, im, ntrans, -1);
+    fft_any(re, im, ntrans, -1);
     for (int k = 0; k < ns; k++) {
         p->spectrum[2 * k] = (float)re[k]; p->spectrum[2 * k + 1] = (float)im[k];
         p->amp_spectrum[k] = hypotf(p->spectrum[2 * k], p->spectrum[2 * k + 1]);
@@ -251,7 +292,7 @@ static void make_array_filtered(ko_probe *p)
     for (int k = 0; k < p->nspec; k++) { re[k] = p->spectrum_filtered[2 * k]; im[k] = p->spectrum_filtered[2 * k + 1]; }
     im[0] = 0.0; im[ntrans / 2] = 0.0;                 /* c2r ignores them */
     for (int k = 1; k < ntrans / 2; k++) { re[ntrans - k] = re[k]; im[ntrans - k] = -im[k]; }
-    fft_c(re, im, ntrans, +1);
+    fft_any(re, im, ntrans, +1);
     for (int i = 0; i < ntrans; i++) p->array_filtered[i] = (float)re[i];
     free(re);
     for (int i = 0; i < ntrans; i++) p->array_filtered[i] = p->array_filtered[i] / (float)ntrans;

@@ -11,7 +11,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from kiwi_amd import synthetic  # noqa: E402
-from tests.common import Scenario, oracle_misfits, spectral_tol, SPECTRAL_NORM_TOL, arith  # noqa: E402
+from tests.common import Scenario, oracle_misfits, slot_scales, spectral_close, arith  # noqa: E402
 
 FAMILIES = ["ac", "rl", "du", "ns", "ew"]            # a component and its negated twin exclude each other (receiver.f90:255-270)
 
@@ -156,23 +156,16 @@ def one_case(rng, verbose):
     p.set_source_params(name, tr)
     p.eval()
     pm, pn, pg = p.get_misfits()
-    if spectral or filtered:                                   # fp32 FFT vs the oracle's fp64 DFT: relative to the norm factor
-        # ... or to the misfit where that is the larger one (a synthetic much bigger than the reference: the round-off of ITS
-        # transforms is what shows; seen: 3.4e-5 of the norm factor = 1.5e-5 of the misfit at misfit / norm = 2.3, L = 2300)
-        scale = np.maximum(np.maximum(nn, np.abs(m)), 1e-30)
-        # an l1 sum over a filtered trace adds the fp32 round-off of the two transforms (~ eps log2 N of the peak per sample)
-        # linearly over the window: relative to the norm factor that grows with the crest factor (seen: 5.2e-4 at L = 2300)
-        # seen: ampspec_l1norm 2.3e-5 at L = 2300; time-domain l2 on filtered traces 2.4e-5 at L = 2300 (two cases of 34 000, in-LDS
-        # transform pair before its complex products were fused multiply-adds)
-        tol = spectral_tol(method, filtered)                   # tests/common.py: the one table of these tolerances
-        bad = np.abs(pm - m) > tol * scale
-        # norm factor of a FILTERED reference: where the filter rejects almost all of a trace, the transforms' round-off (relative
-        # to the unfiltered trace) is what is left of the small remainder (seen, in-LDS transforms: 2.5e-5 of a slot's l2 norm
-        # factor; 1.0e-3 of an l1 norm factor fifty times below the case's largest) -- such slots are judged on the scale of a
-        # twentieth of the case's largest norm factor
-        ntol = max(tol, SPECTRAL_NORM_TOL) if filtered else tol
-        nscale = np.maximum(nn[0], 0.05 * nn[0].max()) if filtered else nn[0]
-        ok = bool(np.all(np.abs(pn[0] - nn[0]) <= ntol * nscale)) and not bad.any()
+    if spectral or filtered:
+        # fp32 transforms against the oracle's fp64 DFT: MISFIT_RTOL of max(norm factor, misfit) plus the round-off an fp32
+        # transform of that length explains (tests/common.py fft_roundoff_bound: grows with log2 N, with the window length for an
+        # L1 sum and with what the frequency filter rejects); slots without a frequency filter under a time-domain norm are
+        # compared on the plain tapered arrays and get no round-off term (they pass through no transform)
+        scales = slot_scales(e, comps, dt)
+        ok, ratio = spectral_close(method, dt, pm[0], m[0], nn[0], scales, pn[0])
+        bad = np.zeros_like(pm, bool)
+        if os.environ.get("KIWI_FUZZ_STATS"):
+            print("FFTSTAT %s filtered=%d L=%d ntrans=%d ratio=%.3f" % (method, int(filtered), L, int(scales[0].max()), ratio))
     else:
         # (fused arithmetic contract: relative to max(misfit, norm factor), tests/common.py misfit_close)
         scale = np.maximum(np.abs(m), (1.0 if arith() == "fused" else 1e-6) * np.maximum(nn, 1e-30))
