@@ -923,7 +923,7 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
         // KIWI_HIP_POISON=1 (tests): rows keep nothing from earlier evaluations -- a descriptor line the kernel reads but
         // geometry_kernel did not write shows as a wild address instead of passing by accident
         if (std::getenv("KIWI_HIP_POISON")) HIPCHECK(hipMemsetAsync(tab, 0x7f, (size_t)(cend - cbeg) * nrec * 128 * sizeof(int), c->stream));
-        c->coef_d.ensure((size_t)(cend - cbeg) * nrec * kCoefLine, &c->dev_bytes);
+        c->coef_d.ensure((size_t)(cend - cbeg) * nrec * kCoefLine + 160, &c->dev_bytes);   // (+ 640 bytes: accumulate_multi_kernel warms 512 bytes from a group's first line)
     }
     // ---- sources of this chunk that can take an earlier source's synthetics (same centroid table, same chunk): not
     // synthesised, compared from that source's row with their own moment and rise time.  Plain time-domain comparator only.
