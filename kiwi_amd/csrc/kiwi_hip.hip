@@ -207,6 +207,8 @@ struct kiwi_hip_ctx {
     std::vector<int> slot_has_filter;
     DevBuf<int> spanbuf_d, ntr_d;
     DevBuf<float> fft_d, refamp_d, filtw_d, reffilt_d, zmask_d, normsrc_d;
+    DevBuf<float> refpair_d, reffiltpair_d;                      // un-tapered slots: reference spectrum / filtered reference per PAIR (SpecParams)
+    bool untapered_fft = false;                                  // some un-tapered slot goes through the transforms
     DevBuf<float2> spec_d;
     DevBuf<FftPair> pairs_d;
     int *ntr_pin = nullptr; size_t ntr_pin_n = 0;               // pinned staging: transform lengths down, pair table up
@@ -513,9 +515,11 @@ void prepare(kiwi_hip_ctx *c)
     c->any_filter = false;
     for (auto &r : c->recv) if (r.enabled && r.ncomp > 0 && r.filter.defined()) c->any_filter = true;
     if (c->floating && c->any_filter) throw std::runtime_error("floating norms with a misfit filter are not supported by the device comparator");
-    if (c->any_untapered && (c->any_filter || c->method == KIWI_AMPSPEC_L2NORM || c->method == KIWI_AMPSPEC_L1NORM))
-        throw std::runtime_error("spectral norms and misfit filters need a misfit taper on every enabled receiver in the device comparator");
     c->fft_needed = !c->synth_only && (c->method == KIWI_AMPSPEC_L2NORM || c->method == KIWI_AMPSPEC_L1NORM || c->any_filter);
+    // Spectral norms / filters on a receiver without a taper (comparator.f90:861-886 over the whole padded probes): the probes' common
+    // span follows the PAIR (fresh-engine semantics as for the un-tapered time-domain norms), so the reference side is transformed per
+    // pair as well -- through the library transforms, see run_chunk
+    c->untapered_fft = c->fft_needed && c->any_untapered;
     c->prepared = true;
 }
 
@@ -636,6 +640,7 @@ __global__ void ref_filt_kernel(const float *__restrict__ fftbuf, const FftPair 
 {
     const FftPair pr = pairs[blockIdx.x];
     const CompDev cd = comps[pr.slot];
+    if (cd.untapered) return;                  // (the window of an un-tapered slot may be longer than the row; its filtered reference is the pair's)
     const float *row = fftbuf + pr.fft_ofs;
     for (int i = threadIdx.x; i < cd.wlen; i += blockDim.x)
         ref_filt[pr.filtofs + i] = (row[i] / (float)pr.ntrans) * zmask[cd.refofs + i];
@@ -685,7 +690,7 @@ void prepare_fft(kiwi_hip_ctx *c, const std::vector<float> &reft_host)
     std::vector<float> zm(reft_host.size(), 1.f);
     for (size_t m = 0; m < c->comps.size(); m++) {
         const CompDev &cd = c->comps[m];
-        plf_taper_array(c->recv[cd.rec].taper, zm.data() + cd.refofs, cd.w0, cd.w0 + cd.wlen - 1, dt, IP_ZERO_ONE);
+        if (c->recv[cd.rec].taper.defined()) plf_taper_array(c->recv[cd.rec].taper, zm.data() + cd.refofs, cd.w0, cd.w0 + cd.wlen - 1, dt, IP_ZERO_ONE);
     }
     c->zmask_d.ensure(zm.size(), &c->dev_bytes);
     HIPCHECK(hipMemcpyAsync(c->zmask_d.p, zm.data(), zm.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
@@ -744,6 +749,7 @@ void make_variants(kiwi_hip_ctx *c, const std::vector<std::pair<int, int>> &want
         std::vector<float> rows((size_t)fofs, 0.f);
         for (auto &pr : prs) {
             const CompDev &cd = c->comps[pr.slot];
+            if (cd.untapered) continue;            // the reference array of an un-tapered slot follows the pair's span: made per pair on the device (run_chunk); only the filter weights of (slot, ntrans) are kept here
             std::memcpy(rows.data() + pr.fft_ofs, c->reft_h.data() + cd.refofs, (size_t)cd.wlen * sizeof(float));
         }
         HIPCHECK(hipMemcpyAsync(c->fft_d.p, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
@@ -759,7 +765,7 @@ void make_variants(kiwi_hip_ctx *c, const std::vector<std::pair<int, int>> &want
             i = j;
         }
     };
-    bool fused = spectral;
+    bool fused = spectral && !c->untapered_fft;          // (un-tapered slots: library transforms throughout, see run_chunk)
     int longest = 0;
     for (auto &pr : prs) { fused = fused && fused_fft_takes(c, pr.ntrans); longest = std::max(longest, pr.ntrans); }
     if (fused) {
@@ -775,7 +781,7 @@ void make_variants(kiwi_hip_ctx *c, const std::vector<std::pair<int, int>> &want
         hipLaunchKernelGGL(ref_amp_kernel, dim3((unsigned)prs.size()), dim3(256), 0, c->stream, c->spec_d.p, prs_d.p, c->filtw_d.p, c->refamp_d.p);
     }
     if (c->any_filter && !spectral) {
-        bool ffused = true;
+        bool ffused = !c->untapered_fft;
         for (auto &pr : prs) ffused = ffused && fused_fft_takes(c, pr.ntrans);
         if (ffused) {
             // filtered references by the transform pair the trial sources go through (spec_fft_filter_norm_kernel); the rows in
@@ -871,6 +877,10 @@ void layout_fft_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc)
     }
     c->fft_d.ensure((size_t)fb, &c->dev_bytes);                 // within the capacity prepare_fft laid out; grows only if not
     c->spec_d.ensure((size_t)sbase, &c->dev_bytes);
+    if (c->untapered_fft) {
+        c->refpair_d.ensure((size_t)sbase, &c->dev_bytes);
+        c->reffiltpair_d.ensure((size_t)fb, &c->dev_bytes);
+    }
     pin_ensure(c->pairs_pin, c->pairs_pin_n, np);
     c->norm_src_h.resize((size_t)c->nsrc * c->nmis, 0.f);
     int last_ntr = -1; size_t last_b = 0;
@@ -1170,15 +1180,37 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
         }
         // amplitude-spectrum norms whose transforms fit spec_fft_norm_kernel: that kernel takes the plain synthetics itself
         // (fold, moment, taper while the row goes into LDS) unless the processed synthetics are to be kept
-        bool spec_fused = spectral && c->fft_needed;
+        bool spec_fused = spectral && c->fft_needed && !c->untapered_fft;
         int spec_longest = 0;
         if (spec_fused) for (auto &b : c->buckets) { spec_fused = spec_fused && fused_fft_takes(c, b.ntrans); spec_longest = std::max(spec_longest, b.ntrans); }
         const bool spec_direct = spec_fused && !proc && !fuse;
         // time-domain norms on filtered traces: the same in-LDS transform, forward and back (spec_fft_filter_norm_kernel)
-        bool filt_fused = !spectral && c->fft_needed && !proc && !fuse;
+        bool filt_fused = !spectral && c->fft_needed && !proc && !fuse && !c->untapered_fft;
         int filt_longest = 0;
         if (filt_fused) for (auto &b : c->buckets) { filt_fused = filt_fused && fused_fft_takes(c, b.ntrans); filt_longest = std::max(filt_longest, b.ntrans); }
         if (filt_fused) mp.fft_mode |= 4;
+        SpecParams sp{ c->method, c->gm.dt, c->syn_factor, c->nmis, isrc0, c->any_filter ? 1 : 0 };
+        if (c->untapered_fft) {
+            // Un-tapered slots, reference side first: the reference's padded array over every PAIR's span through the same
+            // transforms -> amplitude spectrum (x filter) or filtered trace per pair + the pair's norm factor.  (Before
+            // misfit_kernel writes the tapered slots' rows: the way back of the filter overwrites every row.)  Behind it the
+            // synthetics' arrays take the un-tapered slots' rows and everything goes through the transforms together.
+            sp.refpair = c->refpair_d.p; sp.reffiltpair = c->reffiltpair_d.p;
+            const dim3 pg((unsigned)c->nmis, (unsigned)nsrc);
+            hipLaunchKernelGGL(untapered_rows_kernel<true>, pg, dim3(256), 0, c->stream, c->syn_d.p, c->syn_stride, c->comps_d.p, c->reft_d.p,
+                               c->moment_d.p, c->risetime_d.p, isrc0, c->gm.dt, c->nmis, spansrc, nrec, c->pairs_d.p, c->fft_d.p);
+            fft_buckets(c, true);
+            if (spectral) {
+                hipLaunchKernelGGL(pair_refamp_kernel, pg, dim3(256), 0, c->stream, c->spec_d.p, c->pairs_d.p, c->comps_d.p, c->filtw_d.p, sp,
+                                   c->refpair_d.p, c->normsrc_d.p);
+            } else {
+                hipLaunchKernelGGL(spec_filter_kernel, dim3((unsigned)(c->nmis * nsrc)), dim3(256), 0, c->stream,
+                                   c->spec_d.p, c->pairs_d.p, c->comps_d.p, c->filtw_d.p);
+                fft_buckets(c, false);
+                hipLaunchKernelGGL(pair_reffilt_kernel, pg, dim3(256), 0, c->stream, c->fft_d.p, c->pairs_d.p, c->comps_d.p, sp, spansrc, nrec,
+                                   c->risetime_d.p, c->reffiltpair_d.p, c->normsrc_d.p, c->reffilt_d.p);
+            }
+        }
         if (!fuse && !spec_direct)
         hipLaunchKernelGGL(misfit_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream,
                            c->syn_d.p, c->syn_stride, c->comps_d.p, c->reft_d.p, c->tw_d.p, c->moment_d.p,
@@ -1194,7 +1226,11 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
                                isrc0, nsrc, c->misfit_d.p, c->fshift_d.p);
         }
         if (c->fft_needed) {
-            SpecParams sp{ c->method, c->gm.dt, c->syn_factor, c->nmis, isrc0, c->any_filter ? 1 : 0 };
+            if (c->untapered_fft) {
+                const dim3 pg((unsigned)c->nmis, (unsigned)nsrc);
+                hipLaunchKernelGGL(untapered_rows_kernel<false>, pg, dim3(256), 0, c->stream, c->syn_d.p, c->syn_stride, c->comps_d.p, c->reft_d.p,
+                                   c->moment_d.p, c->risetime_d.p, isrc0, c->gm.dt, c->nmis, spansrc, nrec, c->pairs_d.p, c->fft_d.p);
+            }
             if (spec_fused) {
                 // transform, amplitude, filter and norm of every (slot, source) row in one pass through LDS
                 for (auto &b : c->buckets) fused_fft_table(c, b.ntrans);
@@ -1208,7 +1244,7 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
             } else if (spectral) {
                 fft_buckets(c, true);
                 hipLaunchKernelGGL(spec_norm_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream,
-                                   c->spec_d.p, c->pairs_d.p, c->refamp_d.p, c->filtw_d.p, sp, c->misfit_d.p);
+                                   c->spec_d.p, c->pairs_d.p, c->refamp_d.p, c->filtw_d.p, sp, c->misfit_d.p, c->comps_d.p);
             } else if (filt_fused) {
                 for (auto &b : c->buckets) fused_fft_table(c, b.ntrans);
                 const SynRows sr{ c->syn_d.p, c->syn_stride, c->comps_d.p, c->tw_d.p, c->moment_d.p, c->risetime_d.p, synrow };
@@ -1222,7 +1258,7 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
                 fft_buckets(c, false);
                 hipLaunchKernelGGL(filtered_norm_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream,
                                    c->fft_d.p, c->comps_d.p, c->pairs_d.p, c->reffilt_d.p, c->zmask_d.p, sp, c->misfit_d.p,
-                                   proc_which == 3 ? proc : nullptr, c->syn_stride);
+                                   proc_which == 3 ? proc : nullptr, c->syn_stride, spansrc, nrec, c->risetime_d.p);
             }
         }
         hipLaunchKernelGGL(global_kernel, dim3((unsigned)((nsrc + 127) / 128)), dim3(128), 0, c->stream,
@@ -2207,6 +2243,9 @@ int kiwi_hip_get_misfits(kiwi_hip_ctx *c, int isrc0, int nsrc, float *misfit, fl
     HIPCHECK(hipStreamSynchronize(c->stream));
     if (misfit)
         HIPCHECK(hipMemcpy(misfit, c->misfit_d.p + (size_t)isrc0 * c->nmis, (size_t)nsrc * c->nmis * sizeof(float), hipMemcpyDeviceToHost));
+    if (norm && c->untapered_fft)        // (the norm factors of un-tapered pairs are made on the device: pair_refamp_kernel / pair_reffilt_kernel)
+        HIPCHECK(hipMemcpy(c->norm_src_h.data() + (size_t)isrc0 * c->nmis, c->normsrc_d.p + (size_t)isrc0 * c->nmis, (size_t)nsrc * c->nmis * sizeof(float),
+                           hipMemcpyDeviceToHost));
     if (norm)
         for (int s = 0; s < nsrc; s++) {
             if (c->src_status[(size_t)isrc0 + s]) std::memset(norm + (size_t)s * c->nmis, 0, (size_t)c->nmis * sizeof(float));
@@ -2676,6 +2715,8 @@ int kiwi_hip_get_reference(kiwi_hip_ctx *c, int irec, int icomp, int which, int 
         HIPCHECK(hipStreamSynchronize(c->stream));
         const FftPair pr = c->last_pairs[(size_t)slot];
         if (!c->slot_has_filter[slot]) std::memcpy(out, c->reft_h.data() + cd.refofs, (size_t)m * sizeof(float));
+        else if (cd.untapered)             // the filtered reference of the PAIR (current source, slot), the part inside the window (pair_reffilt_kernel)
+            HIPCHECK(hipMemcpy(out, c->reffilt_d.p + pr.filtofs, (size_t)m * sizeof(float), hipMemcpyDeviceToHost));
         else std::memcpy(out, c->reffilt_h.data() + pr.filtofs, (size_t)m * sizeof(float));
     }
     return 0;

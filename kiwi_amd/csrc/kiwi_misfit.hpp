@@ -172,7 +172,8 @@ __global__ __launch_bounds__(256) void misfit_kernel(
     // plain tapered arrays then, comparator.f90:806-813)
     const bool to_fft = mp.fft_mode && (cd.has_filter || (mp.fft_mode & 2));
     if (to_fft && (mp.fft_mode & 4) && !proc) return;      // the transform kernel takes the plain synthetics itself (workgroup-uniform)
-    if (to_fft) {
+    const bool own_row = to_fft && cd.untapered;           // un-tapered: the row is the padded probe array over the PAIR's span (untapered_rows_kernel)
+    if (to_fft && !own_row) {
         const FftPair pr = pairs[(size_t)s * mp.nmis + m];
         frow = fftbuf + pr.fft_ofs;
         for (int i = cd.wlen + threadIdx.x; i < pr.ntrans; i += 256) frow[i] = 0.f;      // zero padding
@@ -182,6 +183,7 @@ __global__ __launch_bounds__(256) void misfit_kernel(
         const float vt = v * tp[i];               // make_array_tapered, comparator.f90:1173-1184
         if (proc) proc[(size_t)s * syn_stride + cd.synofs + cd.halo + i] = mp.write_tapered == 2 ? vt : v;
         if (frow) { frow[i] = vt; continue; }
+        if (own_row) continue;
         if (mp.skip_norm) { vt_out[(size_t)s * syn_stride + cd.synofs + cd.halo + i] = vt; continue; }
         if (i < i_lo || i > i_hi) continue;
         const float a = rt[i];
@@ -232,6 +234,9 @@ struct SpecParams {
     float syn_factor;
     int nmis, isrc0;
     int has_filter;
+    // un-tapered slots (comparator.f90:798-800, 861-886): the reference's padded array follows the pair's span, so its amplitude
+    // spectrum / filtered trace belongs to the PAIR: refpair[pair.spec_ofs + k], reffiltpair[pair.fft_ofs + n] (pair_span below)
+    const float *refpair = nullptr, *reffiltpair = nullptr;
 };
 
 __device__ __forceinline__ double block_sum(double v, double *red)
@@ -247,14 +252,15 @@ __device__ __forceinline__ double block_sum(double v, double *red)
 
 __global__ __launch_bounds__(256) void spec_norm_kernel(
     const float2 *__restrict__ spec, const FftPair *__restrict__ pairs, const float *__restrict__ refamp,
-    const float *__restrict__ filtw, SpecParams sp, float *__restrict__ misfit_out)
+    const float *__restrict__ filtw, SpecParams sp, float *__restrict__ misfit_out, const CompDev *__restrict__ comps)
 {
     __shared__ double red[256];
     const int m = blockIdx.x, s = blockIdx.y;
     const FftPair pr = pairs[(size_t)s * sp.nmis + m];
+    const bool untapered = comps[m].untapered != 0;
     const int nb = pr.ntrans / 2 + 1;
     const float2 *__restrict__ row = spec + pr.spec_ofs;
-    const float *__restrict__ ra = refamp + pr.specofs;
+    const float *__restrict__ ra = untapered ? sp.refpair + pr.spec_ofs : refamp + pr.specofs;
     const float *__restrict__ fw = filtw + pr.specofs;
     const bool unit = (sp.syn_factor == 1.f);
     double acc = 0.0;
@@ -735,12 +741,27 @@ __global__ __launch_bounds__(256) void spec_filter_kernel(float2 *__restrict__ s
     }
 }
 
+// Data span [s0, s1] of the synthetic probe of pair (chunk source s, slot) as a fresh engine sets it (strip span grown by the
+// taps of THIS source's rise time) and, for a transform length N, where the pair's common span starts:
+// allowed_span(union of the data spans, .) = union(1) - floor((N - slen(union)) / 2.)  (comparator.f90:1092-1109).
+__device__ __forceinline__ void pair_span(const int *__restrict__ spansrc, const CompDev &cd, int s, int nrec, float rise, float dt, int N,
+                                          int &s0, int &s1, int &span0)
+{
+    int fold_grow = 0;
+    if (rise > 0.f) fold_grow = ((1 + 2 * (int)roundf(0.5f * rise / dt)) - 1) / 2;
+    strip_span(spansrc + ((size_t)s * nrec + cd.rec) * kSpanInts, cd.spankind, s0, s1);
+    if (s1 < s0) { s0 = cd.rf0; s1 = cd.rf0; }                       // no centroid reached this strip
+    if (fold_grow > 0) { s0 -= fold_grow; s1 += fold_grow + 1; }
+    const int u0 = min(cd.rf0, s0), u1 = max(cd.rf1, s1);
+    span0 = u0 - (N - (u1 - u0 + 1)) / 2;
+}
+
 // time-domain norms on the filtered traces (comparator.f90:810-813,1233-1263): c2r output / ntrans, zeroed
 // where the taper is zero (ip_zero_one mask), against the reference processed the same way
 __global__ __launch_bounds__(256) void filtered_norm_kernel(
     const float *__restrict__ fftbuf, const CompDev *__restrict__ comps, const FftPair *__restrict__ pairs,
     const float *__restrict__ ref_filt, const float *__restrict__ zmask, SpecParams sp, float *__restrict__ misfit_out,
-    float *__restrict__ proc, size_t syn_stride)
+    float *__restrict__ proc, size_t syn_stride, const int *__restrict__ spansrc, int nrec, const float *__restrict__ risetime)
 {
     __shared__ double red[256];
     const int m = blockIdx.x, s = blockIdx.y;
@@ -752,10 +773,23 @@ __global__ __launch_bounds__(256) void filtered_norm_kernel(
     const float *__restrict__ zm = zmask + cd.refofs;
     const bool unit = (sp.syn_factor == 1.f);
     double acc = 0.0, peak = 0.0;
-    for (int i = threadIdx.x; i < cd.wlen; i += 256) {
-        float v = row[i] / (float)pr.ntrans;              // normalize result, comparator.f90:1251
-        v = v * zm[i];                                    // :1254-1258
-        if (proc) proc[(size_t)s * syn_stride + cd.synofs + cd.halo + i] = v;
+    // without a taper: the row is the filtered probe array over the pair's span, the norm runs over the union of the two data
+    // spans (probes_norm_timedomain, comparator.f90:798-800) against the pair's filtered reference, nothing is zeroed
+    int i_lo = 0, i_hi = cd.wlen - 1, shift = 0;
+    if (cd.untapered) {
+        int s0, s1, span0;
+        pair_span(spansrc, cd, s, nrec, risetime[sp.isrc0 + s], sp.dt, pr.ntrans, s0, s1, span0);
+        shift = cd.w0 - span0;                            // row index of window sample i: i + shift
+        i_lo = min(cd.rf0, s0) - cd.w0; i_hi = max(cd.rf1, s1) - cd.w0;
+        rf = sp.reffiltpair + pr.fft_ofs + shift;
+        if (proc)
+            for (int i = threadIdx.x; i < cd.wlen; i += 256)
+                if (i < i_lo || i > i_hi) proc[(size_t)s * syn_stride + cd.synofs + cd.halo + i] = 0.f;
+    }
+    for (int i = i_lo + threadIdx.x; i <= i_hi; i += 256) {
+        float v = row[i + shift] / (float)pr.ntrans;      // normalize result, comparator.f90:1251
+        if (!cd.untapered) v = v * zm[i];                 // :1254-1258
+        if (proc && i >= 0 && i < cd.wlen) proc[(size_t)s * syn_stride + cd.synofs + cd.halo + i] = v;
         const float a = rf[i];
         switch (sp.method) {
         case 1: { const float d = unit ? (a - v) : (1.f * a - sp.syn_factor * v); acc = sq_acc(acc, d); break; }
@@ -793,6 +827,132 @@ __global__ __launch_bounds__(256) void filtered_norm_kernel(
 // probes the span allowed_span(union of the two data spans, max of the two minimum lengths) (:1092-1109) -- so
 // ntrans = next_power_of_two(max(length of the union, 2 len_ref, 2 len_syn)).  spansrc: per (source, receiver) data spans
 // of the horizontal / vertical strips, reduced by geometry_kernel; fold_grow: strip_fold's growth (sparse_trace.f90:379-402).
+// Rows of the un-tapered slots for the transforms: the probe array over the pair's span -- zeros before the data span, the data,
+// the last value repeated behind it (probe_set_array / probe_extend_span, comparator.f90:259-265,320-324) -- of the REFERENCE
+// (REF) or of the trial source's synthetic (folded, scaled by the moment).  reft holds the un-tapered reference over the window,
+// which contains every data span of the batch.
+template <bool REF>
+__global__ __launch_bounds__(256) void untapered_rows_kernel(
+    const float *__restrict__ syn, size_t syn_stride, const CompDev *__restrict__ comps, const float *__restrict__ reft,
+    const float *__restrict__ moment, const float *__restrict__ risetime, int isrc0, float dt, int nmis,
+    const int *__restrict__ spansrc, int nrec, const FftPair *__restrict__ pairs, float *__restrict__ fftbuf)
+{
+    const int m = blockIdx.x, s = blockIdx.y;
+    const CompDev cd = comps[m];
+    if (!cd.untapered) return;
+    const FftPair pr = pairs[(size_t)s * nmis + m];
+    const int N = pr.ntrans;
+    const float rise = risetime[isrc0 + s];
+    int s0, s1, span0;
+    pair_span(spansrc, cd, s, nrec, rise, dt, N, s0, s1, span0);
+    float *__restrict__ frow = fftbuf + pr.fft_ofs;
+    if constexpr (REF) {
+        const float *__restrict__ rt = reft + cd.refofs;
+        for (int n = threadIdx.x; n < N; n += 256) {
+            const int t = span0 + n;
+            frow[n] = t < cd.rf0 ? 0.f : rt[min(t, cd.rf1) - cd.w0];
+        }
+    } else {
+        __shared__ float fw[kMaxFold];
+        __shared__ int fs[kMaxFold];
+        __shared__ float fr[kMaxFold];
+        __shared__ int nfold;
+        if (threadIdx.x == 0) nfold = fold_setup(rise, dt, fw, fs, fr);
+        __syncthreads();
+        const int nf = nfold;
+        const float mom = moment[isrc0 + s];
+        const float *__restrict__ sy = syn + (size_t)s * syn_stride + cd.synofs + cd.halo;       // sy[i] = sample w0 + i
+        for (int n = threadIdx.x; n < N; n += 256) {
+            const int t = span0 + n;
+            frow[n] = t < s0 ? 0.f : folded_scaled_sample(sy, min(t, s1) - cd.w0, nf, fw, fs, fr, mom);
+        }
+    }
+}
+
+// Reference side of the un-tapered amplitude-spectrum norms, per pair: |X[k]| (x filter weight) of the transformed reference
+// row -> refpair, and the pair's norm factor probe_norm_frequencydomain (comparator.f90:888-910) -> normsrc
+__global__ __launch_bounds__(256) void pair_refamp_kernel(
+    const float2 *__restrict__ spec, const FftPair *__restrict__ pairs, const CompDev *__restrict__ comps,
+    const float *__restrict__ filtw, SpecParams sp, float *__restrict__ refpair, float *__restrict__ normsrc)
+{
+    __shared__ double red[256];
+    const int m = blockIdx.x, s = blockIdx.y;
+    if (!comps[m].untapered) return;
+    const FftPair pr = pairs[(size_t)s * sp.nmis + m];
+    const int nb = pr.ntrans / 2 + 1;
+    const float2 *__restrict__ row = spec + pr.spec_ofs;
+    const float *__restrict__ fw = filtw + pr.specofs;
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < nb; k += 256) {
+        const float2 z = row[k];
+        float a = hypotf(z.x, z.y);
+        if (sp.has_filter) a = a * fw[k];
+        refpair[pr.spec_ofs + k] = a;
+        acc += (sp.method == 3) ? (double)a * (double)a : (double)fabsf(a);
+    }
+    const double tot = block_sum(acc, red);
+    if (threadIdx.x == 0) {
+        const float df = 1.f / ((float)pr.ntrans * sp.dt);
+        normsrc[(size_t)(sp.isrc0 + s) * sp.nmis + m] = (sp.method == 3) ? 1.f * (float)sqrt((double)df * tot) : 1.f * (float)((double)df * tot);
+    }
+}
+
+// ... and of the time-domain norms on filtered traces: the filtered reference of the pair (c2r output / ntrans; no taper, so
+// nothing is zeroed: comparator.f90:1251-1258) -> reffiltpair, its norm over the reference's data span
+// (probe_norm_timedomain, :843-845) -> normsrc
+__global__ __launch_bounds__(256) void pair_reffilt_kernel(
+    const float *__restrict__ fftbuf, const FftPair *__restrict__ pairs, const CompDev *__restrict__ comps, SpecParams sp,
+    const int *__restrict__ spansrc, int nrec, const float *__restrict__ risetime,
+    float *__restrict__ reffiltpair, float *__restrict__ normsrc, float *__restrict__ reffilt_win /* of the chunk's first source, over
+    the window at [pair.filtofs + i]: what get_reference(filtered) hands out */)
+{
+    __shared__ double red[256];
+    const int m = blockIdx.x, s = blockIdx.y;
+    const CompDev cd = comps[m];
+    if (!cd.untapered || !cd.has_filter) return;
+    const FftPair pr = pairs[(size_t)s * sp.nmis + m];
+    const int N = pr.ntrans;
+    int s0, s1, span0;
+    pair_span(spansrc, cd, s, nrec, risetime[sp.isrc0 + s], sp.dt, N, s0, s1, span0);
+    const float *__restrict__ row = fftbuf + pr.fft_ofs;
+    double acc = 0.0, peak = 0.0;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float a = row[n] / (float)N;
+        reffiltpair[pr.fft_ofs + n] = a;
+        const int t = span0 + n;
+        if (s == 0 && t >= cd.w0 && t < cd.w0 + cd.wlen) reffilt_win[pr.filtofs + (t - cd.w0)] = a;
+        if (t < cd.rf0 || t > cd.rf1) continue;
+        switch (sp.method) {
+        case 1: acc += (double)a * (double)a; break;
+        case 2: acc += (double)fabsf(a); break;
+        case 5: acc += (double)(a * a); break;
+        default: peak = fmax(peak, (double)fabsf(a)); break;
+        }
+    }
+    double tot;
+    if (sp.method == 6) {
+        red[threadIdx.x] = peak;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (threadIdx.x < st) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + st]);
+            __syncthreads();
+        }
+        tot = red[0];
+    } else {
+        tot = block_sum(acc, red);
+    }
+    if (threadIdx.x == 0) {
+        float nf;
+        switch (sp.method) {
+        case 1: nf = 1.f * (float)sqrt((double)sp.dt * tot); break;
+        case 2: nf = 1.f * (float)((double)sp.dt * tot); break;
+        case 5: nf = (1.f * 1.f) * (float)tot; break;
+        default: nf = 1.f * (float)tot; break;
+        }
+        normsrc[(size_t)(sp.isrc0 + s) * sp.nmis + m] = nf;
+    }
+}
+
 __global__ void fft_size_kernel(const int *__restrict__ spansrc, const CompDev *__restrict__ comps, int nmis, int nsrc, int nrec,
                                 const float *__restrict__ risetime /* of the chunk's sources */, float dt, int *__restrict__ ntr_out)
 {
@@ -814,7 +974,8 @@ __global__ void fft_size_kernel(const int *__restrict__ spansrc, const CompDev *
     const int len_ref = cd.rf1 - cd.rf0 + 1, len_syn = s1 - s0 + 1;
     const int len_u = max(cd.rf1, s1) - min(cd.rf0, s0) + 1;
     const int minlength = max((int)ceilf((float)len_ref * 2.f), (int)ceilf((float)len_syn * 2.f));
-    int need = max(max(len_u, minlength), cd.wlen);
+    int need = max(len_u, minlength);
+    if (!cd.untapered) need = max(need, cd.wlen);                    // (without a taper the window is the batch's, not the pair's)
     int n = 1;
     while (n < need) n *= 2;                                         // next_power_of_two, comparator.f90:1111-1118
     ntr_out[idx] = n;

@@ -1340,9 +1340,6 @@ def test_untapered_comparator_fresh_evaluation_semantics(method):
     assert np.array_equal(pn, np.array(want_n))
     if mid == 8:
         assert np.array_equal(p.get_floating_shifts(), np.array(want_s, np.float32))
-    with pytest.raises(KiwiHipError, match="need a misfit taper"):
-        p.set_misfit_method("ampspec_l2norm")
-        p.eval()
 
 
 @pytest.mark.parametrize("fused", [False, True])
@@ -1511,37 +1508,84 @@ def test_two_sources_per_workgroup_is_bit_identical(monkeypatch, L):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("what", ["ampspec_l2norm", "ampspec_l1norm", "filter"])
-def test_spectral_norms_without_a_taper_are_refused_not_approximated(what):
-    """The one branch of the comparator without a device path (INTEGRATION.md "limits"): amplitude-spectrum norms and
-    misfit filters on a receiver WITHOUT a misfit taper (comparator.f90:861-886 over the whole padded probes, whose spans follow
-    every source evaluated before: :222-271).  The engine says so (`nok >` with the reason, as every error) instead of
-    evaluating something else; the same setup with tapers evaluates.  python/tunguska/misfit.py always sets tapers."""
-    from kiwi_amd.lib import KiwiHipError
-    sc = Scenario(nrec=3)
-    e = sc.oracle()
-    sc.make_references(e)
+@pytest.mark.parametrize("tapers", ["mixed", "none"])
+@pytest.mark.parametrize("what", ["ampspec_l2norm", "ampspec_l1norm", "filter_l2norm", "filter_l1norm"])
+def test_spectral_norms_without_a_taper_fresh_evaluation_semantics(what, tapers):
+    """Amplitude-spectrum norms and misfit filters on receivers WITHOUT a misfit taper (comparator.f90:861-886 over the whole padded
+    probes: zeros before the data span, the end value repeated behind it, :259-265,320-324; common span of a pair
+    allowed_span(union of the data spans, max of twice the data lengths), :464-486,1092-1109).  The reference's probe spans follow every
+    source evaluated before; the device gives every (source, slot) pair the span of a FRESH engine, as for the un-tapered time-domain
+    norms -- compared with a fresh oracle engine per trial source: misfits and norm factors (the reference's spectrum / filtered trace
+    belongs to the pair there, so the norm factor does too).  `mixed`: receivers 1, 2 keep their tapers (variant tables), 3 and 4 have
+    none (per-pair reference arrays) in the same batch; origin times move the strips against the references (another span, another
+    number of repeated end values, two transform lengths), with and without rise time."""
+    sc = Scenario(nrec=4, comps_list=["ned", "ne", "d", "ned"])
+    e0 = sc.oracle()
+    sc.make_references(e0)
+    dt = sc.gf["dt"]
+    method = what[7:] if what.startswith("filter_") else what
+    mid = {"ampspec_l2norm": 3, "ampspec_l1norm": 4, "l2norm": 1, "l1norm": 2}[method]
+    fx, fy = [0.01, 0.03, 0.25, 0.4], [0., 1., 1., 0.]
+    filtered = (1, 3, 4) if what.startswith("filter_") else ()           # receiver 2: no filter (compared on the plain arrays)
+    tapered = (1, 2) if tapers == "mixed" else ()
+    trials = synthetic.bilat_strike_sweep(5, step=2.0)
+    trials[:, 0] = [-1.1, 0.0, 0.6, 2.1, 400.0]              # (the last one far behind the references: a longer union, the next transform length)
+    trials[2, 13] = 0.0
+    trials[4, 13] = 9.0                                      # a long rise time: a longer strip
     p = sc.product()
     for (ir, k), (lo, d) in sc.refs.items():
         p.set_ref_seismogram(ir, k, lo, d)
-    for ir in (1, 2):                                        # receiver 3 keeps no taper
+    for ir in tapered:
         p.set_misfit_taper(ir, *sc.tapers[ir])
-    if what == "filter":
-        p.set_misfit_method("l2norm")
-        for ir in range(1, 4):
-            p.set_misfit_filter(ir, [0.01, 0.03, 0.25, 0.4], [0., 1., 1., 0.])
-    else:
-        p.set_misfit_method(what)
-    p.set_source_params("bilateral", synthetic.bilat_strike_sweep(2, step=2.0))
-    with pytest.raises(KiwiHipError, match="need a misfit taper on every enabled receiver"):
-        p.eval()
-    with pytest.raises(KiwiHipError, match="need a misfit taper on every enabled receiver"):
-        p.misfits_for_params("bilateral", synthetic.bilat_strike_sweep(2, step=2.0))
-    p.set_misfit_taper(3, *sc.tapers[3])                     # with the taper: evaluates
-    p.set_source_params("bilateral", synthetic.bilat_strike_sweep(2, step=2.0))
+    for ir in filtered:
+        p.set_misfit_filter(ir, fx, fy)
+    p.set_misfit_method(method)
+    p.set_source_params("bilateral", trials)
     p.eval()
     pm, pn, pg = p.get_misfits()
-    assert np.all(np.isfinite(pm)) and np.all(pn > 0) and np.all(pg > 0)
+    ntr = set()
+    for i, t in enumerate(trials):
+        e = sc.oracle()
+        for (ir, k), (lo, d) in sc.refs.items():
+            e.set_reference(ir, k, lo, d)
+        for ir in tapered:
+            e.set_taper(ir, *sc.tapers[ir])
+        for ir in filtered:
+            e.set_filter(ir, fx, fy)
+        e.set_misfit_method(mid)
+        e.set_source_params(1, t)
+        m, n, g = e.get_misfits()
+        scales = slot_scales(e, sc.comps, dt)
+        ntr.update(int(x) for x in scales[0])
+        ok, ratio = spectral_close(method, dt, pm[i], m, n, scales, pn[i])
+        assert ok, (i, ratio, pm[i], m, pn[i], n)
+        assert abs(pg[i] - g) <= 2e-5 * abs(g), (i, pg[i], g)
+        e.close()
+    assert len(ntr) >= 2 and np.all(pn > 0)
+    # one source at a time gives the same bits as the batch (nothing of a pair depends on its neighbours)
+    p.set_source_params("bilateral", trials[3:4])
+    p.eval()
+    qm, qn, qg = p.get_misfits()
+    assert qm.tobytes() == pm[3:4].tobytes() and qn.tobytes() == pn[3:4].tobytes()
+    if filtered:
+        # get_reference(filtered) of an un-tapered receiver: the filtered reference of the pair (current source, slot) inside the window
+        e = sc.oracle()
+        for (ir, k), (lo, d) in sc.refs.items():
+            e.set_reference(ir, k, lo, d)
+        for ir in tapered:
+            e.set_taper(ir, *sc.tapers[ir])
+        for ir in filtered:
+            e.set_filter(ir, fx, fy)
+        e.set_misfit_method(mid)
+        e.set_source_params(1, trials[3])
+        e.get_misfits()
+        for ir, k in ((4, 1), (4, 3), (3, 1)):
+            lo_p, dp = p.get_reference(ir, k, 3)
+            lo_o, do = e.reference(ir, k, 3)
+            a, b = max(lo_o, lo_p), min(lo_o + len(do), lo_p + len(dp))
+            assert b - a >= 264                                 # (at least the reference's data span)
+            assert np.max(np.abs(do[a - lo_o:b - lo_o] - dp[a - lo_p:b - lo_p])) <= 2e-5 * np.max(np.abs(do))
+        e.close()
     p.close()
 
 
