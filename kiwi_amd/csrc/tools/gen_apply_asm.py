@@ -21,8 +21,9 @@ Registers (kernel budget: 168 VGPRs at three waves per SIMD):
   v[28:35]  t1a t1b t2a t2b     v[36:43] m0..m3 (products, exact only)     v44 va  v45 va4  v46 vn  v47 vn4
   v[48:87] bank 0   v[88:127] bank 1      (member m of a bank: pair 2m; m < NG: outputs q0,q1 of the m-th component in application
                                           order, m >= NG: outputs q2,q3)
-  s[36:55] coefficient line of the step at hand (CA)   s[56:75] of the next step (CB)   s[76:77] (cl, sl)
-  s80 k  s81 e  s82 e_next  s83 tmp  s84 d  s85 k+1  s[86:87] coefficient pointer
+  s[36:55], s[56:75] coefficient lines of the step at hand and of the next one, swapping roles every step   s[76:77] (cl, sl)
+  s80 k  s81, s82 4 x integer shift of this step / the next (swapping)  s83 tmp  s84 4 d  s[86:87] coefficient pointer
+  v44 address of position smax  v45 4 x shifts (lane k: step k)  v46, v47 addresses of the next reads
 """
 import os
 import sys
@@ -72,7 +73,7 @@ def mac(fused, T, cpair, hi, X, tmp, first=False):
     return [mul], [add]
 
 
-def arithmetic(ng, rot, fused, H, L, acc, K=None, behind=False):
+def arithmetic(ng, rot, fused, H, L, acc, K=None, behind=False, C=None):
     """instruction list of one step: acc = operand names of ar1a ar1b ar2a ar2b dza dzb.  behind: behind the multiplies that
     consume a member of the b[j] bank H, the NEXT step's b[j-1] of that member is read into its registers (address VN)"""
     nH1 = 4 if ng == 10 else 3
@@ -97,7 +98,7 @@ def arithmetic(ng, rot, fused, H, L, acc, K=None, behind=False):
             ti = 0
             for a in items:
                 Ta, Tb = tgt(a)
-                cpair = CA + 2 * a
+                cpair = C + 2 * a
                 first = rot and (not half) and (a == 0 or a == nH1)      # t1 / t2 start from 0 + product
                 for T, m in ((Ta, a), (Tb, ng + a)):
                     X = member(src, m)
@@ -163,61 +164,60 @@ def routine(ng, K, rot, fused):
     name = "apply_group_asm_%d_k%d_%s_%s" % (ng, K, "rot" if rot else "plain", "fused" if fused else "exact")
     acc = ["%0", "%1", "%2", "%3", "%4", "%5"]
     # operands: %6 abase (v), %7 ishv (v), %8 smax (s), %9 n (s), %10 coef (s, 64 bit), %11 cl (s), %12 sl (s)
-    ncw = 2 * ng
     L = []
     a = L.append
+    SI = [SE, SEN]                        # 4 x integer shift of the step at hand / of the next one, swapping roles like the register sets
     a("s_mov_b32 s%d, %%11" % CLSL)
     a("s_mov_b32 s%d, %%12" % (CLSL + 1))
     a("s_mov_b64 %s, %%10" % sp(SCP))
     a("s_mov_b32 s%d, 0" % SK)
-    a("v_readlane_b32 s%d, %%7, 0" % ST)
-    a("s_load_dwordx16 s[%d:%d], %s, 0x0" % (CB, CB + 15, sp(SCP)))
+    a("s_load_dwordx16 s[%d:%d], %s, 0x0" % (CA, CA + 15, sp(SCP)))
     if ng == 10:
-        a("s_load_dwordx4 s[%d:%d], %s, 0x40" % (CB + 16, CB + 19, sp(SCP)))
-    a("s_sub_i32 s%d, %%8, s%d" % (SE, ST))
-    a("s_lshl_b32 s%d, s%d, 2" % (ST, SE))
-    a("v_add_u32 v%d, s%d, %%6" % (VA, ST))
-    a("v_add_u32 v%d, 4, v%d" % (VA4, VA))
-    L += reads(0, ng, K, VA4)            # bank 0 = b[j]
-    L += reads(1, ng, K, VA)             # bank 1 = b[j-1]
+        a("s_load_dwordx4 s[%d:%d], %s, 0x40" % (CA + 16, CA + 19, sp(SCP)))
+    a("v_lshlrev_b32 v%d, 2, %%7" % VA4)               # v45: 4 x the steps' integer shifts (lane k: step k)
+    a("s_lshl_b32 s%d, %%8, 2" % ST)
+    a("v_add_u32 v%d, s%d, %%6" % (VA, ST))           # v44: LDS address of position smax of the lane's first sample ...
+    a("s_nop 1")                                       # (a vector register written by the instruction in front is not yet there for v_readlane)
+    a("v_readlane_b32 s%d, v%d, 0" % (SI[0], VA4))
+    a("v_subrev_u32 v%d, s%d, v%d" % (VN, SI[0], VA))  # ... of position e = smax - ishift: b[j-1] of step 0
+    a("v_add_u32 v%d, 4, v%d" % (VN4, VN))
+    L += reads(0, ng, K, VN4)            # bank 0 = b[j]
+    L += reads(1, ng, K, VN)             # bank 1 = b[j-1]
+    tail = []                            # the steps without a regular successor: out of line, the regular path falls through
     for r in range(2):
         H, Lb = r, 1 - r
+        Cc, Cn = (CA, CB) if r == 0 else (CB, CA)        # the two coefficient buffers swap roles with the register sets
         a(".Lkiwi_step%d_%%=:" % r)
         a("s_waitcnt lgkmcnt(0)")
-        for j in range(0, ncw, 2):
-            a("s_mov_b64 %s, %s" % (sp(CA + j), sp(CB + j)))
-        a("s_add_u32 s%d, s%d, 1" % (SK1, SK))
+        a("s_add_u32 s%d, s%d, 1" % (SK, SK))
         a("s_mov_b32 s%d, 0x7fffffff" % SD)      # d = 0x7fffffff: "no successor" (neither read-behind nor reads behind the step)
-        a("s_cmp_ge_u32 s%d, %%9" % SK1)
+        a("s_cmp_ge_u32 s%d, %%9" % SK)
         a("s_cbranch_scc1 .Lkiwi_plain%d_%%=" % r)
-        a("v_readlane_b32 s%d, %%7, s%d" % (ST, SK1))
+        a("v_readlane_b32 s%d, v%d, s%d" % (SI[1 - r], VA4, SK))
         a("s_add_u32 s%d, s%d, %d" % (SCP, SCP, 80))
         a("s_addc_u32 s%d, s%d, 0" % (SCP + 1, SCP + 1))
-        a("s_load_dwordx16 s[%d:%d], %s, 0x0" % (CB, CB + 15, sp(SCP)))
+        a("s_load_dwordx16 s[%d:%d], %s, 0x0" % (Cn, Cn + 15, sp(SCP)))
         if ng == 10:
-            a("s_load_dwordx4 s[%d:%d], %s, 0x40" % (CB + 16, CB + 19, sp(SCP)))
-        a("s_sub_i32 s%d, %%8, s%d" % (SEN, ST))
-        a("s_sub_i32 s%d, s%d, s%d" % (SD, SE, SEN))
-        a("s_lshl_b32 s%d, s%d, 2" % (ST, SEN))
-        a("v_add_u32 v%d, s%d, %%6" % (VN, ST))
-        a("s_cmp_lg_u32 s%d, 1" % SD)
+            a("s_load_dwordx4 s[%d:%d], %s, 0x40" % (Cn + 16, Cn + 19, sp(SCP)))
+        a("s_sub_i32 s%d, s%d, s%d" % (SD, SI[1 - r], SI[r]))     # 4 x (positions the tile moves back by)
+        a("v_subrev_u32 v%d, s%d, v%d" % (VN, SI[1 - r], VA))
+        a("s_cmp_lg_u32 s%d, 4" % SD)
         a("s_cbranch_scc1 .Lkiwi_plain%d_%%=" % r)
         # regular successor: its b[j-1] is read behind this step's multiplies, into the b[j] bank
-        L += arithmetic(ng, rot, fused, H, Lb, acc, K, True)
-        a("s_branch .Lkiwi_next%d_%%=" % r)
-        a(".Lkiwi_plain%d_%%=:" % r)
-        L += arithmetic(ng, rot, fused, H, Lb, acc)
-        a("s_cmp_eq_u32 s%d, 0x7fffffff" % SD)
-        a("s_cbranch_scc1 .Lkiwi_end_%=")
-        # irregular successor: its b[j] over this step's b[j-1] bank, its b[j-1] over the b[j] bank
-        a("v_add_u32 v%d, 4, v%d" % (VN4, VN))
-        L += reads(Lb, ng, K, VN4)
-        L += reads(H, ng, K, VN)
-        a(".Lkiwi_next%d_%%=:" % r)
-        a("s_mov_b32 s%d, s%d" % (SK, SK1))
-        a("s_mov_b32 s%d, s%d" % (SE, SEN))
+        L += arithmetic(ng, rot, fused, H, Lb, acc, K, True, C=Cc)
         if r == 1:
             a("s_branch .Lkiwi_step0_%=")
+        t = tail.append
+        t(".Lkiwi_plain%d_%%=:" % r)
+        tail += arithmetic(ng, rot, fused, H, Lb, acc, C=Cc)
+        t("s_cmp_eq_u32 s%d, 0x7fffffff" % SD)
+        t("s_cbranch_scc1 .Lkiwi_end_%=")
+        # irregular successor: its b[j] over this step's b[j-1] bank, its b[j-1] over the b[j] bank
+        t("v_add_u32 v%d, 4, v%d" % (VN4, VN))
+        tail += reads(Lb, ng, K, VN4)
+        tail += reads(H, ng, K, VN)
+        t("s_branch .Lkiwi_step%d_%%=" % (1 - r))
+    L += tail
     a(".Lkiwi_end_%=:")
     if VARIANT:
         steps = [i for i, x in enumerate(L) if x.startswith(".Lkiwi_step0")][0]
@@ -225,7 +225,6 @@ def routine(ng, K, rot, fused):
             if "noarith" in VARIANT and x.startswith("v_pk_"): return False
             if "nolds" in VARIANT and i > steps and x.startswith("ds_read"): return False
             if "nocoef" in VARIANT and i > steps and x.startswith("s_load"): return False
-            if "nocopy" in VARIANT and i > steps and x.startswith("s_mov_b64 s[") : return False
             return True
         L = [x for i, x in enumerate(L) if keep(i, x)]
     text = "\\n\\t\"\n        \"".join(L)
