@@ -1,5 +1,3 @@
-
-
 def test_generated_apply_routine_is_what_its_generator_prints():
     """kiwi_amd/csrc/kiwi_apply_asm.inc (the apply of accumulate_multi_kernel as hand-allocated assembly) is generated text: the file in
     the tree is exactly what tools/gen_apply_asm.py prints, and no timing-experiment variant leaked into it."""
