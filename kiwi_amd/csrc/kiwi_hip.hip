@@ -207,6 +207,7 @@ struct kiwi_hip_ctx {
     std::vector<int> slot_has_filter;
     DevBuf<int> spanbuf_d, ntr_d;
     DevBuf<float> fft_d, refamp_d, filtw_d, reffilt_d, zmask_d, normsrc_d;
+    DevBuf<int> synspan_d;                                       // data spans of the synthetic probes of the chunk's un-tapered slots (synspan_kernel)
     DevBuf<float> refpair_d, reffiltpair_d;                      // un-tapered slots: reference spectrum / filtered reference per PAIR (SpecParams)
     bool untapered_fft = false;                                  // some un-tapered slot goes through the transforms
     DevBuf<float2> spec_d;
@@ -404,6 +405,9 @@ void prepare(kiwi_hip_ctx *c)
             discrete_plf_span(r.taper, dt, w);                             // comparator.f90:1157-1169
             if (w[1] < w[0]) throw std::runtime_error("receiver " + std::to_string(ir + 1) + ": empty taper span");
         }
+        if (std::getenv("KIWI_HIP_DEBUG_SPANS"))
+            std::fprintf(stderr, "receiver %d: natural spans h [%d, %d] v [%d, %d], fold halfwidth %d (max rise time %g), window [%d, %d]\n", ir + 1,
+                         nat.empty() ? 0 : nat[4 * ir], nat.empty() ? 0 : nat[4 * ir + 1], nat.empty() ? 0 : nat[4 * ir + 2], nat.empty() ? 0 : nat[4 * ir + 3], hs, (double)c->max_risetime, w[0], w[1]);
         const int wlen = w[1] - w[0] + 1;
         d.wbeg = w[0] - c->halo;
         d.wlen = wlen + 2 * c->halo;
@@ -671,7 +675,7 @@ void prepare_fft(kiwi_hip_ctx *c, const std::vector<float> &reft_host)
         CompDev &cd = c->comps[m];
         const int f0 = cd.rf0, f1 = cd.rf1;
         int s0 = sb[4 * cd.rec + (cd.vertical ? 2 : 0)], s1 = sb[4 * cd.rec + (cd.vertical ? 3 : 1)];
-        if (s1 < s0) { s0 = f0; s1 = f0; }                          // no centroid contributed
+        if (s1 < s0) { s0 = 0; s1 = 0; }                            // no centroid contributed: the reference's empty strip is one zero at sample 0
         if (hs > 0) { s0 -= hs; s1 += hs + 1; }                     // strip_fold grows the strip
         const int len_ref = f1 - f0 + 1, len_syn = s1 - s0 + 1;
         const int len_u = std::max(f1, s1) - std::min(f0, s0) + 1;
@@ -1190,6 +1194,11 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
         if (filt_fused) for (auto &b : c->buckets) { filt_fused = filt_fused && fused_fft_takes(c, b.ntrans); filt_longest = std::max(filt_longest, b.ntrans); }
         if (filt_fused) mp.fft_mode |= 4;
         SpecParams sp{ c->method, c->gm.dt, c->syn_factor, c->nmis, isrc0, c->any_filter ? 1 : 0 };
+        if (c->any_untapered) {      // data spans of the synthetic probes: they follow the synthetics' values where a rise time folds them
+            c->synspan_d.ensure((size_t)nsrc * c->nmis * 2, &c->dev_bytes);
+            hipLaunchKernelGGL(synspan_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream, c->syn_d.p, c->syn_stride, c->comps_d.p,
+                               c->risetime_d.p + isrc0, c->gm.dt, c->nmis, spansrc, nrec, synrow, c->synspan_d.p);
+        }
         if (c->untapered_fft) {
             // Un-tapered slots, reference side first: the reference's padded array over every PAIR's span through the same
             // transforms -> amplitude spectrum (x filter) or filtered trace per pair + the pair's norm factor.  (Before
@@ -1198,7 +1207,7 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
             sp.refpair = c->refpair_d.p; sp.reffiltpair = c->reffiltpair_d.p;
             const dim3 pg((unsigned)c->nmis, (unsigned)nsrc);
             hipLaunchKernelGGL(untapered_rows_kernel<true>, pg, dim3(256), 0, c->stream, c->syn_d.p, c->syn_stride, c->comps_d.p, c->reft_d.p,
-                               c->moment_d.p, c->risetime_d.p, isrc0, c->gm.dt, c->nmis, spansrc, nrec, c->pairs_d.p, c->fft_d.p);
+                               c->moment_d.p, c->risetime_d.p, isrc0, c->gm.dt, c->nmis, spansrc, nrec, c->synspan_d.p, c->pairs_d.p, c->fft_d.p);
             fft_buckets(c, true);
             if (spectral) {
                 hipLaunchKernelGGL(pair_refamp_kernel, pg, dim3(256), 0, c->stream, c->spec_d.p, c->pairs_d.p, c->comps_d.p, c->filtw_d.p, sp,
@@ -1207,19 +1216,19 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
                 hipLaunchKernelGGL(spec_filter_kernel, dim3((unsigned)(c->nmis * nsrc)), dim3(256), 0, c->stream,
                                    c->spec_d.p, c->pairs_d.p, c->comps_d.p, c->filtw_d.p);
                 fft_buckets(c, false);
-                hipLaunchKernelGGL(pair_reffilt_kernel, pg, dim3(256), 0, c->stream, c->fft_d.p, c->pairs_d.p, c->comps_d.p, sp, spansrc, nrec,
-                                   c->risetime_d.p, c->reffiltpair_d.p, c->normsrc_d.p, c->reffilt_d.p);
+                hipLaunchKernelGGL(pair_reffilt_kernel, pg, dim3(256), 0, c->stream, c->fft_d.p, c->pairs_d.p, c->comps_d.p, sp, c->synspan_d.p,
+                                   c->reffiltpair_d.p, c->normsrc_d.p, c->reffilt_d.p);
             }
         }
         if (!fuse && !spec_direct)
         hipLaunchKernelGGL(misfit_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream,
                            c->syn_d.p, c->syn_stride, c->comps_d.p, c->reft_d.p, c->tw_d.p, c->moment_d.p,
                            c->risetime_d.p, mp, c->misfit_d.p, proc, c->fft_d.p, c->vt_d.p,
-                           spansrc, nrec, fold_halfwidth(c->max_risetime, c->gm.dt), c->pairs_d.p, synrow);
+                           c->synspan_d.p, c->pairs_d.p, synrow);
         if (c->floating) {
             hipLaunchKernelGGL(floating_norm_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream,
                                c->vt_d.p, c->syn_stride, c->comps_d.p, c->refx_d.p, c->tw_d.p, fl_method, c->gm.dt,
-                               c->syn_factor, c->nmis, c->max_ns, c->partial_d.p, spansrc, nrec, fold_halfwidth(c->max_risetime, c->gm.dt));
+                               c->syn_factor, c->nmis, c->max_ns, c->partial_d.p, c->synspan_d.p);
             const int nth = nsrc * c->nrec_en;
             hipLaunchKernelGGL(floating_select_kernel, dim3((unsigned)((nth + 127) / 128)), dim3(128), 0, c->stream,
                                c->partial_d.p, c->comps_d.p, c->recfirst_d.p, c->nrec_en, c->nmis, c->max_ns, fl_method,
@@ -1229,7 +1238,7 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
             if (c->untapered_fft) {
                 const dim3 pg((unsigned)c->nmis, (unsigned)nsrc);
                 hipLaunchKernelGGL(untapered_rows_kernel<false>, pg, dim3(256), 0, c->stream, c->syn_d.p, c->syn_stride, c->comps_d.p, c->reft_d.p,
-                                   c->moment_d.p, c->risetime_d.p, isrc0, c->gm.dt, c->nmis, spansrc, nrec, c->pairs_d.p, c->fft_d.p);
+                                   c->moment_d.p, c->risetime_d.p, isrc0, c->gm.dt, c->nmis, spansrc, nrec, c->synspan_d.p, c->pairs_d.p, c->fft_d.p);
             }
             if (spec_fused) {
                 // transform, amplitude, filter and norm of every (slot, source) row in one pass through LDS
@@ -1258,7 +1267,7 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
                 fft_buckets(c, false);
                 hipLaunchKernelGGL(filtered_norm_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream,
                                    c->fft_d.p, c->comps_d.p, c->pairs_d.p, c->reffilt_d.p, c->zmask_d.p, sp, c->misfit_d.p,
-                                   proc_which == 3 ? proc : nullptr, c->syn_stride, spansrc, nrec, c->risetime_d.p);
+                                   proc_which == 3 ? proc : nullptr, c->syn_stride, c->synspan_d.p);
             }
         }
         hipLaunchKernelGGL(global_kernel, dim3((unsigned)((nsrc + 127) / 128)), dim3(128), 0, c->stream,

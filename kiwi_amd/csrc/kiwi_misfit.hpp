@@ -125,13 +125,60 @@ __device__ __forceinline__ float folded_scaled_sample(const float *__restrict__ 
     return v * mom;
 }
 
+// Data span of the synthetic PROBE of every (chunk source, un-tapered slot) as a fresh engine sets it (receiver.f90:853-904):
+// the strip's extent [n0, n1] (geometry_kernel's union over the centroids; one zero at sample 0 when no centroid reached it) and,
+// with a rise time, what strip_fold makes of it (sparse_trace.f90:379-402): the strip is cut to its DATA span first --
+// strip_dataspan, :347-376: from the first sample that is not zero to the first sample of the trailing run of equal values (a
+// Green's function with a static end value repeats it behind every centroid's trace) --, folded, and only ever grows:
+// [min(n0, d1 - h), max(n1, d2 + h + 1)], h = half width of the taps.  The cut depends on the DATA, so this runs behind the accumulate
+// kernel.  synspan[(s * nmis + m) * 2 ...] = (first, last); slots with a taper are left alone.
+__global__ __launch_bounds__(256) void synspan_kernel(
+    const float *__restrict__ syn, size_t syn_stride, const CompDev *__restrict__ comps, const float *__restrict__ risetime /* of the chunk's sources */,
+    float dt, int nmis, const int *__restrict__ spansrc, int nrec, const int *__restrict__ synrow, int *__restrict__ synspan)
+{
+    const int m = blockIdx.x, s = blockIdx.y;
+    const CompDev cd = comps[m];
+    if (!cd.untapered) return;
+    int n0, n1;
+    strip_span(spansrc + ((size_t)(synrow ? synrow[s] : s) * nrec + cd.rec) * kSpanInts, cd.spankind, n0, n1);
+    const bool empty = n1 < n0;
+    if (empty) { n0 = 0; n1 = 0; }
+    const float rise = risetime[s];
+    int h = 0;
+    if (rise > 0.f) h = ((1 + 2 * (int)roundf(0.5f * rise / dt)) - 1) / 2;
+    int lo = n0, hi = n1;
+    if (h > 0) {
+        int d1 = n1, dl = n0 - 1;                     // first sample that is not zero (else the last one); last sample that differs from the end value
+        if (!empty) {
+            const float *__restrict__ sy = syn + (size_t)(synrow ? synrow[s] : s) * syn_stride + cd.synofs + cd.halo;   // sy[i] = sample w0 + i
+            const float last = sy[n1 - cd.w0];
+            for (int t = n0 + (int)threadIdx.x; t <= n1; t += 256) {
+                const float v = sy[t - cd.w0];
+                if (v != 0.f) d1 = min(d1, t);
+                if (v != last) dl = max(dl, t);
+            }
+        }
+        __shared__ int r1[256], r2[256];
+        r1[threadIdx.x] = d1; r2[threadIdx.x] = dl;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) { r1[threadIdx.x] = min(r1[threadIdx.x], r1[threadIdx.x + st]); r2[threadIdx.x] = max(r2[threadIdx.x], r2[threadIdx.x + st]); }
+            __syncthreads();
+        }
+        d1 = r1[0];
+        const int d2 = r2[0] + 1;
+        if (d2 >= d1) { lo = min(n0, d1 - h); hi = max(n1, d2 + h + 1); }      // (an all-zero strip longer than a sample: strip_fold returns at once)
+    }
+    if (threadIdx.x == 0) { synspan[((size_t)s * nmis + m) * 2] = lo; synspan[((size_t)s * nmis + m) * 2 + 1] = hi; }
+}
+
 __global__ __launch_bounds__(256) void misfit_kernel(
     const float *__restrict__ syn, size_t syn_stride, const CompDev *__restrict__ comps,
     const float *__restrict__ reft, const float *__restrict__ tw,
     const float *__restrict__ moment, const float *__restrict__ risetime, MisfitParams mp,
     float *__restrict__ misfit_out, float *__restrict__ proc /* optional [src][stride] processed synthetics */,
     float *__restrict__ fftbuf, float *__restrict__ vt_out /* optional [src][stride] tapered synthetics */,
-    const int *__restrict__ spansrc /* per-source strip spans, un-tapered receivers only */, int nrec, int fold_grow,
+    const int *__restrict__ synspan /* data spans of the synthetic probes (synspan_kernel), un-tapered receivers only */,
     const FftPair *__restrict__ pairs /* [source][slot], fft_mode only */,
     const int *__restrict__ synrow /* optional [source]: read the synthetics of that source -- sources whose centroid tables are
                                       identical differ only in moment / rise time, which are applied here (the reference
@@ -143,11 +190,9 @@ __global__ __launch_bounds__(256) void misfit_kernel(
     // span and the data span of this source's synthetic strip (probes_norm_timedomain, comparator.f90:798-800)
     int i_lo = 0, i_hi = cd.wlen - 1;
     if (cd.untapered) {
-        int s0, s1;
-        strip_span(spansrc + ((size_t)(synrow ? synrow[s] : s) * nrec + cd.rec) * kSpanInts, cd.spankind, s0, s1);
-        int lo = cd.rf0, hi = cd.rf1;
-        if (s1 >= s0) { lo = min(lo, s0 - fold_grow); hi = max(hi, s1 + (fold_grow ? fold_grow + 1 : 0)); }
-        i_lo = max(lo - cd.w0, 0); i_hi = min(hi - cd.w0, cd.wlen - 1);
+        const int s0 = synspan[((size_t)s * mp.nmis + m) * 2], s1 = synspan[((size_t)s * mp.nmis + m) * 2 + 1];
+        const int lo = min(cd.rf0, s0), hi = max(cd.rf1, s1);
+        i_lo = max(lo - cd.w0, 0); i_hi = min(hi - cd.w0, cd.wlen - 1);      // (outside the window both arrays are zero)
     }
     const float mom = moment[mp.isrc0 + s];
     const float rise = risetime[mp.isrc0 + s];
@@ -744,14 +789,10 @@ __global__ __launch_bounds__(256) void spec_filter_kernel(float2 *__restrict__ s
 // Data span [s0, s1] of the synthetic probe of pair (chunk source s, slot) as a fresh engine sets it (strip span grown by the
 // taps of THIS source's rise time) and, for a transform length N, where the pair's common span starts:
 // allowed_span(union of the data spans, .) = union(1) - floor((N - slen(union)) / 2.)  (comparator.f90:1092-1109).
-__device__ __forceinline__ void pair_span(const int *__restrict__ spansrc, const CompDev &cd, int s, int nrec, float rise, float dt, int N,
+__device__ __forceinline__ void pair_span(const int *__restrict__ synspan, const CompDev &cd, int s, int m, int nmis, int N,
                                           int &s0, int &s1, int &span0)
 {
-    int fold_grow = 0;
-    if (rise > 0.f) fold_grow = ((1 + 2 * (int)roundf(0.5f * rise / dt)) - 1) / 2;
-    strip_span(spansrc + ((size_t)s * nrec + cd.rec) * kSpanInts, cd.spankind, s0, s1);
-    if (s1 < s0) { s0 = cd.rf0; s1 = cd.rf0; }                       // no centroid reached this strip
-    if (fold_grow > 0) { s0 -= fold_grow; s1 += fold_grow + 1; }
+    s0 = synspan[((size_t)s * nmis + m) * 2]; s1 = synspan[((size_t)s * nmis + m) * 2 + 1];      // (synspan_kernel)
     const int u0 = min(cd.rf0, s0), u1 = max(cd.rf1, s1);
     span0 = u0 - (N - (u1 - u0 + 1)) / 2;
 }
@@ -761,7 +802,7 @@ __device__ __forceinline__ void pair_span(const int *__restrict__ spansrc, const
 __global__ __launch_bounds__(256) void filtered_norm_kernel(
     const float *__restrict__ fftbuf, const CompDev *__restrict__ comps, const FftPair *__restrict__ pairs,
     const float *__restrict__ ref_filt, const float *__restrict__ zmask, SpecParams sp, float *__restrict__ misfit_out,
-    float *__restrict__ proc, size_t syn_stride, const int *__restrict__ spansrc, int nrec, const float *__restrict__ risetime)
+    float *__restrict__ proc, size_t syn_stride, const int *__restrict__ synspan)
 {
     __shared__ double red[256];
     const int m = blockIdx.x, s = blockIdx.y;
@@ -778,7 +819,7 @@ __global__ __launch_bounds__(256) void filtered_norm_kernel(
     int i_lo = 0, i_hi = cd.wlen - 1, shift = 0;
     if (cd.untapered) {
         int s0, s1, span0;
-        pair_span(spansrc, cd, s, nrec, risetime[sp.isrc0 + s], sp.dt, pr.ntrans, s0, s1, span0);
+        pair_span(synspan, cd, s, m, sp.nmis, pr.ntrans, s0, s1, span0);
         shift = cd.w0 - span0;                            // row index of window sample i: i + shift
         i_lo = min(cd.rf0, s0) - cd.w0; i_hi = max(cd.rf1, s1) - cd.w0;
         rf = sp.reffiltpair + pr.fft_ofs + shift;
@@ -821,12 +862,6 @@ __global__ __launch_bounds__(256) void filtered_norm_kernel(
     }
 }
 
-// Transform length of every (trial source, slot) pair of a chunk, as a FRESH reference engine sizes it for this source:
-// the synthetic probe is set from the source's own strip (probe_set_array, comparator.f90:222-271: data span = strip
-// span, padded to a power of two of at least twice the data length), then probes_adjust_spans (:464-486) gives both
-// probes the span allowed_span(union of the two data spans, max of the two minimum lengths) (:1092-1109) -- so
-// ntrans = next_power_of_two(max(length of the union, 2 len_ref, 2 len_syn)).  spansrc: per (source, receiver) data spans
-// of the horizontal / vertical strips, reduced by geometry_kernel; fold_grow: strip_fold's growth (sparse_trace.f90:379-402).
 // Rows of the un-tapered slots for the transforms: the probe array over the pair's span -- zeros before the data span, the data,
 // the last value repeated behind it (probe_set_array / probe_extend_span, comparator.f90:259-265,320-324) -- of the REFERENCE
 // (REF) or of the trial source's synthetic (folded, scaled by the moment).  reft holds the un-tapered reference over the window,
@@ -835,7 +870,7 @@ template <bool REF>
 __global__ __launch_bounds__(256) void untapered_rows_kernel(
     const float *__restrict__ syn, size_t syn_stride, const CompDev *__restrict__ comps, const float *__restrict__ reft,
     const float *__restrict__ moment, const float *__restrict__ risetime, int isrc0, float dt, int nmis,
-    const int *__restrict__ spansrc, int nrec, const FftPair *__restrict__ pairs, float *__restrict__ fftbuf)
+    const int *__restrict__ spansrc, int nrec, const int *__restrict__ synspan, const FftPair *__restrict__ pairs, float *__restrict__ fftbuf)
 {
     const int m = blockIdx.x, s = blockIdx.y;
     const CompDev cd = comps[m];
@@ -844,7 +879,9 @@ __global__ __launch_bounds__(256) void untapered_rows_kernel(
     const int N = pr.ntrans;
     const float rise = risetime[isrc0 + s];
     int s0, s1, span0;
-    pair_span(spansrc, cd, s, nrec, rise, dt, N, s0, s1, span0);
+    pair_span(synspan, cd, s, m, nmis, N, s0, s1, span0);
+    bool empty;                                              // (an empty strip: zeros, wherever the window lies)
+    { int e0, e1; strip_span(spansrc + ((size_t)s * nrec + cd.rec) * kSpanInts, cd.spankind, e0, e1); empty = e1 < e0; }
     float *__restrict__ frow = fftbuf + pr.fft_ofs;
     if constexpr (REF) {
         const float *__restrict__ rt = reft + cd.refofs;
@@ -864,7 +901,7 @@ __global__ __launch_bounds__(256) void untapered_rows_kernel(
         const float *__restrict__ sy = syn + (size_t)s * syn_stride + cd.synofs + cd.halo;       // sy[i] = sample w0 + i
         for (int n = threadIdx.x; n < N; n += 256) {
             const int t = span0 + n;
-            frow[n] = t < s0 ? 0.f : folded_scaled_sample(sy, min(t, s1) - cd.w0, nf, fw, fs, fr, mom);
+            frow[n] = (t < s0 || empty) ? 0.f : folded_scaled_sample(sy, min(t, s1) - cd.w0, nf, fw, fs, fr, mom);
         }
     }
 }
@@ -902,7 +939,7 @@ __global__ __launch_bounds__(256) void pair_refamp_kernel(
 // (probe_norm_timedomain, :843-845) -> normsrc
 __global__ __launch_bounds__(256) void pair_reffilt_kernel(
     const float *__restrict__ fftbuf, const FftPair *__restrict__ pairs, const CompDev *__restrict__ comps, SpecParams sp,
-    const int *__restrict__ spansrc, int nrec, const float *__restrict__ risetime,
+    const int *__restrict__ synspan,
     float *__restrict__ reffiltpair, float *__restrict__ normsrc, float *__restrict__ reffilt_win /* of the chunk's first source, over
     the window at [pair.filtofs + i]: what get_reference(filtered) hands out */)
 {
@@ -913,7 +950,7 @@ __global__ __launch_bounds__(256) void pair_reffilt_kernel(
     const FftPair pr = pairs[(size_t)s * sp.nmis + m];
     const int N = pr.ntrans;
     int s0, s1, span0;
-    pair_span(spansrc, cd, s, nrec, risetime[sp.isrc0 + s], sp.dt, N, s0, s1, span0);
+    pair_span(synspan, cd, s, m, sp.nmis, N, s0, s1, span0);
     const float *__restrict__ row = fftbuf + pr.fft_ofs;
     double acc = 0.0, peak = 0.0;
     for (int n = threadIdx.x; n < N; n += 256) {
@@ -953,6 +990,14 @@ __global__ __launch_bounds__(256) void pair_reffilt_kernel(
     }
 }
 
+// Transform length of every (trial source, slot) pair of a chunk, as a FRESH reference engine sizes it for this source:
+// the synthetic probe is set from the source's own strip (probe_set_array, comparator.f90:222-271: data span = strip
+// span, padded to a power of two of at least twice the data length), then probes_adjust_spans (:464-486) gives both
+// probes the span allowed_span(union of the two data spans, max of the two minimum lengths) (:1092-1109) -- so
+// ntrans = next_power_of_two(max(length of the union, 2 len_ref, 2 len_syn)).  spansrc: per (source, receiver) data spans
+// of the horizontal / vertical strips, reduced by geometry_kernel; fold_grow: strip_fold's growth (sparse_trace.f90:379-402).
+// (Un-tapered slots: the spans the transforms use follow the synthetics' VALUES where a rise time folds them -- synspan_kernel, behind the
+// accumulate kernel --; the length estimated here, before it, is never shorter than what they need.)
 __global__ void fft_size_kernel(const int *__restrict__ spansrc, const CompDev *__restrict__ comps, int nmis, int nsrc, int nrec,
                                 const float *__restrict__ risetime /* of the chunk's sources */, float dt, int *__restrict__ ntr_out)
 {
@@ -969,7 +1014,7 @@ __global__ void fft_size_kernel(const int *__restrict__ spansrc, const CompDev *
     }
     int s0, s1;
     strip_span(spansrc + ((size_t)s * nrec + cd.rec) * kSpanInts, cd.spankind, s0, s1);
-    if (s1 < s0) { s0 = cd.rf0; s1 = cd.rf0; }                       // no centroid reached this strip
+    if (s1 < s0) { s0 = 0; s1 = 0; }                                 // no centroid reached this strip: the reference's empty strip is one zero at sample 0
     if (fold_grow > 0) { s0 -= fold_grow; s1 += fold_grow + 1; }
     const int len_ref = cd.rf1 - cd.rf0 + 1, len_syn = s1 - s0 + 1;
     const int len_u = max(cd.rf1, s1) - min(cd.rf0, s0) + 1;
@@ -1018,17 +1063,13 @@ __global__ void misfit_finish_kernel(const double *__restrict__ partial, const C
 __global__ __launch_bounds__(256) void floating_norm_kernel(
     const float *__restrict__ vt, size_t syn_stride, const CompDev *__restrict__ comps,
     const float *__restrict__ refx, const float *__restrict__ tw, int method /* 1 l2, 2 l1 */, float dt,
-    float syn_factor, int nmis, int maxns, float *__restrict__ partial, const int *__restrict__ spansrc, int nrec, int fold_grow)
+    float syn_factor, int nmis, int maxns, float *__restrict__ partial, const int *__restrict__ synspan)
 {
     __shared__ double red[256];
     const int m = blockIdx.x, s = blockIdx.y;
     const CompDev cd = comps[m];
     int s_lo = 0x7fffffff, s_hi = -0x7fffffff;          // data span of this source's synthetic strip (un-tapered only)
-    if (cd.untapered) {
-        int s0, s1;
-        strip_span(spansrc + ((size_t)s * nrec + cd.rec) * kSpanInts, cd.spankind, s0, s1);
-        if (s1 >= s0) { s_lo = s0 - fold_grow; s_hi = s1 + (fold_grow ? fold_grow + 1 : 0); }
-    }
+    if (cd.untapered) { s_lo = synspan[((size_t)s * nmis + m) * 2]; s_hi = synspan[((size_t)s * nmis + m) * 2 + 1]; }
     const float *__restrict__ sy = vt + (size_t)s * syn_stride + cd.synofs + cd.halo;
     const float *__restrict__ rx = refx + cd.refxofs;
     const float *__restrict__ tp = tw + cd.refofs;
