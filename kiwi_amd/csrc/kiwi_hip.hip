@@ -405,9 +405,6 @@ void prepare(kiwi_hip_ctx *c)
             discrete_plf_span(r.taper, dt, w);                             // comparator.f90:1157-1169
             if (w[1] < w[0]) throw std::runtime_error("receiver " + std::to_string(ir + 1) + ": empty taper span");
         }
-        if (std::getenv("KIWI_HIP_DEBUG_SPANS"))
-            std::fprintf(stderr, "receiver %d: natural spans h [%d, %d] v [%d, %d], fold halfwidth %d (max rise time %g), window [%d, %d]\n", ir + 1,
-                         nat.empty() ? 0 : nat[4 * ir], nat.empty() ? 0 : nat[4 * ir + 1], nat.empty() ? 0 : nat[4 * ir + 2], nat.empty() ? 0 : nat[4 * ir + 3], hs, (double)c->max_risetime, w[0], w[1]);
         const int wlen = w[1] - w[0] + 1;
         d.wbeg = w[0] - c->halo;
         d.wlen = wlen + 2 * c->halo;
