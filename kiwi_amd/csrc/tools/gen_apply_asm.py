@@ -248,7 +248,7 @@ if __name__ == "__main__":
     for fused in (False, True):
         print("#if KIWI_ARITH == %d" % (1 if fused else 0))
         for ng in (10,):
-            for K in (5, 9):
+            for K in (5, 9, 17):
                 for rot in (True, False):
                     print(routine(ng, K, rot, fused))
         print("#endif")
