@@ -1012,14 +1012,15 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
                                c->recs_d.p, tab, c->coef_d.p, c->pairflag_d.p, c->endz.p, (const int *)nullptr,
                                c->cell_wave ? exact::cellw_range() : kHalo - 10);
     }
-    if (c->fft_needed) {
+    if (c->fft_needed && !c->untapered_fft) {
         // transform length of every (source, slot) pair from the source's own strip spans; the lengths travel to the host
-        // while the accumulate kernel runs
+        // while the accumulate kernel runs.  (With un-tapered slots among them the spans follow the synthetics' values: sized
+        // behind the accumulate kernel, below.)
         const size_t np = (size_t)nsrc * c->nmis;
         c->ntr_d.ensure(np, &c->dev_bytes);
         pin_ensure(c->ntr_pin, c->ntr_pin_n, np);
         hipLaunchKernelGGL(fft_size_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, c->stream, spansrc, c->comps_d.p, c->nmis,
-                           nsrc, nrec, c->risetime_d.p + isrc0, c->gm.dt, c->ntr_d.p);
+                           nsrc, nrec, c->risetime_d.p + isrc0, c->gm.dt, c->ntr_d.p, (const int *)nullptr);
         HIPCHECK(hipMemcpyAsync(c->ntr_pin, c->ntr_d.p, np * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHECK(hipEventRecord(c->size_event, c->stream));
     }
@@ -1157,6 +1158,20 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
         }
     }
     record(c, 1, e2);
+    if (c->any_untapered) {      // data spans of the synthetic probes: they follow the synthetics' values where a rise time folds them
+        c->synspan_d.ensure((size_t)nsrc * c->nmis * 2, &c->dev_bytes);
+        hipLaunchKernelGGL(synspan_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream, c->syn_d.p, c->syn_stride, c->comps_d.p,
+                           c->risetime_d.p + isrc0, c->gm.dt, c->nmis, spansrc, nrec, synrow, c->synspan_d.p);
+    }
+    if (c->untapered_fft) {
+        const size_t np = (size_t)nsrc * c->nmis;
+        c->ntr_d.ensure(np, &c->dev_bytes);
+        pin_ensure(c->ntr_pin, c->ntr_pin_n, np);
+        hipLaunchKernelGGL(fft_size_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, c->stream, spansrc, c->comps_d.p, c->nmis,
+                           nsrc, nrec, c->risetime_d.p + isrc0, c->gm.dt, c->ntr_d.p, (const int *)c->synspan_d.p);
+        HIPCHECK(hipMemcpyAsync(c->ntr_pin, c->ntr_d.p, np * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(hipEventRecord(c->size_event, c->stream));
+    }
     if (c->fft_needed) layout_fft_chunk(c, isrc0, nsrc);
     {
         const bool spectral = (c->method == KIWI_AMPSPEC_L2NORM || c->method == KIWI_AMPSPEC_L1NORM);
@@ -1191,11 +1206,6 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
         if (filt_fused) for (auto &b : c->buckets) { filt_fused = filt_fused && fused_fft_takes(c, b.ntrans); filt_longest = std::max(filt_longest, b.ntrans); }
         if (filt_fused) mp.fft_mode |= 4;
         SpecParams sp{ c->method, c->gm.dt, c->syn_factor, c->nmis, isrc0, c->any_filter ? 1 : 0 };
-        if (c->any_untapered) {      // data spans of the synthetic probes: they follow the synthetics' values where a rise time folds them
-            c->synspan_d.ensure((size_t)nsrc * c->nmis * 2, &c->dev_bytes);
-            hipLaunchKernelGGL(synspan_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream, c->syn_d.p, c->syn_stride, c->comps_d.p,
-                               c->risetime_d.p + isrc0, c->gm.dt, c->nmis, spansrc, nrec, synrow, c->synspan_d.p);
-        }
         if (c->untapered_fft) {
             // Un-tapered slots, reference side first: the reference's padded array over every PAIR's span through the same
             // transforms -> amplitude spectrum (x filter) or filtered trace per pair + the pair's norm factor.  (Before

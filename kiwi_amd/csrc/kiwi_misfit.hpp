@@ -996,10 +996,11 @@ __global__ __launch_bounds__(256) void pair_reffilt_kernel(
 // probes the span allowed_span(union of the two data spans, max of the two minimum lengths) (:1092-1109) -- so
 // ntrans = next_power_of_two(max(length of the union, 2 len_ref, 2 len_syn)).  spansrc: per (source, receiver) data spans
 // of the horizontal / vertical strips, reduced by geometry_kernel; fold_grow: strip_fold's growth (sparse_trace.f90:379-402).
-// (Un-tapered slots: the spans the transforms use follow the synthetics' VALUES where a rise time folds them -- synspan_kernel, behind the
-// accumulate kernel --; the length estimated here, before it, is never shorter than what they need.)
+// (Un-tapered slots: the spans follow the synthetics' VALUES where a rise time folds them -- synspan_kernel, behind the accumulate
+// kernel --; with such slots in the batch the sizing runs behind it as well and takes their spans from there.)
 __global__ void fft_size_kernel(const int *__restrict__ spansrc, const CompDev *__restrict__ comps, int nmis, int nsrc, int nrec,
-                                const float *__restrict__ risetime /* of the chunk's sources */, float dt, int *__restrict__ ntr_out)
+                                const float *__restrict__ risetime /* of the chunk's sources */, float dt, int *__restrict__ ntr_out,
+                                const int *__restrict__ synspan /* or null: spans of the un-tapered slots' synthetic probes (synspan_kernel) */)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nsrc * nmis) return;
@@ -1016,6 +1017,7 @@ __global__ void fft_size_kernel(const int *__restrict__ spansrc, const CompDev *
     strip_span(spansrc + ((size_t)s * nrec + cd.rec) * kSpanInts, cd.spankind, s0, s1);
     if (s1 < s0) { s0 = 0; s1 = 0; }                                 // no centroid reached this strip: the reference's empty strip is one zero at sample 0
     if (fold_grow > 0) { s0 -= fold_grow; s1 += fold_grow + 1; }
+    if (synspan && cd.untapered) { s0 = synspan[(size_t)idx * 2]; s1 = synspan[(size_t)idx * 2 + 1]; }
     const int len_ref = cd.rf1 - cd.rf0 + 1, len_syn = s1 - s0 + 1;
     const int len_u = max(cd.rf1, s1) - min(cd.rf0, s0) + 1;
     const int minlength = max((int)ceilf((float)len_ref * 2.f), (int)ceilf((float)len_syn * 2.f));
