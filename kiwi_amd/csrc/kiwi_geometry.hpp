@@ -165,7 +165,10 @@ __global__ __launch_bounds__(256) void geometry_kernel(
                                   bit 1 some centroid is left out (a trace missing or outside the database), bit 2 some group's rows do
                                   not all end in zero (the tail rule can apply); see cell_pair(), multi_taken() */,
     const unsigned char *__restrict__ endz /* per GF row: its end value is zero (write_tab) */,
-    const int *__restrict__ synrow /* optional [source]: source whose synthetics this one shares; != own index: nothing to do */)
+    const int *__restrict__ synrow /* optional [source]: source whose synthetics this one shares; != own index: nothing to do */,
+    int *__restrict__ lmax_out /* optional [source][receiver], preset to -1: index of the LAST centroid that reaches the rotated add of the
+                                  rotating branch (see the span reduction below) */,
+    const int *__restrict__ lmax_in /* optional: the same, from a pass in front of this one */)
 {
     const int s = blockIdx.y;
     if (synrow && synrow[s] != s) return;
@@ -176,6 +179,7 @@ __global__ __launch_bounds__(256) void geometry_kernel(
     // as copies of its last record that neither store nor count
     const bool live = idx < nc * ep.nrec;
     if (!live) { if (!spanbuf && !spansrc) return; idx = nc * ep.nrec - 1; }
+    int rot_gap = -1, rot_rows[4] = { -1, -1, -1, -1 };   // rotating branch left at a missing horizontal trace: how many of its components went into the temporaries, and the rows
     const int r = idx / nc, c = idx - r * nc;
     const RecvDev &rv = recv[r];
     const float *ce = cent + (size_t)(c0 + c) * 10;
@@ -296,6 +300,8 @@ __global__ __launch_bounds__(256) void geometry_kernel(
             for (; k < nH; k++) if (!stored(gm.ng == 10 ? (k < 3 ? k : (k == 3 ? 8 : k - 1)) : k)) break;
             hfull = (k == nH);
             nlim_h = hfull ? nH : ((g.flags & 2) ? 0 : k);
+            if (!hfull && (g.flags & 2)) { rot_gap = k; for (int q = 0; q < 4; q++) rot_rows[q] = g.row[q]; }
+            if (hfull && (g.flags & 2) && live && lmax_out) atomicMax(&lmax_out[(size_t)s * ep.nrec + r], c);
         }
         if (rv.has_d && hfull) {
             int k = 0;
@@ -343,6 +349,19 @@ __global__ __launch_bounds__(256) void geometry_kernel(
             if (hi_1 >= lo_1) { lo_1 += g.ishift; hi_1 += g.ishift + 1; }
             if (hi_2 >= lo_2) { lo_2 += g.ishift; hi_2 += g.ishift + 1; }
             if (nlim_d && hi_d >= lo_d) { lo_d += g.ishift; hi_d += g.ishift + 1; } else { lo_d = 0x7fffffff; hi_d = -0x7fffffff; }
+        } else if (live && rot_gap > 0 && lmax_in && c < lmax_in[(size_t)s * ep.nrec + r]) {
+            // The rotating branch collects a centroid's horizontals in temporaries that KEEP their extent from centroid to centroid
+            // (seismogram.f90:160-190: `displacement_temp(:)%data(:) = 0.`); a centroid that leaves at a missing trace has extended
+            // them by what it had added so far, and the next centroid that reaches the rotated add passes that extent on to the
+            // strips (strip_extend_to_same_span_4, :193).  So the components in front of the gap count for the strips' spans -- if a
+            // later centroid of this (source, receiver) completes its horizontals.
+            const int nn = (g.flags & 1) ? 1 : 4;
+            for (int i = 0; i < rot_gap; i++) {
+                const int ig = gm.ng == 10 ? (i < 3 ? i : (i == 3 ? 8 : i - 1)) : i;
+                for (int k = 0; k < nn; k++) { const int2 sp = span[rot_rows[k] + ig]; lo_1 = min(lo_1, sp.x); hi_1 = max(hi_1, sp.y); }
+            }
+            lo_1 += g.ishift; hi_1 += g.ishift + 1;
+            lo_2 = lo_1; hi_2 = hi_1;
         }
         // Union over the centroids of one (source, receiver): the lanes of a wave that belong to the same receiver are
         // consecutive (idx = r * nc + c), so a segmented suffix reduction leaves the union of each run in its first lane

@@ -207,6 +207,8 @@ struct kiwi_hip_ctx {
     std::vector<int> slot_has_filter;
     DevBuf<int> spanbuf_d, ntr_d;
     DevBuf<float> fft_d, refamp_d, filtw_d, reffilt_d, zmask_d, normsrc_d;
+    DevBuf<int> lmax_d;                                          // [chunk source][receiver]: last centroid that reaches the rotated add (geometry_kernel, databases with gaps)
+    bool db_gaps = false;                                        // some trace of the database is not stored
     DevBuf<int> synspan_d;                                       // data spans of the synthetic probes of the chunk's un-tapered slots (synspan_kernel)
     DevBuf<float> refpair_d, reffiltpair_d;                      // un-tapered slots: reference spectrum / filtered reference per PAIR (SpecParams)
     bool untapered_fft = false;                                  // some un-tapered slot goes through the transforms
@@ -306,8 +308,18 @@ void natural_spans(kiwi_hip_ctx *c, std::vector<int> &sb)
         if (maxnc == 0) continue;
         EvalParams ep{ c->bilinear, c->xus, c->zus, nrec, s0 };
         dim3 grid((unsigned)((maxnc * nrec + 255) / 256), (unsigned)n);
+        int *lmax = nullptr;
+        if (c->db_gaps) {      // (see geometry_kernel's span reduction: which partly added centroids count follows the centroids' order)
+            c->lmax_d.ensure((size_t)n * nrec, &c->dev_bytes);
+            HIPCHECK(hipMemsetAsync(c->lmax_d.p, 0xff, (size_t)n * nrec * sizeof(int), c->stream));
+            lmax = c->lmax_d.p;
+            hipLaunchKernelGGL(geometry_kernel, grid, dim3(256), 0, c->stream, c->cent_d.p, c->centofs_d.p, ep, c->gm,
+                               c->span.p, c->recv_d.p, (GeoRec *)nullptr, (int *)nullptr, (float *)nullptr, (int *)nullptr, (int *)nullptr, (int *)nullptr, c->endz.p, (const int *)nullptr,
+                               lmax, (const int *)nullptr);
+        }
         hipLaunchKernelGGL(geometry_kernel, grid, dim3(256), 0, c->stream, c->cent_d.p, c->centofs_d.p, ep, c->gm,
-                           c->span.p, c->recv_d.p, (GeoRec *)nullptr, (int *)nullptr, (float *)nullptr, c->spanbuf_d.p, (int *)nullptr, (int *)nullptr, c->endz.p, (const int *)nullptr);
+                           c->span.p, c->recv_d.p, (GeoRec *)nullptr, (int *)nullptr, (float *)nullptr, c->spanbuf_d.p, (int *)nullptr, (int *)nullptr, c->endz.p, (const int *)nullptr,
+                           (int *)nullptr, (const int *)lmax);
     }
     HIPCHECK(hipMemcpyAsync(sb.data(), c->spanbuf_d.p, sb.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));
@@ -673,7 +685,7 @@ void prepare_fft(kiwi_hip_ctx *c, const std::vector<float> &reft_host)
         const int f0 = cd.rf0, f1 = cd.rf1;
         int s0 = sb[4 * cd.rec + (cd.vertical ? 2 : 0)], s1 = sb[4 * cd.rec + (cd.vertical ? 3 : 1)];
         if (s1 < s0) { s0 = 0; s1 = 0; }                            // no centroid contributed: the reference's empty strip is one zero at sample 0
-        if (hs > 0) { s0 -= hs; s1 += hs + 1; }                     // strip_fold grows the strip
+        else if (hs > 0) { s0 -= hs; s1 += hs + 1; }                // strip_fold grows the strip
         const int len_ref = f1 - f0 + 1, len_syn = s1 - s0 + 1;
         const int len_u = std::max(f1, s1) - std::min(f0, s0) + 1;
         const int minlength = std::max((int)std::ceil(len_ref * 2.f), (int)std::ceil(len_syn * 2.f));
@@ -1005,8 +1017,18 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
             c->pairflag_d.ensure((size_t)nsrc * nrec, &c->dev_bytes);
             HIPCHECK(hipMemsetAsync(c->pairflag_d.p, 0, (size_t)nsrc * nrec * sizeof(int), c->stream));
         }
+        int *lmax = nullptr;
+        if (c->db_gaps && spansrc) {      // (a pass in front for the order-dependent part of the strips' spans, see geometry_kernel)
+            c->lmax_d.ensure((size_t)nsrc * nrec, &c->dev_bytes);
+            HIPCHECK(hipMemsetAsync(c->lmax_d.p, 0xff, (size_t)nsrc * nrec * sizeof(int), c->stream));
+            lmax = c->lmax_d.p;
+            hipLaunchKernelGGL(geometry_kernel, grid, dim3(256), 0, c->stream, c->cent_d.p, c->centofs_d.p, ep, c->gm,
+                               c->span.p, c->recv_d.p, (GeoRec *)nullptr, (int *)nullptr, (float *)nullptr, (int *)nullptr, (int *)nullptr, (int *)nullptr, c->endz.p, (const int *)nullptr,
+                               lmax, (const int *)nullptr);
+        }
         hipLaunchKernelGGL(geometry_kernel, grid, dim3(256), 0, c->stream, c->cent_d.p, c->centofs_d.p, ep, c->gm,
-                           c->span.p, c->recv_d.p, c->recs_d.p, tab, c->coef_d.p, (int *)nullptr, spansrc, (cell || duo_maybe) ? c->pairflag_d.p : (int *)nullptr, c->endz.p, (const int *)nullptr);
+                           c->span.p, c->recv_d.p, c->recs_d.p, tab, c->coef_d.p, (int *)nullptr, spansrc, (cell || duo_maybe) ? c->pairflag_d.p : (int *)nullptr, c->endz.p, (const int *)nullptr,
+                           (int *)nullptr, (const int *)lmax);
         if (cell)
             hipLaunchKernelGGL(cellgroup_kernel, grid, dim3(256), 0, c->stream, c->centofs_d.p, ep, c->gm, c->span.p, c->recv_d.p,
                                c->recs_d.p, tab, c->coef_d.p, c->pairflag_d.p, c->endz.p, (const int *)nullptr,
@@ -1476,6 +1498,7 @@ int kiwi_hip_set_gfdb(kiwi_hip_ctx *c, int nx, int nz, int ng, int L, float dt, 
     c->G.alloc(nrows * (size_t)pitch, &c->dev_bytes);
     c->span.alloc(nrows, &c->dev_bytes);
     std::vector<int2> sp(nrows);
+    bool gaps = false;
     std::vector<unsigned char> ez(nrows);
     c->endz.alloc(nrows, &c->dev_bytes);
     const size_t slab = std::max<size_t>(1, ((size_t)64 << 20) / ((size_t)pitch * sizeof(float)));
@@ -1493,6 +1516,7 @@ int kiwi_hip_set_gfdb(kiwi_hip_ctx *c, int nx, int nz, int ng, int L, float dt, 
             const float tail = n > 0 ? src[n - 1] : 0.f;
             for (int k = kRowPad + n; k < pitch; k++) d[k] = tail;
             sp[row] = make_int2(first[row], first[row] + n - 1);       // n == 0 -> empty span = not stored
+            if (n <= 0) gaps = true;
             ez[row] = (tail == 0.f) ? 1 : 0;
         }
         HIPCHECK(hipMemcpy(c->G.p + r0 * (size_t)pitch, stage.data(), nr * (size_t)pitch * sizeof(float), hipMemcpyHostToDevice));
@@ -1500,6 +1524,7 @@ int kiwi_hip_set_gfdb(kiwi_hip_ctx *c, int nx, int nz, int ng, int L, float dt, 
     HIPCHECK(hipMemcpy(c->span.p, sp.data(), nrows * sizeof(int2), hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(c->endz.p, ez.data(), nrows, hipMemcpyHostToDevice));
     c->gm = GfMeta{ nx, nz, ng, pitch, dt, dx, dz, firstx, firstz };
+    c->db_gaps = gaps;
     c->have_db = true;
     c->prepared = false;            // dirtyfy_database, minimizer_engine.f90:1483
     return forward(c, [&](kiwi_hip_ctx *m) { return kiwi_hip_set_gfdb(m, nx, nz, ng, L, dt, dx, dz, firstx, firstz, G, first, nsamp); });

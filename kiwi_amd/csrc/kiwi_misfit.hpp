@@ -147,9 +147,9 @@ __global__ __launch_bounds__(256) void synspan_kernel(
     int h = 0;
     if (rise > 0.f) h = ((1 + 2 * (int)roundf(0.5f * rise / dt)) - 1) / 2;
     int lo = n0, hi = n1;
-    if (h > 0) {
+    if (h > 0 && !empty) {                            // (a strip nothing was added to has no length: strip_fold leaves it alone, :360-363)
         int d1 = n1, dl = n0 - 1;                     // first sample that is not zero (else the last one); last sample that differs from the end value
-        if (!empty) {
+        {
             const float *__restrict__ sy = syn + (size_t)(synrow ? synrow[s] : s) * syn_stride + cd.synofs + cd.halo;   // sy[i] = sample w0 + i
             const float last = sy[n1 - cd.w0];
             for (int t = n0 + (int)threadIdx.x; t <= n1; t += 256) {
@@ -1015,8 +1015,8 @@ __global__ void fft_size_kernel(const int *__restrict__ spansrc, const CompDev *
     }
     int s0, s1;
     strip_span(spansrc + ((size_t)s * nrec + cd.rec) * kSpanInts, cd.spankind, s0, s1);
-    if (s1 < s0) { s0 = 0; s1 = 0; }                                 // no centroid reached this strip: the reference's empty strip is one zero at sample 0
-    if (fold_grow > 0) { s0 -= fold_grow; s1 += fold_grow + 1; }
+    if (s1 < s0) { s0 = 0; s1 = 0; }                                 // no centroid reached this strip: the reference's empty strip is one zero at sample 0, and no rise time grows it
+    else if (fold_grow > 0) { s0 -= fold_grow; s1 += fold_grow + 1; }
     if (synspan && cd.untapered) { s0 = synspan[(size_t)idx * 2]; s1 = synspan[(size_t)idx * 2 + 1]; }
     const int len_ref = cd.rf1 - cd.rf0 + 1, len_syn = s1 - s0 + 1;
     const int len_u = max(cd.rf1, s1) - min(cd.rf0, s0) + 1;

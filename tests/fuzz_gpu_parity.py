@@ -50,13 +50,6 @@ def one_case(rng, verbose):
     # the references stay those of the complete database): the reference leaves a centroid at the first trace it does not
     # find (seismogram.f90:171-250)
     holes = rng.random() < float(os.environ.get("KIWI_FUZZ_HOLES", "0.25"))
-    if notaper and not os.environ.get("KIWI_FUZZ_HOLES_NOTAPER"):
-        # Not combined by default: with traces missing AND no taper the reference's horizontal strips also cover what the rotating
-        # branch had put into its temporary strips before it left a centroid at a missing trace (seismogram.f90:160-203: the temporaries
-        # keep their extent, strip_extend_to_same_span_4 passes it on to the next centroid that completes) -- an extent that follows
-        # the ORDER of the centroids.  The device counts the spans of what is added only (INTEGRATION.md "Limits"): 0.4 % of
-        # such cases differ by a sample of the union span (seen: up to 1e-1 of a filtered L1 norm).
-        holes = False
     if holes:
         e.close()
         nxg, nzg = sc.gf["nsamp"].shape[:2]
