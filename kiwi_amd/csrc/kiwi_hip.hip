@@ -582,9 +582,10 @@ void fft_rows(kiwi_hip_ctx *c, int ntrans, long long count, long long fft_base, 
     }
 }
 
-void fft_buckets(kiwi_hip_ctx *c, bool forward)
+void fft_buckets(kiwi_hip_ctx *c, bool forward, int lds_lo = 1, int lds_hi = 0)
 {
-    for (auto &b : c->buckets) fft_rows(c, b.ntrans, b.count, b.fft_base, b.spec_base, forward);
+    for (auto &b : c->buckets)
+        if (b.ntrans < lds_lo || b.ntrans > lds_hi) fft_rows(c, b.ntrans, b.count, b.fft_base, b.spec_base, forward);      // (the other lengths: in-LDS kernels)
 }
 
 int next_pow2(int n) { int m = 1; while (m < n) m *= 2; return m; }      // comparator.f90:1111-1118 (integer form)
@@ -593,6 +594,13 @@ int next_pow2(int n) { int m = 1; while (m < n) m *= 2; return m; }      // comp
 bool fused_fft_takes(const kiwi_hip_ctx *c, int ntrans)
 {
     return c->fused_fft && ntrans >= (1 << kFusedFftMinLog2) && ntrans <= (1 << kFusedFftMaxLog2) && (ntrans & (ntrans - 1)) == 0;
+}
+
+// the lengths whose pairs go through the in-LDS transforms in this context (SpecParams::lds_lo / lds_hi): decided per PAIR
+void lds_fft_range(const kiwi_hip_ctx *c, int &lo, int &hi)
+{
+    if (c->fused_fft && !c->untapered_fft) { lo = 1 << kFusedFftMinLog2; hi = 1 << kFusedFftMaxLog2; }
+    else { lo = 1; hi = 0; }          // none: library transforms throughout (KIWI_HIP_FUSED_FFT=0; un-tapered slots, see run_chunk)
 }
 
 // twiddle table of one length (layout: fused_fft_table_size / spec_fft_norm_kernel), made in double precision
@@ -637,9 +645,10 @@ FusedFftTables fused_fft_tables(kiwi_hip_ctx *c)
 }
 
 __global__ void ref_amp_kernel(const float2 *__restrict__ spec, const FftPair *__restrict__ pairs,
-                               const float *__restrict__ filtw, float *__restrict__ refamp)
+                               const float *__restrict__ filtw, float *__restrict__ refamp, int lds_lo, int lds_hi)
 {
     const FftPair pr = pairs[blockIdx.x];
+    if (pr.ntrans >= lds_lo && pr.ntrans <= lds_hi) return;
     const int nb = pr.ntrans / 2 + 1;
     const float2 *row = spec + pr.spec_ofs;
     for (int k = threadIdx.x; k < nb; k += blockDim.x) {
@@ -649,9 +658,10 @@ __global__ void ref_amp_kernel(const float2 *__restrict__ spec, const FftPair *_
 }
 
 __global__ void ref_filt_kernel(const float *__restrict__ fftbuf, const FftPair *__restrict__ pairs, const CompDev *__restrict__ comps,
-                                const float *__restrict__ zmask, float *__restrict__ ref_filt)
+                                const float *__restrict__ zmask, float *__restrict__ ref_filt, int lds_lo, int lds_hi)
 {
     const FftPair pr = pairs[blockIdx.x];
+    if (pr.ntrans >= lds_lo && pr.ntrans <= lds_hi) return;
     const CompDev cd = comps[pr.slot];
     if (cd.untapered) return;                  // (the window of an un-tapered slot may be longer than the row; its filtered reference is the pair's)
     const float *row = fftbuf + pr.fft_ofs;
@@ -768,47 +778,51 @@ void make_variants(kiwi_hip_ctx *c, const std::vector<std::pair<int, int>> &want
         HIPCHECK(hipMemcpyAsync(c->fft_d.p, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
         HIPCHECK(hipStreamSynchronize(c->stream));
     }
-    // rows of equal length are contiguous (sorted): one batched transform per length
-    auto for_each_length = [&](bool forward) {
+    int lds_lo, lds_hi;
+    lds_fft_range(c, lds_lo, lds_hi);
+    auto in_lds = [&](int n) { return n >= lds_lo && n <= lds_hi; };
+    // rows of equal length are contiguous (sorted): one batched transform per length; lib_only: the lengths the in-LDS kernels leave
+    auto for_each_length = [&](bool forward, bool lib_only) {
         size_t i = 0;
         while (i < prs.size()) {
             size_t j = i;
             while (j < prs.size() && prs[j].ntrans == prs[i].ntrans) j++;
-            fft_rows(c, prs[i].ntrans, (long long)(j - i), prs[i].fft_ofs, prs[i].spec_ofs, forward);
+            if (!(lib_only && in_lds(prs[i].ntrans))) fft_rows(c, prs[i].ntrans, (long long)(j - i), prs[i].fft_ofs, prs[i].spec_ofs, forward);
             i = j;
         }
     };
-    bool fused = spectral && !c->untapered_fft;          // (un-tapered slots: library transforms throughout, see run_chunk)
+    // Every variant by the transform its trial sources go through -- in LDS or the library's, by its LENGTH, whatever else is in the
+    // batch (a pair's result must not depend on its neighbours): a trial source that reproduces the reference trace bit for bit then
+    // has the misfit 0 exactly.
+    bool any_lds = false, any_lib = false;
     int longest = 0;
-    for (auto &pr : prs) { fused = fused && fused_fft_takes(c, pr.ntrans); longest = std::max(longest, pr.ntrans); }
-    if (fused) {
-        // amplitude spectra of the references by the transform the trial sources go through (spec_fft_norm_kernel): a trial
-        // source that reproduces the reference trace bit for bit then has the misfit 0 exactly
-        for (auto &pr : prs) fused_fft_table(c, pr.ntrans);
-        const FusedFftTables ft = fused_fft_tables(c);
-        SpecParams sp{ c->method, dt, c->syn_factor, c->nmis, 0, c->any_filter ? 1 : 0 };
-        hipLaunchKernelGGL(spec_fft_norm_kernel<1>, dim3((unsigned)prs.size()), dim3(256), (size_t)longest * 4, c->stream, c->fft_d.p, prs_d.p, ft,
-                           (const float *)nullptr, c->filtw_d.p, sp, (float *)nullptr, c->refamp_d.p, SynRows{});
+    for (auto &pr : prs) { if (in_lds(pr.ntrans)) { any_lds = true; longest = std::max(longest, pr.ntrans); fused_fft_table(c, pr.ntrans); } else any_lib = true; }
+    SpecParams sp{ c->method, dt, c->syn_factor, c->nmis, 0, c->any_filter ? 1 : 0 };
+    sp.lds_lo = lds_lo; sp.lds_hi = lds_hi;
+    if (spectral) {
+        if (any_lds)
+            hipLaunchKernelGGL(spec_fft_norm_kernel<1>, dim3((unsigned)prs.size()), dim3(256), (size_t)longest * 4, c->stream, c->fft_d.p, prs_d.p, fused_fft_tables(c),
+                               (const float *)nullptr, c->filtw_d.p, sp, (float *)nullptr, c->refamp_d.p, SynRows{});
+        if (any_lib) {
+            for_each_length(true, true);
+            hipLaunchKernelGGL(ref_amp_kernel, dim3((unsigned)prs.size()), dim3(256), 0, c->stream, c->spec_d.p, prs_d.p, c->filtw_d.p, c->refamp_d.p, lds_lo, lds_hi);
+        }
     } else {
-        for_each_length(true);
-        hipLaunchKernelGGL(ref_amp_kernel, dim3((unsigned)prs.size()), dim3(256), 0, c->stream, c->spec_d.p, prs_d.p, c->filtw_d.p, c->refamp_d.p);
+        for_each_length(true, false);
+        hipLaunchKernelGGL(ref_amp_kernel, dim3((unsigned)prs.size()), dim3(256), 0, c->stream, c->spec_d.p, prs_d.p, c->filtw_d.p, c->refamp_d.p, 1, 0);
     }
     if (c->any_filter && !spectral) {
-        bool ffused = !c->untapered_fft;
-        for (auto &pr : prs) ffused = ffused && fused_fft_takes(c, pr.ntrans);
-        if (ffused) {
-            // filtered references by the transform pair the trial sources go through (spec_fft_filter_norm_kernel); the rows in
-            // fft_d are untouched by the library transform above (out of place)
-            for (auto &pr : prs) fused_fft_table(c, pr.ntrans);
-            SpecParams sp{ c->method, dt, c->syn_factor, c->nmis, 0, 1 };
+        sp.has_filter = 1;
+        if (any_lds)      // filtered references by the transform pair the trial sources go through (spec_fft_filter_norm_kernel); the rows in
+                          // fft_d are untouched by the library transform above (out of place)
             hipLaunchKernelGGL(spec_fft_filter_norm_kernel<1>, dim3((unsigned)prs.size()), dim3(256), (size_t)longest * 4, c->stream, c->fft_d.p, prs_d.p,
                                fused_fft_tables(c), c->comps_d.p, c->filtw_d.p, (const float *)nullptr, c->zmask_d.p, sp, (float *)nullptr,
                                c->reffilt_d.p, SynRows{});
-        } else {
-            hipLaunchKernelGGL(spec_filter_kernel, dim3((unsigned)prs.size()), dim3(256), 0, c->stream, c->spec_d.p, prs_d.p, c->comps_d.p, c->filtw_d.p);
-            for_each_length(false);
+        if (any_lib) {
+            hipLaunchKernelGGL(spec_filter_kernel, dim3((unsigned)prs.size()), dim3(256), 0, c->stream, c->spec_d.p, prs_d.p, c->comps_d.p, c->filtw_d.p, lds_lo, lds_hi);
+            for_each_length(false, true);
             hipLaunchKernelGGL(ref_filt_kernel, dim3((unsigned)prs.size()), dim3(256), 0, c->stream, c->fft_d.p, prs_d.p, c->comps_d.p,
-                               c->zmask_d.p, c->reffilt_d.p);
+                               c->zmask_d.p, c->reffilt_d.p, lds_lo, lds_hi);
         }
     }
     HIPCHECK(hipGetLastError());
@@ -1216,18 +1230,23 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
                                fuse_all ? 0 : fuse_tile,
                                c->method, c->gm.dt, isrc0, nsrc, c->misfit_d.p);
         }
-        // amplitude-spectrum norms whose transforms fit spec_fft_norm_kernel: that kernel takes the plain synthetics itself
-        // (fold, moment, taper while the row goes into LDS) unless the processed synthetics are to be kept
-        bool spec_fused = spectral && c->fft_needed && !c->untapered_fft;
-        int spec_longest = 0;
-        if (spec_fused) for (auto &b : c->buckets) { spec_fused = spec_fused && fused_fft_takes(c, b.ntrans); spec_longest = std::max(spec_longest, b.ntrans); }
-        const bool spec_direct = spec_fused && !proc && !fuse;
-        // time-domain norms on filtered traces: the same in-LDS transform, forward and back (spec_fft_filter_norm_kernel)
-        bool filt_fused = !spectral && c->fft_needed && !proc && !fuse && !c->untapered_fft;
-        int filt_longest = 0;
-        if (filt_fused) for (auto &b : c->buckets) { filt_fused = filt_fused && fused_fft_takes(c, b.ntrans); filt_longest = std::max(filt_longest, b.ntrans); }
-        if (filt_fused) mp.fft_mode |= 4;
+        // Transforms: a pair whose length fits goes through the in-LDS kernels (spec_fft_norm_kernel / spec_fft_filter_norm_kernel), the
+        // others through the library's -- decided per PAIR by its length, so that a pair's result does not depend on what else is in
+        // the batch.  The in-LDS kernels take the plain synthetics themselves (fold, moment, taper while the row goes into LDS)
+        // unless the processed synthetics are to be kept (spectral norms: rows from misfit_kernel then; filtered time-domain norms:
+        // the library pair).
+        int lds_lo = 1, lds_hi = 0;
+        if (c->fft_needed) lds_fft_range(c, lds_lo, lds_hi);
+        const bool direct_ok = !proc && !fuse;
+        if (!spectral && !direct_ok) { lds_lo = 1; lds_hi = 0; }
+        bool any_lds = false, any_lib = false;
+        int lds_longest = 0;
+        if (c->fft_needed)
+            for (auto &b : c->buckets) { if (b.ntrans >= lds_lo && b.ntrans <= lds_hi) { any_lds = true; lds_longest = std::max(lds_longest, b.ntrans); } else any_lib = true; }
+        const bool spec_direct_all = spectral && c->fft_needed && direct_ok && !any_lib;      // no row is needed: misfit_kernel has nothing to do
+        if (c->fft_needed && direct_ok) { mp.fft_mode |= 4; mp.lds_lo = lds_lo; mp.lds_hi = lds_hi; }
         SpecParams sp{ c->method, c->gm.dt, c->syn_factor, c->nmis, isrc0, c->any_filter ? 1 : 0 };
+        sp.lds_lo = lds_lo; sp.lds_hi = lds_hi;
         if (c->untapered_fft) {
             // Un-tapered slots, reference side first: the reference's padded array over every PAIR's span through the same
             // transforms -> amplitude spectrum (x filter) or filtered trace per pair + the pair's norm factor.  (Before
@@ -1243,13 +1262,13 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
                                    c->refpair_d.p, c->normsrc_d.p);
             } else {
                 hipLaunchKernelGGL(spec_filter_kernel, dim3((unsigned)(c->nmis * nsrc)), dim3(256), 0, c->stream,
-                                   c->spec_d.p, c->pairs_d.p, c->comps_d.p, c->filtw_d.p);
+                                   c->spec_d.p, c->pairs_d.p, c->comps_d.p, c->filtw_d.p, 1, 0);
                 fft_buckets(c, false);
                 hipLaunchKernelGGL(pair_reffilt_kernel, pg, dim3(256), 0, c->stream, c->fft_d.p, c->pairs_d.p, c->comps_d.p, sp, c->synspan_d.p,
                                    c->reffiltpair_d.p, c->normsrc_d.p, c->reffilt_d.p);
             }
         }
-        if (!fuse && !spec_direct)
+        if (!fuse && !spec_direct_all)
         hipLaunchKernelGGL(misfit_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream,
                            c->syn_d.p, c->syn_stride, c->comps_d.p, c->reft_d.p, c->tw_d.p, c->moment_d.p,
                            c->risetime_d.p, mp, c->misfit_d.p, proc, c->fft_d.p, c->vt_d.p,
@@ -1269,34 +1288,37 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
                 hipLaunchKernelGGL(untapered_rows_kernel<false>, pg, dim3(256), 0, c->stream, c->syn_d.p, c->syn_stride, c->comps_d.p, c->reft_d.p,
                                    c->moment_d.p, c->risetime_d.p, isrc0, c->gm.dt, c->nmis, spansrc, nrec, c->synspan_d.p, c->pairs_d.p, c->fft_d.p);
             }
-            if (spec_fused) {
-                // transform, amplitude, filter and norm of every (slot, source) row in one pass through LDS
-                for (auto &b : c->buckets) fused_fft_table(c, b.ntrans);
-                const SynRows sr{ c->syn_d.p, c->syn_stride, c->comps_d.p, c->tw_d.p, c->moment_d.p, c->risetime_d.p, synrow };
-                if (spec_direct)
-                    hipLaunchKernelGGL(spec_fft_norm_kernel<2>, dim3((unsigned)nsrc, (unsigned)c->nmis), dim3(256), (size_t)spec_longest * 4, c->stream,
-                                       (const float *)nullptr, c->pairs_d.p, fused_fft_tables(c), c->refamp_d.p, c->filtw_d.p, sp, c->misfit_d.p, (float *)nullptr, sr);
-                else
-                    hipLaunchKernelGGL(spec_fft_norm_kernel<0>, dim3((unsigned)nsrc, (unsigned)c->nmis), dim3(256), (size_t)spec_longest * 4, c->stream,
-                                       c->fft_d.p, c->pairs_d.p, fused_fft_tables(c), c->refamp_d.p, c->filtw_d.p, sp, c->misfit_d.p, (float *)nullptr, sr);
-            } else if (spectral) {
-                fft_buckets(c, true);
-                hipLaunchKernelGGL(spec_norm_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream,
-                                   c->spec_d.p, c->pairs_d.p, c->refamp_d.p, c->filtw_d.p, sp, c->misfit_d.p, c->comps_d.p);
-            } else if (filt_fused) {
-                for (auto &b : c->buckets) fused_fft_table(c, b.ntrans);
-                const SynRows sr{ c->syn_d.p, c->syn_stride, c->comps_d.p, c->tw_d.p, c->moment_d.p, c->risetime_d.p, synrow };
-                hipLaunchKernelGGL(spec_fft_filter_norm_kernel<0>, dim3((unsigned)nsrc, (unsigned)c->nmis), dim3(256), (size_t)filt_longest * 4, c->stream,
-                                   (const float *)nullptr, c->pairs_d.p, fused_fft_tables(c), c->comps_d.p, c->filtw_d.p, c->reffilt_d.p, c->zmask_d.p, sp,
-                                   c->misfit_d.p, (float *)nullptr, sr);
+            const SynRows sr{ c->syn_d.p, c->syn_stride, c->comps_d.p, c->tw_d.p, c->moment_d.p, c->risetime_d.p, synrow };
+            if (any_lds) for (auto &b : c->buckets) if (sp.in_lds(b.ntrans)) fused_fft_table(c, b.ntrans);
+            if (spectral) {
+                if (any_lds) {
+                    // transform, amplitude, filter and norm of a (slot, source) row in one pass through LDS
+                    if (direct_ok)
+                        hipLaunchKernelGGL(spec_fft_norm_kernel<2>, dim3((unsigned)nsrc, (unsigned)c->nmis), dim3(256), (size_t)lds_longest * 4, c->stream,
+                                           (const float *)nullptr, c->pairs_d.p, fused_fft_tables(c), c->refamp_d.p, c->filtw_d.p, sp, c->misfit_d.p, (float *)nullptr, sr);
+                    else
+                        hipLaunchKernelGGL(spec_fft_norm_kernel<0>, dim3((unsigned)nsrc, (unsigned)c->nmis), dim3(256), (size_t)lds_longest * 4, c->stream,
+                                           c->fft_d.p, c->pairs_d.p, fused_fft_tables(c), c->refamp_d.p, c->filtw_d.p, sp, c->misfit_d.p, (float *)nullptr, sr);
+                }
+                if (any_lib) {
+                    fft_buckets(c, true, lds_lo, lds_hi);
+                    hipLaunchKernelGGL(spec_norm_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream,
+                                       c->spec_d.p, c->pairs_d.p, c->refamp_d.p, c->filtw_d.p, sp, c->misfit_d.p, c->comps_d.p);
+                }
             } else {
-                fft_buckets(c, true);
-                hipLaunchKernelGGL(spec_filter_kernel, dim3((unsigned)(c->nmis * nsrc)), dim3(256), 0, c->stream,
-                                   c->spec_d.p, c->pairs_d.p, c->comps_d.p, c->filtw_d.p);
-                fft_buckets(c, false);
-                hipLaunchKernelGGL(filtered_norm_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream,
-                                   c->fft_d.p, c->comps_d.p, c->pairs_d.p, c->reffilt_d.p, c->zmask_d.p, sp, c->misfit_d.p,
-                                   proc_which == 3 ? proc : nullptr, c->syn_stride, c->synspan_d.p);
+                if (any_lds)
+                    hipLaunchKernelGGL(spec_fft_filter_norm_kernel<0>, dim3((unsigned)nsrc, (unsigned)c->nmis), dim3(256), (size_t)lds_longest * 4, c->stream,
+                                       (const float *)nullptr, c->pairs_d.p, fused_fft_tables(c), c->comps_d.p, c->filtw_d.p, c->reffilt_d.p, c->zmask_d.p, sp,
+                                       c->misfit_d.p, (float *)nullptr, sr);
+                if (any_lib) {
+                    fft_buckets(c, true, lds_lo, lds_hi);
+                    hipLaunchKernelGGL(spec_filter_kernel, dim3((unsigned)(c->nmis * nsrc)), dim3(256), 0, c->stream,
+                                       c->spec_d.p, c->pairs_d.p, c->comps_d.p, c->filtw_d.p, lds_lo, lds_hi);
+                    fft_buckets(c, false, lds_lo, lds_hi);
+                    hipLaunchKernelGGL(filtered_norm_kernel, dim3((unsigned)c->nmis, (unsigned)nsrc), dim3(256), 0, c->stream,
+                                       c->fft_d.p, c->comps_d.p, c->pairs_d.p, c->reffilt_d.p, c->zmask_d.p, sp, c->misfit_d.p,
+                                       proc_which == 3 ? proc : nullptr, c->syn_stride, c->synspan_d.p);
+                }
             }
         }
         hipLaunchKernelGGL(global_kernel, dim3((unsigned)((nsrc + 127) / 128)), dim3(128), 0, c->stream,

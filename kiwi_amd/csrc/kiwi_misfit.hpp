@@ -78,6 +78,7 @@ struct MisfitParams {
                          // bit2: the rows are not needed (spec_fft_filter_norm_kernel reads the synthetics)
     int chunk_nsrc;      // sources in this launch (row stride of the FFT groups)
     int skip_norm;       // floating norms: only produce the tapered synthetics (vt_out), norms follow in floating_norm_kernel
+    int lds_lo = 1, lds_hi = 0;      // transform lengths the in-LDS kernels take (SpecParams); bit2 of fft_mode applies to those pairs only
 };
 
 // rise-time fold of a source (receiver.f90:868-886): weights, integer shifts and fractions of the 1 + 2 nint(rise / 2 dt) taps
@@ -216,7 +217,10 @@ __global__ __launch_bounds__(256) void misfit_kernel(
     // without a frequency filter under a time-domain method is compared right here (probes_norm_timedomain takes the
     // plain tapered arrays then, comparator.f90:806-813)
     const bool to_fft = mp.fft_mode && (cd.has_filter || (mp.fft_mode & 2));
-    if (to_fft && (mp.fft_mode & 4) && !proc) return;      // the transform kernel takes the plain synthetics itself (workgroup-uniform)
+    if (to_fft && (mp.fft_mode & 4) && !proc) {            // the in-LDS transform kernel takes the plain synthetics itself (workgroup-uniform)
+        const int nt = pairs[(size_t)s * mp.nmis + m].ntrans;
+        if (nt >= mp.lds_lo && nt <= mp.lds_hi) return;
+    }
     const bool own_row = to_fft && cd.untapered;           // un-tapered: the row is the padded probe array over the PAIR's span (untapered_rows_kernel)
     if (to_fft && !own_row) {
         const FftPair pr = pairs[(size_t)s * mp.nmis + m];
@@ -282,6 +286,11 @@ struct SpecParams {
     // un-tapered slots (comparator.f90:798-800, 861-886): the reference's padded array follows the pair's span, so its amplitude
     // spectrum / filtered trace belongs to the PAIR: refpair[pair.spec_ofs + k], reffiltpair[pair.fft_ofs + n] (pair_span below)
     const float *refpair = nullptr, *reffiltpair = nullptr;
+    // Which PAIRS go through the in-LDS transforms (spec_fft_*_kernel): those with lds_lo <= ntrans <= lds_hi; the others through the
+    // library transforms (spec_norm_kernel, spec_filter_kernel, filtered_norm_kernel).  Decided per pair, not per batch: what a pair's
+    // result is must not depend on the lengths of its neighbours in the batch.  Default: none in LDS.
+    int lds_lo = 1, lds_hi = 0;
+    __host__ __device__ bool in_lds(int ntrans) const { return ntrans >= lds_lo && ntrans <= lds_hi; }
 };
 
 __device__ __forceinline__ double block_sum(double v, double *red)
@@ -302,6 +311,7 @@ __global__ __launch_bounds__(256) void spec_norm_kernel(
     __shared__ double red[256];
     const int m = blockIdx.x, s = blockIdx.y;
     const FftPair pr = pairs[(size_t)s * sp.nmis + m];
+    if (sp.in_lds(pr.ntrans)) return;                     // (that pair went through spec_fft_norm_kernel)
     const bool untapered = comps[m].untapered != 0;
     const int nb = pr.ntrans / 2 + 1;
     const float2 *__restrict__ row = spec + pr.spec_ofs;
@@ -577,6 +587,7 @@ __global__ __launch_bounds__(256) void spec_fft_norm_kernel(
     // (modes 0, 2: source index fastest -- the workgroups in flight share the reference and filter rows of a few slots)
     const int m = MODE != 1 ? (int)blockIdx.y : 0, s = MODE != 1 ? (int)blockIdx.x : 0;
     const FftPair pr = MODE != 1 ? pairs[(size_t)s * sp.nmis + m] : pairs[blockIdx.x];
+    if (!sp.in_lds(pr.ntrans)) return;                    // (library transforms for that pair; workgroup-uniform)
     const int N = pr.ntrans, M = N >> 1;
     const float2 *__restrict__ tw = tabs.tab[31 - __clz(N)];
     if constexpr (MODE == 2) {
@@ -672,6 +683,7 @@ __global__ __launch_bounds__(256) void spec_fft_filter_norm_kernel(
     const FftPair pr = MODE == 0 ? pairs[(size_t)s * sp.nmis + m] : pairs[blockIdx.x];
     const CompDev cd = comps[MODE == 0 ? m : pr.slot];
     if (!cd.has_filter) return;                           // compared by misfit_kernel on the plain tapered arrays
+    if (!sp.in_lds(pr.ntrans)) return;                    // (library transforms for that pair)
     const int N = pr.ntrans, M = N >> 1;
     const float2 *__restrict__ tab = tabs.tab[31 - __clz(N)];
     if constexpr (MODE == 0) {
@@ -772,10 +784,11 @@ __global__ __launch_bounds__(256) void spec_fft_filter_norm_kernel(
 // spectrum_filtered = spectrum * filter(j df) (comparator.f90:1224-1225), in place, before the c2r; block per entry of
 // `pairs` (trial-source pairs of a chunk, or reference variants)
 __global__ __launch_bounds__(256) void spec_filter_kernel(float2 *__restrict__ spec, const FftPair *__restrict__ pairs,
-                                                          const CompDev *__restrict__ comps, const float *__restrict__ filtw)
+                                                          const CompDev *__restrict__ comps, const float *__restrict__ filtw, int lds_lo, int lds_hi)
 {
     const FftPair pr = pairs[blockIdx.x];
     if (!comps[pr.slot].has_filter) return;
+    if (pr.ntrans >= lds_lo && pr.ntrans <= lds_hi) return;      // (that pair goes through spec_fft_filter_norm_kernel)
     const int nb = pr.ntrans / 2 + 1;
     float2 *__restrict__ row = spec + pr.spec_ofs;
     const float *__restrict__ fw = filtw + pr.specofs;
@@ -809,6 +822,7 @@ __global__ __launch_bounds__(256) void filtered_norm_kernel(
     const CompDev cd = comps[m];
     if (!cd.has_filter) return;                           // compared by misfit_kernel on the plain tapered arrays
     const FftPair pr = pairs[(size_t)s * sp.nmis + m];
+    if (sp.in_lds(pr.ntrans)) return;                     // (that pair went through spec_fft_filter_norm_kernel)
     const float *__restrict__ row = fftbuf + pr.fft_ofs;
     const float *__restrict__ rf = ref_filt + pr.filtofs;
     const float *__restrict__ zm = zmask + cd.refofs;
