@@ -65,6 +65,11 @@ def one_case(rng, verbose):
     # a fifth of the cases: some (or all) receivers WITHOUT a misfit taper -- the norms then run over the union of the data spans
     # (time domain) or over the padded probes of the pair (spectral norms, filters); spans of a fresh evaluation: one source
     notaper = rng.random() < float(os.environ.get("KIWI_FUZZ_NOTAPER", "0.2"))
+    if arith() == "fused":
+        # (exact contract only: where a rise time folds an un-tapered strip, its span is cut at the trailing run of EQUAL values
+        # (strip_dataspan) -- a decision on bit patterns, which the fused contract's last-bit differences can move by a sample:
+        # seen once in 8227 cases, 8e-5 of a spectral L1 norm; INTEGRATION.md "Arithmetic contract")
+        notaper = False
     if notaper:
         for ir in rng.choice(nrec, size=int(rng.integers(1, nrec + 1)), replace=False):
             sc.tapers.pop(int(ir) + 1, None)
