@@ -2538,6 +2538,8 @@ int kiwi_hip_get_amp_spectrum(kiwi_hip_ctx *c, int isrc, int irec, int icomp, in
             eval_impl(c, isrc, 1, 0);
             pr = c->last_pairs[(size_t)slot];
         } else {
+            if (c->comps[slot].untapered)
+                throw std::runtime_error("the spectrum of an un-tapered reference follows the probe pair's span: name a source (set_source_params first)");
             if (!c->fft_ready) prepare_fft(c, c->reft_h);
             const CompDev &cd0 = c->comps[slot];
             const int ntr = next_pow2(std::max(2 * (cd0.rf1 - cd0.rf0 + 1), cd0.wlen));
@@ -2555,6 +2557,8 @@ int kiwi_hip_get_amp_spectrum(kiwi_hip_ctx *c, int isrc, int irec, int icomp, in
             std::vector<float2> z(nb);
             HIPCHECK(hipMemcpy(z.data(), c->spec_d.p + pr.spec_ofs, nb * sizeof(float2), hipMemcpyDeviceToHost));
             for (int i = 0; i < nb; i++) out[i] = hypotf(z[i].x, z[i].y) * ((filtered && has_filter) ? c->filtw_h[pr.specofs + i] : 1.f);
+        } else if (c->comps[slot].untapered) {                   // the pair's reference spectrum (pair_refamp_kernel): |spec| x filter weights
+            HIPCHECK(hipMemcpy(out, c->refpair_d.p + pr.spec_ofs, nb * sizeof(float), hipMemcpyDeviceToHost));
         } else {
             std::memcpy(out, c->refamp_h.data() + pr.specofs, nb * sizeof(float));     // |spec| x filter weights
         }

@@ -1567,6 +1567,27 @@ def test_spectral_norms_without_a_taper_fresh_evaluation_semantics(what, tapers)
     p.eval()
     qm, qn, qg = p.get_misfits()
     assert qm.tobytes() == pm[3:4].tobytes() and qn.tobytes() == pn[3:4].tobytes()
+    # output_seismogram_spectra of an un-tapered receiver: the spectra of the PAIR (current source, slot), reference side included
+    e = sc.oracle()
+    for (ir, k), (lo, d) in sc.refs.items():
+        e.set_reference(ir, k, lo, d)
+    for ir in tapered:
+        e.set_taper(ir, *sc.tapers[ir])
+    for ir in filtered:
+        e.set_filter(ir, fx, fy)
+    e.set_misfit_method(mid)
+    e.set_source_params(1, trials[3])
+    e.get_misfits()
+    for ir, k in ((4, 1), (3, 1), (1, 2)):
+        for synth in (True, False):
+            odf, want = e.amp_spectrum(ir, k, synth, False)
+            df, got = p.get_amp_spectrum(ir, k, "synthetics" if synth else "references", False, isrc=0)
+            assert abs(df - odf) <= 1e-7 * odf and got.shape == want.shape, (ir, k, synth)
+            assert np.allclose(got, want, rtol=SPEC_RTOL, atol=2e-6 * want.max()), (ir, k, synth)
+    e.close()
+    if tapers == "none":
+        with pytest.raises(KiwiHipError, match="name a source"):
+            p.get_amp_spectrum(4, 1, "references", False, isrc=-1)
     if filtered:
         # get_reference(filtered) of an un-tapered receiver: the filtered reference of the pair (current source, slot) inside the window
         e = sc.oracle()
