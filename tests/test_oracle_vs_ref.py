@@ -137,6 +137,26 @@ def test_strip_dataspan_and_fold():
         a = ko.strip_fold(lo, d, shifts, amps)
         assert a[0] == olo.value
         assert np.array_equal(a[1].view(np.uint32), out[:on.value].view(np.uint32))
+    # the corner cases the device's span of an un-tapered synthetic rests on (kiwi_misfit.hpp synspan_kernel): all zeros (the fold
+    # leaves a strip of more than one sample alone: its data span is inverted), one sample, one constant value
+    for d in (np.zeros(5, np.float32), np.zeros(1, np.float32), np.full(4, 2.5, np.float32), np.array([0, 0, 1, 3, 3, 3], np.float32),
+              np.array([0, 1, 0, 0], np.float32)):
+        lo, n = 7, len(d)
+        ds = (C.c_int * 2)()
+        R.ref_strip_dataspan(C.c_int(lo), C.c_int(n), fp(d), ds)
+        assert ko.strip_dataspan(lo, d) == (ds[0], ds[1])
+        shifts = np.array([-1, 0, 1], np.float32)
+        amps = np.array([0.25, 0.5, 0.25], np.float32)
+        out = np.zeros(64, np.float32)
+        olo, on = C.c_int(), C.c_int()
+        R.ref_strip_fold(C.c_int(lo), C.c_int(n), fp(d), C.c_int(3), fp(shifts), fp(amps), C.c_int(64), C.byref(olo), C.byref(on), fp(out))
+        a = ko.strip_fold(lo, d, shifts, amps)
+        assert a[0] == olo.value and len(a[1]) == on.value
+        assert np.array_equal(a[1].view(np.uint32), out[:on.value].view(np.uint32))
+        # the span rule the device uses: extent [lo, lo + n - 1] joined with [d1 - 1, d2 + 1 + 1] when the data span is not inverted
+        d1, d2 = ds[0], ds[1]
+        want = (lo, lo + n - 1) if d2 < d1 else (min(lo, d1 - 1), max(lo + n - 1, d2 + 2))
+        assert (olo.value, olo.value + on.value - 1) == want, (d, want, olo.value, on.value)
 
 
 def test_d2r():
