@@ -293,7 +293,7 @@ def kernel_sources_sha256():
     import hashlib
     h = hashlib.sha256()
     for f in ("kiwi_amd/csrc/kiwi_common.hpp", "kiwi_amd/csrc/kiwi_geometry.hpp", "kiwi_amd/csrc/kiwi_accum.inc", "kiwi_amd/csrc/kiwi_accum.hip",
-              "kiwi_amd/csrc/kiwi_accum_api.hpp", "kiwi_amd/csrc/kiwi_misfit.hpp", "kiwi_amd/csrc/kiwi_hip.hip", "kiwi_amd/csrc/kiwi_libm32.hpp",
+              "kiwi_amd/csrc/kiwi_apply_asm.inc", "kiwi_amd/csrc/kiwi_accum_api.hpp", "kiwi_amd/csrc/kiwi_misfit.hpp", "kiwi_amd/csrc/kiwi_hip.hip", "kiwi_amd/csrc/kiwi_libm32.hpp",
               "kiwi_amd/csrc/Makefile"):
         with open(os.path.join(ROOT, f), "rb") as fh:
             h.update(fh.read())
