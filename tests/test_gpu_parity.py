@@ -1508,6 +1508,46 @@ def test_two_sources_per_workgroup_is_bit_identical(monkeypatch, L):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("method", ["ampspec_l2norm", "l2norm"])
+def test_spectral_results_do_not_depend_on_which_transform_the_neighbours_take(method):
+    """In-LDS or library transform is decided per (source, slot) pair by the pair's own length.  A batch with ONE pair the in-LDS
+    kernels do not take (8 samples: a three-sample reference at a receiver the second source does not reach) used to send every
+    pair of the batch -- and the reference variants made in that call -- through the library transforms, so a source's spectral
+    misfits and norm factors differed by an ulp between a batch and an evaluation on its own (found by the randomised sweep).
+    Batch against one source at a time, bit for bit; spectral norm and time-domain norm on filtered traces."""
+    sc = Scenario(nrec=2)
+    e = sc.oracle()
+    sc.make_references(e)
+    e.close()
+    dt = sc.gf["dt"]
+    p = sc.product()
+    for (ir, k), (lo, d) in sc.refs.items():
+        if ir == 2:
+            lo, d = 5, np.array([0.5, -1.0, 0.25], np.float32) * float(np.max(np.abs(d)))
+        p.set_ref_seismogram(ir, k, lo, d)
+    p.set_misfit_taper(1, *sc.tapers[1])
+    p.set_misfit_taper(2, [4.5 * dt, 5.0 * dt, 7.0 * dt, 7.5 * dt], [0., 1., 1., 0.])
+    p.set_misfit_method(method)
+    if method == "l2norm":
+        for ir in (1, 2):
+            p.set_misfit_filter(ir, [0.01, 0.03, 0.25, 0.4], [0., 1., 1., 0.])
+    near = synthetic.bilat_strike_sweep(3, step=2.0)
+    far = synthetic.bilat_strike_sweep(2, step=2.0)
+    far[:, 1] += 400e3                                          # north-shift: no receiver inside the database's range
+    trials = np.vstack([near[:1], far[:1], near[1:], far[1:]]).astype(np.float32)
+    p.set_source_params("bilateral", trials)
+    p.eval()
+    bm, bn, bg = [x.copy() for x in p.get_misfits()]
+    assert np.all(bm[[1, 4]] >= 0) and np.all(np.isfinite(bm)) and np.any(bm[0] != bm[2])
+    for i in range(len(trials)):
+        p.set_source_params("bilateral", trials[i:i + 1])
+        p.eval()
+        m, n, g = p.get_misfits()
+        assert m.tobytes() == bm[i:i + 1].tobytes() and n.tobytes() == bn[i:i + 1].tobytes() and g.tobytes() == bg[i:i + 1].tobytes(), i
+    p.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("tapers", ["mixed", "none"])
 @pytest.mark.parametrize("what", ["ampspec_l2norm", "ampspec_l1norm", "filter_l2norm", "filter_l1norm"])
 def test_spectral_norms_without_a_taper_fresh_evaluation_semantics(what, tapers):
