@@ -151,7 +151,9 @@ def oracle_engine(wl, gf, recv, refs, tapers, cores, fresh=False):
         c = wl["crust"]
         prof = ko.crust_profile(c[0:8], c[8:16], c[16:24], c[24:31])
 
-    def evaluate(t):
+    def evaluate(t, inspect=None):
+        """inspect: called with the engine right after the evaluation (tests read the probes' scales there); its result is
+        appended to (misfits, norms, global)"""
         eng = make() if fresh else e
         try:
             if wl["crust"] is not None:
@@ -159,7 +161,8 @@ def oracle_engine(wl, gf, recv, refs, tapers, cores, fresh=False):
                 eng.set_centroids(cent, mo, ri)
             else:
                 eng.set_source_params(st, t)
-            return eng.get_misfits()
+            res = eng.get_misfits()
+            return res if inspect is None else tuple(res) + (inspect(eng),)
         finally:
             if fresh:
                 eng.close()

@@ -590,12 +590,6 @@ void fft_buckets(kiwi_hip_ctx *c, bool forward, int lds_lo = 1, int lds_hi = 0)
 
 int next_pow2(int n) { int m = 1; while (m < n) m *= 2; return m; }      // comparator.f90:1111-1118 (integer form)
 
-// spec_fft_norm_kernel takes these lengths (LDS holds ntrans / 2 complex points)
-bool fused_fft_takes(const kiwi_hip_ctx *c, int ntrans)
-{
-    return c->fused_fft && ntrans >= (1 << kFusedFftMinLog2) && ntrans <= (1 << kFusedFftMaxLog2) && (ntrans & (ntrans - 1)) == 0;
-}
-
 // the lengths whose pairs go through the in-LDS transforms in this context (SpecParams::lds_lo / lds_hi): decided per PAIR
 void lds_fft_range(const kiwi_hip_ctx *c, int &lo, int &hi)
 {

@@ -82,3 +82,186 @@ def test_corrupt_strip_table_is_an_error_not_an_overflow(tmp_path, monkeypatch):
     monkeypatch.setattr(gfdb_hdf5, "pack_trace", good)
     with pytest.raises(gfdb_hdf5.GfdbError, match="failed to read a trace"):
         gfdb_hdf5.read(str(tmp_path / "bad"))
+
+
+# ---- row f2 pinned from outside: an independent READER of the product's files (h5dump, the HDF5 distribution's own tool) against
+# a layout expectation written down from the reference's writer statement by statement, and an independent WRITER (the reference's
+# Fortran call sequence restated call by call over the C API, tests/gfdb_fortran_call_sequence.c, with the file types a foreign
+# machine would leave) read by the product's reader.  No file written by the reference's own binary exists here: its HDF5 Fortran
+# layer cannot be built in this image.
+
+H5DUMP = "/opt/conda/bin/h5dump"
+
+
+def _h5dump(args):
+    import subprocess
+    return subprocess.run([H5DUMP] + args, capture_output=True, text=True, check=True).stdout
+
+
+def _ddl(text):
+    """h5dump's DDL as nested dicts: {"GROUP /": {"DATASET dt": {"DATATYPE": ..., "DATASPACE": ..., "DATA": [...], ...}}}"""
+    import re
+    toks = re.findall(r'"[^"]*"|[{}]|[^\s{}"]+', text)
+    pos = [0]
+
+    def block():
+        out, key = {}, []
+        while pos[0] < len(toks):
+            t = toks[pos[0]]
+            pos[0] += 1
+            if t == "{":
+                name = " ".join(key)
+                key = []
+                if name.split()[0] in ("DATA", "DATASPACE", "DATATYPE"):          # leaf: keep the raw tokens
+                    depth, leaf = 1, []
+                    while depth:
+                        u = toks[pos[0]]
+                        pos[0] += 1
+                        depth += (u == "{") - (u == "}")
+                        if depth:
+                            leaf.append(u)
+                    head = name.split()
+                    out[head[0]] = " ".join(leaf) if len(head) == 1 else "%s { %s }" % (" ".join(head[1:]), " ".join(leaf))
+                else:
+                    out[name] = block()
+            elif t == "}":
+                if key:
+                    out[" ".join(key)] = True
+                return out
+            else:
+                key.append(t.strip('"'))
+                if key[0] in ("DATATYPE", "DATASPACE") and len(key) == 2 and toks[pos[0]] != "{":
+                    out[key[0]] = key[1]
+                    key = []
+        return out
+
+    return block()
+
+
+def _small_db():
+    """3 distances x 2 depths x 2 components, 12 samples; one trace with a 7-zero gap (two strips), one starting at a negative
+    sample index, one absent"""
+    nx, nz, ng, L = 3, 2, 2, 12
+    data = np.zeros((nx, nz, ng, L), np.float32)
+    first = np.zeros((nx, nz, ng), np.int32)
+    nsamp = np.full((nx, nz, ng), L, np.int32)
+    data[0, 0, 0] = [1, 2, 0, 0, 0, 0, 0, 0, 0, 3, 4, 5]
+    data[1, 1, 1] = [0, 0, 7, 8, 9, 0, 0, 0, 0, 0, 0, 0]
+    data[2, 0, 1] = np.arange(1, 13)
+    first[2, 0, 1] = -4
+    nsamp[2, 1, 0] = 0
+    return dict(dt=0.5, dx=1000., dz=2000., firstx=5000., firstz=100., data=data, first=first, nsamp=nsamp)
+
+
+@pytest.mark.skipif(not os.path.exists(H5DUMP), reason="h5dump not installed")
+def test_files_of_the_writer_as_an_independent_reader_sees_them(tmp_path):
+    """h5dump on a database from gfdb_hdf5.write against what gfdb_io_hdf.f90 creates, statement by statement."""
+    gf = _small_db()
+    base = str(tmp_path / "db")
+    gfdb_hdf5.write(base, gf, nchunks=2)
+    F32 = ("H5T_IEEE_F32LE", "H5T_IEEE_F32BE")                # H5T_NATIVE_REAL of the writing machine
+    I32 = ("H5T_STD_I32LE", "H5T_STD_I32BE")                  # H5T_NATIVE_INTEGER
+    # <base>.index -- gfdb_io_create_index, gfdb_io_hdf.f90:204-220: ten scalars, each a dataset of its own over an H5S_SCALAR
+    # dataspace (h5_save_scalar_*, :683-741); nxc as gfdb.f90:194-198 derives it: 3 / 2 + 1 = 2
+    root = _ddl(_h5dump([base + ".index"]))['HDF5 %s.index' % base]["GROUP /"]
+    want = {"dt": 0.5, "dx": 1000, "dz": 2000, "firstx": 5000, "firstz": 100, "nchunks": 2, "nx": 3, "nxc": 2, "nz": 2, "ng": 2}
+    assert sorted(root) == sorted("DATASET " + k for k in want)
+    for k, v in want.items():
+        d = root["DATASET " + k]
+        assert d["DATASPACE"] == "SCALAR", k
+        assert d["DATATYPE"] in (I32 if k[0] == "n" else F32), (k, d["DATATYPE"])
+        assert float(d["DATA"].split(":")[1]) == v, (k, d["DATA"])
+    # <base>.<ichunk>.chunk -- gfdb_io_create_chunk (:236-312) + gfdb_io_save_trace (:314-427).  Chunk 1 holds distances 1, 2;
+    # chunk 2 the rest (gfdb.f90:250-257: nxcthis = 3 - 1 * 2 = 1)
+    for ichunk, nxc_this in ((1, 2), (2, 1)):
+        fn = "%s.%d.chunk" % (base, ichunk)
+        root = _ddl(_h5dump(["-H", fn]))["HDF5 " + fn]["GROUP /"]
+        assert sorted(root) == ["DATASET index", "GROUP gf"]                     # :265 "index", :290 group "gf"
+        ix = root["DATASET index"]
+        # :252-265: dims = (ng, nz, nxc) in Fortran order = (nxc, nz, ng) in the file's C order, H5T_STD_REF_OBJ
+        assert ix["DATATYPE"] == "H5T_REFERENCE { H5T_STD_REF_OBJECT }"
+        assert ix["DATASPACE"].replace(" ", "") == "SIMPLE{(%d,2,2)/(%d,2,2)}" % (nxc_this, nxc_this)
+        # :344-347: groups "/gf/<ixc>" and below them "<iz>", numbers as list-directed integers with the blanks trimmed
+        # (better_varying_string.f90:1723-1736); :360-362 dataset "<ig>"
+        for ixc in range(1, nxc_this + 1):
+            gx = root["GROUP gf"]["GROUP %d" % ixc]
+            for iz in (1, 2):
+                for ig in (1, 2):
+                    stored = gf["nsamp"][(ichunk - 1) * 2 + ixc - 1, iz - 1, ig - 1] > 0
+                    assert ("DATASET %d" % ig in gx["GROUP %d" % iz]) == stored          # gfdb.f90:750: empty traces are not saved
+                    if not stored:
+                        continue
+                    d = gx["GROUP %d" % iz]["DATASET %d" % ig]
+                    assert d["DATATYPE"] in F32                                          # :362 H5T_NATIVE_REAL
+                    assert d["DATASPACE"].startswith("SIMPLE { (")                     # :359 1-D, packed_size
+                    for a in ("pofs", "ofs"):                                            # :375-383 integer attributes, nstrips long
+                        assert d["ATTRIBUTE " + a]["DATATYPE"] in I32
+                        assert d["ATTRIBUTE " + a]["DATASPACE"] == d["ATTRIBUTE pofs"]["DATASPACE"]
+    # the references resolve to the datasets they were made from (:396-407: coordinate (ig, iz, ixc) in Fortran order), a trace
+    # that was never saved keeps the zero reference of :275-277
+    refs = _ddl(_h5dump(["-d", "/index", base + ".2.chunk"]))["HDF5 %s.2.chunk" % base]["DATASET /index"]["DATA"]
+    refs = [t for t in refs.replace(",", " ").split() if t.startswith("/") or t == "NULL"]
+    assert refs == ["/gf/1/1/1", "/gf/1/1/2", "NULL", "/gf/1/2/2"]
+    # one trace in full: [1 2 0 0 0 0 0 0 0 3 4 5] from sample 0 -- trace_pack (sparse_trace.f90:443-555, maxgap 5) makes the strips
+    # [1 2 0] at 0 and [3 4 5] at 9; trace_to_storable (:795-846) packs them back to back, pofs = 1-based starts (1, 4), ofs =
+    # the strips' first sample indices (0, 9)
+    d = _ddl(_h5dump(["-d", "/gf/1/1/1", base + ".1.chunk"]))["HDF5 %s.1.chunk" % base]["DATASET /gf/1/1/1"]
+
+    def values(s):
+        return [float(x) for x in s.split(":")[1].replace(",", " ").split()]
+
+    assert values(d["DATA"]) == [1, 2, 0, 3, 4, 5]
+    assert values(d["ATTRIBUTE pofs"]["DATA"]) == [1, 4] and values(d["ATTRIBUTE ofs"]["DATA"]) == [0, 9]
+    # ... and the one that starts before sample 0
+    d = _ddl(_h5dump(["-d", "/gf/1/1/2", base + ".2.chunk"]))["HDF5 %s.2.chunk" % base]["DATASET /gf/1/1/2"]
+    assert values(d["DATA"]) == list(range(1, 13)) and values(d["ATTRIBUTE ofs"]["DATA"]) == [-4]
+
+
+@pytest.mark.parametrize("variant", ["native", "BIG", "WIDE"])
+def test_reader_takes_files_made_by_the_fortran_call_sequence(tmp_path, variant):
+    """A database produced by the reference writer's HDF5 call sequence (one gfdb_io_save_trace per trace, references written one
+    element at a time, chunk files re-opened per trace) -- as a little-endian, a big-endian and an 8-byte-integer machine would
+    store it -- reads back into the same dense tables as the product writer's file of the same traces."""
+    import subprocess
+    exe = str(tmp_path / "seq")
+    subprocess.check_call(["gcc", "-O1", "-Wall"] + ([] if variant == "native" else ["-D" + variant]) +
+                          ["-I/opt/conda/include", "-o", exe, os.path.join(os.path.dirname(__file__), "gfdb_fortran_call_sequence.c"),
+                           "-L/opt/conda/lib", "-lhdf5", "-Wl,-rpath,/opt/conda/lib"])
+    sc = Scenario(nx=5, nz=3, ng=10, L=200, variant="static")
+    gf = dict(sc.gf)
+    gf["nsamp"] = gf["nsamp"].copy()
+    gf["nsamp"][3, 2, 7] = 0
+    nx, nz, ng, _ = gf["data"].shape
+    nchunks, nxc = 2, 3                                   # gfdb.f90:194-198: 5 / 2 + 1
+    lines = []
+    for i in range(nx):
+        for j in range(nz):
+            for k in range(ng):
+                n = int(gf["nsamp"][i, j, k])
+                if n == 0:
+                    continue
+                strips = gfdb_hdf5.pack_trace(int(gf["first"][i, j, k]), gf["data"][i, j, k, :n])      # (pinned to trace_pack above)
+                pofs, p = [], 1
+                for o, s in strips:                       # trace_to_storable, sparse_trace.f90:826-832
+                    pofs.append(p)
+                    p += len(s)
+                packed = np.concatenate([s for o, s in strips])
+                lines.append("%d %d %d %d %d %s %s %s" % (i + 1, j + 1, k + 1, len(strips), len(packed), " ".join(map(str, pofs)),
+                                                          " ".join(str(o) for o, s in strips), " ".join("%.9g" % v for v in packed)))
+    base = str(tmp_path / "seqdb")
+    head = "%s %.9g %.9g %.9g %.9g %.9g %d %d %d %d %d %d\n" % (base, gf["dt"], gf["dx"], gf["dz"], gf["firstx"], gf["firstz"], nchunks, nx, nxc,
+                                                                 nz, ng, len(lines))
+    subprocess.run([exe], input=head + "\n".join(lines) + "\n", text=True, check=True)
+    if variant != "native" and os.path.exists(H5DUMP):                         # the file really holds the foreign types
+        txt = _h5dump(["-H", base + ".index"])
+        assert ("H5T_IEEE_F32BE" in txt and "H5T_STD_I32BE" in txt) if variant == "BIG" else "H5T_STD_I64LE" in txt
+    got = gfdb_hdf5.read(base)
+    mine = str(tmp_path / "mine")
+    gfdb_hdf5.write(mine, gf, nchunks=nchunks)
+    want = gfdb_hdf5.read(mine)
+    assert (got["nchunks"], got["nxc"]) == (want["nchunks"], want["nxc"]) == (2, 3)
+    for k in ("dt", "dx", "dz", "firstx", "firstz"):
+        assert got[k] == want[k] == np.float32(gf[k])
+    for k in ("first", "nsamp", "data"):
+        assert np.array_equal(got[k], want[k]), k
+    assert got["nsamp"][3, 2, 7] == 0 and np.count_nonzero(got["nsamp"]) == nx * nz * ng - 1

@@ -65,7 +65,7 @@ def test_cfg3_bilateral_100_centroids_50_receivers():
     e, db, evaluate = bench.oracle_engine(wl, gf, recv, refs, tapers, CORES)
     for i in (2, 11, 23):
         om, on, og = evaluate(tr[i])
-        assert rel(m[i], om, on) <= 1e-6 and abs(g[i] - og) <= 1e-6 * max(og, 0.05 if common.arith() == "fused" else 0.0) and np.array_equal(n[i], on)
+        assert rel(m[i], om, on) <= 1e-6 and common.misfit_close(g[i], og, glob=True) and np.array_equal(n[i], on)
     e.close(); db.close()
     # pieces == whole
     p.eval(0, 7); p.eval(7, 17)
@@ -92,7 +92,7 @@ def test_cfg3_variants_at_full_size(name, ncent_want):
     e, db, evaluate = bench.oracle_engine(wl, gf, recv, refs, tapers, CORES)
     for i in (1, 7, 19):
         om, on, og = evaluate(tr[i])
-        assert rel(m[i], om, on) <= 1e-6 and abs(g[i] - og) <= 1e-6 * max(og, 0.05 if common.arith() == "fused" else 0.0) and np.array_equal(n[i], on)
+        assert rel(m[i], om, on) <= 1e-6 and common.misfit_close(g[i], og, glob=True) and np.array_equal(n[i], on)
     e.close(); db.close()
 
 
@@ -114,7 +114,7 @@ def test_cfg2_moment_tensor_grid():
     e, db, evaluate = bench.oracle_engine(wl, gf, recv, refs, tapers, CORES)
     for i in (3, 100, 257, 511):
         om, on, og = evaluate(tr[i])
-        assert rel(m[i], om, on) <= 1e-6 and abs(g[i] - og) <= 1e-6 * max(og, 0.05 if common.arith() == "fused" else 0.0)
+        assert rel(m[i], om, on) <= 1e-6 and common.misfit_close(g[i], og, glob=True)
     e.close(); db.close()
 
 
@@ -135,7 +135,7 @@ def test_cfg4_mt_eikonal_468_centroids_200_receivers():
     e, db, evaluate = bench.oracle_engine(wl, gf, recv, refs, tapers, CORES)
     for i in (2, 3):
         om, on, og = evaluate(tr[i])
-        assert rel(m[i], om, on) <= 1e-6 and abs(g[i] - og) <= 1e-6 * max(og, 0.05 if common.arith() == "fused" else 0.0) and np.array_equal(n[i], on)
+        assert rel(m[i], om, on) <= 1e-6 and common.misfit_close(g[i], og, glob=True) and np.array_equal(n[i], on)
     e.close(); db.close()
 
 
@@ -149,19 +149,21 @@ def test_cfg5_spectral_comparator_with_filter(name):
     p.set_source_params("bilateral", tr)
     p.eval()
     m, n, g = p.get_misfits()
-    tol = common.spectral_tol(wl["method"], True)        # tests/common.py: the one table of these tolerances
-    assert np.all(m[0] <= tol * n[0])                    # the true source against its own references: FFT rounding only
-    # Spectral tolerance (1e-5 relative for ampspec_*; hipFFT fp32 against the oracle's fp64 DFT -- "parity
-    # unpinned" for FFTW's own rounding).  An amplitude-spectrum misfit is a difference of nearly equal spectra, so its
-    # error scales with the spectra, i.e. with the norm factor: |m - m_oracle| <= 2e-5 n per slot, 1e-5 on the norm factors
-    # and on the global misfit.  The transform length of every (source, slot) pair is what a fresh reference engine gives
-    # that source (comparator.f90:222-271,464-486), hence a fresh oracle engine per source.
+    # the true source against its own references: transform round-off only (the references went through the same kernels)
+    assert np.all(m[0] <= 1e-5 * n[0])
+    # Spectral tolerance: no fixed figure.  Per slot |m - m_oracle| <= 1e-6 max(n, m) + what fp32 transforms of this length explain
+    # (tests/common.py fft_roundoff_bound: c eps log2N of the tapered traces' norms pushed through the norm; the oracle transforms
+    # in fp64 -- FFTW's own rounding is "parity unpinned"), the same for the norm factors; the global misfit within
+    # SURVEY 8c's 1e-5.  The transform length of every (source, slot) pair is what a fresh reference engine gives that source
+    # (comparator.f90:222-271,464-486), hence a fresh oracle engine per source.
     e, db, evaluate = bench.oracle_engine(wl, gf, recv, refs, tapers, CORES, fresh=True)
+    comps = recv[3]
     for i in (1, 9, 15):
-        om, on, og = evaluate(tr[i])
+        om, on, og, scales = evaluate(tr[i], inspect=lambda eng: common.slot_scales(eng, comps, gf["dt"]))
+        ok, ratio = common.spectral_close(wl["method"], gf["dt"], m[i], om, on, scales, pn=n[i])
         r = np.abs(m[i] - om) / on
-        assert np.median(r) <= 5e-6 and r.max() <= tol, (i, np.median(r), r.max())
-        assert abs(g[i] - og) <= 1e-5 * og and rel(n[i], on) <= 1e-5
+        assert ok and np.median(r) <= 5e-6, (i, ratio, np.median(r), r.max())
+        assert abs(g[i] - og) <= 1e-5 * og
     e.close(); db.close()
     p.eval(0, 5); p.eval(5, 11)
     m2, _, g2 = p.get_misfits()

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from kiwi_amd import synthetic, KiwiHipError
-from tests.common import (Scenario, oracle_misfits, spectral_tol, misfit_close, same_bits, arith, MISFIT_RTOL, SYN_RTOL, slot_scales,
+from tests.common import (Scenario, oracle_misfits, misfit_close, same_bits, arith, MISFIT_RTOL, SYN_RTOL, slot_scales,
                           spectral_close, fft_roundoff_bound, FFT_ROUNDOFF_C)
 
 pytestmark = pytest.mark.gpu
@@ -45,8 +45,8 @@ def test_bilateral_misfits_match_oracle(bilinear, variant):
     assert pm.shape == m.shape
     assert np.array_equal(pn[0], n[0])                     # norm factors: host-side, bit exact
     assert np.all(pm[0] <= 1e-6 * pn[0])                   # the true source reproduces its references
-    assert misfit_close(pm[1:], m[1:]), np.max(np.abs(pm[1:] - m[1:]) / np.abs(m[1:]))
-    assert misfit_close(pg[1:], g[1:])
+    assert misfit_close(pm[1:], m[1:], pn[1:]), np.max(np.abs(pm[1:] - m[1:]) / np.abs(m[1:]))
+    assert misfit_close(pg[1:], g[1:], glob=True)
 
 
 @pytest.mark.parametrize("method", ["l1norm", "scalar_product", "peak"])
@@ -151,15 +151,15 @@ def test_moment_tensor_and_circular_sources():
     m, n, g = oracle_misfits(e, 6, mt)
     p.set_source_params("moment_tensor", mt)
     p.eval()
-    pm, _, pg = p.get_misfits()
-    assert misfit_close(pm, m) and misfit_close(pg, g)
+    pm, pn, pg = p.get_misfits()
+    assert misfit_close(pm, m, pn) and misfit_close(pg, g, glob=True)
     circ = np.tile(np.array([0., 0., 0., 10000., 5e19, 80., 70., 100., 3000., 3000., 1.5], np.float32), (4, 1))
     circ[:, 8] = [1500., 2500., 3500., 4500.]
     m, n, g = oracle_misfits(e, 2, circ)
     p.set_source_params("circular", circ)
     p.eval()
-    pm, _, pg = p.get_misfits()
-    assert misfit_close(pm, m) and misfit_close(pg, g)
+    pm, pn, pg = p.get_misfits()
+    assert misfit_close(pm, m, pn) and misfit_close(pg, g, glob=True)
 
 
 def test_risetime_fold_and_synthetics_factor():
@@ -183,7 +183,7 @@ def test_risetime_fold_and_synthetics_factor():
     p.eval()
     pm, pn, pg = p.get_misfits()
     for i in range(3):
-        assert misfit_close(pm[i], ms[i][0]), i
+        assert misfit_close(pm[i], ms[i][0], pn[i]), i
         assert abs(pg[i] - ms[i][2]) <= MISFIT_RTOL * ms[i][2]
 
 
@@ -201,8 +201,8 @@ def test_edge_cases_components_depth_disabled_outofrange():
     pm, pn, pg = p.get_misfits()
     assert pm.shape == m.shape == (4, 3 + 1 + 2 + 3 + 1)
     assert np.array_equal(pn[0], n[0])
-    assert misfit_close(pm, m)
-    assert misfit_close(pg, g)
+    assert misfit_close(pm, m, pn)
+    assert misfit_close(pg, g, glob=True)
     mis, nor, failings = p.make_misfits_for_sources()
     assert mis.shape == (4, 6, 3) and np.all(mis[:, 3] == 0) and failings == []
 
@@ -254,8 +254,8 @@ def test_long_windows_span_several_tiles(bilinear):
     p.eval()
     pm, pn, pg = p.get_misfits()
     assert np.array_equal(pn[0], n[0])
-    assert misfit_close(pm, m), np.max(np.abs(pm - m) / np.abs(m))
-    assert misfit_close(pg, g)
+    assert misfit_close(pm, m, pn), np.max(np.abs(pm - m) / np.abs(m))
+    assert misfit_close(pg, g, glob=True)
     e.set_source_params(1, trials[1])
     e.get_misfits()
     for ir in (1, 3):
@@ -282,8 +282,8 @@ def test_far_field_db_and_spatial_undersampling(ng, us):
     p.set_source_params("bilateral", trials)
     p.eval()
     pm, pn, pg = p.get_misfits()
-    assert misfit_close(pm, m), np.max(np.abs(pm - m) / np.abs(m))
-    assert misfit_close(pg, g)
+    assert misfit_close(pm, m, pn), np.max(np.abs(pm - m) / np.abs(m))
+    assert misfit_close(pg, g, glob=True)
 
 
 SPEC_RTOL = 1e-5      # ampspec / filtered norms: FFT libraries differ (hipFFT fp32 vs the oracle's fp64 DFT rounded to fp32)
@@ -363,7 +363,7 @@ def test_time_domain_norms_with_frequency_filter(method):
     p.eval()
     pm, pn, pg = p.get_misfits()
     assert np.array_equal(pn[0][3:6], n[0][3:6])              # unfiltered receiver: host-side, exact
-    assert misfit_close(pm[:, 3:6], m[:, 3:6])
+    assert misfit_close(pm[:, 3:6], m[:, 3:6], pn[:, 3:6])
     assert np.allclose(pn[0], n[0], rtol=SPEC_RTOL)
     assert np.allclose(pm, m, rtol=SPEC_RTOL, atol=1e-7 * np.abs(n[0]).max()), np.max(np.abs(pm - m) / np.abs(m))
     assert np.allclose(pg, g, rtol=SPEC_RTOL)
@@ -621,7 +621,7 @@ def test_eikonal_sources_with_risetime_fold(stype):
         ncent.append(len(c))
         e.set_centroids(c, mo, ri)
         m, n, g = e.get_misfits()
-        assert misfit_close(pm[i], m), i
+        assert misfit_close(pm[i], m, pn[i]), i
         assert np.array_equal(pn[i], n)
         assert abs(pg[i] - g) <= MISFIT_RTOL * g
     assert min(ncent) > 30 and len(set(ncent)) > 1
@@ -632,7 +632,7 @@ def test_eikonal_sources_with_risetime_fold(stype):
         p.set_source_params(stype, bad)
     p.set_source_params(stype, trials[:1])
     p.eval()
-    assert misfit_close(p.get_misfits()[0][0], pm[0])
+    assert misfit_close(p.get_misfits()[0][0], pm[0], pn[0])
     # ... and inside a batch it is skipped, not fatal (seismosizer.py:703-720): a grid with two "Empty rupture area"
     # points and one nucleation point outside of the rupture region
     grid = np.concatenate([trials[:2], bad, trials[2:3], bad, trials[3:]], 0)
@@ -772,7 +772,7 @@ def test_moment_and_risetime_sweeps_rescale_instead_of_resynthesising(monkeypatc
         assert len({x.tobytes() for x in a[0]}) == 5
     if sid in (1, 6):
         m, n, g = oracle_misfits(e, sid, trials)
-        assert misfit_close(a[0], m) and misfit_close(a[2], g)
+        assert misfit_close(a[0], m, a[1]) and misfit_close(a[2], g, glob=True)
     p.eval(0, 2)                                                        # a chunk that holds the first of a family only
     p.eval(2, len(trials) - 2)                                          # ... the rest refers back across the chunk border: synthesised
     c = p.get_misfits()
@@ -819,7 +819,7 @@ def test_cycle_at_the_first_missing_trace(monkeypatch, bilinear, accum):
     p.eval()
     pm, pn, pg = p.get_misfits()
     assert np.array_equal(pn[0], n[0])
-    assert misfit_close(pm, m), np.max(np.abs(pm - m) / np.abs(m))
+    assert misfit_close(pm, m, pn), np.max(np.abs(pm - m) / np.abs(m))
     # the partial rule is really exercised: some centroid has bit 3 set, and dropping it changes the answer
     flags = np.concatenate([p.get_geometry(0, ir)["flags"] for ir in range(1, 9)])
     rows = np.concatenate([p.get_geometry(0, ir)["row"][:, 0] for ir in range(1, 9)])
@@ -831,8 +831,8 @@ def test_cycle_at_the_first_missing_trace(monkeypatch, bilinear, accum):
     p.set_source_params("bilateral", trials)
     p.eval()
     pm, pn, pg = p.get_misfits()
-    assert misfit_close(pm, m), np.max(np.abs(pm - m) / np.abs(m))
-    assert misfit_close(pg, g)
+    assert misfit_close(pm, m, pn), np.max(np.abs(pm - m) / np.abs(m))
+    assert misfit_close(pg, g, glob=True)
     flags = np.concatenate([p.get_geometry(0, ir)["flags"] for ir in range(1, 9)])
     assert np.any((flags & 8) != 0) and np.any((flags & 10) == 2)
     # sample for sample on one source
@@ -939,7 +939,7 @@ def test_floating_norms(method):
     pm, pn, pg = p.get_misfits()
     assert np.array_equal(pn[0], n[0])
     assert misfit_close(pm, m, n)
-    assert misfit_close(pg, g)
+    assert misfit_close(pg, g, glob=True)
     ps = p.get_floating_shifts()
     assert np.array_equal(ps, np.array(shifts, np.float32))
     assert len(set(ps[:, 0])) > 2                                 # the winning shift does move with the origin time
@@ -989,7 +989,7 @@ def test_synthesis_before_any_reference_is_set():
     p.set_source_params("bilateral", trials)
     p.eval()
     pm, pn, pg = p.get_misfits()
-    assert misfit_close(pm, m) and misfit_close(pg, g)
+    assert misfit_close(pm, m, pn) and misfit_close(pg, g, glob=True)
 
 
 def test_shift_and_autoshift_of_reference_seismograms():
@@ -1006,7 +1006,7 @@ def test_shift_and_autoshift_of_reference_seismograms():
     p.set_source_params("bilateral", trial)
     p.eval()
     pm, pn, pg = p.get_misfits()
-    assert misfit_close(pm, m) and np.array_equal(pn[0], n[0])
+    assert misfit_close(pm, m, pn) and np.array_equal(pn[0], n[0])
     # the cross-correlations autoshift is built on (output_cross_correlations, receiver.f90:597-616)
     for ir in (1, 3):
         want_cc = e.cross_correlations(ir, -5, 5)
@@ -1021,7 +1021,7 @@ def test_shift_and_autoshift_of_reference_seismograms():
     m2, n2, g2 = oracle_misfits(e, 1, trial)
     p.eval()
     pm2, pn2, pg2 = p.get_misfits()
-    assert misfit_close(pm2, m2) and np.array_equal(pn2[0], n2[0]) and misfit_close(pg2, g2)
+    assert misfit_close(pm2, m2, pn2) and np.array_equal(pn2[0], n2[0]) and misfit_close(pg2, g2, glob=True)
     # one receiver only
     one = e.autoshift_ref_seismogram(3, -2, 2) * dt
     assert p.autoshift_ref_seismogram(3, -2 * dt, 2 * dt)[0] == np.float32(one)
@@ -1055,7 +1055,7 @@ def test_sources_sharing_geometry_reuse_blended_tiles(monkeypatch):
     for a, i in zip(syn, (0, 39, 41, 60, 94)):
         assert np.array_equal(a, q.get_synthetics(i, 1, 1, 1)[1])
     m, n, g = oracle_misfits(e, 6, tr[[0, 17, 41, 60, 94]])
-    assert misfit_close(pm[[0, 41, 60, 94]], m[[0, 2, 3, 4]]) and np.all(pm[17] <= 1e-6 * pn[17])
+    assert misfit_close(pm[[0, 41, 60, 94]], m[[0, 2, 3, 4]], pn[[0, 41, 60, 94]]) and np.all(pm[17] <= 1e-6 * pn[17])
 
 
 @pytest.mark.parametrize("method", ["l2norm", "l1norm", "scalar_product", "peak"])
@@ -1150,14 +1150,11 @@ def test_minimize_lm_is_the_reference_minpack_run_with_batched_jacobians(limits)
     optimiser kiwi_hip_lmdif -- pinned bit for bit to the reference's own sminpack lmdif by tests/golden/lm_vectors.npz
     (tests/test_lm_minpack.py) -- driving the SAME engine ONE forward step at a time through lm_forward_step restated in the
     test must take exactly the same path (info, forward steps, final source, misfit: bit for bit), and driving the CPU
-    oracle a close one.  Where the reference build (oracle/_ref) is present its sminpack is run as well; nothing is
-    skipped without it."""
+    oracle a close one.  The reference's sminpack itself is not run here (oracle/_ref stays in the build container):
+    its outputs on the MINPACK problems are the committed fixture kiwi_hip_lmdif is pinned to."""
     from kiwi_amd import lm, lib as klib
     from oracle import ko
     import lm_problems as P
-    R = ko.ref()
-    if R is not None and not hasattr(R, "ref_lmdif"):
-        R = None
     sc = Scenario(nrec=6)
     e, p = build(sc)
     start = sc.true_params.copy()
@@ -1185,13 +1182,11 @@ def test_minimize_lm_is_the_reference_minpack_run_with_batched_jacobians(limits)
     m, n, g = p.get_misfits()
     assert g[0] == np.float32(res.misfit)
 
-    def run_reference_minpack(evaluate, use_ref=False):
+    def run_reference_minpack(evaluate):
         step, state, x0 = _forward_step_factory(evaluate, "bilateral", start, mask, mins, maxs)
         st = dict(P.SETTINGS["minimize_lm"])
-        if use_ref:
-            x, fvec, info, nfev = P.run_reference(R, "kiwi", len(m[0]), len(x0), x0, step, st)
-        else:                 # one point per call of `step`, in lmdif's order
-            x, fvec, info, nfev = P.run_product(klib.load(), klib, "kiwi", len(m[0]), len(x0), x0, step, st)
+        # one point per call of `step`, in lmdif's order
+        x, fvec, info, nfev = P.run_product(klib.load(), klib, "kiwi", len(m[0]), len(x0), x0, step, st)
         return (4 if info == 8 else info), state["steps"], state["cur"], state["global"]
 
     def eval_product(params):
@@ -1200,10 +1195,9 @@ def test_minimize_lm_is_the_reference_minpack_run_with_batched_jacobians(limits)
         mm, _, gg = p.get_misfits()
         return mm[0], gg[0]
 
-    for use_ref in ([False, True] if R is not None else [False]):
-        info, steps, last, glob = run_reference_minpack(eval_product, use_ref)
-        assert (info, steps) == (res.info, res.iterations)
-        assert np.array_equal(last.view(np.uint32), res.params.view(np.uint32)) and np.float32(glob) == np.float32(res.misfit)
+    info, steps, last, glob = run_reference_minpack(eval_product)
+    assert (info, steps) == (res.info, res.iterations)
+    assert np.array_equal(last.view(np.uint32), res.params.view(np.uint32)) and np.float32(glob) == np.float32(res.misfit)
 
     def eval_oracle(params):
         mm, _, gg = oracle_misfits(e, 1, params[None, :])
@@ -1250,7 +1244,7 @@ def test_peak_amplitudes_and_arias_intensities(mode):
     if mode == "tapered":                     # misfits are unaffected by the diagnostic evaluations in between
         m, n, g = oracle_misfits(e, 1, trials)
         p.eval()
-        assert misfit_close(p.get_misfits()[2], g)
+        assert misfit_close(p.get_misfits()[2], g, glob=True)
         p.switch_receiver(2, False)
         assert len(p.get_arias_intensities(1)) == 5
         with pytest.raises(KiwiHipError, match="differentiate argument must be 1"):
@@ -1276,14 +1270,14 @@ def test_descriptor_rows_of_group_starts_only(monkeypatch):
     p.set_source_params("moment_tensor", mt)
     p.eval()
     pm, pn, pg = p.get_misfits()
-    assert misfit_close(pm, m) and misfit_close(pg, g)
+    assert misfit_close(pm, m, pn) and misfit_close(pg, g, glob=True)
     trials = synthetic.bilat_strike_sweep(4, step=5.0)
     trials[:, 13] = 6.0                                  # longer rise time: more time steps per sub-fault
     m, n, g = oracle_misfits(e, 1, trials)
     p.set_source_params("bilateral", trials)
     p.eval()
     pm, pn, pg = p.get_misfits()
-    assert misfit_close(pm, m) and misfit_close(pg, g)
+    assert misfit_close(pm, m, pn) and misfit_close(pg, g, glob=True)
 
 
 def test_point_lp_source():
@@ -1296,7 +1290,7 @@ def test_point_lp_source():
     p.set_source_params("point_lp", trials)
     p.eval()
     pm, pn, pg = p.get_misfits()
-    assert misfit_close(pm, m) and misfit_close(pg, g) and np.array_equal(pn[0], n[0])
+    assert misfit_close(pm, m, pn) and misfit_close(pg, g, glob=True) and np.array_equal(pn[0], n[0])
 
 
 @pytest.mark.parametrize("method", ["l2norm", "l1norm", "floating_l1norm"])
@@ -1336,7 +1330,7 @@ def test_untapered_comparator_fresh_evaluation_semantics(method):
     p.set_source_params("bilateral", trials)
     p.eval()
     pm, pn, pg = p.get_misfits()
-    assert misfit_close(pm, np.array(want_m)) and misfit_close(pg, np.array(want_g, np.float32))
+    assert misfit_close(pm, np.array(want_m), pn) and misfit_close(pg, np.array(want_g, np.float32), glob=True)
     assert np.array_equal(pn, np.array(want_n))
     if mid == 8:
         assert np.array_equal(p.get_floating_shifts(), np.array(want_s, np.float32))
@@ -1365,7 +1359,7 @@ def test_odd_window_lengths_and_offsets(fused):
         p.set_source_params("bilateral", trials)
     p.eval()
     pm, pn, pg = p.get_misfits()
-    assert np.array_equal(pn[0], n[0]) and misfit_close(pm, m) and misfit_close(pg, g)
+    assert np.array_equal(pn[0], n[0]) and misfit_close(pm, m, pn) and misfit_close(pg, g, glob=True)
     lens = {p.get_synthetics(0, ir + 1, 1, 2)[1].size for ir in range(5)}
     assert any(v % 4 for v in lens)
 
@@ -1382,7 +1376,7 @@ def test_all_component_letters():
     p.eval()
     pm, pn, pg = p.get_misfits()
     assert pm.shape[1] == sum(len(c) for c in comps)
-    assert np.array_equal(pn[0], n[0]) and misfit_close(pm, m) and misfit_close(pg, g)
+    assert np.array_equal(pn[0], n[0]) and misfit_close(pm, m, pn) and misfit_close(pg, g, glob=True)
     # w = -e, s = -n, u = -d at one receiver pair sharing the geometry? (receivers differ) -> check against the oracle's traces
     e.set_source_params(1, trials[0])
     e.get_misfits()
@@ -1418,7 +1412,7 @@ def test_many_small_evaluations_recycle_timing_events():
     for _ in range(2500):
         p.eval()
     pm, pn, pg = p.get_misfits()
-    assert misfit_close(pm, m) and misfit_close(pg, g)
+    assert misfit_close(pm, m, pn) and misfit_close(pg, g, glob=True)
     ms, launches = p.kernel_ms()
     assert 0 < launches[1] < 2500
 
@@ -1504,7 +1498,7 @@ def test_two_sources_per_workgroup_is_bit_identical(monkeypatch, L):
     p.set_source_params("bilateral", tr)
     p.eval()
     pm, pn, pg = p.get_misfits()
-    assert misfit_close(pm, m) and misfit_close(pg, g)
+    assert misfit_close(pm, m, pn) and misfit_close(pg, g, glob=True)
 
 
 @pytest.mark.gpu
@@ -1699,7 +1693,6 @@ def test_spectral_results_of_folded_sources_do_not_depend_on_the_batch(method, w
     rm, rn, rg, rs = p.misfits_for_params("mt_eikonal", trials, 2)
     assert np.array_equal(rm, bm) and np.array_equal(rn, bn) and np.array_equal(rg, bg) and not rs.any()
     oprof = ko.crust_profile(*np.split(prof, [8, 16, 24]))
-    tol = spectral_tol(method, with_filter)
     for i in (1, 2, 4):
         ef = sc.oracle()
         sc.apply_setup(ef, True)
@@ -1710,6 +1703,7 @@ def test_spectral_results_of_folded_sources_do_not_depend_on_the_batch(method, w
         c, mo, ri, _ = ko.discretize_eikonal(5, trials[i], sc.effective_dt, oprof, cp, cn)
         ef.set_centroids(c, mo, ri)
         om, on, og = ef.get_misfits()
-        assert np.all(np.abs(bn[i] - on) <= 5e-5 * on), (i, np.max(np.abs(bn[i] - on) / on))
-        assert np.all(np.abs(bm[i] - om) <= tol * np.maximum(on, np.abs(om))), (i, np.max(np.abs(bm[i] - om) / on))
+        # no fixed figure: 1e-6 of max(norm factor, misfit) + what fp32 transforms of the pair's length explain (tests/common.py)
+        ok, ratio = spectral_close(method, sc.gf["dt"], bm[i], om, on, slot_scales(ef, sc.comps, sc.gf["dt"]), bn[i])
+        assert ok, (i, ratio, np.max(np.abs(bm[i] - om) / on), np.max(np.abs(bn[i] - on) / on))
         ef.close()
