@@ -328,17 +328,143 @@ def required_flops(ncent, npts, nrec, ng, W):
 
 def other_contract(p, batch, flops_eval, steps=6):
     """The same resident batch under the OTHER arithmetic contract of the accumulate kernels (exact <-> fused), timed the same
-    way; the engine is left in the contract it came in."""
+    way; the engine is left in the contract it came in.  `fused_vs_exact`: the worst difference of the two contracts' results over
+    the whole timed batch -- per-slot misfits relative to the misfit itself and relative to the slot's norm factor (the fused
+    contract promises 1e-6 of the larger of the two), global misfits relative to sqrt(g^2 + 1)."""
     was = p.arithmetic()
     oth = "exact" if was == "fused" else "fused"
+    p.eval()
+    p.sync()
+    m0, n0, g0 = (np.asarray(x, np.float64).copy() for x in p.get_misfits())
     p.set_arithmetic(oth)
     for _ in range(2):
         p.eval()
     dt, acc_ms = timed_evals(p, steps)
+    m1, n1, g1 = (np.asarray(x, np.float64) for x in p.get_misfits())
     p.set_arithmetic(was)
+    (me, ge), (mf, gf_) = ((m0, g0), (m1, g1)) if was == "exact" else ((m1, g1), (m0, g0))
+    dm = np.abs(mf - me)
+    delta = {"max_abs_diff_over_misfit": float(np.max(dm / np.maximum(np.abs(me), 1e-300))),
+             "max_abs_diff_over_norm_factor": float(np.max(dm / np.maximum(n0, 1e-300))),
+             "max_abs_diff_over_max_of_both": float(np.max(dm / np.maximum(np.maximum(np.abs(me), n0), 1e-300))),
+             "max_global_misfit_diff_over_sqrt_g2_plus_1": float(np.max(np.abs(gf_ - ge) / np.sqrt(ge * ge + 1.0))),
+             "norm_factors_identical": bool(np.array_equal(n0, n1)), "sources": int(len(ge)), "slots": int(me.shape[1])}
     ach = flops_eval * batch / (acc_ms * 1e-3) / 1e12 if acc_ms > 0 else 0.0
     return {"arithmetic": oth, "value": batch * steps / dt, "unit": "evals/s", "steps": steps, "accumulate_ms_per_step": acc_ms,
-            "roofline": {"bound": "valu_issue", "achieved": ach, "peak": valu_peak(oth), "unit": "TFLOP/s", "frac": ach / valu_peak(oth)}}
+            "roofline": {"bound": "valu_issue", "achieved": ach, "peak": valu_peak(oth), "unit": "TFLOP/s", "frac": ach / valu_peak(oth)},
+            "fused_vs_exact": delta}
+
+
+def host_inclusive(p, wl, value_resident, reps=3, piece=0):
+    """The WHOLE path of north_star for the same trial sources: parameter list -> host discretiser (A2-A5) -> upload of the centroid
+    tables -> geometry / accumulate / misfit kernels -> download of every misfit, through the one call the Python and Fortran hosts
+    use for a trial list (kiwi_hip_misfits_for_params: the discretiser of one piece runs under the device's evaluation of another);
+    the loop it replaces is seismosizer.py:682-722.  Nothing is resident when the clock starts except the database, receivers and
+    references.  Leaves the engine holding the head piece of the list."""
+    trials = wl["trials"]
+    p.eval()
+    p.sync()
+    gm, gn, gg = (x.copy() for x in p.get_misfits())
+    p.misfits_for_params(wl["sourcetype"], trials, piece)            # (buffers of the piece size)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        m, n, g, st = p.misfits_for_params(wl["sourcetype"], trials, piece)
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": len(trials) / dt, "unit": "evals/s", "ms_per_step": dt * 1e3, "steps": reps, "trial_sources_per_step": int(len(trials)),
+            "frac_of_resident": len(trials) / dt / value_resident if value_resident > 0 else None,
+            "identical_to_resident": bool(np.array_equal(m, gm) and np.array_equal(n, gn) and np.array_equal(g, gg)),
+            "failed_sources": int(np.count_nonzero(st)),
+            "timed": "parameter list -> host discretiser -> H2D -> kernels -> D2H of all misfits (kiwi_hip_misfits_for_params, "
+                     "pieces of %d sources, discretiser overlapped with the device)" % (piece or (128 if wl["crust"] is not None else 2048))}
+
+
+def sweep_block(device, L, n=20000, first=40000, workload="cfg5"):
+    """A slice of BASELINE.json configs[4] in the default line: `n` consecutive points of the 10^5-point (strike, dip, slip-rake, depth,
+    time) grid that hold the source the references were made from, host-inclusive (one kiwi_hip_misfits_for_params call), spectral
+    comparator with frequency filter; the argmin of the global misfits has to be the planted source.  (`--sweep 100000` runs the
+    whole grid, sharded over the ranks.)"""
+    from kiwi_amd import synthetic
+    wl = synthetic.workload(workload, 512, first)
+    p, gf, recv, refs, tapers, ncent = setup_product(device, wl, L)
+    trials = synthetic.workload(workload, n, first)["trials"]
+    p.misfits_for_params(wl["sourcetype"], trials[:2048])              # warm-up: transform plans, buffers
+    p.sync()
+    t0 = time.perf_counter()
+    m, nn, g, st = p.misfits_for_params(wl["sourcetype"], trials)
+    dt = time.perf_counter() - t0
+    best = int(np.nanargmin(np.where(np.isfinite(g), g, np.inf)))
+    same = np.where(np.all(trials == wl["true"][None, :], axis=1))[0]
+    p.close()
+    return {"workload": "%s: points %d .. %d of the 10^5-point source-parameter grid, %s%s, %d receivers x 3 comp x %d samples"
+                        % (wl["name"], first, first + n - 1, wl["method"], " + frequency filter" if wl["filter"] is not None else "", wl["nrec"], L),
+            "value": n / dt, "unit": "evals/s", "wall_s": dt, "trial_sources": n, "argmin": best, "argmin_misfit": float(g[best]),
+            "true_source_index": int(same[0]) if len(same) else None, "argmin_is_true_source": bool(len(same) and best == int(same[0])),
+            "failed_sources": int(np.count_nonzero(st)),
+            "timed": "parameter list -> host discretiser -> H2D -> kernels -> D2H (inputs NOT resident), one call"}
+
+
+def also_bigdb4(device, L, batch=1024, steps=6):
+    """The HBM regime in the driver's line: the cfg3 source over a 4.2 GB Green's function database (sixteen times the Infinity
+    Cache), one trial location per distance node in shuffled order -- the one workload whose accumulate kernel runs against the
+    memory, i.e. where north_star's "fraction of the HBM roofline" is the meaningful figure.  `achieved` = the node rows the
+    launch has to fetch (sub-fault points x receivers x n_g x n_ip x window x 4 B: the time steps of a point share their rows, every
+    (point, receiver) pair needs its own) over the accumulate kernel's time; counters (`traffic`) from the committed profile of the
+    same kernel sources, the pure-read ceiling of this chip from profiles/microbench/hbm_read.hip."""
+    from kiwi_amd import synthetic
+    wl = synthetic.workload("cfg3-bigdb4", batch, 0)
+    p, gf, recv, refs, tapers, ncent = setup_product(device, wl, L)
+    for _ in range(2):
+        p.eval()
+    dt, acc_ms = timed_evals(p, steps)
+    ar = p.arithmetic()
+    npts, nrec, ng, W = wl["npoints"], wl["nrec"], gf["data"].shape[2], L
+    row_bytes = npts * nrec * ng * 4 * W * 4.0 * batch
+    gbs = row_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
+    flops_eval = required_flops(ncent, npts, nrec, ng, W)
+    prof, note = committed_counters("cfg3-bigdb4", ar)
+    traffic = prof["hbm_bytes_per_launch"] * (batch / prof["batch"]) if prof.get("hbm_bytes_per_launch") else None
+    ceil = read_ceiling()
+    out = {"workload": "cfg3-bigdb4: cfg3 source, %.0f centroids (%.0f points) x %d receivers, database of %.1f GB (%d x %d nodes), one trial "
+                       "location per distance node, shuffled" % (ncent, npts, nrec, gf["data"].nbytes / 1e9, gf["data"].shape[0], gf["data"].shape[1]),
+           "arithmetic": ar, "value": batch * steps / dt, "unit": "evals/s", "trial_sources_per_step": batch, "steps": steps,
+           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                        "traffic": traffic, "traffic_gbs": traffic / (acc_ms * 1e-3) / 1e9 if traffic and acc_ms > 0 else None,
+                        "accumulate_ms_per_step": acc_ms, "algorithmic_bytes_per_step": row_bytes,
+                        "pure_read_ceiling_gbs": ceil, "frac_of_pure_read_ceiling": gbs / ceil["random_rows_gbs"] if ceil and ceil.get("random_rows_gbs") else None,
+                        "valu_frac": flops_eval * batch / (acc_ms * 1e-3) / 1e12 / valu_peak(ar) if acc_ms > 0 else None,
+                        "profile_note": note}}
+    p.close()
+    return out
+
+
+def read_ceiling():
+    """what a pure 16 B / lane read reaches on an MI355X of this pool (profiles/microbench/hbm_read.hip, collected with the profiles)"""
+    try:
+        import glob
+        fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_read.json")))
+        return json.load(open(fs[-1])) if fs else None
+    except Exception:
+        return None
+
+
+def committed_counters(workload, arith):
+    """counters of `workload` from the committed rocprofv3 passes (profiles/r*_summary.json), attached only when they were collected
+    on exactly these kernel sources -> (entry or {}, note)"""
+    prof, note = {}, "no committed profile of this workload"
+    try:
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json"))):
+            js = json.load(open(f))
+            w = js.get("workloads", {}).get(workload + ("@fused" if arith == "fused" else ""))
+            if w and w.get("batch") and os.environ.get("KIWI_HIP_ACCUM") != "direct":
+                if js.get("kernel_sources_sha256") == kernel_sources_sha256():
+                    prof = dict(w, file=os.path.basename(f), profile_head=js.get("head"))
+                    note = "collected on commit %s, same kernel sources as this build" % js.get("head")
+                elif not prof:
+                    note = "%s was collected on other kernel sources (commit %s): counters not attached" % (os.path.basename(f), js.get("head"))
+    except Exception:
+        prof = {}
+    return prof, note
 
 
 def also_cfg3_100pt(p_main, device, L, batch=512, steps=6):
@@ -425,7 +551,7 @@ def main():
                     help="ranks = GPUs of this node (default: WORLD_SIZE when started by a launcher, else 1)")
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5", "cfg5-td", "cfg3-100pt", "cfg3-scatter", "cfg3-bigdb", "cfg3-bigdb4", "cfg3-bigdb4-ordered", "cfg3-w256", "cfg3-w600"],
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg4-nukl", "cfg5", "cfg5-td", "cfg3-100pt", "cfg3-scatter", "cfg3-bigdb", "cfg3-bigdb4", "cfg3-bigdb4-ordered", "cfg3-w256", "cfg3-w600"],
                     help="BASELINE.json configs[1..4]; cfg3 (default) is the one the metric is quoted on")
     ap.add_argument("--batch", type=int, default=0,
                     help="trial sources per GPU per step (default: 12960 cfg2, 4096 cfg3, 1024 cfg3-scatter / cfg3-bigdb, 512 cfg3-100pt / cfg5 / cfg5-td, 128 cfg4)")
@@ -434,6 +560,7 @@ def main():
                          "the ranks, host discretiser and transfers included; reports wall seconds and evals/s")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary figure (cfg3-100pt) of the default run")
     ap.add_argument("--samples", type=int, default=4096)
+    ap.add_argument("--piece", type=int, default=0, help="host_inclusive: sources per piece of the one-call evaluation (0: the library's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -480,7 +607,7 @@ def main():
     from kiwi_amd import synthetic
     if args.batch <= 0:
         # (cfg3: 4096 sources per step -- 0.14 s -- so that the driver's 20 steps time 2.8 s of device work)
-        args.batch = {"cfg2": 12960, "cfg3": 4096, "cfg3-scatter": 1024, "cfg3-bigdb": 1024, "cfg3-100pt": 512, "cfg4": 128, "cfg5": 512,
+        args.batch = {"cfg2": 12960, "cfg3": 4096, "cfg3-scatter": 1024, "cfg3-bigdb": 1024, "cfg3-100pt": 512, "cfg4": 128, "cfg4-nukl": 128, "cfg5": 512,
                       "cfg5-td": 512, "cfg3-w256": 16384, "cfg3-w600": 8192, "cfg3-bigdb4": 1024, "cfg3-bigdb4-ordered": 1024}[args.workload]
     if args.sweep > 0:
         return sweep(args, torch, dist, rank, local_rank, ngpus, force_dist)
@@ -549,22 +676,7 @@ def main():
         no_reuse_gbs = b_eval * args.batch * args.steps / acc_s / 1e9 if acc_s > 0 else 0.0
         # ---- measured counters of this same command from the committed rocprofv3 passes (profiles/r*_summary.json):
         # PMC counters cannot be collected from inside this process, so these are null when no profile matches
-        prof = {}
-        prof_note = "no committed profile of this workload"
-        try:
-            import glob
-            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json"))):
-                js = json.load(open(f))
-                w = js.get("workloads", {}).get(args.workload + ("@fused" if arith == "fused" else ""))
-                if w and w.get("batch") and os.environ.get("KIWI_HIP_ACCUM") != "direct":
-                    # counters are quoted only when they were collected on THESE kernel sources
-                    if js.get("kernel_sources_sha256") == kernel_sources_sha256():
-                        prof = dict(w, file=os.path.basename(f), profile_head=js.get("head"))
-                        prof_note = "collected on commit %s, same kernel sources as this build" % js.get("head")
-                    elif not prof:
-                        prof_note = "%s was collected on other kernel sources (commit %s): counters not attached" % (os.path.basename(f), js.get("head"))
-        except Exception:
-            prof = {}
+        prof, prof_note = committed_counters(args.workload, arith)
         scale = args.batch / prof["batch"] if prof else 0.0
         traffic = prof["hbm_bytes_per_launch"] * scale if prof.get("hbm_bytes_per_launch") else None
         avg_ms = float(ms[1]) / launches_acc
@@ -630,8 +742,12 @@ def main():
             out["cpu_baseline"] = None
         if ngpus == 1 and not args.no_also:
             out["other_contract"] = other_contract(p, args.batch, flops_eval)
+            # the whole path (discretiser + transfers included) for the same trial sources, against the resident-input figure
+            out["host_inclusive"] = host_inclusive(p, wl, value, piece=args.piece)
         if ngpus == 1 and args.workload == "cfg3" and not args.no_also:
             out["also"] = also_cfg3_100pt(p, local_rank, args.samples)
+            out["sweep"] = sweep_block(local_rank, args.samples)
+            out["also_hbm"] = also_bigdb4(local_rank, args.samples)
         print(json.dumps(_finite(out)))
     if dist is not None:
         dist.barrier()

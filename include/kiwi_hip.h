@@ -181,7 +181,7 @@ int kiwi_hip_get_source_status(kiwi_hip_ctx *ctx, int isrc0, int nsrc, int *stat
 int kiwi_hip_source_status_message(int code, char *buf, int buflen);
 
 /* make_misfits_for_sources for a whole trial list in ONE call (python/tunguska/seismosizer.py:682-722), host and device
- * overlapped: the list is cut into pieces of `piece` sources (<= 0: 128 for the eikonal types, 1024 otherwise); while the
+ * overlapped: the list is cut into pieces of `piece` sources (<= 0: 128 for the eikonal types, 2048 otherwise); while the
  * device evaluates one piece a second host thread discretises the next.  Per piece this IS kiwi_hip_set_sources_params +
  * kiwi_hip_eval + kiwi_hip_get_misfits + kiwi_hip_get_source_status, so misfit[nsrc][nmis], norm[nsrc][nmis], global[nsrc]
  * and status[nsrc] (any may be NULL) are bit for bit what those calls return for any piece size; a piece none of whose

@@ -139,8 +139,13 @@ struct IndexHeap {
 };
 
 // eikonal_solver_fmm, eikonal.f90:29-199; arrays (nx,ny) with x fastest
+// `discard`: nodes of exactly this speed are points outside of the rupture whose times the caller throws away (psm_make_*_grid
+// gives them half the slowest speed, source_mt_eikonal.f90:501-517, and overwrites their times with -1 behind the solve).  The march
+// ends when the last node that is NOT one of them has been accepted: an accepted node is never touched again (update_neighbor
+// returns at once for it, eikonal.f90:131), so every time that is kept is the reference's bit for bit; what is left undone is the
+// tail of slow outside nodes (up to a fifth of the grid for an unclipped circle in its bounding box).
 inline void fast_marching(const std::vector<float> &speed, int nx, int ny, const float origin[2], const float delta[2],
-                          const float start[2], std::vector<float> &times)
+                          const float start[2], std::vector<float> &times, float discard = std::numeric_limits<float>::quiet_NaN())
 {
     constexpr int FARAWAY = -1, ALIVE = 0;
     const float inf = std::numeric_limits<float>::max() * 0.1f;
@@ -159,6 +164,9 @@ inline void fast_marching(const std::vector<float> &speed, int nx, int ny, const
     if (nx == 1 && ny == 1) { finish(); return; }
     nodes[id(ix, iy) - 1].bp = ALIVE;
     int nalive = 1;
+    long long wanted = 0;
+    for (size_t k = 0; k < speed.size(); k++) wanted += speed[k] != discard;
+    if (speed[id(ix, iy) - 1] != discard) wanted--;
     IndexHeap heap(nx * ny, nodes.data(), heap_store);
     auto T = [&](int x, int y) -> float & { return nodes[id(x, y) - 1].t; };
     auto S = [&](int x, int y) { return speed[id(x, y) - 1]; };
@@ -218,6 +226,7 @@ inline void fast_marching(const std::vector<float> &speed, int nx, int ny, const
         iy = (imin - 1) / nx + 1;
         nodes[imin - 1].bp = ALIVE;
         nalive++;
+        if (speed[imin - 1] != discard && --wanted == 0) break;
         if (1 < ix) update(ix - 1, iy);
         if (ix < nx) update(ix + 1, iy);
         if (1 < iy) update(ix, iy - 1);
@@ -291,10 +300,10 @@ struct SolveCache {
 };
 
 inline void fast_marching_cached(const std::vector<float> &speed, int nx, int ny, const float origin[2], const float delta[2],
-                                 const float start[2], std::vector<float> &times)
+                                 const float start[2], std::vector<float> &times, float discard)
 {
     SolveCache &sc = SolveCache::get();
-    if (!sc.enabled) { fast_marching(speed, nx, ny, origin, delta, start, times); return; }
+    if (!sc.enabled) { fast_marching(speed, nx, ny, origin, delta, start, times, discard); return; }
     // the start cell exactly as fast_marching computes it: all it takes from `origin` and `start`
     int ix = (int)((start[0] - origin[0]) / delta[0]) + 1, iy = (int)((start[1] - origin[1]) / delta[1]) + 1;
     ix = std::min(std::max(ix, 1), nx);
@@ -305,7 +314,7 @@ inline void fast_marching_cached(const std::vector<float> &speed, int nx, int ny
         sc.hits++;
         return;
     }
-    fast_marching(speed, nx, ny, origin, delta, start, times);
+    fast_marching(speed, nx, ny, origin, delta, start, times, discard);
     sc.misses++;
     auto e = std::make_shared<SolveCache::Entry>();
     e->hash = h; e->nx = nx; e->ny = ny; e->ix = ix; e->iy = iy; e->dx = delta[0]; e->dy = delta[1];
@@ -386,7 +395,7 @@ inline std::string discretize_eikonal(int type, const float *P, float doi, const
     const float invalid = minspeed * 0.5f;
     for (auto &v : speed) if (v == 0.f) v = invalid;
     const float start[2] = { nux, nuy };
-    fast_marching_cached(speed, fx, fy, lo, fd, start, ftimes);      // (exact: hit = same inputs, compared in full)
+    fast_marching_cached(speed, fx, fy, lo, fd, start, ftimes, invalid);      // (exact: hit = same inputs, compared in full)
     for (size_t k = 0; k < speed.size(); k++) if (speed[k] == invalid) ftimes[k] = -1.f;
 
     // coarse grid (psm_to_tdsm_size_*, psm_downsample_grid)

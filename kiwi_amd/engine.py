@@ -404,14 +404,14 @@ class Engine:
     # ------------------------------------------------------------------ seismosizer.py counterparts
     def misfits_for_params(self, sourcetype, params, piece=0):
         """A whole trial list in one call (kiwi_hip_misfits_for_params): the list is evaluated in pieces of `piece` sources
-        (0: 128 for the eikonal types, 1024 otherwise), the host discretiser of one piece running while the device
+        (0: 128 for the eikonal types, 2048 otherwise), the host discretiser of one piece running while the device
         evaluates another; afterwards the engine holds the head of the list (sources 0 .. piece - 1).  Returns (misfit[N,nmis], norm[N,nmis], global[N], status[N]); piece size does not change a bit."""
         p = np.ascontiguousarray(np.atleast_2d(params), np.float32)
         st = SOURCE_TYPES.get(sourcetype, sourcetype)
         if p.shape[1] != self.L.kiwi_hip_source_nparams(st):
             raise KiwiHipError("set_source_params: wrong number of source parameters")
         if piece <= 0:
-            piece = 128 if st in (4, 5) else 1024
+            piece = 128 if st in (4, 5) else 2048
         N, nm = p.shape[0], self.nmisfits()
         m = np.zeros((N, nm), np.float32)
         n = np.zeros((N, nm), np.float32)

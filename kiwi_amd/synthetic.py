@@ -1,9 +1,25 @@
 """Deterministic synthetic inputs for tests and bench.py: a closed-form
 Green's function database, a ring of receivers, reference traces' tapers and trial-source grids.
 No file of the reference is needed; everything is numpy."""
+import os
+
 import numpy as np
 
 EARTH_R = 6371000.0
+
+
+def _slabs(fn, starts):
+    """fn(start) over the slabs of a database, on a few threads when there are many (numpy releases the interpreter lock in
+    the array operations; a 4 GB database takes a minute and a half on one thread)"""
+    starts = list(starts)
+    nthr = min(len(starts), 12, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    if nthr <= 1:
+        for a in starts:
+            fn(a)
+        return
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(nthr) as ex:
+        list(ex.map(fn, starts))
 
 
 def make_gfdb(nx=128, nz=6, ng=10, L=4096, dt=0.5, dx=4000.0, dz=2000.0, firstx=100e3, firstz=6e3,
@@ -29,8 +45,9 @@ def make_gfdb(nx=128, nz=6, ng=10, L=4096, dt=0.5, dx=4000.0, dz=2000.0, firstx=
         stat[0, 0, 6, 0] = -2e-22
         stat_ramp = stat * ramp
     data = np.empty((nx, nz, ng, L), np.float32)
-    slab = max(1, (1 << 26) // (nz * ng * L))
-    for a in range(0, nx, slab):
+    slab = max(1, (1 << 24) // (nz * ng * L))
+
+    def fill(a):
         b = min(nx, a + slab)
         x = (firstx + np.arange(a, b) * dx)[:, None, None, None]
         val = shape / (x / 1e5)
@@ -39,6 +56,8 @@ def make_gfdb(nx=128, nz=6, ng=10, L=4096, dt=0.5, dx=4000.0, dz=2000.0, firstx=
             val[..., 300:309] = 0.0
             val[..., 1000:1009] = 0.0
         data[a:b] = val.astype(np.float32)
+
+    _slabs(fill, range(0, nx, slab))
     if variant != "static":
         data[..., -1] = 0.0
     first = np.rint((firstx + np.arange(nx) * dx) / vel / dt).astype(np.int32)
@@ -58,9 +77,10 @@ def pack_gfdb(gf):
     out = np.empty_like(data)
     nsamp = np.empty((nx, nz, ng), np.int32)
     first = np.empty((nx, nz, ng), np.int32)
-    slab = max(1, (1 << 25) // (nz * ng * L))
+    slab = max(1, (1 << 23) // (nz * ng * L))
     ar = np.arange(L)[None, None, None, :]
-    for a in range(0, nx, slab):
+
+    def pack(a):
         b = min(nx, a + slab)
         d = data[a:b]
         nzm = d != 0
@@ -74,6 +94,8 @@ def pack_gfdb(gf):
         o = np.take_along_axis(d, np.minimum(idx, L - 1), -1)
         o[ar >= ns[..., None]] = 0.0
         out[a:b] = o
+
+    _slabs(pack, range(0, nx, slab))
     lmax = int(nsamp.max())
     g = dict(gf)
     g.update(data=np.ascontiguousarray(out[..., :lmax]) if lmax < L else out, first=first, nsamp=nsamp)
@@ -160,6 +182,23 @@ def mt_eikonal_location_grid(n_north=10, n_east=10, n_depth=5, base=None):
                 p[1] += 400.0 * (a - n_north // 2)
                 p[2] += 400.0 * (b - n_east // 2)
                 p[3] += 250.0 * (c - n_depth // 2)
+                out.append(p)
+    return np.array(out, np.float32)
+
+
+def mt_eikonal_rupture_grid(base=None):
+    """cfg4-nukl trial set: grid over the parameters that shape the rupture itself -- (nucleation-shift-x, nucleation-shift-y,
+    rel-rupture-velocity), what source_mt_eikonal.f90:102-124 is inverted for -- at a fixed location: every trial has its own
+    rupture-front solve (another start cell or another speed grid), the exact solve cache cannot help.  25 x 9 x 6 = 1350."""
+    base = np.array(CFG4_MT_EIKONAL if base is None else base, np.float32)
+    out = []
+    for a in range(25):
+        for b in range(9):
+            for c in range(6):
+                p = base.copy()
+                p[10] = 500.0 * (a - 12)
+                p[11] = 500.0 * (b - 4)
+                p[12] = 0.70 + 0.05 * c
                 out.append(p)
     return np.array(out, np.float32)
 
@@ -254,6 +293,13 @@ def workload(name, nsrc=None, trial0=0):
         n = 32 if nsrc is None else nsrc
         tr = grid[(trial0 + np.arange(n)) % len(grid)]
         return dict(name="cfg4-mt-eikonal", sourcetype="mt_eikonal", true=np.array(CFG4_MT_EIKONAL, np.float32),
+                    trials=tr, nrec=200, nx=160, method="l2norm", filter=None, crust=SYNTH_CRUST,
+                    constraints=CFG4_CONSTRAINTS)
+    if name == "cfg4-nukl":
+        grid = mt_eikonal_rupture_grid()
+        n = 32 if nsrc is None else nsrc
+        tr = grid[(trial0 + np.arange(n)) % len(grid)]
+        return dict(name="cfg4-nukl-mt-eikonal", sourcetype="mt_eikonal", true=np.array(CFG4_MT_EIKONAL, np.float32),
                     trials=tr, nrec=200, nx=160, method="l2norm", filter=None, crust=SYNTH_CRUST,
                     constraints=CFG4_CONSTRAINTS)
     if name == "cfg5":

@@ -13,11 +13,11 @@ import bench                                   # noqa: E402
 from kiwi_amd import synthetic                 # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
-batch = int(sys.argv[2]) if len(sys.argv) > 2 else {"cfg4": 128}.get(name, 256)
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else {"cfg4": 128, "cfg4-nukl": 128}.get(name, 256)
 wl = synthetic.workload(name, batch, 0)
 p, gf, recv, refs, tapers, ncent = bench.setup_product(0, wl, 4096)
 tr = wl["trials"]
-reps = 3 if name == "cfg4" else 10
+reps = 3 if name.startswith("cfg4") else 10
 for rep in range(3):
     t0 = time.perf_counter()
     for _ in range(reps):
