@@ -31,7 +31,7 @@ template <int NG, int T>
 static void grouped_t(const AccumArgs &a, dim3 grid, int ntiles, const int *runs, int pairsel, const int *mate, const int *mate4)
 {
 #define KIWI_G(FV, RV) hipLaunchKernelGGL((accumulate_grouped_kernel<NG, T, FV, RV>), grid, dim3(T), 0, a.stream, KIWI_COMMON_ARGS, ntiles, \
-                                          a.tab, a.coefs, runs, a.fp, a.pairflag, pairsel, mate, mate4, a.synrow, a.fam_ofs, a.fam_list)
+                                          a.tab, a.coefs, runs, a.fp, a.pairflag, pairsel, mate, mate4, a.synrow, a.fam_ofs, a.fam_list, a.compact)
     if (a.fuse) { if (runs) KIWI_G(true, true); else KIWI_G(true, false); }
     else        { if (runs) KIWI_G(false, true); else KIWI_G(false, false); }
 #undef KIWI_G
@@ -51,33 +51,43 @@ void launch_grouped(const AccumArgs &a, dim3 grid, int T, int ntiles, const int 
 #endif
 
 #if KIWI_FAMILY == 3
-template <int NG, int NS>
+template <int NG, int NS, bool COMPACT>
 static void multi_t(const AccumArgs &a, dim3 grid, int ntiles, const int *mate, const int *wider)
 {
-    if (a.fuse) hipLaunchKernelGGL((accumulate_multi_kernel<NG, true, NS>), grid, dim3(256), 0, a.stream, KIWI_COMMON_ARGS, ntiles, a.tab, a.coefs, a.fp,
+    if (a.fuse) hipLaunchKernelGGL((accumulate_multi_kernel<NG, true, NS, COMPACT>), grid, dim3(256), 0, a.stream, KIWI_COMMON_ARGS, ntiles, a.tab, a.coefs, a.fp,
                                    a.pairflag, mate, wider);
-    else        hipLaunchKernelGGL((accumulate_multi_kernel<NG, false, NS>), grid, dim3(256), 0, a.stream, KIWI_COMMON_ARGS, ntiles, a.tab, a.coefs, a.fp,
+    else        hipLaunchKernelGGL((accumulate_multi_kernel<NG, false, NS, COMPACT>), grid, dim3(256), 0, a.stream, KIWI_COMMON_ARGS, ntiles, a.tab, a.coefs, a.fp,
                                    a.pairflag, mate, wider);
+}
+template <int NG, int NS>
+static void multi_c(const AccumArgs &a, dim3 grid, int ntiles, const int *mate, const int *wider)
+{
+    if (a.compact) multi_t<NG, NS, true>(a, grid, ntiles, mate, wider); else multi_t<NG, NS, false>(a, grid, ntiles, mate, wider);
 }
 void launch_multi(const AccumArgs &a, dim3 grid, int NS, int ntiles, const int *mate, const int *wider)
 {
-    if (a.ng == 10) { if (NS == 4) multi_t<10, 4>(a, grid, ntiles, mate, wider); else multi_t<10, 2>(a, grid, ntiles, mate, wider); }
-    else            { if (NS == 4) multi_t<8, 4>(a, grid, ntiles, mate, wider); else multi_t<8, 2>(a, grid, ntiles, mate, wider); }
+    if (a.ng == 10) { if (NS == 4) multi_c<10, 4>(a, grid, ntiles, mate, wider); else multi_c<10, 2>(a, grid, ntiles, mate, wider); }
+    else            { if (NS == 4) multi_c<8, 4>(a, grid, ntiles, mate, wider); else multi_c<8, 2>(a, grid, ntiles, mate, wider); }
 }
 #endif
 
 #if KIWI_FAMILY == 4
-template <int NG>
+template <int NG, bool COMPACT>
 static void cell_t(const AccumArgs &a, dim3 grid, int ntiles, bool per_wave)
 {
 #define KIWI_C(KERNEL) hipLaunchKernelGGL(KERNEL, grid, dim3(256), 0, a.stream, KIWI_COMMON_ARGS, ntiles, a.tab, a.coefs, a.fp, a.pairflag, a.synrow, \
                                           a.fam_ofs, a.fam_list)
-    if (per_wave) { if (a.fuse) KIWI_C((accumulate_cellw_kernel<NG, true>)); else KIWI_C((accumulate_cellw_kernel<NG, false>)); }
-    else          { if (a.fuse) KIWI_C((accumulate_cell_kernel<NG, 256, 2, 0, true>)); else KIWI_C((accumulate_cell_kernel<NG, 256, 2, 0, false>)); }
+    if (per_wave) { if (a.fuse) KIWI_C((accumulate_cellw_kernel<NG, true, COMPACT>)); else KIWI_C((accumulate_cellw_kernel<NG, false, COMPACT>)); }
+    else          { if (a.fuse) KIWI_C((accumulate_cell_kernel<NG, 256, 2, 0, true, COMPACT>)); else KIWI_C((accumulate_cell_kernel<NG, 256, 2, 0, false, COMPACT>)); }
 #undef KIWI_C
 }
-void launch_cell(const AccumArgs &a, dim3 grid, int ntiles) { if (a.ng == 10) cell_t<10>(a, grid, ntiles, false); else cell_t<8>(a, grid, ntiles, false); }
-void launch_cellw(const AccumArgs &a, dim3 grid, int ntiles) { if (a.ng == 10) cell_t<10>(a, grid, ntiles, true); else cell_t<8>(a, grid, ntiles, true); }
+template <int NG>
+static void cell_c(const AccumArgs &a, dim3 grid, int ntiles, bool per_wave)
+{
+    if (a.compact) cell_t<NG, true>(a, grid, ntiles, per_wave); else cell_t<NG, false>(a, grid, ntiles, per_wave);
+}
+void launch_cell(const AccumArgs &a, dim3 grid, int ntiles) { if (a.ng == 10) cell_c<10>(a, grid, ntiles, false); else cell_c<8>(a, grid, ntiles, false); }
+void launch_cellw(const AccumArgs &a, dim3 grid, int ntiles) { if (a.ng == 10) cell_c<10>(a, grid, ntiles, true); else cell_c<8>(a, grid, ntiles, true); }
 int cellw_range() { return kCellwRange; }
 #endif
 

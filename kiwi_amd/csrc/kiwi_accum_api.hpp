@@ -16,6 +16,7 @@ struct AccumArgs {
     const RecvDev *recv; float *syn; size_t syn_stride;
     const int *tab; const float *coefs; FuseParams fp;
     const int *pairflag, *synrow, *fam_ofs, *fam_list;
+    int compact;                         // `tab` holds geometry_kernel's compact descriptors (four ints per record), not 128-int rows
 };
 
 #define KIWI_ACCUM_LAUNCHERS                                                                                                      \

@@ -168,7 +168,8 @@ __global__ __launch_bounds__(256) void geometry_kernel(
     const int *__restrict__ synrow /* optional [source]: source whose synthetics this one shares; != own index: nothing to do */,
     int *__restrict__ lmax_out /* optional [source][receiver], preset to -1: index of the LAST centroid that reaches the rotated add of the
                                   rotating branch (see the span reduction below) */,
-    const int *__restrict__ lmax_in /* optional: the same, from a pass in front of this one */)
+    const int *__restrict__ lmax_in /* optional: the same, from a pass in front of this one */,
+    int4 *__restrict__ off4 /* optional [record]: compact load descriptors INSTEAD of the 512-byte rows of `tab` (see off4 below) */)
 {
     const int s = blockIdx.y;
     if (synrow && synrow[s] != s) return;
@@ -399,12 +400,26 @@ __global__ __launch_bounds__(256) void geometry_kernel(
     const size_t base = (size_t)(c0 - cent_ofs[ep.isrc0]) * ep.nrec + (size_t)r * nc + c;
     out[base] = g;
     if (tab && g.row[0] >= 0) {
+        // Compact descriptors (databases whose components of a node all start at the same sample and whose rows all end in an
+        // exact zero -- what a database reader delivers for traces that die out inside the time range; the host checks it once,
+        // kiwi_hip_set_gfdb): everything a kernel takes from a 512-byte descriptor row then follows from the record's four node
+        // rows and FOUR numbers, the position of trace sample 0 inside the rows of each node -- 16 bytes per record, written by
+        // every thread (coalesced) instead of 432 bytes by the fifth of the lanes that sit at a group start (those rows were
+        // 2.1 GB per 4096 cfg3 sources and 1.8 of this kernel's 4.1 ms).  The kernels rebuild the lane-distributed row from
+        // them (desc_expand, kiwi_accum.inc).
+        if (off4) {
+            const int nn = (g.flags & 1) ? 1 : 4;
+            int o[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) o[k] = kRowPad - span[g.row[k < nn ? k : 0]].x;
+            off4[base] = make_int4(o[0], o[1], o[2], o[3]);
+        }
         // cell mode: only the coefficient line here, cellgroup_kernel completes the rows of the group starts it finds
-        const bool full = !ep.cellmode && (!(g.flags & 4) || starts_group(cent, c0, nc, c, gm.dt));
+        const bool full = !off4 && !ep.cellmode && (!(g.flags & 4) || starts_group(cent, c0, nc, c, gm.dt));
         bool ez;
         if (gm.ng == 10) ez = write_tab<10>(tab + base * 128, coefs + base * kCoefLine, g, span, gm.pitch, rv.sd, full, endz);
         else ez = write_tab<8>(tab + base * 128, coefs + base * kCoefLine, g, span, gm.pitch, rv.sd, full, endz);
-        if (pairflag && !ez) atomicOr(&pairflag[(size_t)s * ep.nrec + r], 4);
+        if (pairflag && !ez && !off4) atomicOr(&pairflag[(size_t)s * ep.nrec + r], 4);
     }
 }
 
@@ -425,7 +440,8 @@ __global__ __launch_bounds__(256) void cellgroup_kernel(const int *__restrict__ 
                                                         const int2 *__restrict__ span, const RecvDev *__restrict__ recv,
                                                         GeoRec *__restrict__ recs, int *__restrict__ tab, float *__restrict__ coefs,
                                                         const int *__restrict__ pairflag, const unsigned char *__restrict__ endz,
-                                                        const int *__restrict__ synrow, int cell_range /* largest shift range of a cell group */)
+                                                        const int *__restrict__ synrow, int cell_range /* largest shift range of a cell group */,
+                                                        int compact /* descriptors come from off4 (geometry_kernel): no rows to complete */)
 {
     const int s = blockIdx.y;
     if (synrow && synrow[s] != s) return;
@@ -461,6 +477,7 @@ __global__ __launch_bounds__(256) void cellgroup_kernel(const int *__restrict__ 
         }
     }
     rr[c].pad = len | ((smax - me.ishift) << 8) | ((me.ishift - smin) << 16);
+    if (compact) return;
     if (gm.ng == 10) write_tab<10>(tab + (base0 + c) * 128, coefs + (base0 + c) * kCoefLine, me, span, gm.pitch, recv[r].sd, true, endz);
     else write_tab<8>(tab + (base0 + c) * 128, coefs + (base0 + c) * kCoefLine, me, span, gm.pitch, recv[r].sd, true, endz);
 }

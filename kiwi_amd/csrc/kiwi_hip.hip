@@ -171,6 +171,7 @@ struct kiwi_hip_ctx {
     DevBuf<float> misfit_d, global_d;
     DevBuf<GeoRec> recs_d;
     DevBuf<int> tab_d;                // grouped kernel load descriptors, 128 ints per GeoRec (written at group starts only)
+    DevBuf<int> off4_d;               // ... or their compact form, 4 ints per GeoRec (db_simple databases; geometry_kernel's off4)
     DevBuf<float> coef_d;             // interpolation coefficients, kCoefLine floats per GeoRec, consecutive (kiwi_common.hpp coef_wl)
     DevBuf<int> pairflag_d;           // cell mode: per (source of the chunk, receiver) "some centroid misses a trace"
     DevBuf<float> syn_d, proc_d;
@@ -209,6 +210,9 @@ struct kiwi_hip_ctx {
     DevBuf<float> fft_d, refamp_d, filtw_d, reffilt_d, zmask_d, normsrc_d;
     DevBuf<int> lmax_d;                                          // [chunk source][receiver]: last centroid that reaches the rotated add (geometry_kernel, databases with gaps)
     bool db_gaps = false;                                        // some trace of the database is not stored
+    bool db_simple = false;           // every node's components start at the same sample and every row ends in an exact zero: the load
+                                      // descriptors of a group follow from four numbers (compact descriptors, geometry_kernel's off4)
+    int compact = 1;                  // use them where the database allows it; env KIWI_HIP_COMPACT=0: the 512-byte rows throughout
     DevBuf<int> synspan_d;                                       // data spans of the synthetic probes of the chunk's un-tapered slots (synspan_kernel)
     DevBuf<float> refpair_d, reffiltpair_d;                      // un-tapered slots: reference spectrum / filtered reference per PAIR (SpecParams)
     bool untapered_fft = false;                                  // some un-tapered slot goes through the transforms
@@ -315,11 +319,11 @@ void natural_spans(kiwi_hip_ctx *c, std::vector<int> &sb)
             lmax = c->lmax_d.p;
             hipLaunchKernelGGL(geometry_kernel, grid, dim3(256), 0, c->stream, c->cent_d.p, c->centofs_d.p, ep, c->gm,
                                c->span.p, c->recv_d.p, (GeoRec *)nullptr, (int *)nullptr, (float *)nullptr, (int *)nullptr, (int *)nullptr, (int *)nullptr, c->endz.p, (const int *)nullptr,
-                               lmax, (const int *)nullptr);
+                               lmax, (const int *)nullptr, (int4 *)nullptr);
         }
         hipLaunchKernelGGL(geometry_kernel, grid, dim3(256), 0, c->stream, c->cent_d.p, c->centofs_d.p, ep, c->gm,
                            c->span.p, c->recv_d.p, (GeoRec *)nullptr, (int *)nullptr, (float *)nullptr, c->spanbuf_d.p, (int *)nullptr, (int *)nullptr, c->endz.p, (const int *)nullptr,
-                           (int *)nullptr, (const int *)lmax);
+                           (int *)nullptr, (const int *)lmax, (int4 *)nullptr);
     }
     HIPCHECK(hipMemcpyAsync(sb.data(), c->spanbuf_d.p, sb.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));
@@ -949,8 +953,13 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
     for (int s = isrc0; s < isrc0 + nsrc; s++) maxnc = std::max(maxnc, c->cent_ofs[s + 1] - c->cent_ofs[s]);
     c->recs_d.ensure((size_t)(cend - cbeg) * nrec, &c->dev_bytes);
     int *tab = nullptr;
+    int *off4 = nullptr;              // compact descriptors: the rows of `tab` are then address space only, nothing writes or reads them
     if (c->accum_mode == 0) {
         c->tab_d.ensure((size_t)(cend - cbeg) * nrec * 128, &c->dev_bytes); tab = c->tab_d.p;
+        if (c->db_simple && c->compact) {
+            c->off4_d.ensure((size_t)(cend - cbeg) * nrec * 4, &c->dev_bytes); off4 = c->off4_d.p;
+            if (std::getenv("KIWI_HIP_POISON")) HIPCHECK(hipMemsetAsync(off4, 0x7f, (size_t)(cend - cbeg) * nrec * 4 * sizeof(int), c->stream));
+        }
         // KIWI_HIP_POISON=1 (tests): rows keep nothing from earlier evaluations -- a descriptor line the kernel reads but
         // geometry_kernel did not write shows as a wild address instead of passing by accident
         if (std::getenv("KIWI_HIP_POISON")) HIPCHECK(hipMemsetAsync(tab, 0x7f, (size_t)(cend - cbeg) * nrec * 128 * sizeof(int), c->stream));
@@ -1032,15 +1041,15 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
             lmax = c->lmax_d.p;
             hipLaunchKernelGGL(geometry_kernel, grid, dim3(256), 0, c->stream, c->cent_d.p, c->centofs_d.p, ep, c->gm,
                                c->span.p, c->recv_d.p, (GeoRec *)nullptr, (int *)nullptr, (float *)nullptr, (int *)nullptr, (int *)nullptr, (int *)nullptr, c->endz.p, (const int *)nullptr,
-                               lmax, (const int *)nullptr);
+                               lmax, (const int *)nullptr, (int4 *)nullptr);
         }
         hipLaunchKernelGGL(geometry_kernel, grid, dim3(256), 0, c->stream, c->cent_d.p, c->centofs_d.p, ep, c->gm,
                            c->span.p, c->recv_d.p, c->recs_d.p, tab, c->coef_d.p, (int *)nullptr, spansrc, (cell || duo_maybe) ? c->pairflag_d.p : (int *)nullptr, c->endz.p, (const int *)nullptr,
-                           (int *)nullptr, (const int *)lmax);
+                           (int *)nullptr, (const int *)lmax, (int4 *)off4);
         if (cell)
             hipLaunchKernelGGL(cellgroup_kernel, grid, dim3(256), 0, c->stream, c->centofs_d.p, ep, c->gm, c->span.p, c->recv_d.p,
                                c->recs_d.p, tab, c->coef_d.p, c->pairflag_d.p, c->endz.p, (const int *)nullptr,
-                               c->cell_wave ? exact::cellw_range() : kHalo - 10);
+                               c->cell_wave ? exact::cellw_range() : kHalo - 10, off4 ? 1 : 0);
     }
     if (c->fft_needed && !c->untapered_fft) {
         // transform length of every (source, slot) pair from the source's own strip spans; the lengths travel to the host
@@ -1062,8 +1071,8 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
         // the kernels of the arithmetic contract in force (kiwi_accum.inc compiled twice: kiwi::exact, kiwi::fused)
         const bool fusedar = c->arith == KIWI_ARITH_FUSED;
         AccumArgs aa{ c->stream, c->gm.ng, c->fuse_now, c->G.p, c->span.p, c->gm.pitch, c->recs_d.p, c->centofs_d.p, isrc0, nrec, c->recv_d.p,
-                      c->syn_d.p, c->syn_stride, c->tab_d.p, c->coef_d.p, FuseParams{ nullptr, nullptr, nullptr, nullptr, 0, 1.f, 0, 0, 0 },
-                      nullptr, synrow, famofs, famlist };
+                      c->syn_d.p, c->syn_stride, off4 ? off4 : c->tab_d.p, c->coef_d.p, FuseParams{ nullptr, nullptr, nullptr, nullptr, 0, 1.f, 0, 0, 0 },
+                      nullptr, synrow, famofs, famlist, off4 ? 1 : 0 };
         if (c->accum_mode == 1) {            // KIWI_HIP_ACCUM=direct: A/B reference kernel, no LDS staging
             if (fusedar) fused::launch_direct(aa, grid); else exact::launch_direct(aa, grid);
         } else {
@@ -1402,6 +1411,7 @@ int kiwi_hip_init(int device, kiwi_hip_ctx **out)
             else if (std::strcmp(m, "exact") != 0) throw std::runtime_error("KIWI_HIP_ARITH: exact or fused");
         }
         if (const char *m = std::getenv("KIWI_HIP_CELL_WAVE")) c->cell_wave = std::atoi(m) ? 1 : 0;
+        if (const char *m = std::getenv("KIWI_HIP_COMPACT")) c->compact = std::atoi(m) ? 1 : 0;
         if (const char *m = std::getenv("KIWI_HIP_CHUNK_MB")) {      // workspace bound per launch (default 16 GiB); tests use it
             const long v = std::atol(m);
             if (v > 0) c->chunk_bytes_limit = (size_t)v << 20;
@@ -1541,6 +1551,13 @@ int kiwi_hip_set_gfdb(kiwi_hip_ctx *c, int nx, int nz, int ng, int L, float dt, 
     HIPCHECK(hipMemcpy(c->endz.p, ez.data(), nrows, hipMemcpyHostToDevice));
     c->gm = GfMeta{ nx, nz, ng, pitch, dt, dx, dz, firstx, firstz };
     c->db_gaps = gaps;
+    {
+        bool simple = !gaps;
+        for (size_t node = 0; simple && node < (size_t)nx * nz; node++)
+            for (int ig = 0; ig < ng; ig++)
+                if (sp[node * ng + ig].x != sp[node * ng].x || !ez[node * ng + ig]) { simple = false; break; }
+        c->db_simple = simple;
+    }
     c->have_db = true;
     c->prepared = false;            // dirtyfy_database, minimizer_engine.f90:1483
     return forward(c, [&](kiwi_hip_ctx *m) { return kiwi_hip_set_gfdb(m, nx, nz, ng, L, dt, dx, dz, firstx, firstz, G, first, nsamp); });

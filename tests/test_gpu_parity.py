@@ -1707,3 +1707,39 @@ def test_spectral_results_of_folded_sources_do_not_depend_on_the_batch(method, w
         ok, ratio = spectral_close(method, sc.gf["dt"], bm[i], om, on, slot_scales(ef, sc.comps, sc.gf["dt"]), bn[i])
         assert ok, (i, ratio, np.max(np.abs(bm[i] - om) / on), np.max(np.abs(bn[i] - on) / on))
         ef.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bilinear", [True, False])
+@pytest.mark.parametrize("mode", ["quad", "single", "cellw", "cell"])
+def test_compact_descriptors_equal_descriptor_rows(monkeypatch, bilinear, mode):
+    """Databases whose components of a node all start at the same sample and whose rows all end in zero (what trace_pack leaves of
+    traces that die out inside the time range): geometry_kernel hands the accumulate kernels FOUR numbers per record instead of a
+    512-byte descriptor row per group start, the kernels rebuild the row (desc_expand).  Same synthetics bit for bit as with the
+    rows (KIWI_HIP_COMPACT=0), for every kernel family, nearest-neighbour and bilinear interpolation; the row table is poisoned, so a
+    kernel that still read it would load from wild addresses."""
+    monkeypatch.setenv("KIWI_HIP_POISON", "1")
+    monkeypatch.setenv("KIWI_HIP_DUO", "4" if mode == "quad" else "0")
+    monkeypatch.setenv("KIWI_HIP_CELL", "1" if mode.startswith("cell") else "0")
+    monkeypatch.setenv("KIWI_HIP_CELL_WAVE", "1" if mode == "cellw" else "0")
+    sc = Scenario(nrec=5, L=700, bilinear=bilinear, comps_list=["ned", "ned", "ar", "ned", "ned"], variant="probe")
+    sc.oracle()                                                 # (packs the database the product is handed)
+    first, nsamp, data = sc.odb.dense_tables()
+    assert np.all(first == first[:, :, :1]) and np.all(nsamp > 0)          # one start per node, nothing missing
+    fine = synthetic.bilat_strike_sweep(8, step=0.05)
+    far = synthetic.bilat_strike_sweep(4, step=7.0)
+    far[:, 1] += 2500.0 * np.arange(4)
+    trials = np.vstack([fine, far, fine[:3]]).astype(np.float32)
+    res = {}
+    for compact in ("1", "0"):
+        monkeypatch.setenv("KIWI_HIP_COMPACT", compact)
+        p = sc.product()
+        p.set_source_params("bilateral", trials)
+        p.set_keep_synthetics(1)
+        p.eval()
+        res[compact] = [p.get_synthetics(s, ir, k, 1)[1] for s in range(len(trials)) for ir in range(1, 6)
+                        for k in range(1, len(sc.comps[ir - 1]) + 1)]
+        p.close()
+    assert len(res["1"]) == len(res["0"]) > 150 and sum(1 for a in res["1"] if np.any(a != 0)) > 100
+    for a, b in zip(res["1"], res["0"]):
+        assert same_bits(a, b)
