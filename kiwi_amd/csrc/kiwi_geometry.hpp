@@ -58,6 +58,53 @@ __device__ __forceinline__ bool starts_group(const float *__restrict__ cent, int
     return pos == c;
 }
 
+// A centroid's interpolation-coefficient line (kCoefLine floats, see kiwi_common.hpp): wl = (1 - w) factor, wr = w factor per GF
+// component in application order, each rounded on its own (sparse_trace.f90:643-647 with the factors of seismogram.f90:171-250)
+template <int NG>
+__device__ __forceinline__ void coef_line(const GeoRec &g, float sd, float (&cf)[20])
+{
+    {
+        const float wr0 = g.wfrac, wl0 = 1.f - g.wfrac;
+        const float fd[4] = { g.f[0] * sd, g.f[1] * sd, g.f[2] * sd, g.f[5] * sd };
+        int i = 0;
+        if (NG == 10) {
+            const float fh[6] = { g.f[0], g.f[1], g.f[2], g.f[5], g.f[3], g.f[4] };
+#pragma unroll
+            for (int q = 0; q < 6; q++, i++) { cf[coef_wl<10>(i)] = wl0 * fh[q]; cf[coef_wr<10>(i)] = wr0 * fh[q]; }
+#pragma unroll
+            for (int q = 0; q < 4; q++, i++) { cf[coef_wl<10>(i)] = wl0 * fd[q]; cf[coef_wr<10>(i)] = wr0 * fd[q]; }
+        } else {
+            const float fh8[5] = { g.f[0], g.f[1], g.f[2], g.f[3], g.f[4] };
+#pragma unroll
+            for (int q = 0; q < 5; q++, i++) { cf[coef_wl<8>(i)] = wl0 * fh8[q]; cf[coef_wr<8>(i)] = wr0 * fh8[q]; }
+#pragma unroll
+            for (int q = 0; q < 3; q++, i++) { cf[coef_wl<8>(i)] = wl0 * fd[q]; cf[coef_wr<8>(i)] = wr0 * fd[q]; }
+#pragma unroll
+            for (; i < 10; i++) { cf[2 * i] = 0.f; cf[2 * i + 1] = 0.f; }
+        }
+    }
+}
+
+// 64 records of 80 bytes (one per lane, consecutive in memory from dst0) through the wave's LDS stage: a lane's 80 bytes as five
+// 16-byte pieces would leave the wave as five stores of 64 scattered pieces each (every piece a partial line for the L2); staged,
+// every store instruction writes 1024 consecutive bytes.  `nlive`: the live lanes are 0 .. nlive - 1.
+__device__ __forceinline__ void store_records_80(int4 *__restrict__ dst0, int4 *__restrict__ stage /* 320 int4 of this wave */, const int4 (&rec)[5],
+                                                 int lane, int nlive)
+{
+#pragma unroll
+    for (int q = 0; q < 5; q++) stage[lane * 5 + q] = rec[q];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+        const int i = q * 64 + lane;
+        if (i < nlive * 5) dst0[i] = stage[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();             // (the stage is reused)
+}
+
 // Load descriptors for accumulate_grouped_kernel, 128 ints per record, laid out so that one coalesced load per wave
 // brings them in lane-distributed: for component ig and node k
 //   tab[4*ig + k]      = (row - row0)*pitch + kRowPad - first   (float index of trace sample 0 relative to the group base
@@ -121,26 +168,7 @@ __device__ __forceinline__ bool write_tab(int *__restrict__ tb, float *__restric
     all_endzero = endzero;
     }
     float cf[20];
-    {
-        const float wr0 = g.wfrac, wl0 = 1.f - g.wfrac;
-        const float fd[4] = { g.f[0] * sd, g.f[1] * sd, g.f[2] * sd, g.f[5] * sd };
-        int i = 0;
-        if (NG == 10) {
-            const float fh[6] = { g.f[0], g.f[1], g.f[2], g.f[5], g.f[3], g.f[4] };
-#pragma unroll
-            for (int q = 0; q < 6; q++, i++) { cf[coef_wl<10>(i)] = wl0 * fh[q]; cf[coef_wr<10>(i)] = wr0 * fh[q]; }
-#pragma unroll
-            for (int q = 0; q < 4; q++, i++) { cf[coef_wl<10>(i)] = wl0 * fd[q]; cf[coef_wr<10>(i)] = wr0 * fd[q]; }
-        } else {
-            const float fh8[5] = { g.f[0], g.f[1], g.f[2], g.f[3], g.f[4] };
-#pragma unroll
-            for (int q = 0; q < 5; q++, i++) { cf[coef_wl<8>(i)] = wl0 * fh8[q]; cf[coef_wr<8>(i)] = wr0 * fh8[q]; }
-#pragma unroll
-            for (int q = 0; q < 3; q++, i++) { cf[coef_wl<8>(i)] = wl0 * fd[q]; cf[coef_wr<8>(i)] = wr0 * fd[q]; }
-#pragma unroll
-            for (; i < 10; i++) { cf[2 * i] = 0.f; cf[2 * i + 1] = 0.f; }
-        }
-    }
+    coef_line<NG>(g, sd, cf);
     int4 *t4 = reinterpret_cast<int4 *>(tb);
     if (full) {
 #pragma unroll
@@ -179,7 +207,7 @@ __global__ __launch_bounds__(256) void geometry_kernel(
     // lanes past the end of the source's records stay in the wave -- the span reduction below is a wave operation --
     // as copies of its last record that neither store nor count
     const bool live = idx < nc * ep.nrec;
-    if (!live) { if (!spanbuf && !spansrc) return; idx = nc * ep.nrec - 1; }
+    if (!live) { if (!spanbuf && !spansrc && !off4) return; idx = nc * ep.nrec - 1; }      // (off4: the staged stores below want whole waves)
     int rot_gap = -1, rot_rows[4] = { -1, -1, -1, -1 };   // rotating branch left at a missing horizontal trace: how many of its components went into the temporaries, and the rows
     const int r = idx / nc, c = idx - r * nc;
     const RecvDev &rv = recv[r];
@@ -395,31 +423,55 @@ __global__ __launch_bounds__(256) void geometry_kernel(
             }
         }
     }
-    if (!live) return;
     if (!out) return;
+    if (!live && !off4) return;
     const size_t base = (size_t)(c0 - cent_ofs[ep.isrc0]) * ep.nrec + (size_t)r * nc + c;
+    if (off4) {
+        // Compact path: records and coefficient lines leave the wave as whole kilobytes (store_records_80).  The lanes still here
+        // are the live ones, a prefix of the wave, and their records are consecutive in memory (idx = r nc + c).
+        __shared__ int4 stage_all[4 * 320];
+        const int lane = threadIdx.x & 63;
+        int4 *stage = stage_all + (threadIdx.x >> 6) * 320;
+        const int nlive = __popcll(__builtin_amdgcn_ballot_w64(live));     // (the other lanes hold copies of the last record: staged, not stored)
+        const unsigned b_lo = __builtin_amdgcn_readfirstlane((unsigned)base), b_hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+        const size_t base0 = ((size_t)b_hi << 32) | b_lo;
+        int4 rec[5];
+        __builtin_memcpy(rec, &g, 80);
+        store_records_80(reinterpret_cast<int4 *>(out + base0), stage, rec, lane, nlive);
+        if (tab) {
+            float cf[20];
+#pragma unroll
+            for (int i = 0; i < 20; i++) cf[i] = 0.f;
+            int4 o = make_int4(0, 0, 0, 0);
+            if (g.row[0] >= 0) {
+                // Compact descriptors (databases whose components of a node all start at the same sample and whose rows all end in an
+                // exact zero -- what a database reader delivers for traces that die out inside the time range; the host checks it once,
+                // kiwi_hip_set_gfdb): everything a kernel takes from a 512-byte descriptor row then follows from the record's four node
+                // rows and FOUR numbers, the position of trace sample 0 inside the rows of each node -- 16 bytes per record, written by
+                // every thread (coalesced) instead of 432 bytes by the fifth of the lanes that sit at a group start (those rows were
+                // 2.1 GB per 4096 cfg3 sources and 1.8 of this kernel's 4.1 ms).  The kernels rebuild the lane-distributed row from
+                // them (desc_expand, kiwi_accum.inc).
+                const int nn = (g.flags & 1) ? 1 : 4;
+                int ok[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) ok[k] = kRowPad - span[g.row[k < nn ? k : 0]].x;
+                o = make_int4(ok[0], ok[1], ok[2], ok[3]);
+                if (gm.ng == 10) coef_line<10>(g, rv.sd, cf); else coef_line<8>(g, rv.sd, cf);
+            }
+            if (live) off4[base] = o;
+            __builtin_memcpy(rec, cf, 80);
+            store_records_80(reinterpret_cast<int4 *>(coefs + base0 * kCoefLine), stage, rec, lane, nlive);
+        }
+        return;
+    }
     out[base] = g;
     if (tab && g.row[0] >= 0) {
-        // Compact descriptors (databases whose components of a node all start at the same sample and whose rows all end in an
-        // exact zero -- what a database reader delivers for traces that die out inside the time range; the host checks it once,
-        // kiwi_hip_set_gfdb): everything a kernel takes from a 512-byte descriptor row then follows from the record's four node
-        // rows and FOUR numbers, the position of trace sample 0 inside the rows of each node -- 16 bytes per record, written by
-        // every thread (coalesced) instead of 432 bytes by the fifth of the lanes that sit at a group start (those rows were
-        // 2.1 GB per 4096 cfg3 sources and 1.8 of this kernel's 4.1 ms).  The kernels rebuild the lane-distributed row from
-        // them (desc_expand, kiwi_accum.inc).
-        if (off4) {
-            const int nn = (g.flags & 1) ? 1 : 4;
-            int o[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) o[k] = kRowPad - span[g.row[k < nn ? k : 0]].x;
-            off4[base] = make_int4(o[0], o[1], o[2], o[3]);
-        }
         // cell mode: only the coefficient line here, cellgroup_kernel completes the rows of the group starts it finds
-        const bool full = !off4 && !ep.cellmode && (!(g.flags & 4) || starts_group(cent, c0, nc, c, gm.dt));
+        const bool full = !ep.cellmode && (!(g.flags & 4) || starts_group(cent, c0, nc, c, gm.dt));
         bool ez;
         if (gm.ng == 10) ez = write_tab<10>(tab + base * 128, coefs + base * kCoefLine, g, span, gm.pitch, rv.sd, full, endz);
         else ez = write_tab<8>(tab + base * 128, coefs + base * kCoefLine, g, span, gm.pitch, rv.sd, full, endz);
-        if (pairflag && !ez && !off4) atomicOr(&pairflag[(size_t)s * ep.nrec + r], 4);
+        if (pairflag && !ez) atomicOr(&pairflag[(size_t)s * ep.nrec + r], 4);
     }
 }
 
