@@ -290,16 +290,48 @@ def launch_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+KERNEL_SOURCES = ("kiwi_common.hpp", "kiwi_geometry.hpp", "kiwi_accum.inc", "kiwi_accum.hip", "kiwi_apply_asm.inc", "kiwi_accum_api.hpp",
+                  "kiwi_misfit.hpp", "kiwi_hip.hip", "kiwi_libm32.hpp", "Makefile")
+
+
+def _code_only(text, makefile=False):
+    """A source text without its comments and blank space: what the compiler is given.  (A comment edit must not orphan the
+    committed counters, and nobody should have to re-stamp a summary by hand after one.)  String literals are left alone."""
+    import re
+    if makefile:
+        return "\n".join(l.rstrip() for l in text.split("\n") if l.strip() and not l.lstrip().startswith("#"))
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c == '"':                                   # string literal: copy through its closing quote
+            j = i + 1
+            while j < n and text[j] != '"':
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        else:
+            out.append(c)
+            i += 1
+    return "\n".join(" ".join(l.split()) for l in "".join(out).split("\n") if l.strip())
+
+
 def kernel_sources_sha256():
-    """Hash of the sources the device code is built from: committed counters are attached to a bench line only when
-    they were collected on exactly these."""
+    """Hash of the CODE the device side is built from (comments and blank space stripped): committed counters are attached to a
+    bench line only when they were collected on exactly this code.  profiles/summarize.py computes the same figure at collection
+    time, next to the hashes of the raw rocprofv3 files the summary was condensed from."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("kiwi_amd/csrc/kiwi_common.hpp", "kiwi_amd/csrc/kiwi_geometry.hpp", "kiwi_amd/csrc/kiwi_accum.inc", "kiwi_amd/csrc/kiwi_accum.hip",
-              "kiwi_amd/csrc/kiwi_apply_asm.inc", "kiwi_amd/csrc/kiwi_accum_api.hpp", "kiwi_amd/csrc/kiwi_misfit.hpp", "kiwi_amd/csrc/kiwi_hip.hip", "kiwi_amd/csrc/kiwi_libm32.hpp",
-              "kiwi_amd/csrc/Makefile"):
-        with open(os.path.join(ROOT, f), "rb") as fh:
-            h.update(fh.read())
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "kiwi_amd", "csrc", f), "r", errors="replace") as fh:
+            h.update(_code_only(fh.read(), makefile=(f == "Makefile")).encode())
+            h.update(b"\0")
     return h.hexdigest()
 
 

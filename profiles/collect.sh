@@ -1,11 +1,12 @@
-# Profile collection (run on the GPU box through gpurun):   TAG=r04 bash profiles/collect.sh
+# Profile collection (run on the GPU box through gpurun):   TAG=r05 bash profiles/collect.sh
 #   WORKLOADS="cfg3 cfg4"  (default: every bench workload)     ARITHS="exact fused"  (default: both arithmetic contracts)
 # Per (workload, contract): one kernel-trace pass (durations, --stats) and the PMC passes bench.py's `roofline` block quotes --
 # memory-side traffic of the L2s (FETCH_SIZE, WRITE_SIZE: separate passes, MI355X_MICROARCH.md "rocprofv3 PMC slots"), L2
 # requests, and the issue-slot counters of the accumulate kernels.  Counters only with --pmc (no trace domains in the same run).
-# Summarise afterwards in the repo (needs git for the commit id):   python profiles/summarize.py r04 gpurun_out/r04
+# Summarise afterwards in the repo (needs git for the commit id):   python profiles/summarize.py r05 gpurun_out/r05
+# (the summary's kernel_sources_sha256 is computed THERE from the comment-stripped sources, and it records the hashes of the raw files)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-TAG=${TAG:-r04}
+TAG=${TAG:-r05}
 O=gpurun_out/$TAG
 mkdir -p $O
 for w in ${WORKLOADS:-cfg3 cfg3-100pt cfg3-scatter cfg3-w256 cfg3-w600 cfg2 cfg4 cfg5 cfg5-td cfg3-bigdb cfg3-bigdb4 cfg3-bigdb4-ordered}; do
@@ -26,3 +27,14 @@ for w in ${WORKLOADS:-cfg3 cfg3-100pt cfg3-scatter cfg3-w256 cfg3-w600 cfg2 cfg4
   find $O/kt_$k -name '*_kernel_trace.csv' -size +8M -delete
  done
 done
+# the pure-read ceiling of THIS box, next to the HBM-regime workload (profiles/microbench/hbm_read.hip): wall clock, then the counters
+# on a known number of bytes
+if [ -z "$NO_MICROBENCH" ]; then
+ (cd profiles/microbench && hipcc --offload-arch=gfx950 -O3 -o hbm_read hbm_read.hip)
+ ./profiles/microbench/hbm_read 4 20 > $O/hbm_read_4g.json 2> $O/hbm_read.err
+ ./profiles/microbench/hbm_read 8 10 > $O/hbm_read_8g.json 2>> $O/hbm_read.err
+ for c in "FETCH_SIZE" "TCC_MISS_sum TCC_HIT_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"; do
+  d=$O/hbmread_pmc_$(echo $c | tr ' ' '_')
+  rocprofv3 --pmc $c -d $d -o run --output-format csv -- ./profiles/microbench/hbm_read 4 3 > /dev/null 2> $d.log
+ done
+fi

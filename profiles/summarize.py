@@ -7,8 +7,11 @@ only when its own build comes from the same sources (`roofline.profile_head`).
 
 Per workload the summary holds what bench.py's `roofline` block quotes (keys under "workloads"):
   ("per launch" = per bench step: a step over a large batch is several dispatches, launches_per_step)
-  hbm_bytes_per_launch        FETCH_SIZE x 2 (gfx950: wide coalesced reads are tallied at half their bytes,
-                              MI355X_MICROARCH.md "HBM") + WRITE_SIZE, summed over the accumulate kernels of one step.
+  hbm_bytes_per_launch        FETCH_SIZE x 2 + WRITE_SIZE, summed over the accumulate kernels of one step.  The x 2: gfx950 tallies
+                              coalesced reads at half their bytes (MI355X_MICROARCH.md "HBM") -- checked on this pool with a pure
+                              read of KNOWN size (profiles/microbench/hbm_read.hip, 4 294 963 200 bytes per pass: FETCH_SIZE
+                              2 097 000 KiB for 16-byte AND for 4-byte loads per lane, TCC_MISS_sum x 128 B and TCC_EA0_RDREQ_sum x
+                              128 B = the bytes read; profiles/README.md round 5).
                               These are the L2's memory-side requests: Infinity-Cache hits are included, so this is an
                               upper bound of what reached HBM.
   l2_request_bytes_per_launch (TCC_HIT_sum + TCC_MISS_sum) x 128 B
@@ -31,8 +34,29 @@ import subprocess  # noqa: E402
 import bench  # noqa: E402
 head = subprocess.run(["git", "-C", os.path.dirname(here), "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
 dirty = bool(subprocess.run(["git", "-C", os.path.dirname(here), "status", "--porcelain", "kiwi_amd/csrc"], capture_output=True, text=True).stdout.strip())
+import hashlib  # noqa: E402
+
+
+def raw_hashes(workload_key):
+    """SHA-256 of every raw rocprofv3 file (and bench line) a workload's entry was condensed from: the summary cannot be edited
+    without these ceasing to match gpurun_out/<tag>/ -- and nothing in it needs editing by hand: the source hash below is computed
+    here, at collection time, from the code alone (bench.kernel_sources_sha256 strips comments)."""
+    hs = {}
+    for d in ("kt", "fetch", "write", "l2", "sq", "sq2"):
+        for f in sorted(glob.glob(os.path.join(src, d + "_" + workload_key, "**", "*.csv"), recursive=True)):
+            if f.endswith("_kernel_trace.csv"):
+                continue
+            hs[os.path.relpath(f, src)] = hashlib.sha256(open(f, "rb").read()).hexdigest()[:16]
+    b = os.path.join(src, "bench_%s.json" % workload_key)
+    if os.path.exists(b):
+        hs[os.path.relpath(b, src)] = hashlib.sha256(open(b, "rb").read()).hexdigest()[:16]
+    return hs
+
+
 out = {"tag": tag, "command": "rocprofv3 <pass> -- python3 bench.py --workload <w> --steps 5 --warmup 2 --no-cpu-baseline --no-also",
        "head": (head + ("+uncommitted kernel changes" if dirty else "")) if head else None, "kernel_sources_sha256": bench.kernel_sources_sha256(),
+       "kernel_sources_sha256_is": "SHA-256 over the comment-stripped text of " + ", ".join(bench.KERNEL_SOURCES) + " (bench.kernel_sources_sha256), "
+                                   "computed by this script when it condensed the raw files",
        "note": "per step = sum over the accumulate kernels of one bench step of the per-dispatch medians; FETCH_SIZE / WRITE_SIZE "
                "are in KiB as rocprofv3 reports them", "workloads": {}}
 # a re-collection of some workloads keeps the entries of the others
@@ -106,6 +130,7 @@ for f in sorted(glob.glob(os.path.join(src, "bench_*.json"))):
             e["scalar_issue_frac"] = total(c_sq2, "SQ_ACTIVE_INST_SCA") * lps / (1024.0 * cyc)
         e["lds_bank_conflict_cycles"] = total(c_sq2, "SQ_LDS_BANK_CONFLICT") * lps
     e["counters"] = {"sq": c_sq, "sq2": c_sq2, "l2": c_l2, "fetch": c_f, "write": c_w}
+    e["raw_sha256_16"] = raw_hashes(w)
     # kernel stats of the trace pass
     fs = glob.glob(os.path.join(src, "kt_" + w, "**", "*_kernel_stats.csv"), recursive=True)
     if fs:
@@ -118,6 +143,26 @@ for f in sorted(glob.glob(os.path.join(src, "bench_*.json"))):
             most = max(int(r["Calls"]) for r in acc)
             e["accumulate_ms"] = lps * sum(float(r["AverageNs"]) / 1e6 for r in acc if int(r["Calls"]) >= most - 1 and int(r["Calls"]) > 2)
     out["workloads"][w] = e
+for f in sorted(glob.glob(os.path.join(src, "hbm_read_*.json"))):          # pure-read microbench collected with the profiles (collect.sh)
+    try:
+        js = json.loads(open(f).read().strip().splitlines()[-1])
+        out.setdefault("hbm_read_microbench", {})[os.path.basename(f)] = js
+        if f.endswith("hbm_read_4g.json"):
+            json.dump(js, open(os.path.join(here, tag + "_hbm_read.json"), "w"))
+    except (ValueError, IndexError):
+        pass
+# ... and what the counters say for its KNOWN number of bytes (4 GiB buffer, every pass reads all of it once)
+mb = {}
+for d in sorted(glob.glob(os.path.join(src, "hbmread_pmc_*"))):
+    for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+        vals = {}
+        for r in csv.DictReader(open(f)):
+            vals.setdefault((r["Kernel_Name"].split("(")[0][:40], r["Counter_Name"]), []).append(float(r["Counter_Value"]))
+        for (k, c), v in vals.items():
+            v.sort()
+            mb.setdefault(k, {})[c] = v[len(v) // 2]
+if mb:
+    out.setdefault("hbm_read_microbench", {})["counters_per_pass_of_4294963200_bytes"] = mb
 json.dump(out, open(os.path.join(here, tag + "_summary.json"), "w"), indent=1)
 for w, e in out["workloads"].items():
     print(w, {k: (round(v, 4) if isinstance(v, float) else v) for k, v in e.items() if k not in ("counters", "bench_line_under_rocprof", "kernel_stats")})
