@@ -195,9 +195,10 @@ def test_bench_line_through_rccl_with_one_rank():
     assert 0.0 < d["roofline"]["frac"] <= 1.0 and d["roofline"]["bound"] == "valu_issue"
 
 
-def test_bench_dress_rehearsal_four_ranks_on_one_gpu():
+@pytest.mark.parametrize("nranks", [4, 8])
+def test_bench_dress_rehearsal_ranks_on_one_gpu(nranks):
     """What the driver runs unattended the first time a multi-GPU node exists -- `bench.py --gpus N` under torch.distributed.run --
-    rehearsed with FOUR ranks on the one GPU of a test box: every rank's engine on device 0 (KIWI_BENCH_DEVICE), the collective
+    rehearsed with FOUR and with EIGHT ranks (the node size the scaling bench is run at) on the one GPU of a test box: every rank's engine on device 0 (KIWI_BENCH_DEVICE), the collective
     through gloo (RCCL wants a device per rank).  Exercises the launcher's environment, shard_range with N = 4, the split of the
     host cores between the ranks' discretiser teams (KIWI_HIP_DISC_THREADS), the barrier / max-over-ranks timing, the all-gather
     of the global misfits in trial order and the JSON contract; the gathered misfits equal a single rank's evaluation of the
@@ -209,14 +210,15 @@ def test_bench_dress_rehearsal_four_ranks_on_one_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, KIWI_BENCH_BACKEND="gloo", KIWI_BENCH_DEVICE="0", KIWI_BENCH_DUMP_MISFITS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("KIWI_HIP_DISC_THREADS", None)
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr",
-                          "127.0.0.1", "--master-port", "29546", "--max-restarts", "0", os.path.join(root, "bench.py"), "--gpus", "4",
-                          "--steps", "2", "--warmup", "1", "--batch", "24", "--workload", "cfg3"], capture_output=True, text=True,
+    batch = 24 if nranks == 4 else 12
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr",
+                          "127.0.0.1", "--master-port", str(29546 + nranks), "--max-restarts", "0", os.path.join(root, "bench.py"), "--gpus", str(nranks),
+                          "--steps", "2", "--warmup", "1", "--batch", str(batch), "--workload", "cfg3"], capture_output=True, text=True,
                          timeout=900, env=env, cwd=root)
     assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    assert d["n_gpus"] == 4 and d["rccl_world_size"] == 4 and d["steps"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
-    assert d["config"]["trial_sources_per_gpu_per_step"] == 24 and d["value"] > 0
+    assert d["n_gpus"] == nranks and d["rccl_world_size"] == nranks and d["steps"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    assert d["config"]["trial_sources_per_gpu_per_step"] == batch and d["value"] > 0
     assert "gloo" in d["collective"]
     got = np.array(d["gathered_global_misfits"], np.float32)
     assert got.shape == (96,)
