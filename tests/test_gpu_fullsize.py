@@ -470,3 +470,19 @@ def test_multi_device_context_equals_one_device(tmp_path, monkeypatch):
         finally:
             p.close()
     assert outs[0] == outs[1] and len(outs[0]) > 500
+
+
+def test_bench_blocks_host_inclusive_and_sweep():
+    """The blocks round 5 added to bench.py's default line, at test size: `host_inclusive` (the timed trial sources through the one-call
+    evaluation: discretiser + transfers + kernels; bit-identical to the resident evaluation) and `sweep` (a slice of configuration 5's
+    10^5-point grid around the planted source, host-inclusive: the argmin is the planted source)."""
+    wl, p, gf, recv, refs, tapers, ncent = setup("cfg3", 96)
+    p.eval()
+    p.sync()
+    h = bench.host_inclusive(p, wl, 1000.0, reps=1, piece=32)
+    assert h["identical_to_resident"] and h["failed_sources"] == 0 and h["trial_sources_per_step"] == 96 and h["value"] > 0
+    assert h["frac_of_resident"] == pytest.approx(h["value"] / 1000.0)
+    p.close()
+    s = bench.sweep_block(0, 4096, n=700, first=50200)          # the planted source is point 50 555 of the grid
+    assert s["true_source_index"] == 355 and s["argmin_is_true_source"] and s["argmin_misfit"] <= 1e-6 and s["failed_sources"] == 0
+    assert s["trial_sources"] == 700 and s["value"] > 0
