@@ -27,14 +27,20 @@ void launch_direct(const AccumArgs &a, dim3 grid)
 #endif
 
 #if KIWI_FAMILY == 2
-template <int NG, int T>
-static void grouped_t(const AccumArgs &a, dim3 grid, int ntiles, const int *runs, int pairsel, const int *mate, const int *mate4)
+template <int NG, int T, bool COMPACT>
+static void grouped_tc(const AccumArgs &a, dim3 grid, int ntiles, const int *runs, int pairsel, const int *mate, const int *mate4)
 {
-#define KIWI_G(FV, RV) hipLaunchKernelGGL((accumulate_grouped_kernel<NG, T, FV, RV>), grid, dim3(T), 0, a.stream, KIWI_COMMON_ARGS, ntiles, \
-                                          a.tab, a.coefs, runs, a.fp, a.pairflag, pairsel, mate, mate4, a.synrow, a.fam_ofs, a.fam_list, a.compact)
+#define KIWI_G(FV, RV) hipLaunchKernelGGL((accumulate_grouped_kernel<NG, T, FV, RV, COMPACT>), grid, dim3(T), 0, a.stream, KIWI_COMMON_ARGS, ntiles, \
+                                          a.tab, a.coefs, runs, a.fp, a.pairflag, pairsel, mate, mate4, a.synrow, a.fam_ofs, a.fam_list)
     if (a.fuse) { if (runs) KIWI_G(true, true); else KIWI_G(true, false); }
     else        { if (runs) KIWI_G(false, true); else KIWI_G(false, false); }
 #undef KIWI_G
+}
+template <int NG, int T>
+static void grouped_t(const AccumArgs &a, dim3 grid, int ntiles, const int *runs, int pairsel, const int *mate, const int *mate4)
+{
+    if (a.compact) grouped_tc<NG, T, true>(a, grid, ntiles, runs, pairsel, mate, mate4);
+    else           grouped_tc<NG, T, false>(a, grid, ntiles, runs, pairsel, mate, mate4);
 }
 void launch_grouped(const AccumArgs &a, dim3 grid, int T, int ntiles, const int *runs, int pairsel, const int *mate, const int *mate4)
 {
