@@ -137,6 +137,8 @@ struct EvalParams {
     int nrec;
     int isrc0;
     int cellmode;      // groups = runs of centroids in the same 4-node GF cell (cellgroup_kernel marks them), not same-point runs
+    int nogaps;        // every trace of the database is stored (kiwi_hip_set_gfdb): no centroid leaves at a missing trace, geometry_kernel
+                       // need not look at the spans of its forty rows to find that out
 };
 
 // is (source s, receiver r) evaluated by accumulate_cell_kernel?  Receivers with horizontal AND vertical components whose

@@ -324,6 +324,13 @@ __global__ __launch_bounds__(256) void geometry_kernel(
             return true;
         };
         bool hfull = true;
+        if (ep.nogaps) {
+            // every trace of the database is stored: all components of both blocks are added (what the loops below find after
+            // forty span look-ups per record -- a third of this kernel's time at cfg3 once the descriptor rows were gone)
+            nlim_h = rv.need_h ? nH : 0;
+            nlim_d = rv.has_d ? nD : 0;
+            if (rv.need_h && (g.flags & 2) && live && lmax_out) atomicMax(&lmax_out[(size_t)s * ep.nrec + r], c);
+        } else {
         if (rv.need_h) {
             int k = 0;
             for (; k < nH; k++) if (!stored(gm.ng == 10 ? (k < 3 ? k : (k == 3 ? 8 : k - 1)) : k)) break;
@@ -336,6 +343,7 @@ __global__ __launch_bounds__(256) void geometry_kernel(
             int k = 0;
             for (; k < nD; k++) if (!stored(k < 3 ? 5 + k : 9)) break;
             nlim_d = k;
+        }
         }
         const bool complete = (!rv.need_h || nlim_h == nH) && (!rv.has_d || nlim_d == nD);
         if (!complete) {

@@ -310,7 +310,7 @@ void natural_spans(kiwi_hip_ctx *c, std::vector<int> &sb)
         int maxnc = 0;
         for (int s = s0; s < s0 + n; s++) maxnc = std::max(maxnc, c->cent_ofs[s + 1] - c->cent_ofs[s]);
         if (maxnc == 0) continue;
-        EvalParams ep{ c->bilinear, c->xus, c->zus, nrec, s0 };
+        EvalParams ep{ c->bilinear, c->xus, c->zus, nrec, s0, 0, c->db_gaps ? 0 : 1 };
         dim3 grid((unsigned)((maxnc * nrec + 255) / 256), (unsigned)n);
         int *lmax = nullptr;
         if (c->db_gaps) {      // (see geometry_kernel's span reduction: which partly added centroids count follows the centroids' order)
@@ -1018,7 +1018,7 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
     const bool cell = c->accum_mode == 0 && (c->cell_mode == 1 || (c->cell_mode < 0 && c->bilinear && c->points_per_centroid > 0.5));
     // several sources per workgroup (accumulate_multi_kernel); decided below, once the runs and the shared synthetics are known
     const bool duo_maybe = c->accum_mode == 0 && c->duo && !cell && c->max_wlen >= 128 && !c->group_threads_env && nsrc >= 2;      // (four sources: 256-sample tiles)
-    EvalParams ep{ c->bilinear, c->xus, c->zus, nrec, isrc0, cell ? 1 : 0 };
+    EvalParams ep{ c->bilinear, c->xus, c->zus, nrec, isrc0, cell ? 1 : 0, c->db_gaps ? 0 : 1 };
     int *spansrc = nullptr;
     if (c->any_untapered || c->want_spansrc || c->fft_needed) {     // per-source strip spans, initialised empty
         const size_t n = (size_t)nsrc * nrec;
