@@ -104,16 +104,19 @@ def arithmetic(ng, rot, fused, H, L, acc, K=None, behind=False, C=None):
                     X = member(src, m)
                     tmp = M[ti % 4]
                     ti += 1
-                    if fused and not first:
+                    sel = "op_sel:[1,0]" if half else "op_sel_hi:[0,1]"
+                    if first:
+                        # t = 0 + p (the reference zeroes the sum, then adds) differs from t = p only where p is -0, and a
+                        # sum that differs in the sign of a zero never reaches an output bit: t1 / t2 are only multiplied by
+                        # cl / sl and ADDED to accumulators that start from +0 -- a round-to-nearest sum is -0 only if both
+                        # operands are, so those are never -0, and x + (+-0) = x for every other x (NaN, infinities alike)
+                        muls.append("v_pk_mul_f32 %s, %s, %s %s" % (T, sp(cpair), vp(X), sel))
+                    elif fused:
                         sel3 = "op_sel:[1,0,0]" if half else "op_sel_hi:[0,1,1]"
                         muls.append("v_pk_fma_f32 %s, %s, %s, %s %s" % (T, sp(cpair), vp(X), T, sel3))
                     else:
-                        sel = "op_sel:[1,0]" if half else "op_sel_hi:[0,1]"
                         muls.append("v_pk_mul_f32 %s, %s, %s %s" % (vp(tmp), sp(cpair), vp(X), sel))
-                        if first:
-                            adds.append("v_pk_add_f32 %s, %s, 0 op_sel_hi:[1,0]" % (T, vp(tmp)))
-                        else:
-                            adds.append("v_pk_add_f32 %s, %s, %s" % (T, T, vp(tmp)))
+                        adds.append("v_pk_add_f32 %s, %s, %s" % (T, T, vp(tmp)))
             out.extend(muls)
             if behind and not half:
                 for a in items:
