@@ -1183,7 +1183,10 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
             // contracted, accumulate_cellw_kernel needs 189 registers for its 168 and spills in its centroid loop (cfg4: 246 ms
             // per 128 sources against 169), and the contracted shared-tile kernel only reaches the uncontracted per-wave one
             // (169.4 against 169.0): these kernels are bound by their descriptor / bookkeeping instructions, not by the
-            // multiplies and adds a fused operation saves.)
+            // multiplies and adds a fused operation saves.  Round 5: with the tail-rule variant of the step taken out of the
+            // interleaved form (a loop over the components, the blend behind it) the contracted kernel still spills 12
+            // registers, two reloads per centroid: 195 ms against 177; uncontracted that form has no spill and is 2.5 % slower
+            // (178.1 against 173.8 ms: cfg4's windows reach past the trace ends often enough).  Neither kept.)
             if (cell) {
                 if (c->cell_wave) exact::launch_cellw(aa, cgrid, ntiles_c); else exact::launch_cell(aa, cgrid, ntiles_c);
             }
