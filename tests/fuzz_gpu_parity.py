@@ -222,6 +222,10 @@ def one_case(rng, verbose):
         # (fused arithmetic contract: relative to max(misfit, norm factor), tests/common.py misfit_close)
         scale = np.maximum(np.abs(m), (1.0 if arith() == "fused" else 1e-6) * np.maximum(nn, 1e-30))
         tol = 1e-6 if mid not in (5,) else 2e-6
+        if arith() == "fused" and mid == 6:
+            # `peak` is ONE sample of the difference trace: no sum averages its round-off, the bound is the synthetics' own
+            # (2e-6 of the trace maximum, tests/common.py SYN_RTOL; seen: 1.1e-6 of the norm factor, case 5303 / 6701)
+            tol = 2e-6
         bad = np.abs(pm - m) > tol * scale
         ok = np.array_equal(pn, nn) and not bad.any()
     # the whole list through the overlapped one-call in random pieces: the same bits as the calls above

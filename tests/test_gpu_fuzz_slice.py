@@ -17,3 +17,15 @@ SEED = 20261003
 def test_fuzz_slice(block):
     bad = [n for n in range(50 * block, 50 * block + 50) if not fz.one_case(np.random.default_rng([SEED, n]), verbose=False)]
     assert not bad, "replay with: python tests/fuzz_gpu_parity.py case %d <index>, indices %s" % (SEED, bad)
+
+
+# cases the long runs have found (seed, index) -- each failed on the library of its day:
+#   5202 / 463, 5608, 6585 (round 5, `fused`, ng = 8): accumulate_multi_kernel's compiled apply started its rotated sums from the first
+#   product, (c1 x) + (c2 y), which the contracted build may fuse either way -- a batch evaluated in pieces of 1 (another kernel) no longer
+#   gave the bits of the whole batch
+FOUND = [(5202, 463), (5202, 5608), (5202, 6585)]
+
+
+@pytest.mark.parametrize("seed,index", FOUND)
+def test_fuzz_found_cases(seed, index):
+    assert fz.one_case(np.random.default_rng([seed, index]), verbose=False), "replay with: python tests/fuzz_gpu_parity.py case %d %d" % (seed, index)
