@@ -201,6 +201,13 @@ int kiwi_hip_effective_cpus(void);
  * Process-wide, shared by all contexts.
  * KIWI_HIP_EIK_CACHE=0 in the environment switches the cache off. */
 int kiwi_hip_eikonal_cache_stats(long long *hits, long long *misses, int reset);
+/* The fast-marching solve on its own (eikonal_solver_fmm, eikonal.f90:29-199; needs no GPU): speed[ny][nx] and times[ny][nx]
+ * with x fastest, origin / delta / start as there.  `discard`: nodes of exactly this speed may be left undone once every other
+ * node is accepted (what the discretiser passes for the points outside of the rupture; NaN = solve all).  plain != 0 runs the
+ * reference's statements one by one, 0 the layout-optimised march the discretiser uses (kiwi_host_fmm.hpp) -- same bits;
+ * *fallbacks (may be NULL) = how often, since the library was loaded, the optimised march handed a solve to the plain one. */
+int kiwi_hip_fast_marching(const float *speed, int nx, int ny, const float *origin, const float *delta, const float *start,
+                           float discard, int plain, float *times, long long *fallbacks);
 
 /* minimize_lm (minimizer_engine.f90:728-874; sminpack/lmdif.f in fp32 with the reference's settings: ftol = xtol =
  * sqrt(spmpar(1)), gtol = 0, maxfev = 500 (n + 1), mode 2 with diag = 1, factor 0.01) over the parameters with

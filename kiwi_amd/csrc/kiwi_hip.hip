@@ -2002,9 +2002,23 @@ int kiwi_hip_eikonal_cache_stats(long long *hits, long long *misses, int reset)
     eik::SolveCache &sc = eik::SolveCache::get();
     if (hits) *hits = sc.hits.load();
     if (misses) *misses = sc.misses.load();
-    if (reset) { sc.hits = 0; sc.misses = 0; }
+    if (reset) { sc.hits = 0; sc.misses = 0; sc.miss_streak = 0; sc.probe = 0; }
     if (reset & 2) { std::lock_guard<std::mutex> lk(sc.mu); sc.slots.clear(); }
     return 0;
+}
+
+int kiwi_hip_fast_marching(const float *speed, int nx, int ny, const float *origin, const float *delta, const float *start,
+                           float discard, int plain, float *times, long long *fallbacks)
+{
+    try {
+        if (!speed || !origin || !delta || !start || !times || nx < 1 || ny < 1) return 2;
+        std::vector<float> t;
+        if (plain) eik::fast_marching_plain(speed, nx, ny, origin, delta, start, t, discard);
+        else eik::fast_marching(speed, nx, ny, origin, delta, start, t, discard);
+        std::memcpy(times, t.data(), t.size() * sizeof(float));
+        if (fallbacks) *fallbacks = eik::fmm_fallbacks().load();
+        return 0;
+    } catch (...) { return 1; }
 }
 
 // One batch of trial sources after the host discretiser, before anything touches the device

@@ -282,6 +282,17 @@ module kiwi_hip_binding
             integer(c_int), value :: reset
         end function
 
+      ! eikonal_solver_fmm (eikonal.f90:29) on its own: speed, times are (nx,ny) arrays
+        integer(c_int) function kiwi_hip_fast_marching( speed, nx, ny, origin, delta, start, discard, plain, times, &
+                                                        fallbacks ) bind(C, name='kiwi_hip_fast_marching')
+            import :: c_int, c_float, c_long_long
+            real(c_float), intent(in) :: speed(*), origin(2), delta(2), start(2)
+            integer(c_int), value :: nx, ny, plain
+            real(c_float), value :: discard
+            real(c_float), intent(out) :: times(*)
+            integer(c_long_long), intent(out) :: fallbacks
+        end function
+
         integer(c_int) function kiwi_hip_eval( ctx, isrc0, nsrc ) bind(C, name='kiwi_hip_eval')
             import :: c_int, c_ptr
             type(c_ptr), value :: ctx

@@ -102,6 +102,8 @@ def load():
         "kiwi_hip_misfits_for_params": [vp, C.c_int, C.c_int, c_float_p, C.c_int, c_float_p, c_float_p, c_float_p, c_int_p],
         "kiwi_hip_effective_cpus": [],
         "kiwi_hip_eikonal_cache_stats": [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_int],
+        "kiwi_hip_fast_marching": [c_float_p, C.c_int, C.c_int, c_float_p, c_float_p, c_float_p, C.c_float, C.c_int, c_float_p,
+                                   C.POINTER(C.c_longlong)],
         "kiwi_hip_eval": [vp, C.c_int, C.c_int],
         "kiwi_hip_sync": [vp],
         "kiwi_hip_set_keep_synthetics": [vp, C.c_int],

@@ -147,3 +147,55 @@ def test_solve_cache_is_exact_and_hits_on_shifted_sources():
         ref = np.load(os.path.join(td, "o.npy"))
     got = np.concatenate([t.ravel() for t in tables])
     assert got.view(np.uint32).tobytes() == ref.view(np.uint32).tobytes()
+
+
+def _random_ruptures(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        st = 4 + i % 2
+        common = [rng.uniform(-1, 1), rng.uniform(-3e3, 3e3), rng.uniform(-3e3, 3e3), rng.uniform(2e3, 3e4)]
+        strike, dip = rng.uniform(-180, 180), rng.uniform(0, 90)
+        bord = [rng.uniform(-2e3, 2e3), rng.uniform(-2e3, 2e3), rng.uniform(5e2, 9e3)]
+        nukl = [rng.uniform(-1, 1) * 0.7 * bord[2], rng.uniform(-1, 1) * 0.7 * bord[2]]
+        relv, rise = rng.uniform(0.5, 1.0), rng.uniform(0, 3)
+        if st == 5:
+            p = common + [1.0, strike, dip] + bord + nukl + [relv] + list(rng.standard_normal(6)) + [rise]
+        else:
+            p = common + [1e18, strike, dip, rng.uniform(-180, 180)] + bord + nukl + [relv, rise] + [0.0] * 5
+        out.append([st, float(rng.choice([0.5, 1.0, 2.0, 4.0]))] + p)
+    return np.array(out, np.float64)
+
+
+def test_optimised_discretiser_equals_the_plain_statements_on_200_random_ruptures():
+    """Round 6 rewrote the host discretiser's three passes over the fine grid -- the fast-marching solve on its own layout
+    (kiwi_host_fmm.hpp), the speed grid and the binning of the arrival times four points at a time (kiwi_host_eikonal.hpp) --
+    and kept the statement-by-statement versions behind KIWI_HIP_EIK_PLAIN=1.  200 random `eikonal` / `mt_eikonal` ruptures
+    (any strike and dip, circles clipped by the default constraints, nucleation points on and off the cell centres, four
+    effective dt), each discretised by both in its own process: identical centroid tables, moments and rise times, identical
+    rejections."""
+    import subprocess
+    import sys
+    import tempfile
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from kiwi_amd import engine as ke; from kiwi_amd.lib import KiwiHipError; "
+            "G = np.load(%r); T = np.load(sys.argv[1]); cp, cn = G['e0_con']; out = []\n"
+            "for row in T:\n"
+            "    st = int(row[0]); p = row[2:2 + (20 if st == 5 else 15)].astype(np.float32)\n"
+            "    try:\n"
+            "        a, mo, ri = ke.discretize_eikonal(st, p, float(row[1]), G['rupture_profile'], cp, cn)\n"
+            "        out.append(np.concatenate([[len(a), mo, ri], a.ravel()]).astype(np.float32))\n"
+            "    except KiwiHipError as e:\n"
+            "        out.append(np.array([-1.0, float(len(str(e)))], np.float32))\n"
+            "np.save(sys.argv[2], np.concatenate(out))") % (
+                os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                os.path.join(os.path.dirname(__file__), "golden", "eikonal_vectors.npz"))
+    trials = _random_ruptures(200, 20261004)
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        np.save(os.path.join(td, "t.npy"), trials)
+        for mode in ("0", "1"):
+            env = dict(os.environ, KIWI_HIP_EIK_PLAIN=mode, KIWI_HIP_EIK_CACHE="0")
+            subprocess.check_call([sys.executable, "-c", code, os.path.join(td, "t.npy"), os.path.join(td, "o%s.npy" % mode)], env=env)
+            res[mode] = np.load(os.path.join(td, "o%s.npy" % mode))
+    assert res["0"].size > 200 * 10
+    assert res["0"].view(np.uint32).tobytes() == res["1"].view(np.uint32).tobytes()
