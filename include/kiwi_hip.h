@@ -187,7 +187,9 @@ int kiwi_hip_source_status_message(int code, char *buf, int buflen);
  * and status[nsrc] (any may be NULL) are bit for bit what those calls return for any piece size; a piece none of whose
  * sources could be discretised is all failings (zeros), not an error.  Pieces are taken from the end of the list, so the
  * context is left with its HEAD (sources 0 .. piece - 1, evaluated), as after kiwi_hip_set_sources_params + kiwi_hip_eval
- * of those.  For the eikonal source types the host discretiser (a fast-marching solve per trial source, eikonal.f90:29-199)
+ * of those.  (Eikonal types, lists of two pieces or more: the last piece of the list -- the first worked on, whose
+ * discretisation nothing hides -- is taken as an eighth, an eighth, a quarter and half of it, and the discretiser runs up to
+ * three pieces ahead of the device.)  For the eikonal source types the host discretiser (a fast-marching solve per trial source, eikonal.f90:29-199)
  * costs as much as the device evaluation; overlapped, a sweep runs at the slower of the two instead of their sum. */
 int kiwi_hip_misfits_for_params(kiwi_hip_ctx *ctx, int sourcetype, int nsrc, const float *params, int piece,
                                 float *misfit, float *norm, float *global, int *status);

@@ -24,7 +24,11 @@
 #include <vector>
 #include <stdexcept>
 #include <omp.h>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <future>
+#include <mutex>
 #include <thread>
 #include <limits>
 
@@ -2414,19 +2418,75 @@ int kiwi_hip_misfits_for_params(kiwi_hip_ctx *c, int sourcetype, int nsrc, const
     // (default piece: 128 eikonal solves keep the discretiser team busy for one device evaluation; for the closed-form source types the
     // host is a few per cent of a piece and larger launches fill the device better -- cfg3, 4096 trials: 31.1 k evals/s at 1024, 32.5 k at 2048)
     if (piece <= 0) piece = source_nparams_eikonal(sourcetype) > 0 ? 128 : 2048;
-    const int npieces = (nsrc + piece - 1) / piece;
-    auto work = [c, sourcetype, np, params, piece, nsrc, npieces](int k) {
+    // pieces [first, first + count) in list order.  Eikonal types: the LAST piece of the list -- the first one worked on, the one
+    // whose discretisation nothing hides -- is cut into a ramp of an eighth, an eighth, a quarter and half a piece, so that the
+    // device starts after an eighth of a piece's fast-marching solves (one per discretiser thread at the default 128 on 16 CPUs)
+    // instead of a whole one (512 cfg4-nukl trials: 137 ms of the call's 1066 were that wait).
+    std::vector<std::pair<int, int>> pieces;
+    for (int s0 = 0; s0 < nsrc; s0 += piece) pieces.emplace_back(s0, std::min(piece, nsrc - s0));
+    if (source_nparams_eikonal(sourcetype) > 0 && pieces.size() >= 2 && pieces.back().second >= 8) {
+        const std::pair<int, int> last = pieces.back();
+        pieces.pop_back();
+        const int e = last.second / 8, q = last.second / 4, h = last.second - 2 * e - q;
+        pieces.emplace_back(last.first, h);
+        pieces.emplace_back(last.first + h, q);
+        pieces.emplace_back(last.first + h + q, e);
+        pieces.emplace_back(last.first + h + q + e, e);
+    }
+    const int npieces = (int)pieces.size();
+    auto work = [c, sourcetype, np, params, npieces, &pieces](int k) {
         HostBatch hb;
-        const int s0 = k * piece;
-        discretise_batch(c, sourcetype, std::min(piece, nsrc - s0), params + (size_t)s0 * np, npieces > 1 ? 1 : 0, hb);
+        discretise_batch(c, sourcetype, pieces[(size_t)k].second, params + (size_t)pieces[(size_t)k].first * np, npieces > 1 ? 1 : 0, hb);
         return hb;
     };
-    // last piece first: the context is left with the HEAD of the list (sources 0 .. piece - 1), its source 0 the list's
-    std::future<HostBatch> next = std::async(std::launch::async, work, npieces - 1);
+    // last piece first: the context is left with the HEAD of the list (sources 0 .. piece - 1), its source 0 the list's.
+    // The discretiser runs AHEAD of the device by up to kAhead pieces (round 6; until then it started a piece when the device
+    // started the one before, and idled once it was done: with the eikonal types' solves at 0.6 of a piece's device time the
+    // device still waited for the host after every short piece of the ramp).
+    struct Ahead {
+        std::mutex mu;
+        std::condition_variable cv;
+        std::deque<HostBatch> q;
+        std::exception_ptr err;
+        bool stop = false;
+    } ahead;
+    constexpr size_t kAhead = 3;
+    std::future<void> producer = std::async(std::launch::async, [&] {
+        try {
+            for (int k = npieces - 1; k >= 0; k--) {
+                HostBatch hb = work(k);
+                std::unique_lock<std::mutex> lk(ahead.mu);
+                ahead.cv.wait(lk, [&] { return ahead.q.size() < kAhead || ahead.stop; });
+                if (ahead.stop) return;
+                ahead.q.push_back(std::move(hb));
+                ahead.cv.notify_all();
+            }
+        } catch (...) {
+            std::lock_guard<std::mutex> lk(ahead.mu);
+            ahead.err = std::current_exception();
+            ahead.cv.notify_all();
+        }
+    });
+    struct StopProducer {                          // (an exception below must not leave the producer waiting for room in the queue)
+        Ahead &a; std::future<void> &f;
+        ~StopProducer() { { std::lock_guard<std::mutex> lk(a.mu); a.stop = true; } a.cv.notify_all(); if (f.valid()) f.wait(); }
+    } stop_producer{ ahead, producer };
+    // KIWI_HIP_TRACE_PIECES=1: per piece on stderr -- ms waited for its discretisation, ms of upload, ms of evaluation + download
+    static const bool trace = [] { const char *e = std::getenv("KIWI_HIP_TRACE_PIECES"); return e && std::atoi(e) != 0; }();
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (int k = npieces - 1; k >= 0; k--) {
-        const HostBatch hb = next.get();
-        if (k > 0) next = std::async(std::launch::async, work, k - 1);
-        const int s0 = k * piece, n = hb.nsrc;
+        const double t_wait = now();
+        HostBatch hb;
+        {
+            std::unique_lock<std::mutex> lk(ahead.mu);
+            ahead.cv.wait(lk, [&] { return !ahead.q.empty() || ahead.err; });
+            if (ahead.q.empty()) std::rethrow_exception(ahead.err);
+            hb = std::move(ahead.q.front());
+            ahead.q.pop_front();
+            ahead.cv.notify_all();
+        }
+        const double t_got = now();
+        const int s0 = pieces[(size_t)k].first, n = hb.nsrc;
         if (status) std::memcpy(status + s0, hb.status.data(), (size_t)n * sizeof(int));
         if (hb.nbad == n) {                       // nothing of this piece to evaluate: every trial of it is a failing
             if (misfit) std::memset(misfit + (size_t)s0 * nmis, 0, (size_t)n * nmis * sizeof(float));
@@ -2435,9 +2495,12 @@ int kiwi_hip_misfits_for_params(kiwi_hip_ctx *c, int sourcetype, int nsrc, const
             continue;
         }
         upload_batch(c, hb);
+        const double t_up = now();
         eval_impl(c, 0, n, c->keep_which);
         if (kiwi_hip_get_misfits(c, 0, n, misfit ? misfit + (size_t)s0 * nmis : nullptr, norm ? norm + (size_t)s0 * nmis : nullptr,
                                  global ? global + s0 : nullptr)) throw std::runtime_error(c->err);
+        if (trace) std::fprintf(stderr, "kiwi_hip piece [%d, %d): waited %.1f ms for the discretiser, upload %.1f ms, evaluation + download %.1f ms\n",
+                                s0, s0 + n, t_got - t_wait, t_up - t_got, now() - t_up);
     }
     return 0;
     GUARD_END(c)

@@ -663,7 +663,8 @@ def test_eikonal_sources_with_risetime_fold(stype):
     # those of the calls above, bit for bit
     big = np.concatenate([grid, bad, bad, trials[:1]], 0)
     want_status = [0, 0, 5, 0, 5, 0, 6, 5, 5, 0]
-    for piece in (1, 2, 3, 4, 7, 10, 0):
+    # (lists of 18 below: the list's last piece is worked on as a ramp of an eighth, an eighth, a quarter and half of it, kiwi_hip.hip)
+    for piece in (1, 2, 3, 4, 5, 6, 7, 10, 0):
         fm, fn, fg, fs = p.misfits_for_params(stype, big, piece)
         assert list(fs) == want_status, piece
         ok = [0, 1, 3, 5, 9]
@@ -671,6 +672,20 @@ def test_eikonal_sources_with_risetime_fold(stype):
         assert np.array_equal(fg[ok], pg[[0, 1, 2, 3, 0]]), piece
         nok = [i for i in range(10) if i not in ok]
         assert np.all(fm[nok] == 0) and np.all(fn[nok] == 0) and np.all(fg[nok] == 0), piece
+    # a head piece of nothing but failings: the engine is left with the first piece that uploaded anything -- with pieces of 2 the
+    # ramp's half piece [4, 5) ... whatever the cut, source 0 of the engine is the first good trial of that piece
+    from kiwi_amd.engine import _pieces
+    headbad = np.concatenate([bad, bad, trials, bad, trials[:2]] + [bad] * 8 + [trials[3:]], 0)
+    for piece in (2, 8, 9, 16):
+        hm, hn, hg, hs = p.misfits_for_params(stype, headbad, piece)
+        assert list(hs) == [5, 5, 0, 0, 0, 0, 5, 0, 0] + [5] * 8 + [0], piece
+        good2 = [2, 3, 4, 5, 7, 8, 17]
+        assert np.array_equal(hm[good2], pm[[0, 1, 2, 3, 0, 1, 3]]) and np.array_equal(hg[good2], pg[[0, 1, 2, 3, 0, 1, 3]]), piece
+        assert len(_pieces(len(headbad), piece, st)) == {2: 9, 8: 3, 9: 5, 16: 2}[piece]
+        first, cnt = next((f, c) for f, c in _pieces(len(headbad), piece, st) if np.any(hs[f:f + c] == 0))
+        assert p.nsrc == cnt, (piece, p.nsrc, cnt)
+        em, en, eg = p.get_misfits()
+        assert np.array_equal(em, hm[first:first + cnt]) and np.array_equal(eg, hg[first:first + cnt]), piece
     mis2, nor2, failings2 = p.make_misfits_for_sources(stype, big, piece=3)
     mis3, nor3, failings3 = p.make_misfits_for_sources(stype, big)
     assert failings2 == [2, 4, 6, 7, 8] == failings3
