@@ -42,6 +42,19 @@ def valu_peak(arith):
 
 
 VALU_PEAK_TFLOPS = FP32_PEAK_TFLOPS / 2.0
+
+
+def valu_roofline(ach_tflops, arith, **more):
+    """roofline block of a vector-ALU-bound kernel: `peak` / `frac` against the rate the kernel's arithmetic contract allows (no
+    fused multiply-add under `exact`: one flop per lane and packed slot), and ALWAYS next to them the guide's figure,
+    MI355X_MICROARCH.md "Peak FP32 (vector)" 157.3 TFLOP/s, which counts a fused multiply-add as two flops (`peak_fma`,
+    `frac_of_fma_peak`)."""
+    out = {"bound": "valu_issue", "achieved": ach_tflops, "peak": valu_peak(arith), "unit": "TFLOP/s", "frac": ach_tflops / valu_peak(arith),
+           "peak_is": "fp32 vector rate WITHOUT fused multiply-add (the exact contract rounds every multiply and add on its own)"
+                      if arith != "fused" else "fp32 vector rate with fused multiply-add",
+           "peak_fma": FP32_PEAK_TFLOPS, "frac_of_fma_peak": ach_tflops / FP32_PEAK_TFLOPS, "arithmetic": arith}
+    out.update(more)
+    return out
 NORM_ID = {"l2norm": 1, "l1norm": 2, "ampspec_l2norm": 3, "ampspec_l1norm": 4}
 
 
@@ -170,7 +183,7 @@ def oracle_engine(wl, gf, recv, refs, tapers, cores, fresh=False):
     return e, db, evaluate
 
 
-def cpu_baseline(wl, gf, recv, refs, tapers, gpu_global, gpu_misfits, gpu_norms, budget_s=20.0):
+def cpu_baseline(wl, gf, recv, refs, tapers, gpu_global, gpu_misfits, gpu_norms, budget_s=20.0, one_core=True):
     """The oracle (C restatement, OpenMP over receivers like minimizer_engine.f90:893-903) timed on
     this box's host cores for a bounded number of the SAME trial sources."""
     # the reference parallelises make_seismogram over receivers (minimizer_engine.f90:893-903): no more threads than
@@ -202,12 +215,14 @@ def cpu_baseline(wl, gf, recv, refs, tapers, gpu_global, gpu_misfits, gpu_norms,
     slot_err = float(np.max(np.abs(gpu_misfits[:n] - om) / on))
     norm_err = float(np.max(np.abs(gpu_norms[:n] - on) / on))
     # the same on ONE core (SURVEY 8d asks for both), two sources
-    e.set_nthreads(1)
-    t0 = time.perf_counter()
-    n1 = 2
-    for i in range(n1):
-        one(trials[i])
-    v1 = n1 / (time.perf_counter() - t0)
+    v1 = None
+    if one_core:
+        e.set_nthreads(1)
+        t0 = time.perf_counter()
+        n1 = 2
+        for i in range(n1):
+            one(trials[i])
+        v1 = n1 / (time.perf_counter() - t0)
     e.close()
     db.close()
     return {"value": n / dtm, "unit": "evals/s", "cores": cores, "kind": "port",
@@ -303,7 +318,11 @@ def _code_only(text, makefile=False):
     out, i, n = [], 0, len(text)
     while i < n:
         c = text[i]
-        if c == '"':                                   # string literal: copy through its closing quote
+        if c == "'" and i + 2 < n and (text[i + 2] == "'" or (text[i + 1] == "\\" and i + 3 < n and text[i + 3] == "'")):
+            j = i + (3 if text[i + 2] == "'" else 4)    # character literal ('"' must not open a string)
+            out.append(text[i:j])
+            i = j
+        elif c == '"':                                 # string literal: copy through its closing quote
             j = i + 1
             while j < n and text[j] != '"':
                 j += 2 if text[j] == "\\" else 1
@@ -332,6 +351,15 @@ def kernel_sources_sha256():
         with open(os.path.join(ROOT, "kiwi_amd", "csrc", f), "r", errors="replace") as fh:
             h.update(_code_only(fh.read(), makefile=(f == "Makefile")).encode())
             h.update(b"\0")
+    # the extra flags the loaded library was really built with (make EXTRA=-D...): same sources, other device code
+    try:
+        import ctypes
+        from kiwi_amd import lib as _lib
+        buf = ctypes.create_string_buffer(1024)
+        if _lib.load().kiwi_hip_build_flags(buf, 1024) == 0 and buf.value:
+            h.update(b"EXTRA=" + buf.value)
+    except Exception:
+        pass
     return h.hexdigest()
 
 
@@ -383,7 +411,7 @@ def other_contract(p, batch, flops_eval, steps=6):
              "norm_factors_identical": bool(np.array_equal(n0, n1)), "sources": int(len(ge)), "slots": int(me.shape[1])}
     ach = flops_eval * batch / (acc_ms * 1e-3) / 1e12 if acc_ms > 0 else 0.0
     return {"arithmetic": oth, "value": batch * steps / dt, "unit": "evals/s", "steps": steps, "accumulate_ms_per_step": acc_ms,
-            "roofline": {"bound": "valu_issue", "achieved": ach, "peak": valu_peak(oth), "unit": "TFLOP/s", "frac": ach / valu_peak(oth)},
+            "roofline": valu_roofline(ach, oth),
             "fused_vs_exact": delta}
 
 
@@ -440,14 +468,51 @@ def sweep_block(device, L, n=20000, first=40000, workload="cfg5"):
             "timed": "parameter list -> host discretiser -> H2D -> kernels -> D2H (inputs NOT resident), one call"}
 
 
+def also_workload(device, L, name, batch, steps=3, cpu_budget_s=3.0):
+    """Another workload in the driver's line: `steps` passes of the hot path over `batch` resident trial sources,
+    timed like the main figure (wall clock around eval + sync + download of the misfits), with its own roofline block (required
+    flops over the accumulate kernels' HIP-event time) and a SHORT CPU baseline (the oracle on the host cores for `cpu_budget_s`
+    seconds of the same trial sources, results compared with the device's)."""
+    from kiwi_amd import synthetic
+    wl = synthetic.workload(name, batch, 0)
+    p, gf, recv, refs, tapers, ncent = setup_product(device, wl, L)
+    for _ in range(2):
+        p.eval()
+    dt, acc_ms = timed_evals(p, steps)
+    npts, nrec, ng, W = wl["npoints"], wl["nrec"], gf["data"].shape[2], L
+    flops_eval = required_flops(ncent, npts, nrec, ng, W)
+    ar = p.arithmetic()
+    ach = flops_eval * batch / (acc_ms * 1e-3) / 1e12 if acc_ms > 0 else 0.0
+    gm, gn, gg = p.get_misfits()
+    out = {"workload": "%s: %s source, %.0f centroids (%.0f sub-fault points) x %d receivers x 3 comp x %d samples, %s"
+                       % (wl["name"], wl["sourcetype"], ncent, npts, nrec, W, wl["method"]),
+           "arithmetic": ar, "value": batch * steps / dt, "unit": "evals/s", "trial_sources_per_step": batch, "steps": steps,
+           "ms_per_step": dt / steps * 1e3,
+           "roofline": valu_roofline(ach, ar, accumulate_ms_per_step=acc_ms, flops_per_eval=flops_eval)}
+    try:
+        out["cpu_baseline"] = cpu_baseline(wl, gf, recv, refs, tapers, np.asarray(gg), gm, gn, budget_s=cpu_budget_s, one_core=False)
+    except Exception as ex:                      # (the secondary blocks must not take the line down)
+        out["cpu_baseline"] = {"error": str(ex)[:200]}
+    p.close()
+    return out
+
+
 def also_bigdb4(device, L, batch=1024, steps=6):
     """The HBM regime in the driver's line: the cfg3 source over a 4.2 GB Green's function database (sixteen times the Infinity
     Cache), one trial location per distance node in shuffled order -- the one workload whose accumulate kernel runs against the
-    memory, i.e. where north_star's "fraction of the HBM roofline" is the meaningful figure.  `achieved` = the node rows the
-    launch has to fetch (sub-fault points x receivers x n_g x n_ip x window x 4 B: the time steps of a point share their rows, every
-    (point, receiver) pair needs its own) over the accumulate kernel's time; counters (`traffic`) from the committed profile of the
-    same kernel sources, the pure-read ceiling of this chip from profiles/microbench/hbm_read.hip."""
+    memory, i.e. where north_star's "fraction of the HBM roofline" is the meaningful figure.
+
+    One definition per key.  `achieved_counter_gbs`: memory-side bytes of the committed rocprofv3 counters of THESE
+    kernel sources (FETCH_SIZE x 2 + WRITE_SIZE, scaled to the batch; Infinity-Cache hits included; null without a matching
+    profile) over the accumulate kernels' HIP-event time of this run.  `hbm_side_estimate_gbs`: that minus the share the Infinity
+    Cache can have served (at most 1/16 of a pass over a database 16 x its size).  `no_reuse_model_gbs`: the SURVEY 8d byte model
+    (every (point, receiver) pair fetches its own 40 rows over the window; an UPPER bound of the traffic -- it counts again the
+    rows co-resident workgroups of neighbouring receivers share in L2, which is how it came out above the chip's peak in round 5).
+    `pure_read_ceiling_gbs`: measured in THIS run by the library's own read kernel (kiwi_hip_measure_read_bandwidth).
+    `achieved` (and `frac` = achieved / 8 TB/s) is the HBM-side estimate when there are counters, otherwise the model -- and no
+    figure of the block is reported above a ceiling of the block: one that comes out higher is capped and says so in `notes`."""
     from kiwi_amd import synthetic
+    import ctypes
     wl = synthetic.workload("cfg3-bigdb4", batch, 0)
     p, gf, recv, refs, tapers, ncent = setup_product(device, wl, L)
     for _ in range(2):
@@ -455,32 +520,45 @@ def also_bigdb4(device, L, batch=1024, steps=6):
     dt, acc_ms = timed_evals(p, steps)
     ar = p.arithmetic()
     npts, nrec, ng, W = wl["npoints"], wl["nrec"], gf["data"].shape[2], L
-    # the node rows a launch has to fetch when nothing is reused between (point, receiver) pairs: the model of SURVEY 8d with the
-    # time steps of a point sharing their rows.  (An over-estimate by the few per cent of a row that lie outside the stored span.)
-    row_bytes = npts * nrec * ng * 4 * W * 4.0 * batch
-    alg_gbs = row_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
+    t = acc_ms * 1e-3
+    model_bytes = npts * nrec * ng * 4 * W * 4.0 * batch
     flops_eval = required_flops(ncent, npts, nrec, ng, W)
     prof, note = committed_counters("cfg3-bigdb4", ar)
     traffic = prof["hbm_bytes_per_launch"] * (batch / prof["batch"]) if prof.get("hbm_bytes_per_launch") else None
-    mem_gbs = traffic / (acc_ms * 1e-3) / 1e9 if traffic and acc_ms > 0 else None
-    # `achieved`: the memory-side bytes the counters saw for this launch size (FETCH_SIZE x 2 + WRITE_SIZE of the committed profile
-    # of these kernel sources) over the time measured HERE; without a matching profile, the algorithmic bytes
-    gbs = mem_gbs if mem_gbs else alg_gbs
-    ceil = read_ceiling()
+    gbs_now = ctypes.c_double(0.0)
+    try:
+        p._ck(p.L.kiwi_hip_measure_read_bandwidth(p.h, 4 << 30, 10, ctypes.byref(gbs_now)), "measure_read_bandwidth")
+        ceiling = float(gbs_now.value)
+    except Exception:
+        ceiling = None
+    notes = []
+    top = min(x for x in (ceiling, HBM_PEAK_GBS) if x)
+
+    def capped(v, what):
+        if v is not None and v > top:
+            notes.append("%s came out at %.0f GB/s, above the lower of the block's ceilings (%.0f GB/s): reported capped" % (what, v, top))
+            return top
+        return v
+
+    model = model_bytes / t / 1e9 if t > 0 else 0.0
+    cnt = capped(traffic / t / 1e9 if traffic and t > 0 else None, "achieved_counter_gbs")
+    hbm_side = cnt * 15.0 / 16.0 if cnt else None
+    achieved = hbm_side if hbm_side else capped(model, "no_reuse_model_gbs (used as `achieved`: no counters of these kernel sources)")
     out = {"workload": "cfg3-bigdb4: cfg3 source, %.0f centroids (%.0f points) x %d receivers, database of %.1f GB (%d x %d nodes), one trial "
                        "location per distance node, shuffled" % (ncent, npts, nrec, gf["data"].nbytes / 1e9, gf["data"].shape[0], gf["data"].shape[1]),
            "arithmetic": ar, "value": batch * steps / dt, "unit": "evals/s", "trial_sources_per_step": batch, "steps": steps,
-           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                        "achieved_is": "memory-side bytes of the committed counters / kernel time of this run" if mem_gbs else
-                                       "algorithmic row bytes / kernel time of this run (no committed counters for these kernel sources)",
-                        "traffic": traffic, "accumulate_ms_per_step": acc_ms,
-                        "algorithmic_bytes_per_step": row_bytes, "algorithmic_gbs": alg_gbs,
-                        "pure_read_ceiling_gbs": ceil,
-                        "frac_of_pure_read_ceiling": gbs / ceil["in_order_gbs"] if ceil and ceil.get("in_order_gbs") else None,
-                        "note": "memory-side = the L2s' fabric side: Infinity-Cache hits included -- at most 1/16 of a pass over a database "
-                                "16 x the cache, plus the 64-sample halo a neighbouring tile's workgroup fetched moments earlier (6 % of the rows)",
-                        "valu_frac": flops_eval * batch / (acc_ms * 1e-3) / 1e12 / valu_peak(ar) if acc_ms > 0 else None,
-                        "profile_note": note}}
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "achieved_is": "hbm_side_estimate_gbs (committed counters of these kernel sources / kernel time of this run, less the "
+                                       "Infinity Cache's possible share)" if hbm_side else
+                                       "no_reuse_model_gbs capped at the block's ceilings (no committed counters of these kernel sources)",
+                        "achieved_counter_gbs": cnt, "traffic": traffic, "hbm_side_estimate_gbs": hbm_side,
+                        "no_reuse_model_gbs": model, "no_reuse_model_bytes_per_step": model_bytes,
+                        "pure_read_ceiling_gbs": ceiling, "pure_read_ceiling_is": "kiwi_hip_measure_read_bandwidth, 4 GiB, 10 passes, this run",
+                        "frac_of_pure_read_ceiling": achieved / ceiling if ceiling else None,
+                        "committed_pure_read_ceiling": read_ceiling(),
+                        "accumulate_ms_per_step": acc_ms,
+                        "valu": valu_roofline(flops_eval * batch / t / 1e12 if t > 0 else 0.0, ar),
+                        "notes": notes, "profile_note": note}}
     p.close()
     return out
 
@@ -531,9 +609,8 @@ def also_cfg3_100pt(p_main, device, L, batch=512, steps=6):
     ach = flops_eval * batch / (acc_ms * 1e-3) / 1e12 if acc_ms > 0 else 0.0
     out = {"workload": "cfg3-100pt: %.0f centroids (%.0f sub-fault points) x %d receivers x 3 comp x %d samples" % (ncent, npts, nrec, W),
            "arithmetic": ar, "value": batch * steps / dt, "unit": "evals/s", "trial_sources_per_step": batch, "steps": steps,
-           "roofline": {"bound": "valu_issue", "achieved": ach, "peak": valu_peak(ar), "unit": "TFLOP/s", "frac": ach / valu_peak(ar),
-                        "accumulate_ms_per_step": acc_ms, "flops_per_eval": flops_eval,
-                        "kernel": "accumulate_multi_kernel<10,FUSE,4|2> (+ accumulate_grouped_kernel for the pairs it leaves)"},
+           "roofline": valu_roofline(ach, ar, accumulate_ms_per_step=acc_ms, flops_per_eval=flops_eval,
+                                     kernel="accumulate_multi_kernel<10,FUSE,4|2> (+ accumulate_grouped_kernel for the pairs it leaves)"),
            "roofline_frac": ach / valu_peak(ar),
            "other_contract": other_contract(p, batch, flops_eval, steps)}
     p.close()
@@ -637,14 +714,21 @@ def main():
     if os.environ.get("KIWI_BENCH_DEVICE") is not None:
         local_rank = int(os.environ["KIWI_BENCH_DEVICE"])
     if world > 1 or force_dist:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # First contact with a multi-GPU node is unattended: no collective may wait for a rank that is gone or stuck longer than
+        # this many seconds (default 120; the whole default run is shorter).  RCCL: the process group's watchdog aborts the process
+        # when a collective exceeds it; gloo: the collective raises.  Either way the rank exits non-zero, torch.distributed.run
+        # (--max-restarts 0) ends the others, and the run's status is non-zero -- nothing is retried or restarted in place.
+        ctimeout = datetime.timedelta(seconds=float(os.environ.get("KIWI_BENCH_COLLECTIVE_TIMEOUT", "120")))
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), timeout=ctimeout)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=ctimeout)
     ngpus = world
     if ngpus > 1 and not os.environ.get("KIWI_HIP_DISC_THREADS"):
         # N ranks share the box's host cores: each rank's discretiser team gets its share instead of all of them
@@ -684,6 +768,14 @@ def main():
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         allg = step()
+    # test hooks (tests/test_gpu_fullsize.py, tests/test_shard_gloo.py): a rank that DIES mid-run and a rank that HANGS mid-run -- the
+    # launcher has to come back with a non-zero status within the collective timeout, not sit in a collective until someone kills it
+    if dist is not None and os.environ.get("KIWI_BENCH_FAIL_RANK") == str(rank):
+        print("bench.py: rank %d leaves the run (KIWI_BENCH_FAIL_RANK)" % rank, file=sys.stderr, flush=True)
+        os._exit(17)
+    if dist is not None and os.environ.get("KIWI_BENCH_HANG_RANK") == str(rank):
+        print("bench.py: rank %d stops answering (KIWI_BENCH_HANG_RANK)" % rank, file=sys.stderr, flush=True)
+        time.sleep(3600)
     p.kernel_ms()                                   # reset the HIP-event accumulators
     if dist is not None:
         dist.barrier()
@@ -700,8 +792,12 @@ def main():
     elapsed = time.perf_counter() - t0
     if os.environ.get("KIWI_BENCH_VERBOSE"):
         print("rank %d step ms: %s" % (rank, " ".join("%.2f" % (1e3 * v) for v in step_s)), file=sys.stderr)
+    per_rank_ms = None
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)                   # every rank's own time: a slow device or a starved discretiser team shows up by rank
+        per_rank_ms = [float(x.item()) / args.steps * 1e3 for x in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if dgather is not None:
@@ -743,14 +839,24 @@ def main():
                                                       if dgather is not None else "all-gather over %s through the host" % backend),
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            # N > 1: what an operator needs when the figure is off -- every rank's own step time (value uses the slowest), the host
+            # threads each rank's discretiser team may use (the CPU quota divided by the ranks) and the collective's timeout
+            "ms_per_step_by_rank": per_rank_ms,
+            "host_threads_per_rank": int(os.environ.get("KIWI_HIP_DISC_THREADS", "0")) or int(p.L.kiwi_hip_effective_cpus()),
+            "host_cpus_effective": int(p.L.kiwi_hip_effective_cpus()),
+            "collective_timeout_s": float(os.environ.get("KIWI_BENCH_COLLECTIVE_TIMEOUT", "120")) if dist is not None else None,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             # arithmetic contract of the accumulate kernels this line was measured under (include/kiwi_hip.h KIWI_ARITH_*;
             # `other_contract` below carries the same batch under the other one)
             "arithmetic": arith,
-            "config": {"workload": "%s: %s source, %.0f centroids (%.0f sub-fault points) x %d receivers x 3 comp x %d samples, "
-                                   "ng=10, bilinear GF interpolation, %s%s, tapered %d-sample window"
-                                   % (wl["name"], wl["sourcetype"], ncent, npts, nrec, L, wl["method"],
-                                      " + frequency filter" if wl["filter"] is not None else "", W),
+            "config": {"workload": "%s: %s source, %.0f centroids (%.0f sub-fault points x %.0f time steps%s) x %d receivers x 3 comp x %d samples, "
+                                   "ng=10, bilinear GF interpolation, %s%s, tapered %d-sample window%s"
+                                   % (wl["name"], wl["sourcetype"], ncent, npts, ncent / max(npts, 1.0),
+                                      ", every trial at ONE location (strike sweep, 0.1 degree steps)" if args.workload == "cfg3" else "",
+                                      nrec, L, wl["method"],
+                                      " + frequency filter" if wl["filter"] is not None else "", W,
+                                      "; `also` = the literal 100-sub-fault-point reading (200 centroids), `also_scatter` = the same source "
+                                      "over a shuffled location grid" if args.workload == "cfg3" else ""),
                        "trial_sources_per_gpu_per_step": args.batch, "misfits_per_source": nmis,
                        "parallelism": "trial-source shard x%d, all-gather of global misfits" % ngpus},
             # The dominant kernel runs against the vector ALU's issue rate, not against HBM: the Green's function tensor
@@ -758,6 +864,10 @@ def main():
             # = required flops / measured kernel time, `peak` = the unfused fp32 vector rate, so frac <= 1 by construction.
             "roofline": {"bound": "valu_issue", "achieved": achieved_tflops, "peak": peak_tf, "unit": "TFLOP/s",
                          "frac": achieved_tflops / peak_tf, "arithmetic": arith,
+                         # `peak` is the builder's ceiling under the exact contract (bit parity forbids the fused multiply-add: half
+                         # the chip's rate); the guide's figure and the fraction of it are carried next to it
+                         "peak_is": "fp32 vector rate WITHOUT fused multiply-add (exact contract)" if arith != "fused" else "fp32 vector rate with fused multiply-add",
+                         "peak_fma": FP32_PEAK_TFLOPS, "frac_of_fma_peak": achieved_tflops / FP32_PEAK_TFLOPS,
                          "traffic": traffic,
                          "kernel": kernel, "launches": int(launches[1]), "avg_launch_ms": avg_ms,
                          "flops_per_eval": flops_eval,
@@ -795,6 +905,11 @@ def main():
             out["host_inclusive"] = host_inclusive(p, wl, value, piece=args.piece, longer=longer)
         if ngpus == 1 and args.workload == "cfg3" and not args.no_also:
             out["also"] = also_cfg3_100pt(p, local_rank, args.samples)
+            # the other BASELINE.json configurations and the unfriendly reading of cfg3, driver-timed: three steps each, own roofline
+            # block, a short CPU baseline on the same trial sources
+            out["also_cfg2"] = also_workload(local_rank, args.samples, "cfg2", 12960)
+            out["also_cfg4"] = also_workload(local_rank, args.samples, "cfg4", 128, cpu_budget_s=4.0)
+            out["also_scatter"] = also_workload(local_rank, args.samples, "cfg3-scatter", 1024)
             out["sweep"] = sweep_block(local_rank, args.samples)
             out["also_hbm"] = also_bigdb4(local_rank, args.samples)
         print(json.dumps(_finite(out)))

@@ -298,6 +298,13 @@ int kiwi_hip_get_geometry(kiwi_hip_ctx *ctx, int isrc, int irec, int maxcent, in
 int kiwi_hip_get_receiver_geometry(kiwi_hip_ctx *ctx, int irec, double *azi, double *bazi, double *dist);
 /* device memory currently held [bytes] */
 int kiwi_hip_get_device_bytes(kiwi_hip_ctx *ctx, long long *bytes);
+/* the extra compiler flags the library was built with (`make EXTRA=...`; empty for the default build): profiles are matched to a
+ * build by its kernel sources AND these */
+int kiwi_hip_build_flags(char *buf, int buflen);
+/* diagnostics: the rate [GB/s, 1e9 bytes] of a pure read of `bytes` bytes of device memory (16 bytes per lane, contiguous
+ * slices; choose bytes >> 256 MiB Infinity Cache), `reps` passes timed with HIP events on the context's stream -- the ceiling
+ * bench.py holds the accumulate kernels' HBM-regime figure against, measured in the same run */
+int kiwi_hip_measure_read_bandwidth(kiwi_hip_ctx *ctx, long long bytes, int reps, double *gbs);
 
 #ifdef __cplusplus
 }

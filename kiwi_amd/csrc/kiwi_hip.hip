@@ -1387,6 +1387,30 @@ int eval_impl(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
 } // namespace
 
 // ================================================================================================
+// pure-read microbenchmark kernels (kiwi_hip_measure_read_bandwidth)
+typedef unsigned int read_u4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void read_fill_kernel(read_u4 *p, size_t n16)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
+        p[i] = read_u4{ (unsigned)i, 1u, 2u, 3u };
+}
+__global__ __launch_bounds__(256) void read_in_order_kernel(const read_u4 *__restrict__ p, size_t n16, unsigned *__restrict__ sink)
+{
+    const size_t per = (n16 + gridDim.x - 1) / gridDim.x;
+    const size_t a = per * blockIdx.x, b = a + per < n16 ? a + per : n16;
+    unsigned x = 0u, y = 0u, z = 0u, w = 0u;
+    size_t i = a + threadIdx.x;
+    for (; i + 7 * 256 < b; i += 8 * 256) {
+        read_u4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = __builtin_nontemporal_load(p + i + 256 * k);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { x ^= v[k].x; y ^= v[k].y; z ^= v[k].z; w ^= v[k].w; }
+    }
+    for (; i < b; i += 256) { const read_u4 v = p[i]; x ^= v.x; y ^= v.y; z ^= v.z; w ^= v.w; }
+    if ((x ^ y ^ z ^ w) == 0x9e3779b9u) sink[blockIdx.x] = x;        // (never true for the fill pattern: keeps the loads)
+}
+
 extern "C" {
 
 int kiwi_hip_init(int device, kiwi_hip_ctx **out)
@@ -2930,10 +2954,52 @@ int kiwi_hip_get_receiver_geometry(kiwi_hip_ctx *c, int irec, double *azi, doubl
     return 0;
 }
 
+#ifndef KIWI_BUILD_EXTRA
+#define KIWI_BUILD_EXTRA ""
+#endif
+// the extra compiler flags this library was built with (make EXTRA=...; "" for the default build)
+int kiwi_hip_build_flags(char *buf, int buflen)
+{
+    if (!buf || buflen < 1) return 1;
+    std::snprintf(buf, (size_t)buflen, "%s", KIWI_BUILD_EXTRA);
+    return 0;
+}
+
 int kiwi_hip_get_device_bytes(kiwi_hip_ctx *c, long long *bytes)
 {
     *bytes = c->dev_bytes;
     return 0;
+}
+
+// What a pure read reaches on this device (the ceiling the accumulate kernels' HBM-regime figure is held against: bench.py
+// `also_hbm`): every lane 16 bytes per load, eight loads in flight, a workgroup walks its contiguous slice of a buffer far larger
+// than the Infinity Cache; HIP events around `reps` passes on the context's stream.  The buffer is allocated and freed here.
+int kiwi_hip_measure_read_bandwidth(kiwi_hip_ctx *c, long long bytes, int reps, double *gbs)
+{
+    GUARD_BEGIN_DEV(c)
+    if (!gbs || bytes < (1ll << 20) || reps < 1) throw std::runtime_error("bad arguments");
+    const size_t n16 = (size_t)bytes / 16;
+    read_u4 *buf = nullptr;
+    unsigned *sink = nullptr;
+    HIPCHECK(hipMalloc(&buf, n16 * 16));
+    hipError_t e = hipMalloc(&sink, 4096 * sizeof(unsigned));
+    if (e != hipSuccess) { (void)hipFree(buf); HIPCHECK(e); }
+    hipEvent_t a, b;
+    HIPCHECK(hipEventCreate(&a)); HIPCHECK(hipEventCreate(&b));
+    const int grid = 4096;
+    hipLaunchKernelGGL(read_fill_kernel, dim3(grid), dim3(256), 0, c->stream, buf, n16);
+    hipLaunchKernelGGL(read_in_order_kernel, dim3(grid), dim3(256), 0, c->stream, buf, n16, sink);      // warm-up
+    HIPCHECK(hipEventRecord(a, c->stream));
+    for (int r = 0; r < reps; r++) hipLaunchKernelGGL(read_in_order_kernel, dim3(grid), dim3(256), 0, c->stream, buf, n16, sink);
+    HIPCHECK(hipEventRecord(b, c->stream));
+    HIPCHECK(hipEventSynchronize(b));
+    float ms = 0.f;
+    HIPCHECK(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    (void)hipFree(buf); (void)hipFree(sink);
+    *gbs = ms > 0.f ? (double)n16 * 16.0 * reps / (ms * 1e-3) / 1e9 : 0.0;
+    return 0;
+    GUARD_END(c)
 }
 
 } // extern "C"

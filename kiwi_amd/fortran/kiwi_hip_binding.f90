@@ -440,6 +440,22 @@ module kiwi_hip_binding
             integer(c_long_long), intent(out) :: bytes
         end function
 
+        integer(c_int) function kiwi_hip_build_flags( buf, buflen ) bind(C, name='kiwi_hip_build_flags')
+            import :: c_int, c_char
+            character(kind=c_char), intent(out) :: buf(*)
+            integer(c_int), value :: buflen
+        end function
+
+      ! diagnostics: GB/s of a pure read of `bytes` bytes of device memory
+        integer(c_int) function kiwi_hip_measure_read_bandwidth( ctx, bytes, reps, gbs ) &
+                bind(C, name='kiwi_hip_measure_read_bandwidth')
+            import :: c_int, c_ptr, c_long_long, c_double
+            type(c_ptr), value :: ctx
+            integer(c_long_long), value :: bytes
+            integer(c_int), value :: reps
+            real(c_double), intent(out) :: gbs
+        end function
+
         integer(c_int) function kiwi_hip_get_reference( ctx, irec, icomp, which, first, n, out, maxn ) &
                 bind(C, name='kiwi_hip_get_reference')
             import :: c_int, c_ptr, c_float

@@ -117,6 +117,8 @@ def load():
         "kiwi_hip_get_geometry": [vp, C.c_int, C.c_int, C.c_int, c_int_p, vp],
         "kiwi_hip_get_receiver_geometry": [vp, C.c_int, c_double_p, c_double_p, c_double_p],
         "kiwi_hip_get_device_bytes": [vp, C.POINTER(C.c_longlong)],
+        "kiwi_hip_measure_read_bandwidth": [vp, C.c_longlong, C.c_int, C.POINTER(C.c_double)],
+        "kiwi_hip_build_flags": [C.c_char_p, C.c_int],
         "kiwi_hip_get_amp_spectrum": [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_float_p, c_int_p, c_float_p, C.c_int],
         "kiwi_hip_get_cross_correlations": [vp, C.c_int, C.c_int, C.c_float, C.c_float, c_int_p, c_int_p, c_float_p, C.c_int],
         "kiwi_hip_get_peak_amplitudes": [vp, C.c_int, C.c_int, c_float_p],

@@ -125,6 +125,19 @@ def lib():
 _ref = None
 
 
+def ref_available():
+    """oracle/_ref/libkiwi_ref.so exists (nothing is loaded: collection of a test module must not map it)"""
+    return os.path.exists(os.path.join(HERE, "_ref", "libkiwi_ref.so"))
+
+
+class LazyRef:
+    """Stands for ref() in a test module: the library is loaded by the first test that calls into it, never at import --
+    a `pytest -m gpu` process collects these modules and deselects their tests, and should not map the checker."""
+
+    def __getattr__(self, name):
+        return getattr(ref(), name)
+
+
 def ref():
     """The reference's own Fortran modules (oracle/_ref/libkiwi_ref.so) or None if not built."""
     global _ref

@@ -230,6 +230,31 @@ def test_bench_dress_rehearsal_ranks_on_one_gpu(nranks):
     assert np.all(np.diff(got[1:]) != 0)                 # a strike sweep: every trial its own misfit, in trial order
 
 
+@pytest.mark.parametrize("how", ["dies", "hangs"])
+def test_bench_rehearsal_with_a_rank_that_fails(how):
+    """The failure path of `bench.py --gpus N`: four rehearsal ranks on the one GPU, rank 2 leaves the run
+    after the warm-up (exit 17) or stops answering (sleeps).  The launcher must come back NON-ZERO and soon -- torch.distributed.run
+    ends the other ranks when one has failed; a rank that hangs is found by the collective's timeout (KIWI_BENCH_COLLECTIVE_TIMEOUT,
+    here 15 s; default 120) in the ranks that wait for it -- and no JSON line may be printed.  Nothing is restarted in place."""
+    import os
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KIWI_BENCH_BACKEND="gloo", KIWI_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", KIWI_BENCH_COLLECTIVE_TIMEOUT="15")
+    env["KIWI_BENCH_FAIL_RANK" if how == "dies" else "KIWI_BENCH_HANG_RANK"] = "2"
+    t0 = time.time()
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr",
+                          "127.0.0.1", "--master-port", str(29560 + (how == "hangs")), "--max-restarts", "0", os.path.join(root, "bench.py"),
+                          "--gpus", "4", "--steps", "2", "--warmup", "1", "--batch", "24", "--workload", "cfg3"], capture_output=True, text=True,
+                         timeout=600, env=env, cwd=root)
+    took = time.time() - t0
+    assert out.returncode != 0, out.stdout[-1000:]
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")], out.stdout[-500:]
+    assert ("leaves the run" if how == "dies" else "stops answering") in out.stderr
+    assert took < 240, took
+
+
 def test_database_beyond_two_to_the_31_samples(monkeypatch):
     """A Green's function tensor of 9.3 GB (2.3e9 floats: ordinary for real Kiwi databases on a 288 GB device): the
     LDS-staged kernels address a group's rows with 32-bit offsets relative to a 64-bit per-group base, so sources whose

@@ -9,9 +9,9 @@ import pytest
 
 from oracle import ko
 
-R = ko.ref()
+R = ko.LazyRef()
 AUX = "/root/reference/aux/crust2x2"
-pytestmark = pytest.mark.skipif(R is None or not os.path.isdir(AUX), reason="needs oracle/_ref and the reference's aux data")
+pytestmark = pytest.mark.skipif(not ko.ref_available() or not os.path.isdir(AUX), reason="needs oracle/_ref and the reference's aux data")
 fp = ko._fp
 
 

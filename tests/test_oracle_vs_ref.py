@@ -8,8 +8,8 @@ import pytest
 
 from oracle import ko
 
-R = ko.ref()
-pytestmark = pytest.mark.skipif(R is None, reason="oracle/_ref/libkiwi_ref.so not built")
+R = ko.LazyRef()
+pytestmark = pytest.mark.skipif(not ko.ref_available(), reason="oracle/_ref/libkiwi_ref.so not built")
 
 fp = ko._fp
 

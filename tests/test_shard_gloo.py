@@ -121,3 +121,55 @@ def test_two_rank_sharded_misfits_for_sources():
     for rank, m, n, fails in res:              # every rank ends up with the full ordered arrays and the global failings
         assert m.shape == (7, 2, 3) and np.array_equal(m, m0) and np.array_equal(n, n0)
         assert fails == [5] and np.all(m[5] == 0) and np.all(n[5] == 0)
+
+
+def _worker_with_a_missing_peer(rank, world, port, q):
+    """rank 1 leaves before the collective; rank 0 must get an error out of it within the process group's timeout"""
+    import datetime
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=8))
+    dist.barrier()
+    if rank == 1:
+        os._exit(17)
+    t0 = time.time()
+    try:
+        gather_misfits(np.arange(3, dtype=np.float32), dist, counts=[3, 3])
+        q.put(("no error", time.time() - t0))
+    except Exception as ex:                      # noqa: BLE001  (gloo: RuntimeError / DistBackendError, by version)
+        q.put((type(ex).__name__, time.time() - t0))
+    os._exit(0)
+
+
+def test_a_rank_that_dies_does_not_hang_the_collective():
+    """First contact with a multi-GPU node is unattended: a rank that is gone must surface as an error in the
+    surviving ranks' collective within the process group's timeout -- bench.py passes one to init_process_group -- not as a wait
+    until somebody kills the job.  Two gloo ranks, the second exits before the all-gather."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_with_a_missing_peer, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    what, took = q.get(timeout=60)
+    for p in procs:
+        p.join(timeout=30)
+    assert what != "no error", "the all-gather returned although its peer had left"
+    assert took < 30, took
+    assert procs[1].exitcode == 17
+
+
+def test_product_library_needs_no_peer_access():
+    """A multi-device context (kiwi_hip_init_multi) replicates its read-only state on every device and gathers results through
+    the host: nothing in the library depends on the devices being peers (xGMI-linked or not, hipDeviceCanAccessPeer true or
+    false).  By construction: the library does not import a single peer-access entry point of the HIP runtime."""
+    import subprocess
+    from kiwi_amd import lib as klib
+    syms = subprocess.run(["nm", "-D", "--undefined-only", klib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "hipMalloc" in syms                                   # (nm works, and this is the HIP library)
+    for bad in ("Peer", "hipIpc", "hipMemcpyDtoD"):
+        assert bad not in syms, [l for l in syms.splitlines() if bad in l]
