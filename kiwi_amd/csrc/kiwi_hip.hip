@@ -1183,16 +1183,15 @@ void run_chunk(kiwi_hip_ctx *c, int isrc0, int nsrc, int proc_which)
             }
             fuse_T = T; fuse_tile = 4 * T; fuse_ntiles = ntiles; fuse_all = cell || duo;
             aa.pairflag = (cell || duo) ? c->pairflag_d.p : (const int *)nullptr;
-            // (The cell kernels run uncontracted under either contract -- bit-identical results are inside any tolerance --:
-            // contracted, accumulate_cellw_kernel needs 189 registers for its 168 and spills in its centroid loop (cfg4: 246 ms
-            // per 128 sources against 169), and the contracted shared-tile kernel only reaches the uncontracted per-wave one
-            // (169.4 against 169.0): these kernels are bound by their descriptor / bookkeeping instructions, not by the
-            // multiplies and adds a fused operation saves.  Round 5: with the tail-rule variant of the step taken out of the
-            // interleaved form (a loop over the components, the blend behind it) the contracted kernel still spills 12
-            // registers, two reloads per centroid: 195 ms against 177; uncontracted that form has no spill and is 2.5 % slower
-            // (178.1 against 173.8 ms: cfg4's windows reach past the trace ends often enough).  Neither kept.)
+            // The per-wave cell kernel has a fused build since round 6 (accum_4_fused.o: compiled WITHOUT contraction like the exact
+            // one, its multiply-adds fused explicitly in the source, kiwi_accum.inc KIWI_EXPLICIT_FMA; zero scratch).  Until then
+            // the cell kernels ran uncontracted under either contract: the contracting compile needs 175-189 registers for the
+            // kernel's 168 (cfg4 246 ms per 128 sources against 169).  The shared-tile kernel (KIWI_HIP_CELL_WAVE=0) still does
+            // -- bit-identical results are inside any tolerance.  KIWI_HIP_CELL_FUSED=0: the exact build under `fused` too (A/B).
             if (cell) {
-                if (c->cell_wave) exact::launch_cellw(aa, cgrid, ntiles_c); else exact::launch_cell(aa, cgrid, ntiles_c);
+                static const bool cell_fused = [] { const char *e = std::getenv("KIWI_HIP_CELL_FUSED"); return !e || std::atoi(e) != 0; }();
+                if (c->cell_wave) { if (fusedar && cell_fused) fused::launch_cellw(aa, cgrid, ntiles_c); else exact::launch_cellw(aa, cgrid, ntiles_c); }
+                else exact::launch_cell(aa, cgrid, ntiles_c);
             }
             // the (group of sources, receiver) combinations accumulate_multi_kernel takes; the grouped kernel behind it returns at once for those
             const int *m2p = any2 ? c->mate_d.p : (const int *)nullptr, *m4p = any4 ? c->mate4_d.p : (const int *)nullptr;
