@@ -62,7 +62,7 @@ def setup_product(device, wl, L):
     from kiwi_amd import Engine, synthetic
     from kiwi_amd.engine import discretize, discretize_eikonal
     nrec = wl["nrec"]
-    gf = synthetic.make_gfdb(nx=wl["nx"], nz=wl.get("nz", 6), L=L)
+    gf = synthetic.make_gfdb(nx=wl["nx"], nz=wl.get("nz", 6), L=L, ng=wl.get("ng", 10), variant=wl.get("variant", "probe"))
     lat, lon, depth, comps, dist = synthetic.make_receivers(nrec)
     p = Engine(device)
     # the engine gets the traces as a database reader delivers them: gap-compressed spans (trace_pack), which is also
@@ -676,7 +676,7 @@ def main():
                     help="ranks = GPUs of this node (default: WORLD_SIZE when started by a launcher, else 1)")
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg4-nukl", "cfg5", "cfg5-td", "cfg3-100pt", "cfg3-scatter", "cfg3-bigdb", "cfg3-bigdb4", "cfg3-bigdb4-ordered", "cfg3-w256", "cfg3-w600"],
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg4-nukl", "cfg5", "cfg5-td", "cfg3-100pt", "cfg3-scatter", "cfg3-bigdb", "cfg3-bigdb4", "cfg3-bigdb4-ordered", "cfg3-w256", "cfg3-w600", "cfg3-ng8", "cfg3-static"],
                     help="BASELINE.json configs[1..4]; cfg3 (default) is the one the metric is quoted on")
     ap.add_argument("--batch", type=int, default=0,
                     help="trial sources per GPU per step (default: 12960 cfg2, 4096 cfg3, 1024 cfg3-scatter / cfg3-bigdb, 512 cfg3-100pt / cfg5 / cfg5-td, 128 cfg4)")
@@ -740,7 +740,7 @@ def main():
     if args.batch <= 0:
         # (cfg3: 4096 sources per step -- 0.14 s -- so that the driver's 20 steps time 2.8 s of device work)
         args.batch = {"cfg2": 12960, "cfg3": 4096, "cfg3-scatter": 1024, "cfg3-bigdb": 1024, "cfg3-100pt": 512, "cfg4": 128, "cfg4-nukl": 128, "cfg5": 512,
-                      "cfg5-td": 512, "cfg3-w256": 16384, "cfg3-w600": 8192, "cfg3-bigdb4": 1024, "cfg3-bigdb4-ordered": 1024}[args.workload]
+                      "cfg5-td": 512, "cfg3-w256": 16384, "cfg3-w600": 8192, "cfg3-bigdb4": 1024, "cfg3-bigdb4-ordered": 1024, "cfg3-ng8": 4096, "cfg3-static": 4096}[args.workload]
     if args.sweep > 0:
         return sweep(args, torch, dist, rank, local_rank, ngpus, force_dist)
     lo, hi = shard_range(args.batch * ngpus, ngpus, rank)
@@ -808,6 +808,7 @@ def main():
         total_evals = args.batch * ngpus * args.steps
         value = total_evals / elapsed
         n_ip, ng, L, W = 4, gf["data"].shape[2], args.samples, (wl.get("window") or args.samples)
+        assert ng == wl.get("ng", 10)
         npts = wl["npoints"]
         acc_s = float(ms[1]) * 1e-3
         launches_acc = max(int(launches[1]), 1)
@@ -850,10 +851,10 @@ def main():
             # `other_contract` below carries the same batch under the other one)
             "arithmetic": arith,
             "config": {"workload": "%s: %s source, %.0f centroids (%.0f sub-fault points x %.0f time steps%s) x %d receivers x 3 comp x %d samples, "
-                                   "ng=10, bilinear GF interpolation, %s%s, tapered %d-sample window%s"
+                                   "ng=%d%s, bilinear GF interpolation, %s%s, tapered %d-sample window%s"
                                    % (wl["name"], wl["sourcetype"], ncent, npts, ncent / max(npts, 1.0),
                                       ", every trial at ONE location (strike sweep, 0.1 degree steps)" if args.workload == "cfg3" else "",
-                                      nrec, L, wl["method"],
+                                      nrec, L, ng, " (static end values, interior gaps)" if wl.get("variant") == "static" else "", wl["method"],
                                       " + frequency filter" if wl["filter"] is not None else "", W,
                                       "; `also` = the literal 100-sub-fault-point reading (200 centroids), `also_scatter` = the same source "
                                       "over a shuffled location grid" if args.workload == "cfg3" else ""),
@@ -910,6 +911,7 @@ def main():
             out["also_cfg2"] = also_workload(local_rank, args.samples, "cfg2", 12960)
             out["also_cfg4"] = also_workload(local_rank, args.samples, "cfg4", 128, cpu_budget_s=4.0)
             out["also_scatter"] = also_workload(local_rank, args.samples, "cfg3-scatter", 1024)
+            out["also_ng8"] = also_workload(local_rank, args.samples, "cfg3-ng8", 4096)          # far-field database (8 components)
             out["sweep"] = sweep_block(local_rank, args.samples)
             out["also_hbm"] = also_bigdb4(local_rank, args.samples)
         print(json.dumps(_finite(out)))

@@ -250,7 +250,7 @@ if __name__ == "__main__":
     print("// KIWI_ARITH selects the exact (v_pk_mul_f32 + v_pk_add_f32) or the fused (v_pk_fma_f32) text")
     for fused in (False, True):
         print("#if KIWI_ARITH == %d" % (1 if fused else 0))
-        for ng in (10,):
+        for ng in (10, 8):
             for K in (5, 9, 17):
                 for rot in (True, False):
                     print(routine(ng, K, rot, fused))

@@ -238,6 +238,14 @@ def workload(name, nsrc=None, trial0=0):
         w = workload("cfg3", nsrc, trial0)
         w.update(name=name, window=int(name[6:]), window_offset=500)
         return w
+    if name in ("cfg3-ng8", "cfg3-static"):
+        # cfg3 over the two other kinds of database real Kiwi installations hold: a far-field database of
+        # EIGHT components (gfdb.f90:57: no near-field terms) and a database with non-zero static end values and interior zero
+        # gaps (make_gfdb variant "static": traces of several strips, rows that do not end in zero -- no compact descriptors,
+        # the tail rule of sparse_trace.f90:696-703 live)
+        w = workload("cfg3", nsrc, trial0)
+        w.update(name=name, **({"ng": 8} if name == "cfg3-ng8" else {"variant": "static"}))
+        return w
     if name == "cfg3-100pt":
         # the north star's "100 sub-faults" taken literally: 25 x 4 sub-fault points of an 18 km x 4.5 km rupture, two
         # source-time-function steps each (200 centroids)

@@ -9,9 +9,9 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 TAG=${TAG:-r05}
 O=gpurun_out/$TAG
 mkdir -p $O
-for w in ${WORKLOADS:-cfg3 cfg3-100pt cfg3-scatter cfg3-w256 cfg3-w600 cfg2 cfg4 cfg5 cfg5-td cfg3-bigdb cfg3-bigdb4 cfg3-bigdb4-ordered}; do
+for w in ${WORKLOADS:-cfg3 cfg3-100pt cfg3-scatter cfg3-w256 cfg3-w600 cfg3-ng8 cfg3-static cfg2 cfg4 cfg4-nukl cfg5 cfg5-td cfg3-bigdb cfg3-bigdb4 cfg3-bigdb4-ordered}; do
  for ar in ${ARITHS:-exact fused}; do
-  case "$w:$ar" in cfg4:fused|cfg3-bigdb*:fused) continue;; esac       # (cell kernels run uncontracted; the HBM regime is measured once)
+  case "$w:$ar" in cfg4-nukl:fused|cfg3-bigdb*:fused) continue;; esac       # (the HBM regime and the nucleation sweep are measured once)
   k=$w; [ $ar = fused ] && k=$w@fused
   export KIWI_HIP_ARITH=$ar
   B="python3 bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline --no-also"

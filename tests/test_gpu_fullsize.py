@@ -73,10 +73,11 @@ def test_cfg3_bilateral_100_centroids_50_receivers():
     assert np.array_equal(m, m2) and np.array_equal(g, g2)
 
 
-@pytest.mark.parametrize("name,ncent_want", [("cfg3-100pt", 200), ("cfg3-scatter", 100)])
+@pytest.mark.parametrize("name,ncent_want", [("cfg3-100pt", 200), ("cfg3-scatter", 100), ("cfg3-ng8", 100), ("cfg3-static", 100)])
 def test_cfg3_variants_at_full_size(name, ncent_want):
-    """The literal "100 sub-faults" source (100 sub-fault points x 2 time steps) and the cfg3 source over a shuffled
-    location grid (no Green's function rows shared between neighbouring trials), full size, oracle spot checks."""
+    """The literal "100 sub-faults" source (100 sub-fault points x 2 time steps), the cfg3 source over a shuffled
+    location grid (no Green's function rows shared between neighbouring trials), over a far-field database of eight
+    components and over a database with static end values and interior gaps -- full size, oracle spot checks."""
     wl, p, gf, recv, refs, tapers, ncent = setup(name, 20)
     assert ncent == ncent_want and wl["nrec"] == 50
     if name == "cfg3-100pt":
