@@ -830,7 +830,7 @@ def main():
         except Exception:
             copy_gbs = None
         kernel = "accumulate_kernel (KIWI_HIP_ACCUM=direct)" if os.environ.get("KIWI_HIP_ACCUM") == "direct" else \
-            ("accumulate_cell_kernel<10,256,2,0> (+ accumulate_grouped_kernel for the pairs it leaves)" if npts > 0.5 * ncent
+            ("accumulate_cellw_kernel<NG,FUSE,COMPACT> (cell runs, a tile per wave; + accumulate_grouped_kernel for the pairs it leaves)" if npts > 0.5 * ncent
              else ("accumulate_grouped_kernel<10,256> (runs of sources sharing their tiles)" if wl["sourcetype"] == "moment_tensor"
                    else "accumulate_multi_kernel<10,FUSE,4|2> (four / two trial sources per workgroup; + accumulate_grouped_kernel for the pairs it leaves)"))
         out = {

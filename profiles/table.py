@@ -7,7 +7,7 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 here = os.path.dirname(os.path.abspath(__file__))
 d = json.load(open(os.path.join(here, tag + "_summary.json")))
-order = ["cfg3", "cfg3-100pt", "cfg3-scatter", "cfg3-w256", "cfg3-w600", "cfg3-bigdb", "cfg3-bigdb4", "cfg3-bigdb4-ordered", "cfg2", "cfg4", "cfg5", "cfg5-td"]
+order = ["cfg3", "cfg3-100pt", "cfg3-scatter", "cfg3-ng8", "cfg3-static", "cfg3-w256", "cfg3-w600", "cfg3-bigdb", "cfg3-bigdb4", "cfg3-bigdb4-ordered", "cfg2", "cfg4", "cfg4-nukl", "cfg5", "cfg5-td"]
 print("| workload | contract | sources / step | evals/s | accumulate ms / step | `frac` | VALU issue | LDS busy | L2 hit | memory-side GB / step (TB/s) | L2 requests GB / step | VALU instructions / step |")
 print("|---|---|---|---|---|---|---|---|---|---|---|---|")
 for w in order:
