@@ -468,7 +468,7 @@ def sweep_block(device, L, n=20000, first=40000, workload="cfg5"):
             "timed": "parameter list -> host discretiser -> H2D -> kernels -> D2H (inputs NOT resident), one call"}
 
 
-def also_workload(device, L, name, batch, steps=3, cpu_budget_s=3.0):
+def also_workload(device, L, name, batch, steps=3, cpu_budget_s=3.0, host_pieces=0):
     """Another workload in the driver's line: `steps` passes of the hot path over `batch` resident trial sources,
     timed like the main figure (wall clock around eval + sync + download of the misfits), with its own roofline block (required
     flops over the accumulate kernels' HIP-event time) and a SHORT CPU baseline (the oracle on the host cores for `cpu_budget_s`
@@ -490,9 +490,14 @@ def also_workload(device, L, name, batch, steps=3, cpu_budget_s=3.0):
            "ms_per_step": dt / steps * 1e3,
            "roofline": valu_roofline(ach, ar, accumulate_ms_per_step=acc_ms, flops_per_eval=flops_eval)}
     try:
-        out["cpu_baseline"] = cpu_baseline(wl, gf, recv, refs, tapers, np.asarray(gg), gm, gn, budget_s=cpu_budget_s, one_core=False)
+        out["cpu_baseline"] = cpu_baseline(wl, gf, recv, refs, tapers, np.asarray(gg), gm, gn, budget_s=cpu_budget_s, one_core=False) if cpu_budget_s > 0 else None
     except Exception as ex:                      # (the secondary blocks must not take the line down)
         out["cpu_baseline"] = {"error": str(ex)[:200]}
+    if host_pieces > 0:
+        # the whole path for a list of `host_pieces` pieces whose head is this batch: parameter list -> discretiser (a fast-marching solve
+        # per trial for the rupture-shape sweep) -> upload -> kernels -> download, the discretiser running ahead of the device
+        longer = synthetic.workload(name, host_pieces * batch, 0)["trials"]
+        out["host_inclusive"] = host_inclusive(p, wl, out["value"], longer=longer)
     p.close()
     return out
 
@@ -912,6 +917,9 @@ def main():
             out["also_cfg4"] = also_workload(local_rank, args.samples, "cfg4", 128, cpu_budget_s=4.0)
             out["also_scatter"] = also_workload(local_rank, args.samples, "cfg3-scatter", 1024)
             out["also_ng8"] = also_workload(local_rank, args.samples, "cfg3-ng8", 4096)          # far-field database (8 components)
+            # BASELINE config 4's source type swept over what it is inverted for -- nucleation point, rupture velocity: a fast-marching
+            # solve per trial on the host --: resident rate and the host-inclusive rate of a four-piece list
+            out["also_nukl"] = also_workload(local_rank, args.samples, "cfg4-nukl", 128, cpu_budget_s=0.0, host_pieces=4)
             out["sweep"] = sweep_block(local_rank, args.samples)
             out["also_hbm"] = also_bigdb4(local_rank, args.samples)
         print(json.dumps(_finite(out)))
