@@ -496,8 +496,8 @@ def also_workload(device, L, name, batch, steps=3, cpu_budget_s=3.0, host_pieces
     if host_pieces > 0:
         # the whole path for a list of `host_pieces` pieces whose head is this batch: parameter list -> discretiser (a fast-marching solve
         # per trial for the rupture-shape sweep) -> upload -> kernels -> download, the discretiser running ahead of the device
-        longer = synthetic.workload(name, host_pieces * batch, 0)["trials"]
-        out["host_inclusive"] = host_inclusive(p, wl, out["value"], longer=longer)
+        longer = synthetic.workload(name, host_pieces, 0)["trials"] if host_pieces > 64 else synthetic.workload(name, host_pieces * batch, 0)["trials"]
+        out["host_inclusive"] = host_inclusive(p, wl, out["value"], longer=longer, reps=2 if host_pieces > 64 else 3)
     p.close()
     return out
 
@@ -919,7 +919,8 @@ def main():
             out["also_ng8"] = also_workload(local_rank, args.samples, "cfg3-ng8", 4096)          # far-field database (8 components)
             # BASELINE config 4's source type swept over what it is inverted for -- nucleation point, rupture velocity: a fast-marching
             # solve per trial on the host --: resident rate and the host-inclusive rate of a four-piece list
-            out["also_nukl"] = also_workload(local_rank, args.samples, "cfg4-nukl", 128, cpu_budget_s=0.0, host_pieces=4)
+            # (host_pieces = 1350: the WHOLE 25 x 9 x 6 grid of the sweep as one list)
+            out["also_nukl"] = also_workload(local_rank, args.samples, "cfg4-nukl", 128, cpu_budget_s=0.0, host_pieces=1350)
             out["sweep"] = sweep_block(local_rank, args.samples)
             out["also_hbm"] = also_bigdb4(local_rank, args.samples)
         print(json.dumps(_finite(out)))
