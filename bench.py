@@ -899,30 +899,37 @@ def main():
         }
         if os.environ.get("KIWI_BENCH_DUMP_MISFITS"):        # (tests: the gathered global misfits of the last step, in trial order)
             out["gathered_global_misfits"] = [float(x) for x in np.asarray(allg).ravel()]
+        def secondary(fn, *a, **k):
+            """a secondary block must never take the driver's line down: what goes wrong in one is reported in its place"""
+            try:
+                return fn(*a, **k)
+            except Exception as ex:              # noqa: BLE001
+                return {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+
         if ngpus == 1 and not args.no_cpu_baseline:
             gm, gn, gg = p.get_misfits()
-            out["cpu_baseline"] = cpu_baseline(wl, gf, recv, refs, tapers, np.asarray(allg), gm, gn)
+            out["cpu_baseline"] = secondary(cpu_baseline, wl, gf, recv, refs, tapers, np.asarray(allg), gm, gn)
         else:
             out["cpu_baseline"] = None
         if ngpus == 1 and not args.no_also:
-            out["other_contract"] = other_contract(p, args.batch, flops_eval)
+            out["other_contract"] = secondary(other_contract, p, args.batch, flops_eval)
             # the whole path (discretiser + transfers included) for the same trial sources, against the resident-input figure
             longer = synthetic.workload(args.workload, 4 * args.batch, 0)["trials"] if wl["crust"] is not None else None
-            out["host_inclusive"] = host_inclusive(p, wl, value, piece=args.piece, longer=longer)
+            out["host_inclusive"] = secondary(host_inclusive, p, wl, value, piece=args.piece, longer=longer)
         if ngpus == 1 and args.workload == "cfg3" and not args.no_also:
-            out["also"] = also_cfg3_100pt(p, local_rank, args.samples)
+            out["also"] = secondary(also_cfg3_100pt, p, local_rank, args.samples)
             # the other BASELINE.json configurations and the unfriendly reading of cfg3, driver-timed: three steps each, own roofline
             # block, a short CPU baseline on the same trial sources
-            out["also_cfg2"] = also_workload(local_rank, args.samples, "cfg2", 12960)
-            out["also_cfg4"] = also_workload(local_rank, args.samples, "cfg4", 128, cpu_budget_s=4.0)
-            out["also_scatter"] = also_workload(local_rank, args.samples, "cfg3-scatter", 1024)
-            out["also_ng8"] = also_workload(local_rank, args.samples, "cfg3-ng8", 4096)          # far-field database (8 components)
+            out["also_cfg2"] = secondary(also_workload, local_rank, args.samples, "cfg2", 12960)
+            out["also_cfg4"] = secondary(also_workload, local_rank, args.samples, "cfg4", 128, cpu_budget_s=4.0)
+            out["also_scatter"] = secondary(also_workload, local_rank, args.samples, "cfg3-scatter", 1024)
+            out["also_ng8"] = secondary(also_workload, local_rank, args.samples, "cfg3-ng8", 4096)          # far-field database (8 components)
             # BASELINE config 4's source type swept over what it is inverted for -- nucleation point, rupture velocity: a fast-marching
             # solve per trial on the host --: resident rate and the host-inclusive rate of a four-piece list (VERDICT r05 item 1)
             # (host_pieces = 1350: the WHOLE 25 x 9 x 6 grid of the sweep as one list)
-            out["also_nukl"] = also_workload(local_rank, args.samples, "cfg4-nukl", 128, cpu_budget_s=0.0, host_pieces=1350)
-            out["sweep"] = sweep_block(local_rank, args.samples)
-            out["also_hbm"] = also_bigdb4(local_rank, args.samples)
+            out["also_nukl"] = secondary(also_workload, local_rank, args.samples, "cfg4-nukl", 128, cpu_budget_s=0.0, host_pieces=1350)
+            out["sweep"] = secondary(sweep_block, local_rank, args.samples)
+            out["also_hbm"] = secondary(also_bigdb4, local_rank, args.samples)
         print(json.dumps(_finite(out)))
     if dist is not None:
         dist.barrier()

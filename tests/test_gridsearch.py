@@ -115,3 +115,22 @@ def test_misfit_grid_finds_minimum_and_bootstraps():
     e.compute(FakeEngine())
     e.postprocess()
     assert np.array_equal(e.best_source, np.array(BASE, np.float32)) and e.get_best_misfit() == e.ref_misfit
+
+
+def test_pieces_of_the_one_call_evaluation_cover_the_list():
+    """kiwi_amd.engine._pieces mirrors how kiwi_hip_misfits_for_params cuts a trial list (kiwi_hip.hip): pieces of `piece` sources in
+    list order; for the eikonal types (4, 5) the last piece as half, a quarter, an eighth and an eighth of it -- the device starts
+    after an eighth of a piece's fast-marching solves.  Whatever the cut: the pieces tile [0, n) in order, the head piece is
+    [0, piece), no piece is empty, and the closed-form types are never ramped."""
+    from kiwi_amd.engine import _pieces
+    for st in (1, 4, 5, 6):
+        for n in (1, 2, 7, 8, 9, 127, 128, 129, 200, 512, 1350):
+            for piece in (1, 2, 8, 9, 16, 128, 2048):
+                ps = _pieces(n, piece, st)
+                assert ps[0][0] == 0 and ps[0][1] == min(piece, n)
+                assert all(c > 0 for _, c in ps)
+                assert all(a[0] + a[1] == b[0] for a, b in zip(ps, ps[1:])) and ps[-1][0] + ps[-1][1] == n
+                if st not in (4, 5) or n <= piece:
+                    assert ps == [(s0, min(piece, n - s0)) for s0 in range(0, n, piece)]
+    assert _pieces(512, 128, 5) == [(0, 128), (128, 128), (256, 128), (384, 64), (448, 32), (480, 16), (496, 16)]
+    assert _pieces(512, 128, 1) == [(0, 128), (128, 128), (256, 128), (384, 128)]
