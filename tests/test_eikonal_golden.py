@@ -199,3 +199,32 @@ def test_optimised_discretiser_equals_the_plain_statements_on_200_random_rupture
             res[mode] = np.load(os.path.join(td, "o%s.npy" % mode))
     assert res["0"].size > 200 * 10
     assert res["0"].view(np.uint32).tobytes() == res["1"].view(np.uint32).tobytes()
+
+
+GB = np.load(os.path.join(os.path.dirname(__file__), "golden", "eikonal_vectors_big.npz"))
+
+
+@pytest.mark.parametrize("k", range(int(GB["n"])))
+def test_reference_tables_at_the_resolution_of_config_4(k):
+    """Ruptures of 8 .. 15 km radius at effective dt 0.5 s -- the 25 m fine grid of BASELINE config 4, 10^5 .. 1.4 10^6 points per
+    fast-marching solve, centroid tables of up to 5000 rows -- discretised by the reference's own modules
+    (tests/golden/make_golden_eikonal_big.py).  The oracle restatement and the product's host discretiser (round 6: the march on
+    its own layout, the grid passes four points at a time; and their statement-by-statement versions, in a child process) reproduce
+    those tables bit for bit."""
+    import subprocess
+    import sys
+    cp, cn = GB["e%d_con" % k]
+    st, p, edt = int(GB["e%d_type" % k]), GB["e%d_params" % k], float(GB["e%d_edt" % k])
+    want = GB["e%d_cent" % k]
+    a, mo, ri, _ = ko.discretize_eikonal(st, p, edt, oracle_profile(GB["rupture_profile"]), cp, cn)
+    assert np.array_equal(a.view(np.uint32), want.view(np.uint32))
+    b, bmo, bri = ke.discretize_eikonal(st, p, edt, GB["rupture_profile"], cp, cn)
+    assert np.array_equal(b.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(np.array([bmo, bri], np.float32), GB["e%d_mr" % k])
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from kiwi_amd import engine as ke; G = np.load(%r); k = int(sys.argv[1]); "
+            "cp, cn = G['e%%d_con' %% k]; a, mo, ri = ke.discretize_eikonal(int(G['e%%d_type' %% k]), G['e%%d_params' %% k], float(G['e%%d_edt' %% k]), "
+            "G['rupture_profile'], cp, cn); sys.exit(0 if np.array_equal(a.view(np.uint32), G['e%%d_cent' %% k].view(np.uint32)) else 3)") % (
+                os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                os.path.join(os.path.dirname(__file__), "golden", "eikonal_vectors_big.npz"))
+    env = dict(os.environ, KIWI_HIP_EIK_PLAIN="1")
+    assert subprocess.call([sys.executable, "-c", code, str(k)], env=env) == 0
