@@ -139,6 +139,8 @@ def _worker_with_a_missing_peer(rank, world, port, q):
         q.put(("no error", time.time() - t0))
     except Exception as ex:                      # noqa: BLE001  (gloo: RuntimeError / DistBackendError, by version)
         q.put((type(ex).__name__, time.time() - t0))
+    q.close()
+    q.join_thread()                              # (the queue's feeder thread has to flush before the process goes: os._exit does not wait for it)
     os._exit(0)
 
 
@@ -155,11 +157,11 @@ def test_a_rank_that_dies_does_not_hang_the_collective():
     procs = [ctx.Process(target=_worker_with_a_missing_peer, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    what, took = q.get(timeout=60)
+    what, took = q.get(timeout=300)            # (generous: the suite may share its cores with a build)
     for p in procs:
-        p.join(timeout=30)
+        p.join(timeout=60)
     assert what != "no error", "the all-gather returned although its peer had left"
-    assert took < 30, took
+    assert took < 120, took                    # the process group's timeout is 8 s; nowhere near the "until somebody kills the job" it replaces
     assert procs[1].exitcode == 17
 
 
